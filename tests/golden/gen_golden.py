@@ -1,0 +1,358 @@
+"""Golden-vector generator.  BUILD CONTAINER ONLY (needs /root/reference).
+
+Imports the real reference through oracle/refharness/ref_import.py and freezes its outputs on
+seeded inputs into small .npz/.pt fixtures next to this file.  The fixtures are DATA (inputs and
+expected outputs); no reference source text is stored.
+
+    python tests/golden/gen_golden.py            # regenerates everything (~2 min)
+"""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+from oracle.refharness.ref_import import load_reference  # noqa: E402
+
+
+def _load_synth():
+    spec = importlib.util.spec_from_file_location("synthetic", os.path.join(ROOT, "mmt-psm_amd", "synthetic.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+synth = _load_synth()
+mb, make_cfg = load_reference()
+C = mb._C
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------- native ops
+def gen_nms():
+    g = torch.Generator().manual_seed(11)
+    d = {}
+    # case 0: SURVEY App. C known answer
+    d["b0"] = torch.tensor([[0, 0, 10, 10], [1, 1, 11, 11], [50, 50, 60, 60], [0, 0, 10, 10.5]])
+    d["s0"] = torch.tensor([.5, .9, .3, .8])
+    d["t0"] = 0.5
+    # case 1: 500 random overlapping boxes, distinct scores
+    xy = torch.rand(500, 2, generator=g) * 200
+    wh = torch.rand(500, 2, generator=g) * 80 + 4
+    d["b1"] = torch.cat([xy, xy + wh], 1)
+    d["s1"] = torch.rand(500, generator=g)
+    d["t1"] = 0.7
+    # case 2: the >= boundary (D9): IoU exactly 0.5 must be suppressed on the CPU path
+    d["b2"] = torch.tensor([[0., 0., 9., 9.], [0., 0., 9., 4.], [0., 5., 9., 9.], [20., 20., 29., 29.]])
+    d["s2"] = torch.tensor([0.9, 0.8, 0.7, 0.6])
+    d["t2"] = 0.5
+    # case 3: 2000 boxes score-sorted like the RPN path, thr 0.7
+    xy = torch.rand(2000, 2, generator=g) * 400
+    wh = torch.rand(2000, 2, generator=g) * 120 + 2
+    d["b3"] = torch.cat([xy, xy + wh], 1)
+    d["s3"] = torch.sort(torch.rand(2000, generator=g), descending=True)[0]
+    d["t3"] = 0.7
+    # case 4: single box; case 5: identical boxes with distinct scores
+    d["b4"] = torch.tensor([[3., 4., 10., 12.]])
+    d["s4"] = torch.tensor([0.3])
+    d["t4"] = 0.5
+    d["b5"] = torch.tensor([[1., 1., 5., 5.]] * 6)
+    d["s5"] = torch.tensor([.1, .6, .3, .5, .2, .4])
+    d["t5"] = 0.5
+    out = {}
+    for i in range(6):
+        out["b%d" % i] = d["b%d" % i].float()
+        out["s%d" % i] = d["s%d" % i].float()
+        out["t%d" % i] = np.float32(d["t%d" % i])
+        out["k%d" % i] = C.nms(d["b%d" % i].float(), d["s%d" % i].float(), float(d["t%d" % i]))
+    out["k_empty"] = C.nms(torch.zeros(0, 4), torch.zeros(0), 0.5)
+    save("nms", **out)
+
+
+def gen_roi_align():
+    g = torch.Generator().manual_seed(12)
+    out = {}
+    x0 = torch.arange(2 * 3 * 8 * 8).view(2, 3, 8, 8).float()
+    r0 = torch.tensor([[0, 0, 0, 7, 7], [1, 2, 2, 5, 6.5]])
+    cases = [(x0, r0, 0.5, 2, 2, 2)]
+    x1 = torch.randn(2, 16, 40, 48, generator=g)
+    r1 = []
+    for i in range(40):
+        b = i % 2
+        x = torch.rand(1, generator=g).item() * 180 - 20
+        y = torch.rand(1, generator=g).item() * 150 - 20
+        w = torch.rand(1, generator=g).item() * 120
+        h = torch.rand(1, generator=g).item() * 100
+        r1.append([b, x, y, x + w, y + h])
+    r1 += [[0, -50, -50, -40, -45], [1, 500, 500, 600, 600], [0, 10, 10, 10, 10], [1, 0, 0, 191, 159],
+           [0, 30.5, 20.25, 31.0, 20.5]]
+    r1 = torch.tensor(r1, dtype=torch.float32)
+    cases.append((x1, r1, 0.25, 7, 7, 2))
+    cases.append((x1, r1, 0.25, 14, 14, 2))
+    cases.append((x1, r1, 0.125, 7, 7, 0))  # adaptive sampling grid
+    cases.append((x1, r1[:0], 0.25, 7, 7, 2))  # empty
+    x2 = torch.randn(1, 4, 5, 7, generator=g)
+    r2 = torch.tensor([[0, 0, 0, 100, 100], [0, 2, 1, 3, 2]], dtype=torch.float32)
+    cases.append((x2, r2, 1.0 / 16, 3, 5, 2))  # non-square pooled size
+    for i, (x, r, sc, ph, pw, sr) in enumerate(cases):
+        out["x%d" % i] = x
+        out["r%d" % i] = r
+        out["p%d" % i] = np.array([sc, ph, pw, sr], dtype=np.float64)
+        out["y%d" % i] = C.roi_align_forward(x, r, sc, ph, pw, sr)
+    out["n"] = np.int64(len(cases))
+    save("roi_align", **out)
+
+
+def gen_small_ops():
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    from maskrcnn_benchmark.modeling.rpn.anchor_generator import generate_anchors, AnchorGenerator
+    from maskrcnn_benchmark.modeling.matcher import Matcher
+    from maskrcnn_benchmark.modeling.poolers import LevelMapper
+    from maskrcnn_benchmark.layers import smooth_l1_loss
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.boxlist_ops import boxlist_iou
+    from maskrcnn_benchmark.structures.image_list import ImageList
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.loss import sharpen
+    g = torch.Generator().manual_seed(13)
+    out = {}
+    xy = torch.rand(64, 2, generator=g) * 300
+    wh = torch.rand(64, 2, generator=g) * 150 + 1
+    props = torch.cat([xy, xy + wh], 1)
+    xy = torch.rand(64, 2, generator=g) * 300
+    wh = torch.rand(64, 2, generator=g) * 150 + 1
+    refs = torch.cat([xy, xy + wh], 1)
+    for nm, w in (("10", (10., 10., 5., 5.)), ("1", (1., 1., 1., 1.))):
+        bc = BoxCoder(w)
+        enc = bc.encode(refs, props)
+        out["enc" + nm] = enc
+        codes = torch.randn(64, 12, generator=g) * 2
+        codes[0, 2] = 50.0  # exercises bbox_xform_clip
+        out["codes" + nm] = codes
+        out["dec" + nm] = bc.decode(codes, props)
+    out["props"] = props
+    out["refs"] = refs
+    for st, sz in zip((4, 8, 16, 32, 64), (32, 64, 128, 256, 512)):
+        out["cell%d" % st] = generate_anchors(st, (sz,), (0.5, 1.0, 2.0)).float()
+    out["cell16_9"] = generate_anchors(16, (128, 256, 512), (0.5, 1, 2))  # the in-file KAT table
+    ag = AnchorGenerator((32, 64, 128, 256, 512), (0.5, 1.0, 2.0), (4, 8, 16, 32, 64), 0)
+    il = ImageList(torch.zeros(2, 3, 96, 128), [(90, 120), (96, 128)])
+    feats = [torch.zeros(2, 1, 24, 32), torch.zeros(2, 1, 12, 16), torch.zeros(2, 1, 6, 8),
+             torch.zeros(2, 1, 3, 4), torch.zeros(2, 1, 2, 2)]
+    anc = ag(il, feats)
+    for i in range(2):
+        out["anc_img%d" % i] = torch.cat([a.bbox for a in anc[i]], 0)
+        out["vis_img%d" % i] = torch.cat([a.get_field("visibility") for a in anc[i]], 0)
+    a = BoxList(refs[:7], (500, 500))
+    b = BoxList(props, (500, 500))
+    iou = boxlist_iou(a, b)
+    out["iou"] = iou
+    out["match_rpn"] = Matcher(0.7, 0.3, allow_low_quality_matches=True)(iou.clone())
+    out["match_roi"] = Matcher(0.5, 0.5, allow_low_quality_matches=False)(iou.clone())
+    big = torch.cat([props, props * 4, props * 0.1], 0)
+    out["lvl_boxes"] = big
+    out["lvl"] = LevelMapper(2, 5)([BoxList(big, (2000, 2000))])
+    xx = torch.randn(100, 4, generator=g)
+    yy = torch.randn(100, 4, generator=g)
+    out["sl1_x"] = xx
+    out["sl1_y"] = yy
+    out["sl1_b9"] = smooth_l1_loss(xx, yy, beta=1. / 9, size_average=False)
+    out["sl1_b1"] = smooth_l1_loss(xx, yy, beta=1, size_average=False)
+    p = torch.softmax(torch.randn(10, 3, generator=g), 1)
+    out["sharp_p"] = p
+    out["sharp"] = sharpen(p, 0.5)
+    save("small_ops", **out)
+
+
+def gen_mt_losses():
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.loss import make_roi_box_loss_evaluator
+    from maskrcnn_benchmark.modeling.detector.generalized_rcnn import fg_hint_loss
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.engine.MTtrainer import weight_sum_losses
+    out = {}
+    g = torch.Generator().manual_seed(1234)
+    for case, (R, typ) in enumerate(((12, "bce"), (257, "bce"), (257, "kl"), (64, "mse"))):
+        cfg = make_cfg(["MT.CLS_LOSS_TYPE", typ])
+        ev = make_roi_box_loss_evaluator(cfg)
+        if R == 12:
+            labels = torch.tensor([1, 2, 0, 0, 0, 1, 0, 2, 0, 0, 1, 0])
+        else:
+            labels = (torch.rand(R, generator=g) * 3).long() * (torch.rand(R, generator=g) > 0.5).long()
+        t = [torch.randn(R, 3, generator=g) for _ in range(4)]
+        s = torch.randn(R, 3, generator=g)
+        bl = BoxList(torch.zeros(R, 4), (10, 10))
+        bl.add_field("labels", labels)
+        out["psm%d_labels" % case] = labels
+        out["psm%d_t" % case] = torch.stack(t)
+        out["psm%d_s" % case] = s
+        out["psm%d" % case] = ev.evaluatePSM([s], [x.clone() for x in t], [bl])
+        if case == 0:
+            tp = [[torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 4, 4, generator=g)] for _ in range(4)]
+            sp = [[torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 4, 4, generator=g)]]
+            mk = [(torch.rand(16, 16, generator=g) > 0.5).long() for _ in range(2)]
+            for i in range(4):
+                out["mgd0_t%d_0" % i] = tp[i][0]
+                out["mgd0_t%d_1" % i] = tp[i][1]
+            out["mgd0_s_0"] = sp[0][0]
+            out["mgd0_s_1"] = sp[0][1]
+            out["mgd0_m"] = torch.stack(mk)
+            out["mgd0"] = fg_hint_loss(tp, sp, mk)
+    # MGD at 5 levels with a non-divisible mask size (the D11 mis-registration path: 100 -> 128 pad)
+    g = torch.Generator().manual_seed(77)
+    sh = [(2, 8, 32, 32), (2, 8, 16, 16), (2, 8, 8, 8), (2, 8, 4, 4), (2, 8, 2, 2)]
+    tp = [[torch.randn(s, generator=g) for s in sh] for _ in range(4)]
+    sp = [[torch.randn(s, generator=g) for s in sh]]
+    mk = [(torch.rand(100, 100, generator=g) > 0.6).long() * 2 for _ in range(2)]
+    for i in range(4):
+        for l in range(5):
+            out["mgd1_t%d_%d" % (i, l)] = tp[i][l]
+    for l in range(5):
+        out["mgd1_s_%d" % l] = sp[0][l]
+    out["mgd1_m"] = torch.stack(mk)
+    out["mgd1"] = fg_hint_loss(tp, sp, mk)
+    # loss weighting table (engine/MTtrainer.py:67-109) and EMA alpha (:277-281)
+    rows = []
+    bal = {"mt_classifier": 0.2, "nms_loss": 1.0, "mt_fg_loss": 1.0}
+    for step in (0, 1, 999, 1000, 1001, 1100, 1249, 1250, 3000, 6750, 6751, 6900, 6999, 7000):
+        ld = {"loss_classifier": 1.0, "mt_classifier": 1.0, "mt_fg_loss": 1.0, "nms_loss": 1.0}
+        w = weight_sum_losses(ld, step, 250, 250, 7000, l=5.0, balanced=bal, start_mt=1000)
+        rows.append([step, w["loss_classifier"], w["mt_classifier"], w["mt_fg_loss"], w["nms_loss"]])
+    out["wsl"] = np.array(rows, dtype=np.float64)
+    # EMA: 21 steps on a small vector through the reference trainer's update rule
+    t = torch.zeros(5)
+    s0 = torch.arange(5).float()
+    tr = []
+    for it in range(21):
+        s = s0 * (1 + 0.1 * it)
+        alpha = min(1 - 1 / (it + 1), 0.99)
+        t.mul_(alpha).add_(s, alpha=1 - alpha)
+        tr.append(t.clone())
+    out["ema_trace"] = torch.stack(tr)
+    save("mt_losses", **out)
+
+
+def gen_masks():
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head.inference import paste_mask_in_image
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head.loss import project_masks_on_boxes
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    masks = torch.rand(12, 28, 28, generator=g)
+    boxes = torch.tensor([[10.3, 12.7, 60.2, 80.9], [-5.0, -3.0, 20.0, 30.0], [100.0, 90.0, 140.5, 127.9],
+                          [50.0, 50.0, 50.5, 50.5], [0.0, 0.0, 149.0, 127.0], [70.2, 3.3, 90.9, 33.1],
+                          [120.0, 100.0, 170.0, 150.0], [33.3, 44.4, 55.5, 66.6], [5.5, 5.5, 9.5, 9.5],
+                          [60.0, 60.0, 61.0, 100.0], [1.0, 100.0, 140.0, 110.0], [140.0, 2.0, 149.0, 20.0]])
+    out["paste_masks"] = masks
+    out["paste_boxes"] = boxes
+    out["paste_out"] = torch.stack([paste_mask_in_image(m, b, 128, 150, 0.5, 1) for m, b in zip(masks, boxes)])
+    imgs, tg = synth.make_labeled(1, 200, 8, seed=5)
+    t = tg[0]
+    polys = [[p.tolist() for p in inst] for inst in t["polys"]]
+    # also a two-polygon instance (rleMerge union path)
+    polys.append([polys[0][0], polys[1][0]])
+    seg = SegmentationMask(polys, (200, 200), mode="poly")
+    props = torch.cat([t["boxes"], t["boxes"][:1]], 0).clone()
+    props += torch.randn(props.shape, generator=g) * 3
+    props = props.clamp(0, 199)
+    bl = BoxList(props, (200, 200))
+    out["proj_boxes"] = props
+    out["proj_npoly"] = np.array([len(p) for p in polys])
+    flat = []
+    for inst in polys:
+        for p in inst:
+            flat.append(np.asarray(p, dtype=np.float32))
+    out["proj_polylens"] = np.array([len(p) for p in flat])
+    out["proj_polys"] = np.concatenate(flat)
+    out["proj_out"] = project_masks_on_boxes(seg, bl, 28)
+    save("masks", **out)
+
+
+# ------------------------------------------------------------------------------- model level
+def to_ref_targets(tgs):
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+    res = []
+    for t in tgs:
+        bl = BoxList(t["boxes"], t["size"], mode="xyxy")
+        bl.add_field("labels", t["labels"])
+        bl.add_field("masks", SegmentationMask([[p.tolist() for p in inst] for inst in t["polys"]], t["size"], mode="poly"))
+        res.append(bl)
+    return res
+
+
+def gen_model(size=160, n_inst=4, tag="model160"):
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    cfg = make_cfg()
+    torch.manual_seed(0)
+    student = build_detection_model(cfg, is_student=True)
+    teacher = build_detection_model(cfg, is_teacher=True)
+    shapes = {k: tuple(v.shape) for k, v in student.state_dict().items()}
+    with open(os.path.join(HERE, "state_shapes.json"), "w") as f:
+        json.dump({"shapes": {k: list(v) for k, v in shapes.items()},
+                   "param_order": [k for k, _ in student.named_parameters()],
+                   "trainable": [k for k, p in student.named_parameters() if p.requires_grad]}, f)
+    sd = synth.make_weights(shapes, seed=0)
+    student.load_state_dict(sd, strict=False)
+    teacher.load_state_dict(sd, strict=False)
+    student.train()
+    teacher.eval()
+    imgs, tgs = synth.make_labeled(2, size, n_inst, seed=1234)
+    unl = synth.make_unlabeled(2, size, 3, seed=4321)
+    out = {}
+    torch.manual_seed(99)
+    il = to_image_list(list(imgs), 32)
+    ld = student(il, to_ref_targets(tgs))
+    for k, v in ld.items():
+        out["sup_" + k] = v.detach()
+    torch.manual_seed(100)
+    t_list = [to_image_list(list(u), 32) for u in unl[:2]]
+    s_list = [to_image_list(list(u), 32) for u in unl[-1:]]
+    with torch.no_grad():
+        tr = teacher.forward_teacher(t_list)
+    for i, r in enumerate(tr["result_t"]):
+        out["t_res%d_bbox" % i] = r.bbox
+        out["t_res%d_labels" % i] = r.get_field("labels")
+        out["t_res%d_objectness" % i] = r.get_field("objectness")
+    out["t_logits"] = torch.stack(tr["class_logit_t"])
+    for i, e in enumerate(tr["embedding"]):
+        for l, m in enumerate(e):
+            out["t_emb%d_%d_stats" % (i, l)] = torch.stack([m.mean(), m.abs().mean(), m[0, 0, 0, 0], m[-1, -1, -1, -1]])
+    out["t_seg"] = torch.stack(tr["seg_mask"]).to(torch.int16)
+    torch.manual_seed(101)
+    sl = student.forward_student(s_list, tr)
+    for k, v in sl.items():
+        out["stu_" + k] = v.detach()
+    save(tag, **out)
+    print({k: float(v) for k, v in out.items() if v.numel() == 1})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["nms", "roi", "small", "mt", "masks", "model"]
+    if "nms" in which:
+        gen_nms()
+    if "roi" in which:
+        gen_roi_align()
+    if "small" in which:
+        gen_small_ops()
+    if "mt" in which:
+        gen_mt_losses()
+    if "masks" in which:
+        gen_masks()
+    if "model" in which:
+        gen_model()

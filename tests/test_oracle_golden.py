@@ -1,0 +1,160 @@
+"""Pins the ORACLE (oracle/) against golden vectors captured from the reference itself
+(tests/golden/gen_golden.py).  CPU only.  SURVEY.md section 8(c)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold, T
+from oracle import model as om
+from oracle import native
+
+
+def test_nms_golden():
+    g = gold("nms")
+    for i in range(6):
+        keep = native.nms(T(g["b%d" % i]), T(g["s%d" % i]), float(g["t%d" % i]))
+        assert keep.dtype == torch.int64
+        assert keep.tolist() == g["k%d" % i].tolist(), i
+    assert native.nms(torch.zeros(0, 4), torch.zeros(0), 0.5).numel() == 0
+    # SURVEY App. C known answer and the CPU `>=` boundary (D9)
+    assert g["k0"].tolist() == [1, 2]
+    assert g["k2"].tolist() == [0, 3]
+
+
+def test_roi_align_forward_golden():
+    g = gold("roi_align")
+    for i in range(int(g["n"])):
+        sc, ph, pw, sr = g["p%d" % i]
+        y = native.roi_align_forward(T(g["x%d" % i]), T(g["r%d" % i]), float(sc), int(ph), int(pw), int(sr))
+        assert y.shape == g["y%d" % i].shape
+        np.testing.assert_array_equal(y.numpy(), g["y%d" % i])  # same op order -> bit-exact
+    assert np.allclose(g["y0"].reshape(-1)[:6], [7.875, 9.625, 21.875, 23.625, 71.875, 73.625])
+
+
+def test_roi_align_backward_gradcheck():
+    # the reference has no CPU backward (csrc/ROIAlign.h:44): pin ours by fp64 gradcheck against the
+    # forward that test_roi_align_forward_golden pinned
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 9, 11, dtype=torch.float64, generator=g, requires_grad=True)
+    rois = torch.tensor([[0, 1.3, 2.1, 20.7, 17.2], [1, -4.0, -3.0, 9.0, 8.0], [1, 30., 30., 60., 50.],
+                         [0, 5., 5., 5., 5.]], dtype=torch.float64)
+    for sr in (2, 0):
+        assert torch.autograd.gradcheck(lambda t: native.roi_align(t, rois, (3, 4), 0.5, sr), (x,),
+                                        eps=1e-6, atol=1e-6)
+
+
+def test_box_coder_anchors_matcher_golden():
+    g = gold("small_ops")
+    props, refs = T(g["props"]), T(g["refs"])
+    for nm, w in (("10", (10., 10., 5., 5.)), ("1", (1., 1., 1., 1.))):
+        np.testing.assert_array_equal(om.box_encode(refs, props, w).numpy(), g["enc" + nm])
+        np.testing.assert_array_equal(om.box_decode(T(g["codes" + nm]), props, w).numpy(), g["dec" + nm])
+    for st, sz in zip((4, 8, 16, 32, 64), (32, 64, 128, 256, 512)):
+        np.testing.assert_array_equal(om.cell_anchors(st, sz, (0.5, 1.0, 2.0)).numpy(), g["cell%d" % st])
+    # the in-file known-answer table of rpn/anchor_generator.py:168-193 is the 1-based (matlab)
+    # table; the code subtracts 1 from the base window (:213), so every coordinate is one less
+    assert (g["cell16_9"][0] + 1).tolist() == [-83., -39., 100., 56.]
+    assert (g["cell16_9"][8] + 1).tolist() == [-167., -343., 184., 360.]
+    cfg = om.default_cfg()
+    anc = om.make_anchors(cfg, [(90, 120), (96, 128)], [(24, 32), (12, 16), (6, 8), (3, 4), (2, 2)])
+    for i in range(2):
+        np.testing.assert_array_equal(torch.cat([a.bbox for a in anc[i]]).numpy(), g["anc_img%d" % i])
+        np.testing.assert_array_equal(torch.cat([a.fields["visibility"] for a in anc[i]]).numpy(),
+                                      g["vis_img%d" % i].astype(bool))
+    iou = om.box_iou(om.Boxes(refs[:7], (500, 500)), om.Boxes(props, (500, 500)))
+    np.testing.assert_array_equal(iou.numpy(), g["iou"])
+    np.testing.assert_array_equal(om.matcher(iou.clone(), 0.7, 0.3, True).numpy(), g["match_rpn"])
+    np.testing.assert_array_equal(om.matcher(iou.clone(), 0.5, 0.5, False).numpy(), g["match_roi"])
+    np.testing.assert_array_equal(om.level_map([om.Boxes(T(g["lvl_boxes"]), (2000, 2000))], 2, 5).numpy(), g["lvl"])
+    x, y = T(g["sl1_x"]), T(g["sl1_y"])
+    assert om.smooth_l1(x, y, 1. / 9, False).item() == pytest.approx(float(g["sl1_b9"]), rel=1e-6)
+    assert om.smooth_l1(x, y, 1, False).item() == pytest.approx(float(g["sl1_b1"]), rel=1e-6)
+    np.testing.assert_allclose(om.sharpen(T(g["sharp_p"]), 0.5).numpy(), g["sharp"], rtol=1e-6)
+
+
+def test_psm_mgd_golden():
+    g = gold("mt_losses")
+    for case, typ in enumerate(("bce", "bce", "kl", "mse")):
+        cfg = om.default_cfg(mt_cls_loss_type=typ)
+        t = [x for x in T(g["psm%d_t" % case])]
+        v = om.psm_loss(cfg, [T(g["psm%d_s" % case])], t, T(g["psm%d_labels" % case]))
+        assert v.item() == pytest.approx(float(g["psm%d" % case]), rel=1e-6), case
+    assert float(g["psm0"]) == pytest.approx(0.5389122, rel=1e-6)
+    tp = [[T(g["mgd0_t%d_%d" % (i, l)]) for l in range(2)] for i in range(4)]
+    sp = [[T(g["mgd0_s_%d" % l]) for l in range(2)]]
+    v = om.fg_hint_loss(tp, sp, [m for m in T(g["mgd0_m"])])
+    assert v.item() == pytest.approx(float(g["mgd0"]), rel=1e-6)
+    assert float(g["mgd0"]) == pytest.approx(1.7665445, rel=1e-6)
+    tp = [[T(g["mgd1_t%d_%d" % (i, l)]) for l in range(5)] for i in range(4)]
+    sp = [[T(g["mgd1_s_%d" % l]) for l in range(5)]]
+    v = om.fg_hint_loss(tp, sp, [m for m in T(g["mgd1_m"])])
+    assert v.item() == pytest.approx(float(g["mgd1"]), rel=1e-6)
+
+
+def test_loss_weighting_and_ema_golden():
+    g = gold("mt_losses")
+    cfg = om.default_cfg()
+    for row in g["wsl"]:
+        step = int(row[0])
+        ld = {"loss_classifier": 1.0, "mt_classifier": 1.0, "mt_fg_loss": 1.0, "nms_loss": 1.0}
+        w = om.weight_sum_losses(cfg, ld, step, 7000)
+        got = [w["loss_classifier"], w["mt_classifier"], w["mt_fg_loss"], w["nms_loss"]]
+        np.testing.assert_allclose(got, row[1:], rtol=1e-12)
+    t = torch.zeros(5)
+    s0 = torch.arange(5).float()
+    for it in range(21):
+        om.ema_update([t], [s0 * (1 + 0.1 * it)], om.ema_alpha(cfg, it))
+        np.testing.assert_array_equal(t.numpy(), g["ema_trace"][it])
+
+
+def test_mask_paste_and_targets_golden():
+    g = gold("masks")
+    for m, b, ref in zip(T(g["paste_masks"]), T(g["paste_boxes"]), g["paste_out"]):
+        np.testing.assert_array_equal(om.paste_mask(m, b, 128, 150, 0.5, 1).numpy(), ref)
+    flat = T(g["proj_polys"])
+    lens = g["proj_polylens"].tolist()
+    polys_flat, o = [], 0
+    for n in lens:
+        polys_flat.append(flat[o:o + n].clone())
+        o += n
+    polys, k = [], 0
+    for n in g["proj_npoly"].tolist():
+        polys.append(polys_flat[k:k + n])
+        k += n
+    out = om.project_masks_on_boxes(polys, T(g["proj_boxes"]), 28)
+    np.testing.assert_array_equal(out.numpy(), g["proj_out"])
+    assert 0.05 < out.mean().item() < 0.95
+
+
+def _targets(tgs):
+    return [om.Boxes(t["boxes"], t["size"], {"labels": t["labels"], "masks": t["polys"]}) for t in tgs]
+
+
+def test_model_end_to_end_golden(synth, weights):
+    """Supervised forward, forward_teacher and forward_student of the oracle reproduce the
+    reference's loss dicts / teacher dict on the same seeded inputs, weights and RNG seeds."""
+    g = gold("model160")
+    cfg = om.default_cfg()
+    sd = weights
+    imgs, tgs = synth.make_labeled(2, 160, 4, seed=1234)
+    unl = synth.make_unlabeled(2, 160, 3, seed=4321)
+    torch.manual_seed(99)
+    ld = om.forward_supervised(sd, cfg, imgs, _targets(tgs))
+    for k, v in ld.items():
+        assert v.item() == pytest.approx(float(g["sup_" + k]), rel=1e-5), k
+    torch.manual_seed(100)
+    tr = om.forward_teacher(sd, cfg, unl[:2])
+    for i, r in enumerate(tr["result_t"]):
+        np.testing.assert_allclose(r.bbox.numpy(), g["t_res%d_bbox" % i], rtol=0, atol=1e-4)
+        np.testing.assert_array_equal(r.fields["labels"].numpy(), g["t_res%d_labels" % i])
+    np.testing.assert_allclose(torch.stack(tr["class_logit_t"]).numpy(), g["t_logits"], rtol=1e-4, atol=1e-5)
+    for i, e in enumerate(tr["embedding"]):
+        for l, m in enumerate(e):
+            st = torch.stack([m.mean(), m.abs().mean(), m[0, 0, 0, 0], m[-1, -1, -1, -1]])
+            np.testing.assert_allclose(st.numpy(), g["t_emb%d_%d_stats" % (i, l)], rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(torch.stack(tr["seg_mask"]).numpy(), g["t_seg"].astype(np.int64))
+    torch.manual_seed(101)
+    sl = om.forward_student(sd, cfg, unl[-1:], tr)
+    for k, v in sl.items():
+        assert v.item() == pytest.approx(float(g["stu_" + k]), rel=1e-5), k
+    assert float(g["stu_mt_fg_loss"]) > 1e-3  # non-degenerate MGD
