@@ -1,0 +1,172 @@
+/* mmtpsm.h -- C ABI of libmmtpsm.so, the MI355X (gfx950) implementation of the MMT-PSM hot path.
+ *
+ * Drop-in boundary: these are the entry points that the reference's Python binds through its
+ * torch extension `maskrcnn_benchmark._C` (csrc/vision.cpp:7-13) and through ATen (conv / linear /
+ * losses behind maskrcnn_benchmark.layers).  Plain pointers and sizes only, no torch types.
+ * Every pointer is a DEVICE pointer unless marked [host].  Every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*; the reference launches on the current stream,
+ * cuda/ROIAlign_cuda.cu:273).  Return value: 0 on success, otherwise a hipError_t (launch
+ * failure) or a negative MMT_E* code (bad arguments); the Python side turns non-zero into
+ * RuntimeError like the reference's AT_ASSERTM / AT_ERROR (csrc/ROIAlign.h:19-45).
+ *
+ * Layout: activations are NHWC fp32 (channels innermost); conv weights are [Cout][KH][KW][Cin]
+ * (torch channels_last memory of an (O,I,H,W) tensor); ROI lists are [K][5] = (batch, x1, y1, x2, y2)
+ * exactly as the reference (cuda/ROIAlign_cuda.cu:64-122).
+ */
+#ifndef MMTPSM_H
+#define MMTPSM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMT_EINVAL (-22)
+
+/* library / device info: writes "gfx950 ..." into buf [host]; returns ABI version */
+int mmt_version(void);
+
+/* ---------------------------------------------------------------- ROIAlign (NHWC, FPN-fused)
+ * replaces _C.roi_align_forward / _C.roi_align_backward (csrc/ROIAlign.h:11-45,
+ * cuda/ROIAlign_cuda.cu:64-122,177-254) and the per-level gather/scatter of Pooler.forward
+ * (modeling/poolers.py:91-121): one launch pools all K ROIs from up to 4 pyramid levels.
+ *   feats[l]   NHWC [N, H[l], W[l], C]         scales[l] spatial scale of level l
+ *   rois       [K,5]                            levels int32 [K] (level of each ROI, 0..L-1)
+ *   out        [K, PH, PW, C]
+ * sampling_ratio > 0: fixed grid; <= 0: ceil(roi_size / pooled_size) like the reference. */
+typedef struct {
+  const float* feat[4];
+  float* grad_feat[4]; /* backward only */
+  int H[4];
+  int W[4];
+  float scale[4];
+  int num_levels;
+  int N;
+  int C;
+} mmt_pyramid;
+
+int mmt_roi_align_forward(const mmt_pyramid* pyr /*[host]*/, const float* rois, const int32_t* levels,
+                          int K, int PH, int PW, int sampling_ratio, float* out, void* stream);
+/* grad_feat[l] must be zero-initialised by the caller; accumulates with fp32 atomics */
+int mmt_roi_align_backward(const mmt_pyramid* pyr /*[host]*/, const float* rois, const int32_t* levels,
+                           int K, int PH, int PW, int sampling_ratio, const float* grad_out, void* stream);
+
+/* ---------------------------------------------------------------- batched NMS
+ * replaces _C.nms (csrc/nms.h:10-28; CPU semantics cpu/nms_cpu.cpp:37-64: "+1" areas, suppress on
+ * IoU >= thr) for B independent segments in one launch pair (RPN: one segment per (image, level),
+ * rpn/inference.py:130-135; detections: one per (image, class), box_head/inference.py:124-126).
+ *   boxes     [total,4] xyxy, each segment ALREADY SORTED by descending score
+ *   seg_off   int32 [B+1] segment boundaries into boxes
+ *   max_n     upper bound on segment length (multiple of 64 not required)
+ *   mask_ws   workspace, B * max_n * ceil(max_n/64) uint64
+ *   keep      int32 [B, max_n]: positions (within the sorted segment) of kept boxes, ascending
+ *   keep_cnt  int32 [B]
+ * The greedy sweep runs ON DEVICE (the reference copies the mask to the host, cuda/nms.cu:99-123). */
+int mmt_nms_batched(const float* boxes, const int32_t* seg_off, int B, int max_n, float thr,
+                    uint64_t* mask_ws, int32_t* keep, int32_t* keep_cnt, void* stream);
+
+/* ---------------------------------------------------------------- implicit-GEMM convolution (fp32 MFMA)
+ * replaces ATen/cuDNN conv2d + FrozenBatchNorm2d (layers/batch_norm.py:19-24) + ReLU + residual
+ * add (backbone/resnet.py:254-274) + FPN lateral/top-down add (backbone/fpn.py:57-62), nn.Linear
+ * (1x1 conv on a [R,1,1,C] tensor), and -- with transformed weights -- their data gradients.
+ *   y[n,ho,wo,co] = epi( sum_{kh,kw,ci} x[n, ho*stride+kh-pad, wo*stride+kw-pad, ci] * w[co,kh,kw,ci] )
+ *   epi(v) = v*scale[co] + shift[co]  (+ residual)  -> relu?  -> * (mask>0 ? mask_scale : 0)?  -> * mul?
+ * residual modes: 0 none, 1 same shape, 2 nearest-x2 upsample of a [N,Ho/2,Wo/2,Cout] tensor (FPN
+ * forward), 3 2x2 sum of a [N,2Ho,2Wo,Cout] tensor (FPN backward).
+ * out_stride > 1 scatters row (n,ho,wo) to y[n, ho*out_stride, wo*out_stride] of a
+ * [N, Ho*out_stride(+), Wo*out_stride(+), Cout] tensor the caller zeroed (data-grad of strided 1x1). */
+typedef struct {
+  const float* x;
+  const float* w;
+  const float* scale; /* [Cout] or NULL */
+  const float* shift; /* [Cout] or NULL */
+  const float* res;   /* residual or NULL */
+  const float* mask;  /* [N,Ho,Wo,Cout] or NULL: output multiplied by (mask>0)*mask_scale */
+  const float* mul;   /* [N,Ho,Wo,Cout] or NULL: output multiplied elementwise */
+  float* y;
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+  int relu, res_mode, out_stride, out_H, out_W; /* out_H/out_W: full dims of y when out_stride>1 */
+  float mask_scale;
+} mmt_conv_args;
+
+int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
+
+/* weight gradient: dw[co,kh,kw,ci] += rowscale[co] * sum_{n,ho,wo} dy[n,ho,wo,co] * x[n,ho*s+kh-p,wo*s+kw-p,ci]
+ * accumulated with fp32 atomics into dw (the caller's flat gradient buffer); optional
+ * dbias[co] += sum dy[..,co] (bias_scale applied).  Uses N,H,W,Cin,Cout,KH,KW,stride,pad,Ho,Wo of a. */
+int mmt_conv_wgrad(const mmt_conv_args* a /*[host]; x = input, mask/mul/res unused*/, const float* dy,
+                   const float* rowscale /*[Cout] or NULL*/, float* dw, float* dbias /*or NULL*/, void* stream);
+
+/* weight re-layout for data gradients: wd[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci] * scale[co] */
+int mmt_weight_flip_transpose(const float* w, const float* scale /*or NULL*/, float* wd, int Cout, int KH, int KW,
+                              int Cin, void* stream);
+
+/* stem max-pool 3x3 s2 p1 (backbone/resnet.py:292), NHWC */
+int mmt_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+
+/* ---------------------------------------------------------------- losses (forward value + gradient in one launch)
+ * mask-logit BCE (mask_head/loss.py:177-179): logits [P,28*28,NC] NHWC, labels int32 [P], targets [P,28*28] {0,1};
+ * loss (1 float, accumulated; zero it first) = mean BCEWithLogits(logits[p,:,label_p], target); grad [P,28*28,NC]
+ * fully written (zeros off the label channel), scaled by grad_scale. */
+int mmt_mask_bce(const float* logits, const int32_t* labels, const float* targets, int P, int HW, int NC,
+                 float grad_scale, float* loss, float* grad, void* stream);
+
+/* MGD feature-hint loss (detector/generalized_rcnn.py:243-282), one pyramid LEVEL, all teacher pyramids:
+ *   term_i = sum((s - t_i')^2 * m) / (sum(m)*C + 1e-7),  t_i' = horizontally flipped t_i if flip[i]
+ * s, t_i NHWC [N,H,W,C]; m [N,H,W] {0,1}.
+ * forward : acc[i] += sum((s-t_i')^2 m)  (i < nt),  acc[nt] += sum(m)      (acc zeroed by the caller)
+ * backward: grad_s = 2 m * sum_i coef[i] (s - t_i')   (coef: DEVICE array [nt], = upstream/(n_terms*den_i)) */
+typedef struct {
+  const float* t[8];
+  int flip[8];
+  int nt;
+} mmt_mgd_teachers;
+int mmt_mgd_level_forward(const float* s, const mmt_mgd_teachers* T /*[host]*/, const float* m, int N, int H, int W,
+                          int C, float* acc, void* stream);
+int mmt_mgd_level_backward(const float* s, const mmt_mgd_teachers* T /*[host]*/, const float* m, int N, int H, int W,
+                           int C, const float* coef, float* grad_s, void* stream);
+/* binary mask pyramid level: m[n,h,w] = adaptive_avg_pool2d(seg[n], (H,W)) > 0.5, seg int32 [N,IH,IW] */
+int mmt_mask_pool(const int32_t* seg, int N, int IH, int IW, int H, int W, float* m, void* stream);
+
+/* PSM loss rows (box_head/loss.py:185-237,267-287).  For every ROI r:
+ *   tbar = mean_k teacher[k,r,:];  t = softmax(tbar);  kind 0 ('ce'): t = sharpen(t, temp) if sharpen
+ *   rowloss[r] = roww[r] * sum_c( -t_c * log_softmax(student[r])_c )          (kind 0)
+ *              = roww[r] * sum_c( t_c * (log t_c - log_softmax(student[r])_c) ) (kind 1, 'kl')
+ *   rowgrad[r,c] = roww[r] * (softmax(student[r])_c - t_c)
+ * roww[r] in {0, 1, CLS_BALANCE_WEIGHT}: 0 = not selected, 1 = positive, w = kept hard negative.  The caller
+ * normalises by 1/(S*3) ('ce': .mean(0).sum()/3) or 1/(S*NC) ('kl': element mean), S = #selected. */
+int mmt_psm_rows(const float* teacher, int Kaug, const float* student, int R, int NC, const float* roww,
+                 float temp, int sharpen, int kind, float* rowloss, float* rowgrad, void* stream);
+/* per-ROI perturbation sensitivity v[r] = sum_c std_k(q[k,r,c]) (unbiased, :164-173,191-194); q = softmax of the
+ * teacher logits when use_softmax (MT.CLS_LOSS_TYPE == 'bce'), the raw logits otherwise */
+int mmt_psm_variance(const float* teacher, int Kaug, int R, int NC, int use_softmax, float* v, void* stream);
+
+/* ---------------------------------------------------------------- optimiser / EMA on flat parameter storage
+ * EMA teacher update (engine/MTtrainer.py:277-281): t.mul_(alpha).add_(s, alpha=1-alpha); alpha is the Python
+ * double, the kernel uses (float)alpha and (float)(1-alpha) like the reference's scalar casts */
+int mmt_ema_update(float* teacher, const float* student, int64_t n, double alpha, void* stream);
+/* SGD with momentum, torch.optim.SGD semantics (solver/build.py:5-23): g += wd*p; buf = first ? g : mom*buf + g;
+ * p -= lr*buf */
+int mmt_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float wd, float momentum,
+                     int first, void* stream);
+
+/* teacher pseudo-mask (mask_head/inference.py:29-65,169-246 + generalized_rcnn.py:129-132): for every detection
+ * d of image img[d]: prob = sigmoid(logits[d,:,:,label[d]]) (logits NHWC [D,M,M,NC]), zero-pad by 1, expand the
+ * box by (M+2)/M, bilinear-resize (align_corners=False) to the integer box, threshold, and add 1 to
+ * seg[img[d]] (int32 [N,IH,IW], zeroed by the caller) at every pixel above thresh. */
+int mmt_paste_masks(const float* logits, const int32_t* labels, const float* boxes /*[D,4]*/, const int32_t* img,
+                    int D, int M, int NC, int IH, int IW, float thresh, int32_t* seg, void* stream);
+
+/* polygon -> MxM mask targets (mask_head/loss.py:37-75, structures/segmentation_mask.py:96-133,
+ * pycoco/maskApi.c:166-206 rleFrPoly + :53-74 union) for P positive ROIs.
+ *   poly_xy   float32 concatenated vertices (x,y interleaved) of all polygons
+ *   poly_off  int32 [NP+1] vertex offsets of each polygon
+ *   roi_poly  int32 [P+1]: polygons roi_poly[p]..roi_poly[p+1]-1 belong to ROI p (its matched instance)
+ *   boxes     [P,4] proposals;  out [P,M,M] float {0,1};  overflow int32[1] set if a ROI exceeded the
+ *   crossing-list capacity (never for 28x28 targets of sane polygons) */
+int mmt_polygon_targets(const float* poly_xy, const int32_t* poly_off, const int32_t* roi_poly, const float* boxes,
+                        int P, int M, float* out, int32_t* overflow, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,256 @@
+// Fused loss kernels of the mean-teacher hot path (all HBM-bound; value and gradient come from one
+// or two streaming passes instead of the ~100 small ATen launches the reference issues).
+//
+//   mask_bce     <- mask_head/loss.py:177-179   F.binary_cross_entropy_with_logits(logits[pos,label], tgt)
+//   mgd_level_*  <- detector/generalized_rcnn.py:243-282  fg_hint_loss (MGD), one level x all teachers
+//   mask_pool    <- generalized_rcnn.py:259-264  adaptive_avg_pool2d(mask) binarised at 0.5
+//   psm_rows     <- box_head/loss.py:185-237,267-287,311-315  evaluatePSM / cls_loss / sharpen
+//   psm_variance <- box_head/loss.py:164-173,191-194  std over the K teacher views of softmax probs
+#include "common.h"
+
+// ----------------------------------------------------------------------------- mask BCE
+__global__ __launch_bounds__(256) void mask_bce_kernel(const float* __restrict__ logits,
+                                                       const int* __restrict__ labels,
+                                                       const float* __restrict__ tgt, long total, int HW, int NC,
+                                                       float inv_n, float gscale, float* __restrict__ loss,
+                                                       float* __restrict__ grad) {
+  float part = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int p = (int)(i / HW);
+    const int lab = labels[p];
+    const float x = logits[i * NC + lab];
+    const float t = tgt[i];
+    // (1-t)*x + max(-x,0) + log(1 + exp(-|x|))
+    part += (1.f - t) * x + fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));
+    const float sg = 1.f / (1.f + expf(-x));
+    for (int c = 0; c < NC; c++) grad[i * NC + c] = (c == lab) ? (sg - t) * inv_n * gscale : 0.f;
+  }
+  part = wave_sum(part);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+
+extern "C" int mmt_mask_bce(const float* logits, const int32_t* labels, const float* targets, int P, int HW,
+                            int NC, float grad_scale, float* loss, float* grad, void* stream) {
+  const long total = (long)P * HW;
+  if (total == 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mask_bce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, labels, targets,
+                     total, HW, NC, 1.f / (float)total, grad_scale, loss, grad);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ----------------------------------------------------------------------------- MGD
+struct MgdT {
+  const float* t[8];
+  int flip[8];
+  int nt;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void mgd_kernel(const float* __restrict__ s, MgdT T, const float* __restrict__ m,
+                                                  long npix, int W, int C4, float* __restrict__ acc,
+                                                  const float* __restrict__ coef, float* __restrict__ grad) {
+  // one thread per (pixel, float4 of channels)
+  float num[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) num[i] = 0.f;
+  float msum = 0.f;
+  float cf[8];
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) cf[i] = i < T.nt ? coef[i] : 0.f;
+  }
+  const long total = npix * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long pix = i / C4;
+    const int c4 = (int)(i - pix * C4);
+    const float mk = m[pix];
+    const int w = (int)(pix % W);
+    const long fpix = pix - w + (W - 1 - w);
+    const f32x4 sv = ((const f32x4*)s)[i];
+    if (!BWD && c4 == 0) msum += mk;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (k >= T.nt) break;
+      const f32x4 tv = ((const f32x4*)T.t[k])[(T.flip[k] ? fpix : pix) * C4 + c4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float d = sv[e] - tv[e];
+        if (BWD) g[e] += cf[k] * d; else num[k] += d * d * mk;
+      }
+    }
+    if (BWD) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) g[e] *= 2.f * mk;
+      ((f32x4*)grad)[i] = g;
+    }
+  }
+  if (!BWD) {
+    __shared__ float red[4][9];
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float v = wave_sum(num[k]);
+      if ((threadIdx.x & 63) == 0) red[wv][k] = v;
+    }
+    const float ms = wave_sum(msum);
+    if ((threadIdx.x & 63) == 0) red[wv][8] = ms;
+    __syncthreads();
+    if (threadIdx.x < 9) {
+      const int k = threadIdx.x;
+      const float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+      if (k == 8) atomicAdd(acc + T.nt, v);
+      else if (k < T.nt) atomicAdd(acc + k, v);
+    }
+  }
+}
+
+static int mgd_launch(bool bwd, const float* s, const mmt_mgd_teachers* T, const float* m, int N, int H, int W,
+                      int C, float* acc, const float* coef, float* grad, void* stream) {
+  if (!T || T->nt < 1 || T->nt > 8 || (C & 3)) return MMT_EINVAL;
+  MgdT q;
+  for (int i = 0; i < 8; i++) { q.t[i] = T->t[i < T->nt ? i : 0]; q.flip[i] = T->flip[i < T->nt ? i : 0]; }
+  q.nt = T->nt;
+  const long npix = (long)N * H * W;
+  const long total = npix * (C / 4);
+  if (total == 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (bwd)
+    hipLaunchKernelGGL(mgd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, q, m, npix, W, C / 4,
+                       acc, coef, grad);
+  else
+    hipLaunchKernelGGL(mgd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, q, m, npix, W, C / 4,
+                       acc, coef, grad);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_mgd_level_forward(const float* s, const mmt_mgd_teachers* T, const float* m, int N, int H, int W,
+                                     int C, float* acc, void* stream) {
+  return mgd_launch(false, s, T, m, N, H, W, C, acc, nullptr, nullptr, stream);
+}
+extern "C" int mmt_mgd_level_backward(const float* s, const mmt_mgd_teachers* T, const float* m, int N, int H,
+                                      int W, int C, const float* coef, float* grad_s, void* stream) {
+  return mgd_launch(true, s, T, m, N, H, W, C, nullptr, coef, grad_s, stream);
+}
+
+__global__ __launch_bounds__(256) void mask_pool_kernel(const int* __restrict__ seg, int N, int IH, int IW, int H,
+                                                        int W, float* __restrict__ m) {
+  const long total = (long)N * H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    const int h = (int)((i / W) % H);
+    const int n = (int)(i / ((long)W * H));
+    // adaptive pooling window: [floor(h*IH/H), ceil((h+1)*IH/H))
+    const int h0 = (int)(((long)h * IH) / H), h1 = (int)((((long)h + 1) * IH + H - 1) / H);
+    const int w0 = (int)(((long)w * IW) / W), w1 = (int)((((long)w + 1) * IW + W - 1) / W);
+    float sum = 0.f;
+    for (int y = h0; y < h1; y++)
+      for (int x = w0; x < w1; x++) sum += (float)seg[((long)n * IH + y) * IW + x];
+    const float avg = sum / (float)((h1 - h0) * (w1 - w0));
+    m[i] = avg > 0.5f ? 1.f : 0.f;
+  }
+}
+
+extern "C" int mmt_mask_pool(const int32_t* seg, int N, int IH, int IW, int H, int W, float* m, void* stream) {
+  const long total = (long)N * H * W;
+  if (total == 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(mask_pool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, seg, N, IH, IW, H, W, m);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ----------------------------------------------------------------------------- PSM
+#define PSM_MAXC 16
+
+__global__ __launch_bounds__(256) void psm_rows_kernel(const float* __restrict__ teacher, int K,
+                                                       const float* __restrict__ student, int R, int NC,
+                                                       const float* __restrict__ roww, float temp, int do_sharpen,
+                                                       int kind, float* __restrict__ rowloss,
+                                                       float* __restrict__ rowgrad) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const float w = roww[r];
+  float t[PSM_MAXC], sl[PSM_MAXC];
+  float tmax = -INFINITY, smax = -INFINITY;
+  for (int c = 0; c < NC; c++) {
+    float a = 0.f;
+    for (int k = 0; k < K; k++) a += teacher[((long)k * R + r) * NC + c];
+    t[c] = a / (float)K;
+    tmax = fmaxf(tmax, t[c]);
+    sl[c] = student[(long)r * NC + c];
+    smax = fmaxf(smax, sl[c]);
+  }
+  float tsum = 0.f, ssum = 0.f;
+  for (int c = 0; c < NC; c++) { t[c] = expf(t[c] - tmax); tsum += t[c]; ssum += expf(sl[c] - smax); }
+  const float lse = smax + logf(ssum);
+  for (int c = 0; c < NC; c++) t[c] /= tsum;
+  if (kind == 0 && do_sharpen) {
+    float ps = 0.f;
+    for (int c = 0; c < NC; c++) { t[c] = powf(t[c], 1.f / temp); ps += t[c]; }
+    for (int c = 0; c < NC; c++) t[c] /= ps;
+  }
+  float l = 0.f;
+  for (int c = 0; c < NC; c++) {
+    const float logp = sl[c] - lse;
+    if (kind == 0) l += -t[c] * logp;
+    else l += t[c] > 0.f ? t[c] * (logf(t[c]) - logp) : 0.f;
+    rowgrad[(long)r * NC + c] = w * (expf(logp) - t[c]);
+  }
+  rowloss[r] = w * l;
+}
+
+extern "C" int mmt_psm_rows(const float* teacher, int Kaug, const float* student, int R, int NC, const float* roww,
+                            float temp, int sharpen, int kind, float* rowloss, float* rowgrad, void* stream) {
+  if (NC > PSM_MAXC || Kaug < 1) return MMT_EINVAL;
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(psm_rows_kernel, dim3(mmt_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, teacher, Kaug,
+                     student, R, NC, roww, temp, sharpen, kind, rowloss, rowgrad);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void psm_var_kernel(const float* __restrict__ teacher, int K, int R, int NC,
+                                                      int use_softmax, float* __restrict__ v) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  float mean[PSM_MAXC], m2[PSM_MAXC];
+  for (int c = 0; c < NC; c++) { mean[c] = 0.f; m2[c] = 0.f; }
+  // two-pass: probabilities are recomputed (K*NC tiny)
+  for (int pass = 0; pass < 2; pass++) {
+    for (int k = 0; k < K; k++) {
+      float p[PSM_MAXC];
+      float mx = -INFINITY, sm = 0.f;
+      for (int c = 0; c < NC; c++) { p[c] = teacher[((long)k * R + r) * NC + c]; mx = fmaxf(mx, p[c]); }
+      if (use_softmax) for (int c = 0; c < NC; c++) { p[c] = expf(p[c] - mx); sm += p[c]; }
+      else sm = 1.f;
+      for (int c = 0; c < NC; c++) {
+        const float q = p[c] / sm;
+        if (pass == 0) mean[c] += q; else { const float d = q - mean[c]; m2[c] += d * d; }
+      }
+    }
+    if (pass == 0) for (int c = 0; c < NC; c++) mean[c] /= (float)K;
+  }
+  float out = 0.f;
+  for (int c = 0; c < NC; c++) out += sqrtf(m2[c] / (float)(K - 1));
+  v[r] = out;
+}
+
+extern "C" int mmt_psm_variance(const float* teacher, int Kaug, int R, int NC, int use_softmax, float* v,
+                                void* stream) {
+  if (NC > PSM_MAXC || Kaug < 2) return MMT_EINVAL;
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(psm_var_kernel, dim3(mmt_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, teacher, Kaug, R, NC,
+                     use_softmax, v);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}

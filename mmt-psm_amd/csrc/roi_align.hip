@@ -1,0 +1,161 @@
+// ROIAlign forward/backward for gfx950, NHWC, all FPN levels in one launch.
+//
+// Replaces cuda/ROIAlign_cuda.cu:64-122 (forward, 1 thread per output element over NCHW) and
+// :177-254 (backward) of the reference, plus the per-level gather/scatter loop of
+// modeling/poolers.py:116-119.  Mapping here: one 64-lane wave owns one (roi, bin); lanes run over
+// channels (float4 per lane => 256 channels per pass), so every tap is a coalesced 1 KiB read and
+// every gradient scatter is a coalesced run of fp32 atomics.  The bilinear geometry is wave-uniform
+// (derived from blockIdx / readfirstlane) and therefore lives on the scalar unit.
+//
+// Numerics: same expression order as cpu/ROIAlign_cpu.cpp:113-219 (w1*v1 + w2*v2 + w3*v3 + w4*v4
+// accumulated sample by sample, then / count); this file is built with -ffp-contract=off so no FMA
+// is formed and results are bit-identical to the reference CPU path.
+#include "common.h"
+
+struct Pyr {
+  const float* feat[4];
+  float* grad[4];
+  int H[4], W[4];
+  float scale[4];
+  int N, C;
+};
+
+struct Bilin {
+  int yl, xl, yh, xh;
+  float w1, w2, w3, w4;
+  bool empty;
+};
+
+__device__ __forceinline__ Bilin bilin(int H, int W, float y, float x) {
+  Bilin b;
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
+    b.empty = true; b.yl = b.xl = b.yh = b.xh = 0; b.w1 = b.w2 = b.w3 = b.w4 = 0.f; return b;
+  }
+  b.empty = false;
+  if (y <= 0) y = 0;
+  if (x <= 0) x = 0;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+  if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+  float ly = y - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
+  b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
+  b.yl = y_low; b.xl = x_low; b.yh = y_high; b.xh = x_high;
+  return b;
+}
+
+template <bool BWD, int VEC>
+__global__ __launch_bounds__(256) void roi_align_kernel(Pyr p, const float* __restrict__ rois,
+                                                        const int* __restrict__ levels, int K, int PH, int PW,
+                                                        int sr, float* __restrict__ out_or_gout) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long bin = (long)blockIdx.x * 4 + wave;
+  const long nbins = (long)K * PH * PW;
+  if (bin >= nbins) return;
+  const int pw = (int)(bin % PW);
+  const int ph = (int)((bin / PW) % PH);
+  const int k = (int)(bin / ((long)PW * PH));
+  const int lv = levels[k];
+  const float* r = rois + (long)k * 5;
+  const int b = (int)r[0];
+  const float scale = p.scale[lv];
+  const int H = p.H[lv], W = p.W[lv], C = p.C;
+  const float rsw = r[1] * scale, rsh = r[2] * scale, rew = r[3] * scale, reh = r[4] * scale;
+  const float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+  const float bh = rh / (float)PH, bw = rw / (float)PW;
+  const int gh = sr > 0 ? sr : (int)ceilf(rh / PH);
+  const int gw = sr > 0 ? sr : (int)ceilf(rw / PW);
+  const float count = (float)(gh * gw);
+  const float* feat = p.feat[lv] + (long)b * H * W * C;
+  float* gfeat = BWD ? p.grad[lv] + (long)b * H * W * C : nullptr;
+  float* o = out_or_gout + bin * C;
+
+  for (int c0 = lane * VEC; c0 < C; c0 += 64 * VEC) {
+    float acc[VEC], g[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { acc[j] = 0.f; g[j] = 0.f; }
+    if (BWD) {
+      if (VEC == 4) { const f32x4 t = *(const f32x4*)(o + c0); g[0] = t[0]; g[1 % VEC] = t[1]; g[2 % VEC] = t[2]; g[3 % VEC] = t[3]; }
+      else g[0] = o[c0];
+    }
+    for (int iy = 0; iy < gh; iy++) {
+      const float yy = rsh + ph * bh + (float)(iy + .5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ix++) {
+        const float xx = rsw + pw * bw + (float)(ix + .5f) * bw / (float)gw;
+        const Bilin q = bilin(H, W, yy, xx);
+        const long o1 = ((long)q.yl * W + q.xl) * C + c0, o2 = ((long)q.yl * W + q.xh) * C + c0;
+        const long o3 = ((long)q.yh * W + q.xl) * C + c0, o4 = ((long)q.yh * W + q.xh) * C + c0;
+        if (!BWD) {
+          float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+          if (VEC == 4) {
+            const f32x4 a1 = *(const f32x4*)(feat + o1), a2 = *(const f32x4*)(feat + o2);
+            const f32x4 a3 = *(const f32x4*)(feat + o3), a4 = *(const f32x4*)(feat + o4);
+#pragma unroll
+            for (int j = 0; j < VEC; j++) { v1[j] = a1[j]; v2[j] = a2[j]; v3[j] = a3[j]; v4[j] = a4[j]; }
+          } else { v1[0] = feat[o1]; v2[0] = feat[o2]; v3[0] = feat[o3]; v4[0] = feat[o4]; }
+#pragma unroll
+          for (int j = 0; j < VEC; j++) acc[j] += q.w1 * v1[j] + q.w2 * v2[j] + q.w3 * v3[j] + q.w4 * v4[j];
+        } else if (!q.empty) {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            atomicAdd(gfeat + o1 + j, g[j] * q.w1 / count);
+            atomicAdd(gfeat + o2 + j, g[j] * q.w2 / count);
+            atomicAdd(gfeat + o3 + j, g[j] * q.w3 / count);
+            atomicAdd(gfeat + o4 + j, g[j] * q.w4 / count);
+          }
+        }
+      }
+    }
+    if (!BWD) {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) acc[j] = acc[j] / count;
+      if (VEC == 4) { f32x4 t; t[0] = acc[0]; t[1] = acc[1 % VEC]; t[2] = acc[2 % VEC]; t[3] = acc[3 % VEC]; *(f32x4*)(o + c0) = t; }
+      else o[c0] = acc[0];
+    }
+  }
+}
+
+static int fill(Pyr& q, const mmt_pyramid* p) {
+  if (!p || p->num_levels < 1 || p->num_levels > 4 || p->C < 1) return MMT_EINVAL;
+  for (int l = 0; l < 4; l++) {
+    int s = l < p->num_levels ? l : 0;
+    q.feat[l] = p->feat[s]; q.grad[l] = p->grad_feat[s];
+    q.H[l] = p->H[s]; q.W[l] = p->W[s]; q.scale[l] = p->scale[s];
+  }
+  q.N = p->N; q.C = p->C;
+  return 0;
+}
+
+extern "C" int mmt_roi_align_forward(const mmt_pyramid* pyr, const float* rois, const int32_t* levels, int K,
+                                     int PH, int PW, int sampling_ratio, float* out, void* stream) {
+  Pyr q;
+  int e = fill(q, pyr);
+  if (e) return e;
+  long nbins = (long)K * PH * PW;
+  if (nbins == 0) return 0;
+  if (q.C & 3)
+    hipLaunchKernelGGL((roi_align_kernel<false, 1>), dim3(mmt_cdiv(nbins, 4)), dim3(256), 0, (hipStream_t)stream, q,
+                       rois, levels, K, PH, PW, sampling_ratio, out);
+  else
+    hipLaunchKernelGGL((roi_align_kernel<false, 4>), dim3(mmt_cdiv(nbins, 4)), dim3(256), 0, (hipStream_t)stream, q,
+                       rois, levels, K, PH, PW, sampling_ratio, out);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_roi_align_backward(const mmt_pyramid* pyr, const float* rois, const int32_t* levels, int K,
+                                      int PH, int PW, int sampling_ratio, const float* grad_out, void* stream) {
+  Pyr q;
+  int e = fill(q, pyr);
+  if (e) return e;
+  long nbins = (long)K * PH * PW;
+  if (nbins == 0) return 0;
+  if (q.C & 3)
+    hipLaunchKernelGGL((roi_align_kernel<true, 1>), dim3(mmt_cdiv(nbins, 4)), dim3(256), 0, (hipStream_t)stream, q,
+                       rois, levels, K, PH, PW, sampling_ratio, const_cast<float*>(grad_out));
+  else
+    hipLaunchKernelGGL((roi_align_kernel<true, 4>), dim3(mmt_cdiv(nbins, 4)), dim3(256), 0, (hipStream_t)stream, q,
+                       rois, levels, K, PH, PW, sampling_ratio, const_cast<float*>(grad_out));
+  MMT_LAUNCH_CHECK();
+  return 0;
+}

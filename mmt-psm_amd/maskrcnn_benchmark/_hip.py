@@ -1,0 +1,371 @@
+"""ctypes binding of libmmtpsm.so (include/mmtpsm.h) -- the ONLY compute backend of this package.
+
+There is no CPU or eager-PyTorch fallback: if the shared library is missing, or a tensor that reaches
+an op is not a CUDA/HIP tensor, the call raises.  PyTorch is used for device memory, streams and
+autograd bookkeeping only; tensors cross the boundary as raw device pointers.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmmtpsm.so")
+
+c_void_p, c_int, c_float, c_double, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_int64
+
+
+class Pyramid(ctypes.Structure):
+    _fields_ = [("feat", c_void_p * 4), ("grad_feat", c_void_p * 4), ("H", c_int * 4), ("W", c_int * 4),
+                ("scale", c_float * 4), ("num_levels", c_int), ("N", c_int), ("C", c_int)]
+
+
+class ConvArgs(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p),
+                ("mask", c_void_p), ("mul", c_void_p), ("y", c_void_p),
+                ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int), ("KH", c_int),
+                ("KW", c_int), ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int),
+                ("relu", c_int), ("res_mode", c_int), ("out_stride", c_int), ("out_H", c_int), ("out_W", c_int),
+                ("mask_scale", c_float)]
+
+
+class MgdTeachers(ctypes.Structure):
+    _fields_ = [("t", c_void_p * 8), ("flip", c_int * 8), ("nt", c_int)]
+
+
+_SIGS = {
+    "mmt_version": [],
+    "mmt_roi_align_forward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mmt_roi_align_backward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mmt_nms_batched": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_conv_forward": [ctypes.POINTER(ConvArgs), c_void_p],
+    "mmt_conv_wgrad": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_weight_flip_transpose": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "mmt_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mmt_mask_bce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "mmt_mgd_level_forward": [c_void_p, ctypes.POINTER(MgdTeachers), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mmt_mgd_level_backward": [c_void_p, ctypes.POINTER(MgdTeachers), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mmt_mask_pool": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mmt_psm_rows": [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mmt_psm_variance": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mmt_ema_update": [c_void_p, c_void_p, c_int64, c_double, c_void_p],
+    "mmt_sgd_momentum": [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int, c_void_p],
+    "mmt_paste_masks": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
+    "mmt_polygon_targets": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libmmtpsm.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmmtpsm.so not found at %s: build it with `make -C mmt-psm_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            f = getattr(L, name)
+            f.restype = c_int
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def _check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed with code %d" % (what, code))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError("%s must be a GPU tensor: the MI355X HIP library is the only backend" % name)
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def nhwc(x):
+    """(N,C,H,W)-shaped tensor -> same tensor guaranteed dense in NHWC memory order."""
+    _dev(x)
+    if x.dim() != 4:
+        raise RuntimeError("expected a 4-D activation")
+    if x.dtype != torch.float32:
+        raise RuntimeError("fp32 activations only")
+    if not x.permute(0, 2, 3, 1).is_contiguous():
+        x = x.contiguous(memory_format=torch.channels_last)
+        if not x.permute(0, 2, 3, 1).is_contiguous():  # C==1 / H==W==1 corner cases of torch's format logic
+            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return x
+
+
+def empty_nhwc(n, c, h, w, device, zero=False):
+    f = torch.zeros if zero else torch.empty
+    return f((n, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------ ROIAlign
+def _pyramid(feats, scales, grads=None):
+    p = Pyramid()
+    p.num_levels = len(feats)
+    p.N, p.C = feats[0].shape[0], feats[0].shape[1]
+    for i, f in enumerate(feats):
+        p.feat[i] = f.data_ptr()
+        p.grad_feat[i] = grads[i].data_ptr() if grads is not None else None
+        p.H[i], p.W[i] = f.shape[2], f.shape[3]
+        p.scale[i] = float(scales[i])
+    return p
+
+
+def roi_align_forward(feats, scales, rois, levels, ph, pw, sr):
+    """feats: list of (N,C,H,W) NHWC-dense tensors; rois (K,5) fp32; levels (K,) int32 -> (K,C,ph,pw) NHWC-dense"""
+    feats = [nhwc(f) for f in feats]
+    rois = _dev(rois).float().contiguous()
+    levels = _dev(levels).to(torch.int32).contiguous()
+    K = rois.shape[0]
+    out = empty_nhwc(K, feats[0].shape[1], ph, pw, rois.device)
+    if K:
+        p = _pyramid(feats, scales)
+        _check(lib().mmt_roi_align_forward(ctypes.byref(p), _p(rois), _p(levels), K, ph, pw, sr, _p(out), _stream()),
+               "mmt_roi_align_forward")
+    return out
+
+
+def roi_align_backward(grad_out, shapes, scales, rois, levels, ph, pw, sr):
+    """-> list of zero-initialised-then-accumulated gradients, one per level (N,C,H,W) NHWC-dense"""
+    g = nhwc(grad_out)
+    rois = _dev(rois).float().contiguous()
+    levels = _dev(levels).to(torch.int32).contiguous()
+    grads = [empty_nhwc(s[0], s[1], s[2], s[3], g.device, zero=True) for s in shapes]
+    K = rois.shape[0]
+    if K:
+        p = _pyramid(grads, scales, grads)
+        _check(lib().mmt_roi_align_backward(ctypes.byref(p), _p(rois), _p(levels), K, ph, pw, sr, _p(g), _stream()),
+               "mmt_roi_align_backward")
+    return grads
+
+
+# ------------------------------------------------------------------------------------------ NMS
+def nms_batched(boxes, seg_off, max_n, thr):
+    """boxes (T,4) score-sorted within each segment; seg_off int32 (B+1) on device.
+    -> keep (B,max_n) int32 positions within the segment, cnt (B,) int32"""
+    boxes = _dev(boxes).float().contiguous()
+    seg_off = _dev(seg_off).to(torch.int32).contiguous()
+    B = seg_off.numel() - 1
+    words = (max_n + 63) // 64
+    ws = torch.empty((B * max_n * words,), dtype=torch.int64, device=boxes.device)
+    keep = torch.empty((B, max_n), dtype=torch.int32, device=boxes.device)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=boxes.device)
+    if B and max_n:
+        _check(lib().mmt_nms_batched(_p(boxes), _p(seg_off), B, max_n, float(thr), _p(ws), _p(keep), _p(cnt), _stream()),
+               "mmt_nms_batched")
+    return keep, cnt
+
+
+# ------------------------------------------------------------------------------------------ conv
+def _conv_args(x, w, stride, pad, Ho, Wo):
+    a = ConvArgs()
+    N, Cin, H, W = x.shape
+    Cout, Cin_w, KH, KW = w.shape
+    if Cin_w != Cin:
+        raise RuntimeError("conv channel mismatch: x has %d, w has %d" % (Cin, Cin_w))
+    a.x, a.w = x.data_ptr(), w.data_ptr()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
+    a.stride, a.pad, a.Ho, a.Wo = stride, pad, Ho, Wo
+    a.out_stride, a.mask_scale = 1, 1.0
+    return a
+
+
+def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
+                 mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None):
+    """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory)."""
+    x = nhwc(x)
+    w = nhwc(w)
+    N, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    a = _conv_args(x, w, stride, pad, Ho, Wo)
+    if out_stride > 1:
+        oh, ow = out_hw
+        y = empty_nhwc(N, Cout, oh, ow, x.device, zero=True)
+        a.out_stride, a.out_H, a.out_W = out_stride, oh, ow
+    else:
+        y = empty_nhwc(N, Cout, Ho, Wo, x.device)
+    a.y = y.data_ptr()
+    a.scale, a.shift = _p(scale), _p(shift)
+    a.relu = 1 if relu else 0
+    if res is not None:
+        res = nhwc(res)
+        a.res, a.res_mode = res.data_ptr(), res_mode
+    if mask is not None:
+        mask = nhwc(mask)
+        a.mask, a.mask_scale = mask.data_ptr(), float(mask_scale)
+    if mul is not None:
+        mul = nhwc(mul)
+        a.mul = mul.data_ptr()
+    _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
+    return y
+
+
+def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
+    """accumulates into dw (same memory layout as the weight) and dbias"""
+    x = nhwc(x)
+    dy = nhwc(dy)
+    Cout, Cin, KH, KW = w_shape
+    a = ConvArgs()
+    N, _, H, W = x.shape
+    a.x = x.data_ptr()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
+    a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
+    a.out_stride = 1
+    _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _stream()), "mmt_conv_wgrad")
+
+
+def weight_flip_transpose(w, scale=None):
+    """w (Cout,Cin,KH,KW) channels_last-dense -> (Cin,Cout,KH,KW) channels_last-dense, taps flipped, rows scaled"""
+    w = nhwc(w)
+    Cout, Cin, KH, KW = w.shape
+    wd = empty_nhwc(Cin, Cout, KH, KW, w.device)
+    _check(lib().mmt_weight_flip_transpose(_p(w), _p(scale), _p(wd), Cout, KH, KW, Cin, _stream()),
+           "mmt_weight_flip_transpose")
+    return wd
+
+
+def maxpool3x3s2(x):
+    x = nhwc(x)
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = empty_nhwc(N, C, Ho, Wo, x.device)
+    _check(lib().mmt_maxpool3x3s2(_p(x), _p(y), N, H, W, C, Ho, Wo, _stream()), "mmt_maxpool3x3s2")
+    return y
+
+
+# ------------------------------------------------------------------------------------------ losses
+def mask_bce(logits, labels, targets, grad_scale=1.0):
+    """logits (P,NC,M,M) NHWC-dense, labels (P,) int, targets (P,M,M) -> (loss scalar tensor, grad like logits)"""
+    logits = nhwc(logits)
+    P, NC, M, _ = logits.shape
+    labels = _dev(labels).to(torch.int32).contiguous()
+    targets = _dev(targets).float().contiguous()
+    loss = torch.zeros((), dtype=torch.float32, device=logits.device)
+    grad = empty_nhwc(P, NC, M, M, logits.device)
+    _check(lib().mmt_mask_bce(_p(logits), _p(labels), _p(targets), P, M * M, NC, float(grad_scale), _p(loss), _p(grad),
+                              _stream()), "mmt_mask_bce")
+    return loss, grad
+
+
+def _teachers(ts, flips):
+    T = MgdTeachers()
+    T.nt = len(ts)
+    for i, (t, f) in enumerate(zip(ts, flips)):
+        T.t[i] = t.data_ptr()
+        T.flip[i] = 1 if f else 0
+    return T
+
+
+def mgd_level_forward(s, ts, flips, m):
+    """-> acc (nt+1,) = [num_i..., msum]"""
+    s = nhwc(s)
+    ts = [nhwc(t) for t in ts]
+    N, C, H, W = s.shape
+    acc = torch.zeros((len(ts) + 1,), dtype=torch.float32, device=s.device)
+    T = _teachers(ts, flips)
+    _check(lib().mmt_mgd_level_forward(_p(s), ctypes.byref(T), _p(m), N, H, W, C, _p(acc), _stream()),
+           "mmt_mgd_level_forward")
+    return acc
+
+
+def mgd_level_backward(s, ts, flips, m, coef):
+    s = nhwc(s)
+    ts = [nhwc(t) for t in ts]
+    N, C, H, W = s.shape
+    g = empty_nhwc(N, C, H, W, s.device)
+    T = _teachers(ts, flips)
+    coef = coef.float().contiguous()
+    _check(lib().mmt_mgd_level_backward(_p(s), ctypes.byref(T), _p(m), N, H, W, C, _p(coef), _p(g), _stream()),
+           "mmt_mgd_level_backward")
+    return g
+
+
+def mask_pool(seg, H, W):
+    """seg (N,IH,IW) int32 -> (N,H,W) float {0,1}"""
+    seg = _dev(seg).to(torch.int32).contiguous()
+    N, IH, IW = seg.shape
+    m = torch.empty((N, H, W), dtype=torch.float32, device=seg.device)
+    _check(lib().mmt_mask_pool(_p(seg), N, IH, IW, H, W, _p(m), _stream()), "mmt_mask_pool")
+    return m
+
+
+def psm_rows(teacher, student, roww, temp, sharpen, kind):
+    teacher = _dev(teacher).float().contiguous()
+    student = _dev(student).float().contiguous()
+    roww = _dev(roww).float().contiguous()
+    K, R, NC = teacher.shape
+    rl = torch.empty((R,), dtype=torch.float32, device=teacher.device)
+    rg = torch.empty((R, NC), dtype=torch.float32, device=teacher.device)
+    _check(lib().mmt_psm_rows(_p(teacher), K, _p(student), R, NC, _p(roww), float(temp), int(sharpen), int(kind),
+                              _p(rl), _p(rg), _stream()), "mmt_psm_rows")
+    return rl, rg
+
+
+def psm_variance(teacher, use_softmax=True):
+    teacher = _dev(teacher).float().contiguous()
+    K, R, NC = teacher.shape
+    v = torch.empty((R,), dtype=torch.float32, device=teacher.device)
+    _check(lib().mmt_psm_variance(_p(teacher), K, R, NC, 1 if use_softmax else 0, _p(v), _stream()), "mmt_psm_variance")
+    return v
+
+
+# ------------------------------------------------------------------------------------------ optimiser / EMA
+def ema_update(teacher_flat, student_flat, alpha):
+    _dev(teacher_flat)
+    _dev(student_flat)
+    assert teacher_flat.numel() == student_flat.numel() and teacher_flat.is_contiguous() and student_flat.is_contiguous()
+    _check(lib().mmt_ema_update(_p(teacher_flat), _p(student_flat), teacher_flat.numel(), float(alpha), _stream()),
+           "mmt_ema_update")
+
+
+def sgd_momentum(p, g, buf, lr, wd, momentum, first):
+    _dev(p)
+    _check(lib().mmt_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), float(lr), float(wd), float(momentum),
+                                  1 if first else 0, _stream()), "mmt_sgd_momentum")
+
+
+# ------------------------------------------------------------------------------------------ masks
+def paste_masks(logits, labels, boxes, img, N, IH, IW, thresh):
+    """logits (D,NC,M,M) NHWC-dense -> seg (N,IH,IW) int32"""
+    logits = nhwc(logits)
+    D, NC, M, _ = logits.shape
+    labels = _dev(labels).to(torch.int32).contiguous()
+    boxes = _dev(boxes).float().contiguous()
+    img = _dev(img).to(torch.int32).contiguous()
+    seg = torch.zeros((N, IH, IW), dtype=torch.int32, device=logits.device)
+    _check(lib().mmt_paste_masks(_p(logits), _p(labels), _p(boxes), _p(img), D, M, NC, IH, IW, float(thresh), _p(seg),
+                                 _stream()), "mmt_paste_masks")
+    return seg
+
+
+def polygon_targets(poly_xy, poly_off, roi_poly, boxes, M):
+    poly_xy = _dev(poly_xy).float().contiguous()
+    poly_off = _dev(poly_off).to(torch.int32).contiguous()
+    roi_poly = _dev(roi_poly).to(torch.int32).contiguous()
+    boxes = _dev(boxes).float().contiguous()
+    P = boxes.shape[0]
+    out = torch.empty((P, M, M), dtype=torch.float32, device=boxes.device)
+    ovf = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    _check(lib().mmt_polygon_targets(_p(poly_xy), _p(poly_off), _p(roi_poly), _p(boxes), P, M, _p(out), _p(ovf), _stream()),
+           "mmt_polygon_targets")
+    return out, ovf

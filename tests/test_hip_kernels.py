@@ -1,0 +1,321 @@
+"""Kernel-level parity: every libmmtpsm.so entry point against the oracle / golden vectors.
+Runs on the MI355X box only (-m gpu); calls go through the C ABI (ctypes)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import gold, T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from maskrcnn_benchmark import _hip
+    _hip.lib()
+    assert torch.cuda.is_available()
+    return _hip
+
+
+def cl(x):  # NCHW cpu tensor -> NHWC-dense cuda tensor
+    return x.cuda().contiguous(memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------------------------------ ROIAlign
+def test_roi_align_forward_golden(hip):
+    g = gold("roi_align")
+    for i in range(int(g["n"])):
+        sc, ph, pw, sr = g["p%d" % i]
+        x, r = T(g["x%d" % i]), T(g["r%d" % i])
+        lv = torch.zeros(r.shape[0], dtype=torch.int32)
+        y = hip.roi_align_forward([cl(x)], [float(sc)], r.cuda(), lv.cuda(), int(ph), int(pw), int(sr))
+        ref = g["y%d" % i]
+        assert tuple(y.shape) == ref.shape
+        np.testing.assert_array_equal(y.cpu().numpy(), ref)  # bit-exact: same op order, no FMA contraction
+
+
+def test_roi_align_fpn_fused_and_backward(hip):
+    from oracle import native
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(2, 32, 64 >> l, 80 >> l, generator=g) for l in range(4)]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    K = 300
+    xy = torch.rand(K, 2, generator=g) * torch.tensor([300., 240.]) - 10
+    wh = torch.rand(K, 2, generator=g) * 150 + 1
+    rois = torch.cat([(torch.arange(K) % 2).float()[:, None], xy, xy + wh], 1)
+    lv = (torch.rand(K, generator=g) * 4).long().clamp(max=3)
+    for res in (7, 14):
+        y = hip.roi_align_forward([cl(f) for f in feats], scales, rois.cuda(), lv.cuda().int(), res, res, 2)
+        ref = torch.zeros(K, 32, res, res)
+        for l in range(4):
+            idx = (lv == l).nonzero().squeeze(1)
+            ref[idx] = native.roi_align_forward(feats[l], rois[idx], scales[l], res, res, 2)
+        np.testing.assert_array_equal(y.cpu().numpy(), ref.numpy())
+        go = torch.randn(K, 32, res, res, generator=g)
+        grads = hip.roi_align_backward(cl(go), [f.shape for f in feats], scales, rois.cuda(), lv.cuda().int(), res, res, 2)
+        for l in range(4):
+            idx = (lv == l).nonzero().squeeze(1)
+            gr = native.roi_align_backward(go[idx], rois[idx], scales[l], res, res, *feats[l].shape, 2)
+            np.testing.assert_allclose(grads[l].cpu().numpy(), gr.numpy(), rtol=1e-4, atol=1e-5)  # atomic order
+
+
+# ------------------------------------------------------------------------------------------ NMS
+def _nms_via_hip(hip, boxes, scores, thr):
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    b = boxes[order].cuda()
+    n = b.shape[0]
+    seg = torch.tensor([0, n], dtype=torch.int32).cuda()
+    keep, cnt = hip.nms_batched(b, seg, max(n, 1), thr)
+    k = keep[0, :int(cnt[0])].cpu().long()
+    return torch.sort(order[k])[0]
+
+
+def test_nms_golden(hip):
+    g = gold("nms")
+    for i in range(6):
+        keep = _nms_via_hip(hip, T(g["b%d" % i]), T(g["s%d" % i]), float(g["t%d" % i]))
+        assert keep.tolist() == g["k%d" % i].tolist(), i
+
+
+def test_nms_batched_segments(hip):
+    from oracle import native
+    g = torch.Generator().manual_seed(9)
+    segs, boxes = [0], []
+    refs = []
+    for n in (2000, 1, 777, 64, 65, 1999, 128, 0, 300, 2000):
+        xy = torch.rand(n, 2, generator=g) * 600
+        wh = torch.rand(n, 2, generator=g) * 200 + 1
+        b = torch.cat([xy, xy + wh], 1)
+        s = torch.sort(torch.rand(n, generator=g), descending=True)[0]
+        boxes.append(b)
+        segs.append(segs[-1] + n)
+        refs.append(native.nms(b, s, 0.7))
+    keep, cnt = hip.nms_batched(torch.cat(boxes).cuda(), torch.tensor(segs, dtype=torch.int32).cuda(), 2000, 0.7)
+    for i, r in enumerate(refs):
+        assert keep[i, :int(cnt[i])].cpu().tolist() == r.tolist(), i
+
+
+# ------------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad
+    (2, 64, 40, 48, 256, 1, 1, 0),
+    (2, 256, 40, 48, 128, 1, 2, 0),
+    (2, 128, 20, 24, 128, 3, 1, 1),
+    (1, 256, 64, 64, 256, 3, 1, 1),
+    (2, 4, 64, 80, 64, 7, 2, 3),
+    (2, 256, 16, 20, 15, 1, 1, 0),
+    (3, 96, 9, 11, 40, 3, 1, 1),
+    (1, 12544, 1, 1, 1024, 1, 1, 0),
+    (2, 16, 130, 130, 200, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_epilogues(hip, case):
+    N, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    if Cin == 12544:
+        N = 300
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), None, s, p)
+    res = torch.randn(ref.shape, generator=g)
+    y = hip.conv_forward(cl(x), cl(w), stride=s, pad=p)
+    scl = ref.abs().max().item()
+    assert (y.cpu().double() - ref).abs().max().item() < 2e-5 * max(scl, 1.0)
+    y2 = hip.conv_forward(cl(x), cl(w), scale.cuda(), shift.cuda(), s, p, relu=True, res=cl(res), res_mode=1)
+    ref2 = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    assert (y2.cpu().double() - ref2).abs().max().item() < 2e-5 * max(scl, 1.0)
+
+
+def test_conv_fpn_residual_modes_and_scatter(hip):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 64, 16, 24, generator=g)
+    w = torch.randn(32, 64, 1, 1, generator=g) / 8
+    b = torch.randn(32, generator=g)
+    top = torch.randn(2, 32, 8, 12, generator=g)
+    y = hip.conv_forward(cl(x), cl(w), None, b.cuda(), res=cl(top), res_mode=2)
+    ref = F.conv2d(x, w, b) + F.interpolate(top, scale_factor=2, mode="nearest")
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    fine = torch.randn(2, 32, 32, 48, generator=g)
+    y = hip.conv_forward(cl(x), cl(w), res=cl(fine), res_mode=3)
+    ref = F.conv2d(x, w) + F.avg_pool2d(fine, 2) * 4
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    # strided scatter + relu-mask (data gradient of a stride-2 1x1 conv into a 33x49 input)
+    msk = torch.randn(2, 32, 33, 49, generator=g)
+    xs = x[:, :, :, :24]
+    xs = F.pad(xs, (0, 1, 0, 1))[:, :, :17, :25]
+    y = hip.conv_forward(cl(xs), cl(w), out_stride=2, out_hw=(33, 49), mask=cl(msk), mask_scale=2.0)
+    ref = torch.zeros(2, 32, 33, 49)
+    ref[:, :, ::2, ::2] = F.conv2d(xs, w)
+    ref = ref * (msk > 0).float() * 2.0
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    mul = torch.rand(2, 32, 16, 24, generator=g)
+    y = hip.conv_forward(cl(x), cl(w), relu=True, mul=cl(mul))
+    np.testing.assert_allclose(y.cpu().numpy(), (F.relu(F.conv2d(x, w)) * mul).numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", [(2, 128, 20, 24, 128, 3, 1, 1), (2, 256, 24, 24, 128, 1, 2, 0),
+                                  (2, 256, 16, 20, 15, 1, 1, 0), (3, 32, 9, 11, 40, 3, 1, 1),
+                                  (64, 1024, 1, 1, 12, 1, 1, 0)])
+def test_conv_wgrad_and_dgrad(hip, case):
+    N, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).requires_grad_()
+    bnscale = torch.rand(Cout, generator=g) + 0.5
+    y = F.conv2d(x, w, None, s, p) * bnscale.view(1, -1, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw = torch.zeros(Cout, Cin, k, k).cuda().contiguous(memory_format=torch.channels_last)
+    dw = hip.nhwc(dw)
+    db = torch.zeros(Cout).cuda()
+    hip.conv_wgrad(cl(x.detach()), cl(dy), (Cout, Cin, k, k), s, p, dw, rowscale=bnscale.cuda(), dbias=db)
+    tol = 3e-5 * max(1.0, w.grad.abs().max().item()) * (N * H * W) ** 0.5
+    assert (dw.cpu() - w.grad).abs().max().item() < tol
+    np.testing.assert_allclose(db.cpu().numpy(), dy.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    if s == 1:
+        wd = hip.weight_flip_transpose(cl(w.detach()), bnscale.cuda())
+        dx = hip.conv_forward(cl(dy), wd, stride=1, pad=k - 1 - p)
+        assert (dx.cpu() - x.grad).abs().max().item() < 3e-5 * max(1.0, x.grad.abs().max().item()) * 10
+    else:
+        wd = hip.weight_flip_transpose(cl(w.detach()), bnscale.cuda())
+        dx = hip.conv_forward(cl(dy), wd, out_stride=s, out_hw=(H, W))
+        assert (dx.cpu() - x.grad).abs().max().item() < 3e-4
+
+
+def test_maxpool(hip):
+    x = torch.randn(2, 64, 33, 47)
+    y = hip.maxpool3x3s2(cl(x))
+    np.testing.assert_array_equal(y.cpu().numpy(), F.max_pool2d(x, 3, 2, 1).numpy())
+
+
+# ------------------------------------------------------------------------------------------ losses
+def test_mask_bce(hip):
+    g = torch.Generator().manual_seed(2)
+    P = 37
+    logits = (torch.randn(P, 3, 28, 28, generator=g) * 3).requires_grad_()
+    labels = (torch.rand(P, generator=g) * 2).long() + 1
+    tgt = (torch.rand(P, 28, 28, generator=g) > 0.5).float()
+    ref = F.binary_cross_entropy_with_logits(logits[torch.arange(P), labels], tgt)
+    ref.backward()
+    loss, grad = hip.mask_bce(cl(logits.detach()), labels.cuda(), tgt.cuda(), 1.0)
+    assert loss.item() == pytest.approx(ref.item(), rel=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), logits.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_mgd_golden_and_grad(hip):
+    from oracle import model as om
+    g = gold("mt_losses")
+    for name, nl in (("mgd0", 2), ("mgd1", 5)):
+        tp = [[T(g["%s_t%d_%d" % (name, i, l)]) for l in range(nl)] for i in range(4)]
+        sp = [T(g["%s_s_%d" % (name, l)]).clone().requires_grad_() for l in range(nl)]
+        masks = T(g[name + "_m"])
+        ref = om.fg_hint_loss(tp, [sp], [m for m in masks])
+        ref.backward()
+        seg = masks.int().cuda()
+        terms = []
+        accs = []
+        for l in range(nl):
+            N, C, H, W = sp[l].shape
+            m = hip.mask_pool(seg, H, W)
+            acc = hip.mgd_level_forward(cl(sp[l].detach()), [cl(tp[i][l]) for i in range(4)], [i % 2 == 1 for i in range(4)], m)
+            den = acc[4] * C + 1e-7
+            terms.append(acc[:4] / den)
+            accs.append((m, den))
+        loss = torch.cat(terms).mean()
+        assert loss.item() == pytest.approx(float(g[name]), rel=2e-5)
+        for l in range(nl):
+            m, den = accs[l]
+            coef = torch.full((4,), 1.0 / (4 * nl), device="cuda") / den
+            gs = hip.mgd_level_backward(cl(sp[l].detach()), [cl(tp[i][l]) for i in range(4)],
+                                        [i % 2 == 1 for i in range(4)], m, coef)
+            np.testing.assert_allclose(gs.cpu().numpy(), sp[l].grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_psm_golden_and_grad(hip):
+    from oracle import model as om
+    g = gold("mt_losses")
+    for case, typ in enumerate(("bce", "bce", "kl")):
+        cfg = om.default_cfg(mt_cls_loss_type=typ)
+        t = T(g["psm%d_t" % case])
+        s = T(g["psm%d_s" % case]).clone().requires_grad_()
+        labels = T(g["psm%d_labels" % case])
+        ref = om.psm_loss(cfg, [s], [x for x in t], labels)
+        ref.backward()
+        v = hip.psm_variance(t.cuda(), use_softmax=(typ == "bce"))
+        vref = torch.std(torch.stack([F.softmax(x, 1) if typ == "bce" else x for x in t]), dim=0).sum(-1)
+        np.testing.assert_allclose(v.cpu().numpy(), vref.numpy(), rtol=1e-4, atol=1e-6)
+        pos, neg = labels > 0, labels == 0
+        vn = torch.where(neg, vref, torch.full_like(vref, -1.0))
+        order = torch.argsort(vn, descending=True, stable=True)
+        nkeep = min(int(neg.sum()), int(pos.sum()) // 2)
+        roww = pos.float()
+        w_neg = 1.5 if typ == "bce" else 1.0
+        roww[order[:nkeep]] = w_neg
+        S = int(pos.sum()) + nkeep
+        kind = 0 if typ == "bce" else 1
+        rl, rg = hip.psm_rows(t.cuda(), s.detach().cuda(), roww.cuda(), 0.5, 1, kind)
+        norm = 1.0 / (S * 3)
+        assert (rl.sum() * norm).item() == pytest.approx(float(g["psm%d" % case]), rel=2e-5)
+        np.testing.assert_allclose((rg * norm).cpu().numpy(), s.grad.numpy(), rtol=1e-4, atol=1e-8)
+
+
+def test_ema_and_sgd(hip):
+    g = gold("mt_losses")
+    from oracle import model as om
+    cfg = om.default_cfg()
+    t = torch.zeros(8).cuda()
+    s0 = torch.zeros(8)
+    s0[:5] = torch.arange(5).float()
+    for it in range(21):
+        hip.ema_update(t, (s0 * (1 + 0.1 * it)).cuda(), om.ema_alpha(cfg, it))
+        np.testing.assert_array_equal(t[:5].cpu().numpy(), g["ema_trace"][it])
+    n = 1000003
+    gen = torch.Generator().manual_seed(1)
+    a, b = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+    ta = a.clone()
+    ta.mul_(0.99).add_(b, alpha=1 - 0.99)
+    ca = a.cuda()
+    hip.ema_update(ca, b.cuda(), 0.99)
+    np.testing.assert_allclose(ca.cpu().numpy(), ta.numpy(), rtol=1e-6, atol=1e-7)
+    # SGD vs torch.optim.SGD over 3 steps
+    p = torch.nn.Parameter(a.clone())
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    cp, buf = a.clone().cuda(), torch.zeros(n).cuda()
+    for step in range(3):
+        gr = torch.randn(n, generator=gen)
+        p.grad = gr.clone()
+        opt.step()
+        hip.sgd_momentum(cp, gr.cuda(), buf, 0.01, 1e-4, 0.9, step == 0)
+    np.testing.assert_allclose(cp.cpu().numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ masks
+def test_paste_masks_golden(hip):
+    g = gold("masks")
+    probs, boxes, ref = T(g["paste_masks"]), T(g["paste_boxes"]), g["paste_out"]
+    logits = torch.log(probs / (1 - probs))  # sigmoid^-1; the kernel applies sigmoid itself
+    D = probs.shape[0]
+    lg = torch.zeros(D, 3, 28, 28)
+    lg[:, 1] = logits
+    seg = hip.paste_masks(cl(lg), torch.ones(D).int().cuda(), boxes.cuda(), torch.zeros(D).int().cuda(), 1, 128, 150, 0.5)
+    want = ref.astype(np.int32).sum(0)
+    got = seg[0].cpu().numpy()
+    mism = (got != want).sum()
+    # logit->sigmoid round trip may move a probability across 0.5 by one ulp; allow a handful of pixels
+    assert mism <= 3, mism
+
+
+def test_polygon_targets_golden(hip):
+    g = gold("masks")
+    lens = g["proj_polylens"]
+    poly_off = np.concatenate([[0], np.cumsum(lens // 2)]).astype(np.int32)
+    roi_poly = np.concatenate([[0], np.cumsum(g["proj_npoly"])]).astype(np.int32)
+    out, ovf = hip.polygon_targets(T(g["proj_polys"]).cuda(), T(poly_off).cuda(), T(roi_poly).cuda(),
+                                   T(g["proj_boxes"]).cuda(), 28)
+    assert int(ovf) == 0
+    np.testing.assert_array_equal(out.cpu().numpy(), g["proj_out"])
