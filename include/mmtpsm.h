@@ -96,6 +96,9 @@ int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
 int mmt_conv_wgrad(const mmt_conv_args* a /*[host]; x = input, mask/mul/res unused*/, const float* dy,
                    const float* rowscale /*[Cout] or NULL*/, float* dw, float* dbias /*or NULL*/, void* stream);
 
+/* bias gradient: out[c] += sum_m dy[m][c]  (dy [M,C] row-major, out zeroed or accumulated by the caller) */
+int mmt_colsum(const float* dy, int M, int C, float* out, void* stream);
+
 /* weight re-layout for data gradients: wd[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci] * scale[co] */
 int mmt_weight_flip_transpose(const float* w, const float* scale /*or NULL*/, float* wd, int Cout, int KH, int KW,
                               int Cin, void* stream);
@@ -160,7 +163,7 @@ int mmt_paste_masks(const float* logits, const int32_t* labels, const float* box
  * pycoco/maskApi.c:166-206 rleFrPoly + :53-74 union) for P positive ROIs.
  *   poly_xy   float32 concatenated vertices (x,y interleaved) of all polygons
  *   poly_off  int32 [NP+1] vertex offsets of each polygon
- *   roi_poly  int32 [P+1]: polygons roi_poly[p]..roi_poly[p+1]-1 belong to ROI p (its matched instance)
+ *   roi_poly  int32 [P,2]: polygons roi_poly[p][0]..roi_poly[p][1]-1 belong to ROI p (its matched instance)
  *   boxes     [P,4] proposals;  out [P,M,M] float {0,1};  overflow int32[1] set if a ROI exceeded the
  *   crossing-list capacity (never for 28x28 targets of sane polygons) */
 int mmt_polygon_targets(const float* poly_xy, const int32_t* poly_off, const int32_t* roi_poly, const float* boxes,

@@ -497,6 +497,15 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   return 0;
 }
 
+extern "C" int mmt_colsum(const float* dy, int M, int C, float* out, void* stream) {
+  if (M <= 0 || C <= 0) return 0;
+  const int rpb = 1024;
+  hipLaunchKernelGGL(colsum_kernel, dim3(mmt_cdiv(C, 64), mmt_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, M,
+                     C, out, rpb);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmt_weight_flip_transpose(const float* w, const float* scale, float* wd, int Cout, int KH, int KW,
                                          int Cin, void* stream) {
   if (!w || !wd) return MMT_EINVAL;

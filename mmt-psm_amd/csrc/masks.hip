@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void polygon_kernel(const float* __restrict__ x
   const int per = (npix + 63) / 64;
   for (int i = 0; i < per; i++) acc[i] = 0;
 
-  for (int pi = roi_poly[p]; pi < roi_poly[p + 1]; pi++) {
+  for (int pi = roi_poly[2 * p]; pi < roi_poly[2 * p + 1]; pi++) {
     const int v0 = poly_off[pi], k = poly_off[pi + 1] - v0;
     if (lane == 0) ncross = 0;
     __syncthreads();

@@ -40,6 +40,7 @@ _SIGS = {
     "mmt_nms_batched": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_conv_forward": [ctypes.POINTER(ConvArgs), c_void_p],
     "mmt_conv_wgrad": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_colsum": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "mmt_weight_flip_transpose": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_mask_bce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
@@ -189,8 +190,9 @@ def _conv_args(x, w, stride, pad, Ho, Wo):
 
 
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
-                 mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None):
-    """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory)."""
+                 mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0):
+    """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory).
+    y_out/y_offset (elements): write into an existing NHWC tensor at a shifted base (transposed-conv taps)."""
     x = nhwc(x)
     w = nhwc(w)
     N, Cin, H, W = x.shape
@@ -200,11 +202,11 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     a = _conv_args(x, w, stride, pad, Ho, Wo)
     if out_stride > 1:
         oh, ow = out_hw
-        y = empty_nhwc(N, Cout, oh, ow, x.device, zero=True)
+        y = y_out if y_out is not None else empty_nhwc(N, Cout, oh, ow, x.device, zero=True)
         a.out_stride, a.out_H, a.out_W = out_stride, oh, ow
     else:
-        y = empty_nhwc(N, Cout, Ho, Wo, x.device)
-    a.y = y.data_ptr()
+        y = y_out if y_out is not None else empty_nhwc(N, Cout, Ho, Wo, x.device)
+    a.y = y.data_ptr() + 4 * int(y_offset)
     a.scale, a.shift = _p(scale), _p(shift)
     a.relu = 1 if relu else 0
     if res is not None:
@@ -212,7 +214,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         a.res, a.res_mode = res.data_ptr(), res_mode
     if mask is not None:
         mask = nhwc(mask)
-        a.mask, a.mask_scale = mask.data_ptr(), float(mask_scale)
+        a.mask, a.mask_scale = mask.data_ptr() + 4 * int(y_offset), float(mask_scale)
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
@@ -232,6 +234,13 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
     a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
     a.out_stride = 1
     _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _stream()), "mmt_conv_wgrad")
+
+
+def colsum(dy2d, out):
+    """out[c] += sum_m dy2d[m, c]; dy2d any dense tensor whose memory is [M][C] row-major"""
+    C = out.numel()
+    M = dy2d.numel() // C
+    _check(lib().mmt_colsum(_p(dy2d), M, C, _p(out), _stream()), "mmt_colsum")
 
 
 def weight_flip_transpose(w, scale=None):

@@ -1,0 +1,162 @@
+"""Mean-teacher engine (reference: engine/MTtrainer.py:16-281): per-iteration
+  [A] student(image, target)  [B] teacher.forward_teacher(K augs)  [C] student.forward_student(aug, teacher dict)
+  [D] weighted loss sum -> backward -> SGD  [E] EMA teacher update.
+Arithmetic of loss weighting (weight_sum_losses, including the reference's ramp-down-with-ramp-up-length quirk)
+and of the EMA (alpha = min(1 - 1/(it+1), MT.ALPHA)) is reproduced; EMA and SGD are single launches over flat
+storage; with WORLD_SIZE > 1 the student gradients are averaged by ONE RCCL all-reduce over the flat gradient
+buffer (new functionality: the reference has no gradient synchronisation at all)."""
+import logging
+import time
+from functools import partial
+
+import torch
+import torch.distributed as dist
+
+from maskrcnn_benchmark import _hip as H
+from maskrcnn_benchmark.engine.flat import flatten_model
+from maskrcnn_benchmark.utils.miscellaneous import sigmoid_rampdown, sigmoid_rampup
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def reduce_loss_dict(loss_dict):
+    """MTtrainer.py:16-42: rank 0 gets the average (logging only)"""
+    ws = get_world_size()
+    if ws < 2:
+        return dict(loss_dict)
+    with torch.no_grad():
+        names = list(loss_dict.keys())
+        allv = torch.stack([loss_dict[k].reshape(()) for k in names], 0)
+        dist.reduce(allv, dst=0)
+        if dist.get_rank() == 0:
+            allv /= ws
+        return {k: v for k, v in zip(names, allv)}
+
+
+def mt_weight(step, rampup_length, rampdown_length, total_length, l=1, start_mt=1000):
+    if (step - start_mt) < rampup_length and (step - start_mt) > 0:
+        return l * sigmoid_rampup(step - start_mt, rampup_length)
+    if (total_length - step) < rampdown_length:
+        return l * sigmoid_rampdown(total_length - step, rampup_length)  # sic: ramp-UP length (MTtrainer.py:92)
+    return l
+
+
+def weight_sum_losses(loss_dict, step, rampup_length, rampdown_length, total_length, l=1, balanced=None, start_mt=1000):
+    """MTtrainer.py:67-109"""
+    w = mt_weight(step, rampup_length, rampdown_length, total_length, l, start_mt)
+    out = {}
+    for k, v in loss_dict.items():
+        v = w * v if "mt" in k else v
+        if balanced is not None and k in balanced:
+            v = v * balanced[k]
+        out[k] = v
+    return out
+
+
+def init_teacher_weight(model_s, model_t):
+    flatten_model(model_t).data.copy_(flatten_model(model_s).data)
+
+
+def allreduce_gradients(flat):
+    """data-parallel exchange step: average the flat student gradient over ranks (RCCL over xGMI)"""
+    ws = get_world_size()
+    if ws > 1:
+        dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM)
+        flat.grad.mul_(1.0 / ws)
+
+
+class MTtrainer(object):
+    def __init__(self, model_s, model_t, data_loader, optimizer, scheduler, ckpt_s, ckpt_t, checkpoint_period, cfg):
+        self.cfg = cfg
+        self.logger = logging.getLogger("maskrcnn_benchmark.trainer")
+        self.scheduler, self.optimizer = scheduler, optimizer
+        self.max_iter = len(data_loader["source"])
+        self.start_iter = 0
+        self.student, self.teacher = model_s, model_t
+        self.student_bs, self.teacher_bs = cfg.MT.AUG_S, cfg.MT.AUG_K
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.checkpoint_period, self.ckpt_s, self.ckpt_t = checkpoint_period, ckpt_s, ckpt_t
+        self.lambda_value, self.alpha = cfg.MT.LAMBDA, cfg.MT.ALPHA
+        self.start_mt = cfg.MT.START_MT
+        self.balanced_weight = {"mt_classifier": cfg.MT.CLS_LOSS, "nms_loss": cfg.MODEL.RELATION_NMS.LOSS,
+                                "mt_fg_loss": cfg.MT.FG_HINT}
+        self.dataloader_s = data_loader["source"]
+        self.dataloader_u = data_loader.get("no_label") if cfg.DATASETS.NO_LABEL else None
+        self.n_step_unlabel = cfg.MT.N_STEP_UNLABEL
+        self.weight_sum_loss = partial(weight_sum_losses, rampup_length=cfg.MT.RAMPUP_STEP,
+                                       rampdown_length=cfg.MT.RAMPDOWN_STEP, total_length=self.max_iter,
+                                       l=self.lambda_value, balanced=self.balanced_weight, start_mt=self.start_mt)
+        self.flat_s = flatten_model(self.student)
+        self.flat_t = flatten_model(self.teacher)
+        self._unl_iter = None
+
+    # ---- one iteration (the unit bench.py times)
+    def train_step(self, iteration, data_s, target_s, data_u_list=None):
+        loss_dict = self.forward_source(data_s, target_s)
+        if iteration > self.start_mt and self.lambda_value > 0 and data_u_list is not None:
+            loss_dict.update(self.forward_unlabel(data_u_list))
+        self.scheduler.step()
+        losses_dict = self.weight_sum_loss(loss_dict, iteration)
+        losses = sum(v for v in losses_dict.values())
+        self.optimizer.zero_grad()
+        losses.backward()
+        allreduce_gradients(self.flat_s)
+        self.optimizer.step()
+        if self.lambda_value > 0 and iteration > (self.start_mt - 10):
+            self.update_teacher(iteration - (self.start_mt - 10))
+        return losses_dict
+
+    def train(self):
+        self.student.train()
+        self.teacher.eval()
+        t0 = time.time()
+        for iteration, (data_s, target_s, _) in enumerate(self.dataloader_s, self.start_iter):
+            data_u = None
+            if iteration > self.start_mt and self.lambda_value > 0 and self.dataloader_u is not None:
+                data_u = self._next_unlabeled()
+            losses_dict = self.train_step(iteration, data_s, target_s, data_u)
+            if iteration % 20 == 0 or iteration == self.max_iter:
+                red = reduce_loss_dict(losses_dict)
+                self.logger.info("iter: %d  %s  lr: %.6f  max mem: %.0f", iteration,
+                                 "  ".join("%s: %.4f" % (k, float(v)) for k, v in red.items()),
+                                 self.optimizer.param_groups[0]["lr"], torch.cuda.max_memory_allocated() / 2 ** 20)
+            if self.ckpt_s is not None and iteration > 0 and iteration % self.checkpoint_period == 0:
+                self.save_model(iteration)
+        self.logger.info("Total training time: %.1f s", time.time() - t0)
+
+    def _next_unlabeled(self):
+        if self._unl_iter is None:
+            self._unl_iter = iter(self.dataloader_u)
+        try:
+            return next(self._unl_iter)[0]
+        except StopIteration:
+            self._unl_iter = iter(self.dataloader_u)
+            return next(self._unl_iter)[0]
+
+    def save_model(self, iteration=0, final=False):
+        name = "model_final" if final else "model_{:07d}".format(iteration)
+        self.ckpt_s.save(name)
+        if iteration > self.start_mt and self.ckpt_t is not None:
+            self.ckpt_t.save("t_" + name)
+
+    def forward_source(self, image, target):
+        return self.student(image.to(self.device), [t.to(self.device) for t in target])
+
+    def forward_unlabel(self, data_u_list):
+        """MTtrainer.py:247-275 (N_STEP_UNLABEL = 1)"""
+        teacher_list = [f.to(self.device) for f in data_u_list[:self.teacher_bs]]
+        student = [s.to(self.device) for s in data_u_list[-self.student_bs:]]
+        with torch.no_grad():
+            try:
+                teacher_results = self.teacher.forward_teacher(teacher_list)
+            except ValueError as e:  # no pseudo boxes for an image: the reference skips the pair (bare except)
+                self.logger.info("teacher produced no boxes (%s), skip this pair", e)
+                return {}
+        return self.student.forward_student(student, teacher_results)
+
+    def update_teacher(self, it):
+        """MTtrainer.py:277-281 as one launch over the flat parameter buffers"""
+        alpha = min(1 - 1 / (it + 1), self.alpha)
+        H.ema_update(self.flat_t.data, self.flat_s.data, alpha)

@@ -1,0 +1,59 @@
+"""Flat parameter storage: all parameters of a model live in ONE fp32 device buffer
+[trainable weights | trainable biases | frozen], each nn.Parameter being a view (conv weights keep their
+channels_last strides).  Gradients and SGD momentum mirror the layout.  This is what turns the reference's
+132-tensor EMA loop (engine/MTtrainer.py:277-281), its 121-group SGD (solver/build.py:18) and the (new) data
+parallel gradient all-reduce into single launches / single collectives over contiguous memory."""
+import torch
+
+
+def _is_bias(name):
+    return "bias" in name  # solver/build.py:14
+
+
+class FlatParams(object):
+    def __init__(self, model):
+        named = list(model.named_parameters())
+        tw = [(n, p) for n, p in named if p.requires_grad and not _is_bias(n)]
+        tb = [(n, p) for n, p in named if p.requires_grad and _is_bias(n)]
+        fz = [(n, p) for n, p in named if not p.requires_grad]
+        dev = named[0][1].device
+
+        def pad4(n):
+            return (n + 3) // 4 * 4
+
+        self.index = {}
+        off = 0
+        for group in (tw, tb, fz):
+            for n, p in group:
+                self.index[n] = (off, p.numel())
+                off += pad4(p.numel())  # 16-byte aligned views for the float4 kernels
+            off = pad4(off)
+            if group is tw:
+                self.n_weights = off
+            elif group is tb:
+                self.n_biases = off - self.n_weights
+        self.n_trainable = self.n_weights + self.n_biases
+        self.total = off
+        self.data = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.n_trainable, dtype=torch.float32, device=dev)
+        self.momentum = torch.zeros(self.n_trainable, dtype=torch.float32, device=dev)
+        for n, p in named:
+            o, k = self.index[n]
+            view = self._view_like(self.data[o:o + k], p)
+            view.copy_(p.data)
+            p.data = view
+            if p.requires_grad:
+                p.grad = self._view_like(self.grad[o:o + k], p)
+
+    @staticmethod
+    def _view_like(flat, p):
+        if p.dim() == 4:  # memory is [O][H][W][I] (channels_last) for every 4-D weight on the path
+            o, i, h, w = p.shape
+            return flat.view(o, h, w, i).permute(0, 3, 1, 2)
+        return flat.view(p.shape)
+
+
+def flatten_model(model):
+    if getattr(model, "_flat", None) is None:
+        model._flat = FlatParams(model)
+    return model._flat

@@ -1,0 +1,298 @@
+"""Autograd nodes of the hot path: every forward AND backward is a sequence of libmmtpsm.so launches.
+
+Gradient convention used by all nodes here (it is what lets ReLU backward ride in GEMM epilogues instead
+of costing an elementwise HBM pass per activation):
+
+    the gradient w.r.t. a tensor that is the OUTPUT OF A FUSED ReLU is always delivered ALREADY MASKED
+    by (tensor > 0).  Every consumer of such a tensor is one of the nodes below and is told so with
+    `input_relu=True`; it applies the mask in the epilogue of its data-gradient GEMM (mask = its saved input).
+
+Weight gradients are returned to autograd as fresh tensors (fp32-atomic split-K accumulation inside
+`mmt_conv_wgrad`), so shared weights (RPN head over 5 levels, box head over sup/unsup passes) are summed
+by autograd into the flat gradient buffer.
+
+Reference ops replaced: layers/misc.py:30-64 (Conv2d / ConvTranspose2d), layers/batch_norm.py:19-24,
+backbone/resnet.py:254-274 (bottleneck), backbone/fpn.py:43-69, layers/roi_align.py:11-44,
+mask_head/loss.py:177-179, detector/generalized_rcnn.py:243-282, box_head/loss.py:185-287.
+"""
+import torch
+
+from .. import _hip as H
+
+
+def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False):
+    dw = torch.zeros_like(H.nhwc(w))
+    db = torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device) if with_bias else None
+    H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
+    return dw, db
+
+
+def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, res=None, res_mode=0):
+    """data gradient of y = conv(x, w) (* scale[co]) w.r.t. x, with optional fused (x>0) mask / residual add"""
+    wd = H.weight_flip_transpose(w, scale)
+    kh = w.shape[2]
+    if stride == 1:
+        return H.conv_forward(g, wd, stride=1, pad=kh - 1 - pad, mask=mask, mask_scale=mask_scale, res=res,
+                              res_mode=res_mode)
+    if kh != 1:
+        raise RuntimeError("strided data-gradient is implemented for 1x1 convolutions (STRIDE_IN_1X1) only")
+    return H.conv_forward(g, wd, out_stride=stride, out_hw=tuple(x_shape[2:]), mask=mask, mask_scale=mask_scale,
+                          res=res, res_mode=res_mode)
+
+
+class ConvFn(torch.autograd.Function):
+    """y = relu?(conv(x, w) + b)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, relu, input_relu):
+        x = H.nhwc(x)
+        y = H.conv_forward(x, w, None, b, stride, pad, relu=relu)
+        ctx.save_for_backward(x, w)
+        ctx.cfgv = (stride, pad, input_relu, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        stride, pad, input_relu, has_b = ctx.cfgv
+        g = H.nhwc(g)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            dw, db = _wgrad(x, g, w, stride, pad, None, has_b)
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None)
+        return dx, dw, db, None, None, None, None
+
+
+def conv(x, w, b=None, stride=1, pad=0, relu=False, input_relu=False):
+    return ConvFn.apply(x, w, b, stride, pad, relu, input_relu)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = relu?(x @ w.T + b) * mul  -- a 1x1 'conv' over R rows; `mul` carries the scaled dropout mask"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, input_relu, in_mask_scale, mul):
+        R, K = x.shape
+        O = w.shape[0]
+        x4 = x.contiguous().view(R, K, 1, 1)
+        w4 = w.view(O, K, 1, 1)
+        y = H.conv_forward(x4, w4, None, b, relu=relu, mul=None if mul is None else mul.view(R, O, 1, 1))
+        ctx.save_for_backward(x4, w4)
+        ctx.cfgv = (input_relu, in_mask_scale, b is not None)
+        return y.view(R, O)
+
+    @staticmethod
+    def backward(ctx, g):
+        x4, w4 = ctx.saved_tensors
+        input_relu, in_mask_scale, has_b = ctx.cfgv
+        R, K = x4.shape[:2]
+        O = w4.shape[0]
+        g4 = g.contiguous().view(R, O, 1, 1)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw, db = _wgrad(x4, g4, w4, 1, 0, None, has_b)
+            dw = dw.view(O, K)
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad(g4, w4, x4.shape, 1, 0, None, x4 if input_relu else None, in_mask_scale).view(R, K)
+        return dx, dw, db, None, None, None, None
+
+
+def linear(x, w, b=None, relu=False, input_relu=False, in_mask_scale=1.0, mul=None):
+    return LinearFn.apply(x, w, b, relu, input_relu, in_mask_scale, mul)
+
+
+class BottleneckFn(torch.autograd.Function):
+    """BottleneckWithFixedBatchNorm.forward (backbone/resnet.py:254-274) as 3-4 fused launches:
+    conv1x1(s)+BN+ReLU -> conv3x3+BN+ReLU -> conv1x1+BN (+ downsample 1x1(s)+BN) + residual + ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, wd, bn, stride):
+        s1, b1, s2, b2, s3, b3, sd, bd = bn
+        x = H.nhwc(x)
+        o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True)
+        o2 = H.conv_forward(o1, w2, s2, b2, 1, 1, relu=True)
+        r = x if wd is None else H.conv_forward(x, wd, sd, bd, stride, 0)
+        out = H.conv_forward(o2, w3, s3, b3, 1, 0, relu=True, res=r, res_mode=1)
+        ctx.save_for_backward(x, o1, o2, w1, w2, w3, wd if wd is not None else x.new_zeros(()))
+        ctx.bn = (s1, s2, s3, sd)
+        ctx.stride = stride
+        ctx.has_ds = wd is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, o1, o2, w1, w2, w3, wd = ctx.saved_tensors
+        s1, s2, s3, sd = ctx.bn
+        stride = ctx.stride
+        g = H.nhwc(g)  # masked by (out > 0) by the consumer
+        dw3, _ = _wgrad(o2, g, w3, 1, 0, s3)
+        d_o2 = _dgrad(g, w3, o2.shape, 1, 0, s3, mask=o2)
+        dw2, _ = _wgrad(o1, d_o2, w2, 1, 1, s2)
+        d_o1 = _dgrad(d_o2, w2, o1.shape, 1, 1, s2, mask=o1)
+        dw1, _ = _wgrad(x, d_o1, w1, stride, 0, s1)
+        dwd = dx = None
+        if ctx.has_ds:
+            dwd, _ = _wgrad(x, g, wd, stride, 0, sd)
+        if ctx.needs_input_grad[0]:
+            if ctx.has_ds:
+                t = _dgrad(d_o1, w1, (x.shape[0], x.shape[1], g.shape[2], g.shape[3]), 1, 0, s1)  # compact Ho x Wo
+                dx = _dgrad(g, wd, x.shape, stride, 0, sd, mask=x, res=t, res_mode=1) if stride > 1 else \
+                    _dgrad(g, wd, x.shape, 1, 0, sd, mask=x, res=t, res_mode=1)
+            else:
+                dx = _dgrad(d_o1, w1, x.shape, 1, 0, s1, mask=x, res=g, res_mode=1)
+        return dx, dw1, dw2, dw3, dwd, None, None
+
+
+class FPNFn(torch.autograd.Function):
+    """FPN.forward (backbone/fpn.py:43-69): 4 lateral 1x1 (+bias) with the nearest-x2 top-down add fused in the
+    epilogue, 4 output 3x3 (+bias).  Returns P2..P5 (P6 = P5[::2, ::2] is taken by the caller)."""
+
+    @staticmethod
+    def forward(ctx, c2, c3, c4, c5, wi1, bi1, wi2, bi2, wi3, bi3, wi4, bi4, wl1, bl1, wl2, bl2, wl3, bl3, wl4, bl4):
+        cs = [H.nhwc(c) for c in (c2, c3, c4, c5)]
+        wi, bi = (wi1, wi2, wi3, wi4), (bi1, bi2, bi3, bi4)
+        wl, bl = (wl1, wl2, wl3, wl4), (bl1, bl2, bl3, bl4)
+        inner = [None] * 4
+        inner[3] = H.conv_forward(cs[3], wi[3], None, bi[3])
+        for k in (2, 1, 0):
+            inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2)
+        outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1) for k in range(4)]
+        ctx.save_for_backward(*cs, *inner, *wi, *wl)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g2, g3, g4, g5):
+        sv = ctx.saved_tensors
+        cs, inner, wi, wl = sv[0:4], sv[4:8], sv[8:12], sv[12:16]
+        gs = [g2, g3, g4, g5]
+        gs = [H.nhwc(g) if g is not None else torch.zeros_like(inner[k]) for k, g in enumerate(gs)]
+        d_in = [None] * 4
+        dwl, dbl, dwi, dbi, dcs = [None] * 4, [None] * 4, [None] * 4, [None] * 4, [None] * 4
+        for k in range(4):  # finest first: d_inner_k = dgrad(layer_k) + 2x2-sum(d_inner_{k-1})
+            dwl[k], dbl[k] = _wgrad(inner[k], gs[k], wl[k], 1, 1, None, True)
+            d_in[k] = _dgrad(gs[k], wl[k], inner[k].shape, 1, 1, None, res=d_in[k - 1] if k > 0 else None,
+                             res_mode=3 if k > 0 else 0)
+        for k in range(4):
+            dwi[k], dbi[k] = _wgrad(cs[k], d_in[k], wi[k], 1, 0, None, True)
+            if ctx.needs_input_grad[k]:
+                dcs[k] = _dgrad(d_in[k], wi[k], cs[k].shape, 1, 0, None, mask=cs[k])  # C_k is a ReLU output
+        out = list(dcs)
+        for k in range(4):
+            out += [dwi[k], dbi[k]]
+        for k in range(4):
+            out += [dwl[k], dbl[k]]
+        return tuple(out)
+
+
+class DeconvFn(torch.autograd.Function):
+    """relu?(ConvTranspose2d(k=2, s=2)(x) + b)  (mask_head/roi_mask_predictors.py:34-36): four tap GEMMs that
+    scatter straight into the 2x-upsampled NHWC output; w is (Cin, Cout, 2, 2) in channels_last memory, i.e.
+    [ci][kh][kw][co] -- already the layout the data-gradient (a stride-2 2x2 conv) wants."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, input_relu):
+        x = H.nhwc(x)
+        w = H.nhwc(w)
+        P, Cin, h, wd_ = x.shape
+        Cout = w.shape[1]
+        y = H.empty_nhwc(P, Cout, 2 * h, 2 * wd_, x.device)
+        wf = w.permute(2, 3, 1, 0).contiguous()  # [kh][kw][co][ci]
+        for kh in range(2):
+            for kw in range(2):
+                H.conv_forward(x, wf[kh, kw].view(Cout, Cin, 1, 1), None, b, relu=relu, out_stride=2,
+                               out_hw=(2 * h, 2 * wd_), y_out=y, y_offset=(kh * 2 * wd_ + kw) * Cout)
+        ctx.save_for_backward(x, w)
+        ctx.cfgv = (input_relu, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        input_relu, has_b = ctx.cfgv
+        g = H.nhwc(g)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            H.conv_wgrad(g, x, tuple(w.shape), 2, 0, dw)  # 'input' = g (28x28), 'dy' = x (14x14)
+            if has_b:
+                db = torch.zeros((w.shape[1],), dtype=torch.float32, device=w.device)
+                H.colsum(g, db)
+        if ctx.needs_input_grad[0]:
+            dx = H.conv_forward(g, w, stride=2, pad=0, mask=x if input_relu else None)
+        return dx, dw, db, None, None
+
+
+class RoiAlignFpnFn(torch.autograd.Function):
+    """Pooler.forward (modeling/poolers.py:91-121) + _ROIAlign (layers/roi_align.py:11-44) for all levels at once"""
+
+    @staticmethod
+    def forward(ctx, rois, levels, res, scales, sr, *feats):
+        feats = [H.nhwc(f) for f in feats]
+        out = H.roi_align_forward(feats, scales, rois, levels, res, res, sr)
+        ctx.save_for_backward(rois, levels)
+        ctx.cfgv = (res, scales, sr, [tuple(f.shape) for f in feats])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rois, levels = ctx.saved_tensors
+        res, scales, sr, shapes = ctx.cfgv
+        grads = H.roi_align_backward(g, shapes, scales, rois, levels, res, res, sr)
+        return (None, None, None, None, None) + tuple(
+            gr if ctx.needs_input_grad[5 + i] else None for i, gr in enumerate(grads))
+
+
+class MaskBCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, targets):
+        loss, grad = H.mask_bce(logits, labels, targets, 1.0)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, = ctx.saved_tensors
+        return grad * g, None, None
+
+
+class PSMLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, student, teacher, roww, norm, temp, sharpen, kind):
+        rl, rg = H.psm_rows(teacher, student, roww, temp, sharpen, kind)
+        ctx.save_for_backward(rg * norm)
+        return rl.sum() * norm
+
+    @staticmethod
+    def backward(ctx, g):
+        rg, = ctx.saved_tensors
+        return rg * g, None, None, None, None, None, None
+
+
+class MGDLossFn(torch.autograd.Function):
+    """fg_hint_loss (detector/generalized_rcnn.py:243-282): mean over (teacher pyramid x level) masked-L2 terms"""
+
+    @staticmethod
+    def forward(ctx, seg, flips, n_levels, *embs):
+        students = [H.nhwc(e) for e in embs[:n_levels]]
+        nt = (len(embs) - n_levels) // n_levels
+        teachers = [[H.nhwc(embs[n_levels + i * n_levels + l]) for i in range(nt)] for l in range(n_levels)]
+        terms, saved = [], []
+        for l, s in enumerate(students):
+            m = H.mask_pool(seg, s.shape[2], s.shape[3])
+            acc = H.mgd_level_forward(s, teachers[l], flips, m)
+            den = acc[nt] * s.shape[1] + 1e-7
+            terms.append(acc[:nt] / den)
+            saved.append((m, den))
+        ctx.students, ctx.teachers, ctx.saved, ctx.flips = students, teachers, saved, flips
+        ctx.n_terms = nt * n_levels
+        # reference order: for teacher: for level -> mean is order independent up to rounding
+        return torch.stack(terms, 1).reshape(-1).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = []
+        for s, ts, (m, den) in zip(ctx.students, ctx.teachers, ctx.saved):
+            coef = (g / ctx.n_terms / den).expand(len(ts)).contiguous()
+            grads.append(H.mgd_level_backward(s, ts, ctx.flips, m, coef))
+        return (None, None, None) + tuple(grads) + (None,) * (len(ctx.teachers[0]) * len(ctx.students))

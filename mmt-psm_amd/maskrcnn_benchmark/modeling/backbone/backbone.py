@@ -1,0 +1,149 @@
+"""R-50-FPN backbone (reference: modeling/backbone/backbone.py:19-44, resnet.py:61-307, fpn.py:7-74).
+
+Same attribute tree / state-dict keys (backbone.body.stem.*, backbone.body.layerK.N.convM / bnM /
+downsample.{0,1}, backbone.fpn.fpn_inner{1-4} / fpn_layer{1-4}).  Execution differs: the whole body is NHWC,
+every FrozenBatchNorm + ReLU + residual add lives in a conv epilogue, a bottleneck is 3-4 launches and one
+autograd node, the FPN is one autograd node; the frozen stem + layer1 (FREEZE_CONV_BODY_AT=2,
+resnet.py:106-115) run without recording anything for backward."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from maskrcnn_benchmark import _hip as H
+from maskrcnn_benchmark.layers import Conv2d, FrozenBatchNorm2d, fused
+
+
+class StemWithFixedBatchNorm(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        out = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+        self.conv1 = Conv2d(3, out, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(out)
+
+    def forward(self, x):
+        # the MFMA loader wants 16-byte channel groups: pad RGB -> 4 channels (zero weight on the 4th)
+        n, c, h, w = x.shape
+        x4 = x.new_zeros((n, h, w, 4))
+        x4[..., :3] = x.permute(0, 2, 3, 1)
+        w4 = self.conv1.weight.new_zeros((self.conv1.out_channels, 7, 7, 4))
+        w4[..., :3] = self.conv1.weight.detach().permute(0, 2, 3, 1)
+        s, b = self.bn1.folded()
+        y = H.conv_forward(x4.permute(0, 3, 1, 2), w4.permute(0, 3, 1, 2), s, b, 2, 3, relu=True)
+        return H.maxpool3x3s2(y)
+
+
+class BottleneckWithFixedBatchNorm(nn.Module):
+    def __init__(self, in_channels, bottleneck_channels, out_channels, num_groups=1, stride_in_1x1=True, stride=1):
+        super().__init__()
+        if num_groups != 1 or not stride_in_1x1:
+            raise NotImplementedError("R-50 hot path: NUM_GROUPS=1, STRIDE_IN_1X1=True")
+        self.downsample = None
+        if in_channels != out_channels:
+            self.downsample = nn.Sequential(Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False),
+                                            FrozenBatchNorm2d(out_channels))
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=stride, bias=False)
+        self.bn1 = FrozenBatchNorm2d(bottleneck_channels)
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = FrozenBatchNorm2d(bottleneck_channels)
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(out_channels)
+        self.stride = stride
+
+    def forward(self, x):
+        s1, b1 = self.bn1.folded()
+        s2, b2 = self.bn2.folded()
+        s3, b3 = self.bn3.folded()
+        wd = sd = bd = None
+        if self.downsample is not None:
+            wd = self.downsample[0].weight
+            sd, bd = self.downsample[1].folded()
+        return fused.BottleneckFn.apply(x, self.conv1.weight, self.conv2.weight, self.conv3.weight, wd,
+                                        (s1, b1, s2, b2, s3, b3, sd, bd), self.stride)
+
+
+class ResNet(nn.Module):
+    BLOCKS = {"R-50-FPN": (3, 4, 6, 3), "R-101-FPN": (3, 4, 23, 3)}
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.stem = StemWithFixedBatchNorm(cfg)
+        in_ch = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+        width = cfg.MODEL.RESNETS.NUM_GROUPS * cfg.MODEL.RESNETS.WIDTH_PER_GROUP
+        out2 = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
+        self.stages = []
+        for i, n in enumerate(self.BLOCKS[cfg.MODEL.BACKBONE.CONV_BODY], 1):
+            f = 2 ** (i - 1)
+            blocks, stride = [], (2 if i > 1 else 1)
+            for _ in range(n):
+                blocks.append(BottleneckWithFixedBatchNorm(in_ch, width * f, out2 * f, 1,
+                                                           cfg.MODEL.RESNETS.STRIDE_IN_1X1, stride))
+                stride, in_ch = 1, out2 * f
+            self.add_module("layer%d" % i, nn.Sequential(*blocks))
+            self.stages.append("layer%d" % i)
+        self.freeze_at = cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT
+        for si in range(self.freeze_at):
+            m = self.stem if si == 0 else getattr(self, "layer%d" % si)
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def forward(self, x):
+        outs = []
+        with torch.no_grad():
+            x = self.stem(x)
+        for i, name in enumerate(self.stages, 1):
+            if i < self.freeze_at:
+                with torch.no_grad():
+                    x = getattr(self, name)(x)
+            else:
+                x = getattr(self, name)(x)
+            outs.append(x)
+        return outs
+
+
+class FPN(nn.Module):
+    def __init__(self, in_channels_list, out_channels, top_blocks=None):
+        super().__init__()
+        self.inner_blocks, self.layer_blocks = [], []
+        for idx, c in enumerate(in_channels_list, 1):
+            inner, layer = Conv2d(c, out_channels, 1), Conv2d(out_channels, out_channels, 3, 1, 1)
+            for m in (inner, layer):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+            self.add_module("fpn_inner%d" % idx, inner)
+            self.add_module("fpn_layer%d" % idx, layer)
+            self.inner_blocks.append("fpn_inner%d" % idx)
+            self.layer_blocks.append("fpn_layer%d" % idx)
+        self.top_blocks = top_blocks
+
+    def forward(self, x):
+        args = list(x)
+        for n in self.inner_blocks:
+            m = getattr(self, n)
+            args += [m.weight, m.bias]
+        for n in self.layer_blocks:
+            m = getattr(self, n)
+            args += [m.weight, m.bias]
+        res = list(fused.FPNFn.apply(*args))
+        if self.top_blocks is not None:
+            res.extend(self.top_blocks(res[-1]))
+        return tuple(res)
+
+
+class LastLevelMaxPool(nn.Module):
+    def forward(self, x):
+        return [x[:, :, ::2, ::2]]  # max_pool2d(kernel 1, stride 2) == subsampling (fpn.py:72-74)
+
+
+def build_resnet_fpn_backbone(cfg):
+    body = ResNet(cfg)
+    c2 = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
+    fpn = FPN([c2, c2 * 2, c2 * 4, c2 * 8], cfg.MODEL.BACKBONE.OUT_CHANNELS, LastLevelMaxPool())
+    return nn.Sequential(OrderedDict([("body", body), ("fpn", fpn)]))
+
+
+def build_backbone(cfg):
+    if cfg.MODEL.BACKBONE.CONV_BODY not in ResNet.BLOCKS:
+        raise KeyError("cfg.MODEL.BACKBONE.CONV_BODY: {} is not on the MI355X hot path".format(
+            cfg.MODEL.BACKBONE.CONV_BODY))
+    return build_resnet_fpn_backbone(cfg)

@@ -1,0 +1,45 @@
+"""BalancedPositiveNegativeSampler (reference: modeling/balanced_positive_negative_sampler.py:5-72).
+
+Device formulation: instead of nonzero + two randperm per image (4 host syncs per image) each candidate draws a
+uniform key and the `num_pos` / `num_neg` smallest keys among positives / negatives are kept -- the same
+uniform-without-replacement distribution, no data-dependent shapes.  `replay` (tests) substitutes recorded
+index sets so a run can be compared decision-for-decision with the CPU oracle."""
+import torch
+
+
+class BalancedPositiveNegativeSampler(object):
+    def __init__(self, batch_size_per_image, positive_fraction):
+        self.batch_size_per_image = batch_size_per_image
+        self.positive_fraction = positive_fraction
+        self.replay = None  # callable(tag) -> list of (pos_idx, neg_idx) or None
+
+    def __call__(self, matched_idxs, tag=None):
+        pos_out, neg_out = [], []
+        rec = self.replay(tag) if (self.replay is not None and tag is not None) else None
+        for i, m in enumerate(matched_idxs):
+            if rec is not None:
+                pi, ni = rec[i]
+                pm = torch.zeros_like(m, dtype=torch.bool)
+                nm = torch.zeros_like(m, dtype=torch.bool)
+                pm[pi.to(m.device)] = True
+                nm[ni.to(m.device)] = True
+            else:
+                pos, neg = m >= 1, m == 0
+                num_pos = int(self.batch_size_per_image * self.positive_fraction)
+                n_pos_avail = pos.sum()
+                num_pos_t = torch.clamp(n_pos_avail, max=num_pos)
+                num_neg_t = torch.minimum(neg.sum(), self.batch_size_per_image - num_pos_t)
+                key = torch.rand(m.shape, device=m.device)
+                pm = self._take(key, pos, num_pos_t)
+                nm = self._take(key, neg, num_neg_t)
+            pos_out.append(pm)
+            neg_out.append(nm)
+        return pos_out, neg_out
+
+    @staticmethod
+    def _take(key, member, count):
+        k = torch.where(member, key, torch.full_like(key, 2.0))
+        order = torch.argsort(k)
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(order.numel(), device=order.device)
+        return member & (rank < count)

@@ -1,0 +1,153 @@
+"""GeneralizedRCNN with the mean-teacher entry points (reference: modeling/detector/generalized_rcnn.py:17-282).
+
+forward(images, targets)            supervised student step -> loss dict / eval detections
+forward_teacher(images)             coarse inference -> pseudo labels + masks; K-aug x flip pyramids; per-view logits
+forward_student(images, result_t)   MGD (mt_fg_loss) + PSM (mt_classifier)
+
+Same attribute tree (backbone, rpn, box_heads, mask_heads, hint_adaptor), same dict keys.  IR-Net branches
+(relation_nms / mask relation) are BASELINE config 5 and not built yet (out-of-scope list)."""
+import torch
+from torch import nn
+
+from maskrcnn_benchmark.layers import fused
+from maskrcnn_benchmark.structures.image_list import to_image_list
+from ..backbone import build_backbone
+from ..rpn.rpn import build_rpn
+from ..roi_heads.roi_heads import box_roi_heads, mask_roi_heads
+from ..roi_heads.box_head.box_head import MaskRCNNFPNAdaptor
+
+
+class GeneralizedRCNN(nn.Module):
+    def __init__(self, cfg, is_teacher=False, is_student=False):
+        super().__init__()
+        if cfg.MODEL.RELATION_NMS.USE_RELATION_NMS or cfg.MODEL.RELATION_MASK.USE_RELATION:
+            raise NotImplementedError("IR-Net (RELATION_NMS / RELATION_MASK) is BASELINE config 5: not on the "
+                                      "MI355X path yet; set both to False")
+        self.cfg = cfg
+        self.backbone = build_backbone(cfg)
+        self.rpn = build_rpn(cfg, is_teacher)
+        self.box_heads = box_roi_heads(cfg)
+        self.mask_heads = mask_roi_heads(cfg, is_student)
+        self.relation_nms = None
+        self.mt_fg_hint = cfg.MT.FG_HINT
+        self.mt_cls = cfg.MT.CLS_LOSS
+        self.hint_adaptor = MaskRCNNFPNAdaptor(cfg)
+        self.taps = None  # dict: records stage outputs (tests / debugging)
+
+    # ---- test instrumentation: replay of recorded discrete decisions (sampler index sets, dropout masks, proposals)
+    def set_replay(self, replay):
+        self._replay = replay
+        fa = (lambda tag: replay.take_all(tag)) if replay is not None else None
+        fn = (lambda tag: replay.take_next(tag)) if replay is not None else None
+        self.rpn.loss_evaluator.fg_bg_sampler.replay = fa
+        self.box_heads.box.loss_evaluator.fg_bg_sampler.replay = fa
+        self.box_heads.box.feature_extractor.replay = fn
+
+    def _tap(self, name, value):
+        rp = getattr(self, "_replay", None)
+        if rp is not None and rp.has(name):
+            from maskrcnn_benchmark.structures.bounding_box import BoxList
+            rec, new = rp.take_all(name), []
+            for r, old in zip(rec, value):
+                b = BoxList(r[0].to(old.bbox.device), old.size, "xyxy")
+                if name == "detections":
+                    b.add_field("scores", r[1].to(old.bbox.device))
+                    b.add_field("objectness", r[1].to(old.bbox.device))
+                    b.add_field("labels", r[2].to(old.bbox.device))
+                else:
+                    b.add_field("objectness", r[1].to(old.bbox.device))
+                new.append(b)
+            value = new
+        if self.taps is not None:
+            self.taps[name] = value
+        return value
+
+    def set_module_mode(self, mode):
+        self.rpn.set_teacher_mode(mode)
+        self.box_heads.box.set_teacher_mode(mode)
+        self.mask_heads.mask.set_teacher_mode(mode)
+
+    def forward(self, images, targets=None, tta=None):
+        if self.training and targets is None:
+            raise ValueError("In training mode, targets should be passed")
+        images = to_image_list(images)
+        features = self.backbone(images.tensors)
+        proposals, proposal_losses = self.rpn(images, features, targets)
+        proposals = self._tap("rpn_proposals" if self.training else "infer_proposals", proposals)
+        x, result, losses, class_logits, box_regression = self.box_heads(features, proposals, targets)
+        if not self.training:
+            result = self._tap("detections", result)
+        result, detector_losses = self.mask_heads(losses, features, result, targets, images)
+        if self.training:
+            out = {}
+            out.update(detector_losses)
+            out.update(proposal_losses)
+            return out
+        return result
+
+    def forward_teacher(self, images, targets=None):
+        if targets is not None:
+            raise NotImplementedError("forward_teacher with ground-truth targets is not used by MTtrainer")
+        integral = []
+        self.set_module_mode("test")
+        teacher_infer = self.forward(images[0])
+        if self.mt_fg_hint > 0:
+            for t in teacher_infer:
+                integral.append(t.get_field("mask").sum(0)[0])
+            for t in teacher_infer:
+                t.remove_field("mask")
+        self.set_module_mode("train")
+        images = [to_image_list(im) for im in images]
+        aug_features = self.extract_aug_feat(images)
+        _, _, _, _, proposals, _, ffi_boxes = self.rpn.forward_teacher(images[0], aug_features[0], teacher_infer)
+        proposals = self._tap("teacher_proposals", proposals)
+        embeddings = self.get_emb_feature(aug_features) if self.cfg.MT.FG_HINT else None
+        result, class_logits = None, None
+        if self.cfg.MT.CLS_LOSS:
+            _, result, _, class_logits, _ = self.box_heads.forward_teacher(aug_features, proposals, teacher_infer)
+        return {"result_t": result, "class_logit_t": class_logits, "embedding": embeddings, "seg_mask": integral,
+                "ffi_boxes": ffi_boxes}
+
+    def forward_student(self, images, result_t):
+        images = [to_image_list(im) for im in images] if isinstance(images, list) else [to_image_list(images)]
+        feat_list = self.extract_aug_feat(images, teacher=False)
+        loss_dict = {}
+        if self.cfg.MT.FG_HINT:
+            loss_dict.update(mt_fg_loss=self.get_fg_feature_loss(feat_list, result_t["seg_mask"], result_t["embedding"]))
+        if self.cfg.MT.CLS_LOSS:
+            loss_dict.update(self.box_heads.forward_student(feat_list, result_t["result_t"], result_t["class_logit_t"]))
+        return loss_dict
+
+    def extract_aug_feat(self, imglist, teacher=True):
+        """generalized_rcnn.py:201-215 (ImageList.hflip mutates in place, as in the reference)"""
+        feats = []
+        if teacher:
+            for img in imglist:
+                f = self.backbone(img.tensors)
+                img.hflip()
+                feats.extend([f, self.backbone(img.tensors)])
+        else:
+            for i, img in enumerate(imglist):
+                if i % 2 == 1:
+                    img.hflip()
+                feats.append(self.backbone(img.tensors))
+        return feats
+
+    def get_emb_feature(self, feature_list):
+        return [self.hint_adaptor(f) for f in feature_list]
+
+    def get_fg_feature_loss(self, feature_list, seg_mask, teacher_feat):
+        return fg_hint_loss(teacher_feat, self.get_emb_feature(feature_list), seg_mask)
+
+
+def fg_hint_loss(teachers, students, masks):
+    """MGD (generalized_rcnn.py:243-282): teachers = list over views of 5-level embeddings (odd views were
+    computed on mirrored inputs and are un-mirrored inside the kernel), students = [5-level embeddings]."""
+    if len(students) != 1:
+        raise NotImplementedError("AUG_S > 1 (mirrored student views) is not on the shipped recipe")
+    seg = torch.stack([m.to(torch.int32) for m in masks]).contiguous()
+    s = students[0]
+    nl = len(s)
+    flips = [i % 2 == 1 for i in range(len(teachers))]
+    flat_t = [t[l].detach() for t in teachers for l in range(nl)]
+    return fused.MGDLossFn.apply(seg, flips, nl, *s, *flat_t)

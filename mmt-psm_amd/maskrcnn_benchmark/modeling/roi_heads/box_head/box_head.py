@@ -1,0 +1,318 @@
+"""Box head (reference: modeling/roi_heads/box_head/{box_head,roi_box_feature_extractors,roi_box_predictors,
+loss,inference}.py).  Same module tree (feature_extractor.fc6/fc7, predictor.cls_score/bbox_pred,
+hint adaptor) and the same three entry points: forward / forward_teacher / forward_student.
+
+Execution: 4-level ROIAlign in one launch -> fc6/fc7 on the fp32 MFMA GEMM with bias+ReLU(+dropout) in the
+epilogue -> cls_score and bbox_pred as ONE 15-wide GEMM; PSM loss as two small kernels."""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from maskrcnn_benchmark import _hip as H
+from maskrcnn_benchmark.layers import Conv2d, Linear, fused, smooth_l1_loss
+from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+from maskrcnn_benchmark.modeling.matcher import Matcher
+from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from maskrcnn_benchmark.modeling.poolers import Pooler
+from maskrcnn_benchmark.structures.bounding_box import BoxList
+from maskrcnn_benchmark.structures.boxlist_ops import boxlist_iou
+from maskrcnn_benchmark.utils.miscellaneous import batch_boxlist_hflip
+
+
+class MaskRCNNFPNAdaptor(nn.Module):
+    """MGD hint adaptors: 5 independent 1x1 convs (roi_box_feature_extractors.py:45-75)"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        out = 128 if cfg.MT.T_ADAPT is True else 256
+        for i in range(1, 6):
+            m = Conv2d(256, out, 1, 1, 0)
+            nn.init.kaiming_uniform_(m.weight, a=1)
+            nn.init.constant_(m.bias, 0)
+            self.add_module("adapter_%d" % i, m)
+
+    def forward(self, features_s):
+        return [getattr(self, "adapter_%d" % (i + 1))(f) for i, f in enumerate(features_s)]
+
+
+class FPN2MLPFeatureExtractor(nn.Module):
+    """roi_box_feature_extractors.py:77-125.  fc6.weight is held with its 12544 columns in (h, w, c) order --
+    the order the NHWC ROIAlign output flattens to -- and converted from/to the reference's (c, h, w) order at
+    the state-dict boundary, so checkpoints stay interchangeable."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        res = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        self.pooler = Pooler((res, res), cfg.MODEL.ROI_BOX_HEAD.POOLER_SCALES, cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO)
+        self.res, self.ch = res, cfg.MODEL.BACKBONE.OUT_CHANNELS
+        rep = cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM
+        self.fc6 = Linear(self.ch * res * res, rep)
+        self.fc7 = Linear(rep, rep)
+        self.p_drop = cfg.MODEL.ROI_BOX_HEAD.DO
+        self.replay = None
+        self._register_state_dict_hook(self._to_reference_layout)
+        self._register_load_state_dict_pre_hook(self._from_reference_layout)
+
+    def _perm(self, w, to_ref):
+        O = w.shape[0]
+        if to_ref:
+            return w.view(O, self.res, self.res, self.ch).permute(0, 3, 1, 2).reshape(O, -1)
+        return w.view(O, self.ch, self.res, self.res).permute(0, 2, 3, 1).reshape(O, -1)
+
+    @staticmethod
+    def _to_reference_layout(module, sd, prefix, local_metadata):
+        k = prefix + "fc6.weight"
+        if k in sd:
+            sd[k] = module._perm(sd[k], True).contiguous()
+
+    def _from_reference_layout(self, sd, prefix, *args):
+        k = prefix + "fc6.weight"
+        if k in sd:
+            sd[k] = self._perm(sd[k], False).contiguous()
+
+    def forward(self, x, proposals, filp=False, istrain=False):
+        x = self.pooler(x, proposals)                      # (R, C, 7, 7) NHWC-dense
+        x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)  # (R, 7*7*C) view
+        x = self.fc6(x, relu=True)
+        mul = None
+        if self.p_drop > 0 and istrain:
+            rec = self.replay("dropout") if self.replay is not None else None
+            keep = rec.to(x.device) if rec is not None else torch.empty(
+                (x.shape[0], self.fc7.out_features), device=x.device).bernoulli_(1 - self.p_drop)
+            mul = keep / (1 - self.p_drop)
+        return self.fc7(x, relu=True, input_relu=True, mul=mul)
+
+
+class FPNPredictor(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        nc, rep = cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES, cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM
+        self.cls_score = Linear(rep, nc)
+        self.bbox_pred = Linear(rep, nc * 4)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        self.nc = nc
+
+    def forward(self, x, in_mask_scale=1.0):
+        w = torch.cat([self.cls_score.weight, self.bbox_pred.weight], 0)
+        b = torch.cat([self.cls_score.bias, self.bbox_pred.bias], 0)
+        o = fused.linear(x, w, b, False, True, in_mask_scale)
+        return o[:, :self.nc], o[:, self.nc:]
+
+
+def sharpen(p, temp=0.5):
+    pt = p ** (1 / temp)
+    return (pt / pt.sum(dim=1, keepdim=True)).detach()
+
+
+class FastRCNNLossComputation(object):
+    def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, cfg=None):
+        self.proposal_matcher, self.fg_bg_sampler, self.box_coder, self.cfg = proposal_matcher, fg_bg_sampler, box_coder, cfg
+
+    def prepare_targets(self, proposals, targets):
+        labels, regs = [], []
+        for p, t in zip(proposals, targets):
+            m = self.proposal_matcher(boxlist_iou(t, p))
+            mi = m.clamp(min=0)
+            lab = t.get_field("labels")[mi].to(torch.int64)
+            lab = torch.where(m == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(lab), lab)
+            lab = torch.where(m == Matcher.BETWEEN_THRESHOLDS, torch.full_like(lab, -1), lab)
+            labels.append(lab)
+            regs.append(self.box_coder.encode(t.bbox[mi], p.bbox))
+        return labels, regs
+
+    def subsample(self, proposals, targets):
+        """box_head/loss.py:82-116"""
+        labels, regs = self.prepare_targets(proposals, targets)
+        pos, neg = self.fg_bg_sampler(labels, tag="roi_sampler")
+        out = []
+        for p, lab, rg, pm, nm in zip(proposals, labels, regs, pos, neg):
+            p.add_field("labels", lab)
+            p.add_field("regression_targets", rg)
+            out.append(p[torch.nonzero(pm | nm).squeeze(1)])
+        self._proposals = out
+        return out
+
+    def __call__(self, class_logits, box_regression):
+        """box_head/loss.py:118-162"""
+        class_logits, box_regression = torch.cat(class_logits, 0), torch.cat(box_regression, 0)
+        props = self._proposals
+        labels = torch.cat([p.get_field("labels") for p in props], 0)
+        regt = torch.cat([p.get_field("regression_targets") for p in props], 0)
+        cls = F.cross_entropy(class_logits, labels)
+        posf = (labels > 0).to(torch.float32)
+        idx = (4 * labels.clamp(min=0))[:, None] + torch.arange(4, device=labels.device)[None, :]
+        sel = torch.gather(box_regression, 1, idx)
+        d = torch.abs(sel - regt)
+        sl1 = torch.where(d < 1.0, 0.5 * d * d, d - 0.5)  # smooth_l1(beta=1, sum)
+        return cls, (sl1 * posf[:, None]).sum() / labels.numel()
+
+    def evaluatePSM(self, class_logits, class_logits_t, proposals):
+        """box_head/loss.py:164-237,267-287: hard-negative mining by teacher disagreement + sharpened soft CE"""
+        cfg = self.cfg
+        labels = torch.cat([p.get_field("labels") for p in proposals], 0)
+        teacher = torch.stack([t.detach() for t in class_logits_t]).contiguous()  # (K, R, NC)
+        typ = cfg.MT.CLS_LOSS_TYPE
+        kind = {"bce": 0, "ce": 0, "kl": 1}.get(typ)
+        if kind is None:
+            raise NotImplementedError("MT.CLS_LOSS_TYPE=%s: the MI355X path implements 'bce'/'ce' and 'kl'" % typ)
+        pos, neg = labels > 0, labels == 0
+        n_pos, n_neg = pos.sum(), neg.sum()
+        if cfg.MT.RANK_FILTER > 0:
+            if cfg.MT.HARD_NEG:
+                v = H.psm_variance(teacher, use_softmax=(typ == "bce"))
+            else:
+                v = torch.rand(labels.shape, device=labels.device)
+            vn = torch.where(neg, v, torch.full_like(v, -1.0))
+            order = torch.argsort(vn, descending=True, stable=True)
+            rank = torch.empty_like(order)
+            rank[order] = torch.arange(order.numel(), device=order.device)
+            n_keep = torch.minimum(n_neg, n_pos // 2)
+            keep_neg = neg & (rank < n_keep)
+            wneg = cfg.MT.CLS_BALANCE_WEIGHT if (cfg.MT.HARD_NEG and kind == 0) else 1.0
+            roww = pos.to(torch.float32) + keep_neg.to(torch.float32) * wneg
+            S = (n_pos + n_keep).to(torch.float32)
+        else:
+            roww = torch.ones(labels.shape, device=labels.device)
+            S = torch.tensor(float(labels.numel()), device=labels.device)
+        nc = teacher.shape[2]
+        norm = 1.0 / (S * (3.0 if kind == 0 else float(nc)))
+        losses = [fused.PSMLossFn.apply(cl, teacher, roww, norm, cfg.MT.TEMP, 1 if cfg.MT.SHARPEN else 0, kind)
+                  for cl in class_logits]
+        return torch.mean(torch.stack(losses), dim=0)
+
+
+def make_roi_box_loss_evaluator(cfg):
+    r = cfg.MODEL.ROI_HEADS
+    return FastRCNNLossComputation(Matcher(r.FG_IOU_THRESHOLD, r.BG_IOU_THRESHOLD, allow_low_quality_matches=False),
+                                   BalancedPositiveNegativeSampler(r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION),
+                                   BoxCoder(weights=r.BBOX_REG_WEIGHTS), cfg=cfg)
+
+
+class PostProcessor(nn.Module):
+    """box_head/inference.py:11-145: softmax, decode, clip, per-class score threshold + NMS, keep top-k.
+    All (image, class) NMS problems of the batch go through one `mmt_nms_batched` call."""
+
+    def __init__(self, score_thresh=0.05, nms=0.5, detections_per_img=100, box_coder=None, cfg=None):
+        super().__init__()
+        self.score_thresh, self.nms, self.detections_per_img = score_thresh, nms, detections_per_img
+        self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(10., 10., 5., 5.))
+
+    def forward(self, x, boxes):
+        class_logits, box_regression = x
+        prob = F.softmax(class_logits, -1)
+        per = [len(b) for b in boxes]
+        dev = prob.device
+        cat = torch.cat([b.bbox for b in boxes], 0)
+        dec = self.box_coder.decode(box_regression.reshape(sum(per), -1), cat)
+        nc = prob.shape[1]
+        segs, metas = [], []
+        for pr, bx, b in zip(prob.split(per, 0), dec.split(per, 0), boxes):
+            w, h = b.size
+            lim = torch.tensor([w - 1, h - 1, w - 1, h - 1], dtype=torch.float32, device=dev)
+            bx = torch.minimum(bx.reshape(-1, 4).clamp(min=0), lim).reshape(-1, nc * 4)
+            for j in range(1, nc):
+                sc = pr[:, j]
+                masked = torch.where(sc > self.score_thresh, sc, torch.full_like(sc, -1.0))
+                ss, order = torch.sort(masked, descending=True, stable=True)
+                segs.append((bx[:, j * 4:(j + 1) * 4][order], ss, order))
+                metas.append((b.size, j))
+        n_valid = torch.stack([(s[1] >= 0).sum() for s in segs]).tolist()  # host sync (as the reference's nonzero)
+        bl, offs = [], [0]
+        for s, nv in zip(segs, n_valid):
+            bl.append(s[0][:nv])
+            offs.append(offs[-1] + nv)
+        kmax = max(max(n_valid), 1)
+        keep, cnt = H.nms_batched(torch.cat(bl, 0), torch.tensor(offs, dtype=torch.int32, device=dev), kmax, self.nms)
+        cnts = cnt.tolist()
+        results, si = [], 0
+        for b in boxes:
+            parts = []
+            for j in range(1, nc):
+                bxs, ss, order = segs[si]
+                kp = keep[si, :cnts[si]].long()
+                kp = torch.sort(order[kp])[0]  # `_C.nms` returns ascending ORIGINAL indices (nms_cpu.cpp:64)
+                inv = torch.empty_like(order)
+                inv[order] = torch.arange(order.numel(), device=dev)
+                sel = inv[kp]
+                parts.append((bxs[sel], ss[sel], torch.full((len(kp),), j, dtype=torch.int64, device=dev)))
+                si += 1
+            bb = torch.cat([p[0] for p in parts], 0)
+            sc = torch.cat([p[1] for p in parts], 0)
+            lb = torch.cat([p[2] for p in parts], 0)
+            n = bb.shape[0]
+            if n > self.detections_per_img > 0:
+                thr = torch.kthvalue(sc, n - self.detections_per_img + 1)[0]
+                k = torch.nonzero(sc >= thr).squeeze(1)
+                bb, sc, lb = bb[k], sc[k], lb[k]
+            r = BoxList(bb, b.size, "xyxy")
+            r.add_field("scores", sc)
+            r.add_field("objectness", sc)
+            r.add_field("labels", lb)
+            results.append(r)
+        return results
+
+
+def make_roi_box_post_processor(cfg):
+    r = cfg.MODEL.ROI_HEADS
+    return PostProcessor(r.SCORE_THRESH, r.NMS, r.DETECTIONS_PER_IMG, BoxCoder(weights=r.BBOX_REG_WEIGHTS), cfg=cfg)
+
+
+class ROIBoxHead(nn.Module):
+    def __init__(self, cfg, relation=True):
+        super().__init__()
+        self.feature_extractor = FPN2MLPFeatureExtractor(cfg)
+        self.predictor = FPNPredictor(cfg)
+        self.post_processor = make_roi_box_post_processor(cfg)
+        self.loss_evaluator = make_roi_box_loss_evaluator(cfg)
+        self.cfg = cfg
+        self.mode = None
+
+    def set_teacher_mode(self, mode):
+        self.mode = mode
+
+    def _scale(self, istrain):
+        p = self.feature_extractor.p_drop
+        return 1.0 / (1 - p) if (p > 0 and istrain) else 1.0
+
+    def forward(self, features, proposals, targets=None):
+        if self.training:
+            with torch.no_grad():
+                proposals = self.loss_evaluator.subsample(proposals, targets)
+        x = self.feature_extractor(features, proposals, istrain=self.training)
+        class_logits, box_regression = self.predictor(x, self._scale(self.training))
+        if not self.training:
+            with torch.no_grad():
+                proposals = self.post_processor((class_logits, box_regression), proposals)
+            return x, proposals, {}, class_logits, box_regression
+        lc, lb = self.loss_evaluator([class_logits], [box_regression])
+        return x, proposals, dict(loss_classifier=lc, loss_box_reg=lb), class_logits, box_regression
+
+    def _forward_single(self, proposals, targets, feats_list, istrain=False):
+        if targets is not None:
+            proposals = self.loss_evaluator.subsample(proposals, targets)
+        proposals_b = batch_boxlist_hflip(proposals)
+        feats, logits, regs = [], [], []
+        for i, feat in enumerate(feats_list):
+            x = self.feature_extractor(feat, proposals if i % 2 == 0 else proposals_b, istrain=istrain)
+            cl, br = self.predictor(x, self._scale(istrain))
+            feats.append(x)
+            logits.append(cl)
+            regs.append(br)
+        return feats, logits, regs, proposals
+
+    def forward_teacher(self, feature_tuple, proposals, targets):
+        feats, logits, regs, proposals = self._forward_single(proposals, targets, feature_tuple, istrain=False)
+        return feats, proposals, {}, logits, regs
+
+    def forward_student(self, features, proposals, class_logits_t):
+        _, logits, _, _ = self._forward_single(proposals, targets=None, feats_list=features, istrain=True)
+        if self.cfg.MT.CLS_LOSS > 0:
+            cls_loss = self.loss_evaluator.evaluatePSM(logits, class_logits_t, proposals)
+        else:
+            cls_loss = torch.zeros((1,), device=logits[0].device)
+        return dict(mt_classifier=cls_loss)
+
+
+def build_roi_box_head(cfg, relation=True):
+    return ROIBoxHead(cfg, relation=relation)

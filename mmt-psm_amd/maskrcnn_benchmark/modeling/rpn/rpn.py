@@ -1,0 +1,282 @@
+"""RPN (reference: modeling/rpn/rpn.py:14-221, rpn/inference.py:17-272, rpn/loss.py:22-214).
+
+API kept: RPNModule.forward(images, features, targets) -> (list[BoxList], losses),
+RPNModule.forward_teacher(...), set_teacher_mode, `rpn.head.{conv,cls_logits,bbox_pred}` parameters,
+`rpn.anchor_generator.cell_anchors.*` buffers.
+
+Execution: head = fused 3x3+bias+ReLU conv followed by ONE 1x1 GEMM producing
+objectness and the 4A deltas together (15 channels), all NHWC so the (N,H,W,A[,4]) order the post-processor
+wants is the memory order.  Post-processing is batched over images: per level one top-k / gather / decode /
+clip over the whole batch, then a SINGLE `mmt_nms_batched` launch pair over all (image, level) segments with
+the greedy sweep on the device (the reference does 5*N separate NMS calls each with a D2H mask copy).
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from maskrcnn_benchmark import _hip as H
+from maskrcnn_benchmark.layers import Conv2d, smooth_l1_loss
+from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+from maskrcnn_benchmark.modeling.matcher import Matcher
+from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from maskrcnn_benchmark.structures.bounding_box import BoxList
+from maskrcnn_benchmark.structures.boxlist_ops import box_iou_tensor
+from .anchor_generator import make_anchor_generator
+
+
+class RPNHead(nn.Module):
+    def __init__(self, cfg, in_channels, num_anchors):
+        super().__init__()
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self.cls_logits = Conv2d(in_channels, num_anchors, kernel_size=1, stride=1)
+        self.bbox_pred = Conv2d(in_channels, num_anchors * 4, kernel_size=1, stride=1)
+        for l in (self.conv, self.cls_logits, self.bbox_pred):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+        self.num_anchors = num_anchors
+
+    def forward(self, x):
+        """-> (logits [(N,A,H,W)], bbox_reg [(N,4A,H,W)]) as NHWC-dense views of one 5A-channel tensor"""
+        A = self.num_anchors
+        w = torch.cat([self.cls_logits.weight, self.bbox_pred.weight], 0).contiguous(memory_format=torch.channels_last)
+        b = torch.cat([self.cls_logits.bias, self.bbox_pred.bias], 0)
+        logits, regs = [], []
+        from maskrcnn_benchmark.layers import fused
+        for f in x:
+            t = self.conv(f, relu=True)
+            o = fused.conv(t, w, b, 1, 0, False, True)
+            logits.append(o[:, :A])
+            regs.append(o[:, A:])
+        return logits, regs
+
+
+def _flat(obj, reg):
+    """(N,A,H,W),(N,4A,H,W) NHWC-dense views -> (N, HWA), (N, HWA, 4) without copies when possible"""
+    N, A, Hh, Ww = obj.shape
+    return obj.permute(0, 2, 3, 1).reshape(N, -1), reg.permute(0, 2, 3, 1).reshape(N, -1, 4)
+
+
+class RPNPostProcessor(nn.Module):
+    def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder=None, fpn_post_nms_top_n=None,
+                 is_teacher=False):
+        super().__init__()
+        self.pre_nms_top_n, self.post_nms_top_n = pre_nms_top_n, post_nms_top_n
+        self.nms_thresh, self.min_size = nms_thresh, min_size
+        self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
+        self.is_teacher = is_teacher
+
+    def forward(self, anchors, objectness, box_regression, targets=None):
+        """anchors: list[image] of list[level] BoxList -> list[BoxList] (rpn/inference.py:139-172)"""
+        N, L = len(anchors), len(objectness)
+        dev = objectness[0].device
+        sizes = [a[0].size for a in anchors]  # (W,H) per image
+        lim = torch.tensor([[s[0] - 1, s[1] - 1, s[0] - 1, s[1] - 1] for s in sizes], dtype=torch.float32, device=dev)
+        cand_box, cand_score, cand_extra, ks = [], [], [], []
+        for lvl in range(L):
+            o, r = _flat(objectness[lvl].detach(), box_regression[lvl].detach())
+            o = o.sigmoid()
+            k = min(self.pre_nms_top_n, o.shape[1])
+            sc, idx = o.topk(k, dim=1, sorted=True)
+            r = torch.gather(r, 1, idx[:, :, None].expand(-1, -1, 4))
+            anc = anchors[0][lvl].bbox[idx.reshape(-1)].view(N, k, 4)  # same grid for every image
+            props = self.box_coder.decode(r.reshape(-1, 4), anc.reshape(-1, 4)).view(N, k, 4)
+            props = torch.minimum(props.clamp(min=0), lim[:, None, :])  # clip_to_image(remove_empty=False)
+            if self.min_size > 0:
+                ws = props[..., 2] - props[..., 0] + 1
+                hs = props[..., 3] - props[..., 1] + 1
+                sc = torch.where((ws >= self.min_size) & (hs >= self.min_size), sc, torch.full_like(sc, -1.0))
+            cand_box.append(props)
+            cand_score.append(sc)
+            cand_extra.append((r, idx, lvl))
+            ks.append(k)
+        kmax = max(ks)
+        # one batched NMS over all (image, level) segments, image-major so that per-image lists are contiguous
+        boxes = torch.cat([torch.cat([cand_box[l][n] for l in range(L)], 0) for n in range(N)], 0)
+        scores = torch.cat([torch.cat([cand_score[l][n] for l in range(L)], 0) for n in range(N)], 0)
+        per_img = sum(ks)
+        offs = [0]
+        for n in range(N):
+            for l in range(L):
+                offs.append(offs[-1] + ks[l])
+        seg_off = torch.tensor(offs, dtype=torch.int32, device=dev)
+        keep, cnt = H.nms_batched(boxes, seg_off, kmax, self.nms_thresh)
+        if self.post_nms_top_n > 0:
+            cnt = cnt.clamp(max=self.post_nms_top_n)
+        total = N * per_img
+        pos = seg_off[:-1, None].long() + keep.long()
+        valid = torch.arange(kmax, device=dev)[None, :] < cnt[:, None]
+        kept = torch.zeros(total + 1, dtype=torch.bool, device=dev)
+        kept[torch.where(valid, pos, torch.full_like(pos, total)).reshape(-1)] = True
+        kept = kept[:total] & (scores >= 0)
+        training = self.training
+        if L > 1:
+            masked = torch.where(kept, scores, torch.full_like(scores, -1.0))
+            if training:  # one top-k over the whole batch (rpn/inference.py:223-234)
+                k = min(self.fpn_post_nms_top_n, total)
+                _, top = masked.topk(k, sorted=True)
+                sel = torch.zeros(total, dtype=torch.bool, device=dev)
+                sel[top] = True
+                kept = kept & sel
+                order = None
+            else:  # per image top-k, score-sorted (rpn/inference.py:235-242)
+                k = min(self.fpn_post_nms_top_n, per_img)
+                tv, top = masked.view(N, per_img).topk(k, dim=1, sorted=True)
+                order = (top, tv >= 0)
+        else:
+            order = None
+        extra = None
+        if self.is_teacher:
+            extra = {
+                "box_reg": torch.cat([torch.cat([cand_extra[l][0][n] for l in range(L)], 0) for n in range(N)], 0),
+                "rpn_topk": torch.cat([torch.cat([cand_extra[l][1][n] for l in range(L)], 0) for n in range(N)], 0),
+                "rpn_ancher_level": torch.cat([torch.cat([torch.full((ks[l],), l, dtype=torch.int64, device=dev)
+                                                          for l in range(L)], 0) for n in range(N)], 0),
+            }
+        out = []
+        if order is None:
+            counts = kept.view(N, per_img).sum(1).tolist()  # the one host sync of the proposal pipeline
+            idx_all = kept.nonzero().squeeze(1)
+            st = 0
+            for n in range(N):
+                ii = idx_all[st:st + counts[n]]
+                st += counts[n]
+                out.append(self._boxlist(boxes, scores, extra, ii, sizes[n]))
+        else:
+            top, ok = order
+            counts = ok.sum(1).tolist()
+            for n in range(N):
+                ii = top[n, :counts[n]] + n * per_img
+                out.append(self._boxlist(boxes, scores, extra, ii, sizes[n]))
+        if training and targets is not None:  # add_gt_proposals (rpn/inference.py:55-76)
+            res = []
+            for b, t in zip(out, targets):
+                g = BoxList(torch.cat([b.bbox, t.bbox.to(dev)], 0), b.size, "xyxy")
+                g.add_field("objectness", torch.cat([b.get_field("objectness"), torch.ones(len(t), device=dev)], 0))
+                res.append(g)
+            out = res
+        return out
+
+    @staticmethod
+    def _boxlist(boxes, scores, extra, ii, size):
+        b = BoxList(boxes[ii], size, "xyxy")
+        b.add_field("objectness", scores[ii])
+        if extra is not None:
+            for k, v in extra.items():
+                b.add_field(k, v[ii])
+        return b
+
+
+def make_rpn_postprocessor(config, rpn_box_coder, is_train, is_teacher=False):
+    r = config.MODEL.RPN
+    return RPNPostProcessor(
+        pre_nms_top_n=r.PRE_NMS_TOP_N_TRAIN if is_train else r.PRE_NMS_TOP_N_TEST,
+        post_nms_top_n=r.POST_NMS_TOP_N_TRAIN if is_train else r.POST_NMS_TOP_N_TEST,
+        nms_thresh=r.NMS_THRESH, min_size=r.MIN_SIZE, box_coder=rpn_box_coder,
+        fpn_post_nms_top_n=r.FPN_POST_NMS_TOP_N_TRAIN if is_train else r.FPN_POST_NMS_TOP_N_TEST,
+        is_teacher=is_teacher)
+
+
+class RPNLossComputation(object):
+    def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, cfg=None):
+        self.proposal_matcher, self.fg_bg_sampler, self.box_coder = proposal_matcher, fg_bg_sampler, box_coder
+
+    def prepare_targets(self, anchors, targets):
+        """anchors: list[image] of (bbox (A,4), visibility (A,), area (A,)) ; rpn/loss.py:56-83"""
+        labels, regs = [], []
+        for (ab, vis, aarea), t in zip(anchors, targets):
+            tb = t.bbox.to(ab.device)
+            m = self.proposal_matcher(box_iou_tensor(tb, t.area().to(ab.device), ab, aarea))
+            lab = (m >= 0).to(torch.float32)
+            lab = torch.where(vis, lab, torch.full_like(lab, -1.0))
+            lab = torch.where(m == Matcher.BETWEEN_THRESHOLDS, torch.full_like(lab, -1.0), lab)
+            labels.append(lab)
+            regs.append(self.box_coder.encode(tb[m.clamp(min=0)], ab))
+        return labels, regs
+
+    @staticmethod
+    def _cat_anchors(anchors):
+        out = []
+        for per_img in anchors:
+            b = torch.cat([a.bbox for a in per_img], 0)
+            v = torch.cat([a.get_field("visibility") for a in per_img], 0)
+            out.append((b, v, (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)))
+        return out
+
+    def teacher_sample_selection(self, anchors, objectness, box_regression, targets):
+        """rpn/loss.py:85-136 -- its outputs are unused downstream (generalized_rcnn.py:146-148); only the RNG
+        draw matters for seed-for-seed parity, so the device sampler is exercised and nothing else."""
+        labels, _ = self.prepare_targets(self._cat_anchors(anchors), targets)
+        self.fg_bg_sampler(labels, tag="teacher_rpn_sampler")
+
+    def __call__(self, anchors, objectness, box_regression, targets):
+        labels, regt = self.prepare_targets(self._cat_anchors(anchors), targets)
+        pos, neg = self.fg_bg_sampler(labels, tag="rpn_sampler")
+        pos, neg = torch.cat(pos, 0), torch.cat(neg, 0)
+        of, rf = [], []
+        for o, r in zip(objectness, box_regression):
+            o2, r2 = _flat(o, r)
+            of.append(o2)
+            rf.append(r2)
+        obj = torch.cat(of, 1).reshape(-1)
+        reg = torch.cat(rf, 1).reshape(-1, 4)
+        labels, regt = torch.cat(labels, 0), torch.cat(regt, 0)
+        samp = pos | neg
+        n_samp = samp.sum().clamp(min=1).to(torch.float32)
+        posf = pos.to(torch.float32)
+        # masked sums instead of boolean gathers: same values, no device->host sync (rpn/loss.py:183-194)
+        d = torch.abs(reg - regt)
+        beta = 1.0 / 9
+        sl1 = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
+        box_loss = (sl1 * posf[:, None]).sum() / n_samp
+        bce = F.binary_cross_entropy_with_logits(obj, labels.clamp(min=0), reduction="none")
+        obj_loss = (bce * samp.to(torch.float32)).sum() / n_samp
+        return obj_loss, box_loss
+
+
+def make_rpn_loss_evaluator(cfg, box_coder):
+    r = cfg.MODEL.RPN
+    return RPNLossComputation(Matcher(r.FG_IOU_THRESHOLD, r.BG_IOU_THRESHOLD, allow_low_quality_matches=True),
+                              BalancedPositiveNegativeSampler(r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION),
+                              box_coder, cfg)
+
+
+class RPNModule(nn.Module):
+    def __init__(self, cfg, is_teacher=False):
+        super().__init__()
+        self.mode = None
+        self.cfg = cfg.clone()
+        self.anchor_generator = make_anchor_generator(cfg)
+        self.head = RPNHead(cfg, cfg.MODEL.BACKBONE.OUT_CHANNELS, self.anchor_generator.num_anchors_per_location()[0])
+        coder = BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self.box_selector_train = make_rpn_postprocessor(cfg, coder, is_train=True, is_teacher=is_teacher)
+        self.box_selector_test = make_rpn_postprocessor(cfg, coder, is_train=False, is_teacher=is_teacher)
+        self.loss_evaluator = make_rpn_loss_evaluator(cfg, coder)
+
+    def set_teacher_mode(self, mode):
+        self.mode = mode
+
+    def forward(self, images, features, targets=None):
+        objectness, rpn_box_regression = self.head(features)
+        anchors = self.anchor_generator(images, features)
+        if self.training or self.mode == "train":
+            with torch.no_grad():
+                boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
+            lo, lb = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
+            return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}
+        with torch.no_grad():
+            boxes = self.box_selector_test(anchors, objectness, rpn_box_regression)
+        return boxes, {}
+
+    def forward_teacher(self, images, features, targets=None):
+        """rpn/rpn.py:146-177 (single pyramid branch; FFI imitation boxes are a compared method, off)"""
+        objectness, rpn_box_regression = self.head(features)
+        anchors = self.anchor_generator(images, features)
+        with torch.no_grad():
+            boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
+            self.loss_evaluator.teacher_sample_selection(anchors, objectness, rpn_box_regression, targets)
+        return None, None, None, None, boxes, {}, None
+
+
+def build_rpn(cfg, is_teacher=False):
+    return RPNModule(cfg, is_teacher=is_teacher)

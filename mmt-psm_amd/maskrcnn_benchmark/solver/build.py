@@ -1,0 +1,77 @@
+"""Optimiser / schedule (reference: solver/build.py:5-34, solver/lr_scheduler.py:10-53).
+
+Same arithmetic as torch.optim.SGD with one parameter group per tensor (bias: lr x BIAS_LR_FACTOR, no weight
+decay), but executed as two launches of `mmt_sgd_momentum` over a model's FLAT parameter storage
+(engine/flat.py): [trainable weights | trainable biases | frozen]."""
+from bisect import bisect_right
+
+from maskrcnn_benchmark import _hip as H
+
+
+class FlatSGD(object):
+    def __init__(self, flat, base_lr, momentum, weight_decay, bias_lr_factor, weight_decay_bias):
+        self.flat = flat
+        self.base_lr, self.momentum = base_lr, momentum
+        self.weight_decay, self.bias_lr_factor, self.weight_decay_bias = weight_decay, bias_lr_factor, weight_decay_bias
+        self.lr_factor = 1.0
+        self.steps = 0
+        # mirrors torch's param_groups enough for the trainer's logging line (MTtrainer.py:217)
+        self.param_groups = [{"lr": base_lr}]
+
+    def zero_grad(self):
+        self.flat.grad.zero_()
+
+    def step(self):
+        f = self.flat
+        first = self.steps == 0
+        lr = self.base_lr * self.lr_factor
+        nw, nb = f.n_weights, f.n_biases
+        if nw:
+            H.sgd_momentum(f.data[:nw], f.grad[:nw], f.momentum[:nw], lr, self.weight_decay, self.momentum, first)
+        if nb:
+            H.sgd_momentum(f.data[nw:nw + nb], f.grad[nw:nw + nb], f.momentum[nw:nw + nb], lr * self.bias_lr_factor,
+                           self.weight_decay_bias, self.momentum, first)
+        self.steps += 1
+        self.param_groups[0]["lr"] = lr
+
+
+class WarmupMultiStepLR(object):
+    """lr_scheduler.py:10-53 (get_lr formula), driving FlatSGD.lr_factor"""
+
+    def __init__(self, optimizer, milestones, gamma=0.1, warmup_factor=1.0 / 3, warmup_iters=500,
+                 warmup_method="linear", last_epoch=-1):
+        if list(milestones) != sorted(milestones):
+            raise ValueError("Milestones should be a list of increasing integers. Got {}".format(milestones))
+        if warmup_method not in ("constant", "linear"):
+            raise ValueError("Only 'constant' or 'linear' warmup_method accepted, got {}".format(warmup_method))
+        self.optimizer, self.milestones, self.gamma = optimizer, list(milestones), gamma
+        self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
+        self.last_epoch = last_epoch
+        self.step()
+
+    def factor(self):
+        w = 1
+        if self.last_epoch < self.warmup_iters:
+            if self.warmup_method == "constant":
+                w = self.warmup_factor
+            else:
+                a = self.last_epoch / self.warmup_iters
+                w = self.warmup_factor * (1 - a) + a
+        return w * self.gamma ** bisect_right(self.milestones, self.last_epoch)
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.lr_factor = self.factor()
+
+
+def make_optimizer(cfg, model):
+    from maskrcnn_benchmark.engine.flat import flatten_model
+    flat = flatten_model(model)
+    s = cfg.SOLVER
+    return FlatSGD(flat, s.BASE_LR, s.MOMENTUM, s.WEIGHT_DECAY, s.BIAS_LR_FACTOR, s.WEIGHT_DECAY_BIAS)
+
+
+def make_lr_scheduler(cfg, optimizer):
+    s = cfg.SOLVER
+    return WarmupMultiStepLR(optimizer, s.STEPS, s.GAMMA, warmup_factor=s.WARMUP_FACTOR, warmup_iters=s.WARMUP_ITERS,
+                             warmup_method=s.WARMUP_METHOD)

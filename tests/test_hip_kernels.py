@@ -314,7 +314,8 @@ def test_polygon_targets_golden(hip):
     g = gold("masks")
     lens = g["proj_polylens"]
     poly_off = np.concatenate([[0], np.cumsum(lens // 2)]).astype(np.int32)
-    roi_poly = np.concatenate([[0], np.cumsum(g["proj_npoly"])]).astype(np.int32)
+    ends = np.cumsum(g["proj_npoly"])
+    roi_poly = np.stack([ends - g["proj_npoly"], ends], 1).astype(np.int32)
     out, ovf = hip.polygon_targets(T(g["proj_polys"]).cuda(), T(poly_off).cuda(), T(roi_poly).cuda(),
                                    T(g["proj_boxes"]).cuda(), 28)
     assert int(ovf) == 0
