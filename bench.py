@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Benchmark of the MMT-PSM mean-teacher step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full iteration of engine/MTtrainer.py on ONE per-GPU batch of synthetic crops already resident
+in HBM: [A] supervised student forward on 2 labeled 1000x1000 crops, [B] teacher.forward_teacher on 2 unlabeled
+crops x AUG_K=2 views x flip (+ coarse inference), [C] student.forward_student on the AUG_S=1 view (MGD + PSM),
+[D] weighted loss, backward, (RCCL all-reduce of the flat student gradient when N > 1), SGD, [E] EMA teacher.
+img = one source crop consumed per step (2 labeled + 2 unlabeled = 4 per GPU per step); weak scaling.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: conv_fwd_kernel<128,128,2,2>, fp32 MFMA) and
+`cpu_baseline` (the CPU oracle timed on this node's host cores on a bounded sample; baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mmt-psm_amd"))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+CROP = 1000
+N_LAB, N_UNLAB, N_INST = 2, 2, 12
+
+
+def build(device, rank):
+    import synthetic
+    from maskrcnn_benchmark.config import make_default_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    from maskrcnn_benchmark.solver import make_optimizer, make_lr_scheduler
+    from maskrcnn_benchmark.engine.MTtrainer import MTtrainer, init_teacher_weight
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+
+    cfg = make_default_cfg()
+    torch.manual_seed(0)
+    student = build_detection_model(cfg, is_student=True)
+    teacher = build_detection_model(cfg, is_teacher=True)
+    shapes = {k: tuple(v.shape) for k, v in student.state_dict().items()}
+    sd = synthetic.make_weights(shapes, seed=0)  # identical on every rank (DP replicas start equal)
+    student.load_state_dict(sd, strict=False)
+    teacher.load_state_dict(sd, strict=False)
+    student.to(device)
+    teacher.to(device)
+    student.train()
+    teacher.eval()
+    opt = make_optimizer(cfg, student)
+    sched = make_lr_scheduler(cfg, opt)
+    loaders = {"source": [None] * cfg.SOLVER.MAX_ITER, "no_label": None}
+    trainer = MTtrainer(student, teacher, loaders, opt, sched, None, None, 10 ** 9, cfg)
+    init_teacher_weight(student, teacher)
+
+    imgs, tgs = synthetic.make_labeled(N_LAB, CROP, N_INST, seed=1234 + rank)
+    unl = synthetic.make_unlabeled(N_UNLAB, CROP, cfg.MT.AUG_K + cfg.MT.AUG_S, seed=4321 + rank)
+    targets = []
+    for t in tgs:
+        b = BoxList(t["boxes"].to(device), t["size"], "xyxy")
+        b.add_field("labels", t["labels"].to(device))
+        b.add_field("masks", SegmentationMask([[p for p in inst] for inst in t["polys"]], t["size"], mode="poly"))
+        targets.append(b)
+    imgs = imgs.to(device)
+    unl = [u.to(device) for u in unl]
+
+    def batch():
+        # what the collators hand over (data/collate_batch.py:5-77): zero-padded to /32; hflip() mutates the
+        # teacher ImageLists in place, so they are rebuilt from the resident crops every step
+        return (to_image_list(list(imgs), cfg.DATALOADER.SIZE_DIVISIBILITY), targets,
+                [to_image_list(list(u), cfg.DATALOADER.SIZE_DIVISIBILITY) for u in unl])
+
+    return cfg, trainer, batch
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement pinned to the reference, oracle/model.py) on a bounded sample: ONE full step
+    (A-E) on 1 labeled + 1 unlabeled 1000x1000 crop = half a per-GPU batch.  Baseline only."""
+    import synthetic
+    from oracle import model as om
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = om.default_cfg()
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "state_shapes.json")))["shapes"]
+    trainable = set(json.load(open(os.path.join(ROOT, "tests", "golden", "state_shapes.json")))["trainable"])
+    sd = synthetic.make_weights(shapes, seed=0)
+    sd = {k: v.requires_grad_(k in trainable) for k, v in sd.items()}
+    tsd = {k: v.detach().clone() for k, v in sd.items()}
+    imgs, tgs = synthetic.make_labeled(1, CROP, N_INST, seed=1234)
+    unl = synthetic.make_unlabeled(1, CROP, 3, seed=4321)
+    targets = [om.Boxes(t["boxes"], t["size"], {"labels": t["labels"], "masks": t["polys"]}) for t in tgs]
+    torch.manual_seed(0)
+    t0 = time.time()
+    ld = om.forward_supervised(sd, ocfg, imgs, targets)
+    tr = om.forward_teacher(tsd, ocfg, unl[:2])
+    ld.update(om.forward_student(sd, ocfg, unl[-1:], tr))
+    ld = om.weight_sum_losses(ocfg, ld, 1100, 7000)
+    sum(ld.values()).backward()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if v.grad is not None:
+                v.add_(v.grad, alpha=-0.005)
+        om.ema_update([tsd[k] for k in sd if sd[k].dtype == torch.float32 and k in trainable],
+                      [sd[k].detach() for k in sd if sd[k].dtype == torch.float32 and k in trainable], 0.99)
+    dt = time.time() - t0
+    return {"value": round(2.0 / dt, 5), "unit": "imgs/sec", "cores": cores, "kind": "port",
+            "sample": "1 full MT step (sup fwd, teacher K=2xflip, student MGD+PSM, bwd, SGD, EMA) on 1 labeled + 1 "
+                      "unlabeled 1000x1000 crop (half a per-GPU batch), fp32, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    from maskrcnn_benchmark import _hip
+    _hip.lib()
+    cfg, trainer, batch = build(device, rank)
+    it0 = cfg.MT.START_MT + cfg.MT.RAMPUP_STEP + 100  # mean-teacher branch active, consistency weight = lambda
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(i):
+        il, targets, ul = batch()
+        return trainer.train_step(it0 + i, il, targets, ul)
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    _hip.PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    prof, _hip.PROFILE = _hip.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        imgs_per_step = (N_LAB + N_UNLAB) * world
+        value = imgs_per_step * args.steps / dt
+        flops = sum(p[0] for p in prof)
+        ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out = {
+            "metric": "imgs/sec (student+teacher step, 1000x1000, AUG_K=2)",
+            "value": round(value, 4), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MMT-PSM mean-teacher step (BASELINE configs[2]; configs[3] when n_gpus>1): per GPU 2 "
+                                   "labeled + 2 unlabeled 1000x1000x3 crops, AUG_K=2 + flip, AUG_S=1, MT.LAMBDA 5, "
+                                   "PSM+MGD, EMA teacher, fwd+bwd+SGD, R50-FPN fp32, IR-Net off",
+                       "image_forwards_per_step_per_gpu": 14, "parallelism": "dp%d" % world,
+                       "losses": {k: round(float(v), 5) for k, v in losses.items()}},
+            "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": len(prof) // max(args.steps, 1),
+                         "avg_launch_ms": round(ms / max(len(prof), 1), 4),
+                         "share_of_step_time": round(ms / (dt * 1e3), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

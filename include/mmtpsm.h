@@ -89,6 +89,9 @@ typedef struct {
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
+/* which tile configuration mmt_conv_forward picks for these shapes: 0 = 128x32, 1 = 128x128 (the dominant
+ * kernel of the step, conv_fwd_kernel<128,128,2,2>), 2 = 64x64.  Used by bench.py for the roofline line. */
+int mmt_conv_variant(const mmt_conv_args* a /*[host]*/);
 
 /* weight gradient: dw[co,kh,kw,ci] += rowscale[co] * sum_{n,ho,wo} dy[n,ho,wo,co] * x[n,ho*s+kh-p,wo*s+kw-p,ci]
  * accumulated with fp32 atomics into dw (the caller's flat gradient buffer); optional

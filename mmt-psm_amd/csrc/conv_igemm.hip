@@ -454,6 +454,21 @@ int launch_fwd(const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
+static int pick_variant(const ConvP& p) {
+  if (p.Cout <= 32) return 0;
+  // enough 128x128 tiles to fill 256 CUs twice, else go to 64x64 tiles (4x the blocks)
+  const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
+  if (t128 >= 384 && p.Cout > 64) return 1;
+  return 2;
+}
+
+extern "C" int mmt_conv_variant(const mmt_conv_args* a) {
+  ConvP p;
+  int e = fill(p, a);
+  if (e) return e;
+  return pick_variant(p);
+}
+
 extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   ConvP p;
   int e = fill(p, a);
@@ -461,11 +476,11 @@ extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   if (!p.w || !p.y) return MMT_EINVAL;
   if (p.M == 0 || p.Cout == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (p.Cout <= 32) return launch_fwd<128, 32, 4, 1>(p, s);
-  // enough 128x128 tiles to fill 256 CUs twice, else go to 64x64 tiles (4x the blocks)
-  const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
-  if (t128 >= 384 && p.Cout > 64) return launch_fwd<128, 128, 2, 2>(p, s);
-  return launch_fwd<64, 64, 2, 2>(p, s);
+  switch (pick_variant(p)) {
+    case 0: return launch_fwd<128, 32, 4, 1>(p, s);
+    case 1: return launch_fwd<128, 128, 2, 2>(p, s);
+    default: return launch_fwd<64, 64, 2, 2>(p, s);
+  }
 }
 
 extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const float* rowscale, float* dw,

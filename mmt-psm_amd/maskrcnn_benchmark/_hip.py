@@ -39,6 +39,7 @@ _SIGS = {
     "mmt_roi_align_backward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_nms_batched": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_conv_forward": [ctypes.POINTER(ConvArgs), c_void_p],
+    "mmt_conv_variant": [ctypes.POINTER(ConvArgs)],
     "mmt_conv_wgrad": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_colsum": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "mmt_weight_flip_transpose": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
@@ -56,6 +57,9 @@ _SIGS = {
 }
 
 _lib = None
+# bench.py sets this to a list: every launch of the dominant conv kernel (128x128 tiles) is then bracketed by a pair
+# of events on the launch stream and recorded as (algorithmic FLOPs, start, stop)
+PROFILE = None
 
 
 def lib():
@@ -218,6 +222,13 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
+    if PROFILE is not None and lib().mmt_conv_variant(ctypes.byref(a)) == 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
+        e1.record()
+        PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1))
+        return y
     _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
     return y
 
