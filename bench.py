@@ -85,7 +85,9 @@ def cpu_baseline():
     (A-E) on 1 labeled + 1 unlabeled 1000x1000 crop = half a per-GPU batch.  Baseline only."""
     import synthetic
     from oracle import model as om
-    cores = os.cpu_count() or 1
+    # intra-op threads are capped: on a 256-core host torch/oneDNN with 256 threads is ~20x SLOWER on these shapes
+    # (measured: 775 s vs ~40 s); `cores` in the JSON is the thread count actually used
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     ocfg = om.default_cfg()
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "state_shapes.json")))["shapes"]
@@ -158,7 +160,7 @@ def main():
         losses = step(args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    prof, _hip.PROFILE = _hip.PROFILE, None
+    prof, _hip.PROFILE = [p for p in _hip.PROFILE if p[3][0] == 'fwd1'], None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -206,42 +206,86 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
     __syncthreads();
   }
 
-  // ---- epilogue
-  const int col_l = lane & 31, rq = lane >> 5;
+  // ---- epilogue: accumulators -> LDS (the operand ring is free now) -> row-major float4 rows, so that stores,
+  // residual / mask / mul loads are all 16 B per lane and fully coalesced (a 128-wide tile row = 512 B), and the
+  // (img,ho,wo) decode is per row instead of per element.  Matters for the low-K 1x1 layers, which are
+  // store-bound: their whole runtime is this epilogue.
+  {
+    float* ct = lds;  // [BM][BN]
+    const int col_l = lane & 31, rq = lane >> 5;
 #pragma unroll
-  for (int b = 0; b < TN; b++) {
-    const int c = n0 + (wn * TN + b) * 32 + col_l;
-    if (c >= p.Cout) continue;
-    const float sc = p.scale ? p.scale[c] : 1.f;
-    const float sh = p.shift ? p.shift[c] : 0.f;
+    for (int a = 0; a < TM; a++)
 #pragma unroll
-    for (int a = 0; a < TM; a++) {
+      for (int b = 0; b < TN; b++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+        for (int r = 0; r < 16; r++) {
+          const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+          ct[row * BN + (wn * TN + b) * 32 + col_l] = acc[a][b][r];
+        }
+    __syncthreads();
+    constexpr int C4 = BN / 4, RPP = 256 / C4;
+    const int cc = tid % C4, r0 = tid / C4;
+    const int c = n0 + cc * 4;
+    if (c < p.Cout) {
+      const bool vec = (p.Cout & 3) == 0;
+      const int nv = vec ? 4 : min(4, p.Cout - c);
+      float sc[4], sh[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        sc[e] = (p.scale && e < nv) ? p.scale[c + e] : 1.f;
+        sh[e] = (p.shift && e < nv) ? p.shift[c + e] : 0.f;
+      }
+      auto ld = [&](const float* q, float* o) {
+        if (vec) { const f32x4 t = ldg4(q); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
+        else { for (int e = 0; e < 4; e++) o[e] = e < nv ? q[e] : 0.f; }
+      };
+      for (int row = r0; row < BM; row += RPP) {
         const int m = m0 + row;
-        if (m >= p.M) continue;
-        float v = acc[a][b][r] * sc + sh;
+        if (m >= p.M) break;
+        const f32x4 t = *(const f32x4*)(ct + row * BN + cc * 4);
+        float v[4] = {t[0] * sc[0] + sh[0], t[1] * sc[1] + sh[1], t[2] * sc[2] + sh[2], t[3] * sc[3] + sh[3]};
         long oidx = (long)m * p.Cout + c;
+        float u[4];
         if (p.res_mode >= 2 || p.out_stride > 1) {
           const int img = m / HoWo, rem = m - img * HoWo;
           const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
           if (p.res_mode == 2) {
             const int h2 = p.Ho >> 1, w2 = p.Wo >> 1;
-            v += p.res[(((long)img * h2 + (ho >> 1)) * w2 + (wo >> 1)) * p.Cout + c];
+            ld(p.res + (((long)img * h2 + (ho >> 1)) * w2 + (wo >> 1)) * p.Cout + c, u);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += u[e];
           } else if (p.res_mode == 3) {
             const int h2 = p.Ho * 2, w2 = p.Wo * 2;
             const float* rp = p.res + (((long)img * h2 + 2 * ho) * w2 + 2 * wo) * p.Cout + c;
-            v += (rp[0] + rp[p.Cout]) + (rp[(long)w2 * p.Cout] + rp[(long)w2 * p.Cout + p.Cout]);
+            float u1[4], u2[4], u3[4];
+            ld(rp, u); ld(rp + p.Cout, u1); ld(rp + (long)w2 * p.Cout, u2); ld(rp + (long)w2 * p.Cout + p.Cout, u3);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += (u[e] + u1[e]) + (u2[e] + u3[e]);
           }
           if (p.out_stride > 1)
             oidx = (((long)img * p.out_H + ho * p.out_stride) * p.out_W + wo * p.out_stride) * p.Cout + c;
         }
-        if (p.res_mode == 1) v += p.res[(long)m * p.Cout + c];
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.mask) v = p.mask[oidx] > 0.f ? v * p.mask_scale : 0.f;
-        if (p.mul) v *= p.mul[(long)m * p.Cout + c];
-        p.y[oidx] = v;
+        if (p.res_mode == 1) {
+          ld(p.res + (long)m * p.Cout + c, u);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += u[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.mask) {
+          ld(p.mask + oidx, u);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = u[e] > 0.f ? v[e] * p.mask_scale : 0.f;
+        }
+        if (p.mul) {
+          ld(p.mul + (long)m * p.Cout + c, u);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] *= u[e];
+        }
+        if (vec) *(f32x4*)(p.y + oidx) = f32x4{v[0], v[1], v[2], v[3]};
+        else for (int e = 0; e < nv; e++) p.y[oidx + e] = v[e];
       }
     }
   }
@@ -290,6 +334,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvP p, const fl
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   f32x4 ra[4], rb[4];
+  // (img, ho, wo) of this thread's 4 rows, advanced by 32 rows per tile with carries instead of divisions
+  int r_img[4], r_ho[4], r_wo[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int m = ms + kr + 8 * j;
+    r_img[j] = m / HoWo;
+    const int rem = m - r_img[j] * HoWo;
+    r_ho[j] = rem / p.Wo;
+    r_wo[j] = rem - r_ho[j] * p.Wo;
+  }
+  const bool inc_ok = p.Wo >= 8;
   auto load_tile = [&](int mt) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -307,13 +362,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvP p, const fl
       ra[j] = v;
       f32x4 u = {0.f, 0.f, 0.f, 0.f};
       if (mok && bcol_ok) {
-        const int img = m / HoWo, rem = m - img * HoWo;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        int img, ho, wo;
+        if (inc_ok) { img = r_img[j]; ho = r_ho[j]; wo = r_wo[j]; }
+        else { img = m / HoWo; const int rem = m - img * HoWo; ho = rem / p.Wo; wo = rem - ho * p.Wo; }
         const int ih = ho * p.stride - p.pad + bkh, iw = wo * p.stride - p.pad + bkw;
         if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
           u = ldg4(p.x + (((long)img * p.H + ih) * p.W + iw) * p.Cin + bci);
       }
       rb[j] = u;
+      if (inc_ok) {
+        r_wo[j] += 32;
+        while (r_wo[j] >= p.Wo) { r_wo[j] -= p.Wo; r_ho[j]++; }
+        while (r_ho[j] >= p.Ho) { r_ho[j] -= p.Ho; r_img[j]++; }
+      }
     }
   };
   auto store_tile = [&](int buf) {

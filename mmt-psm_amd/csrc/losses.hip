@@ -143,27 +143,33 @@ extern "C" int mmt_mgd_level_backward(const float* s, const mmt_mgd_teachers* T,
 
 __global__ __launch_bounds__(256) void mask_pool_kernel(const int* __restrict__ seg, int N, int IH, int IW, int H,
                                                         int W, float* __restrict__ m) {
+  // one wave per output pixel, lanes sweep the pooling window; the sum of small integers is exact in fp32 in any
+  // order, so this equals adaptive_avg_pool2d's sequential sum bit for bit
   const long total = (long)N * H * W;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  const int lane = threadIdx.x & 63;
+  for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (long)gridDim.x * 4) {
     const int w = (int)(i % W);
     const int h = (int)((i / W) % H);
     const int n = (int)(i / ((long)W * H));
     // adaptive pooling window: [floor(h*IH/H), ceil((h+1)*IH/H))
     const int h0 = (int)(((long)h * IH) / H), h1 = (int)((((long)h + 1) * IH + H - 1) / H);
     const int w0 = (int)(((long)w * IW) / W), w1 = (int)((((long)w + 1) * IW + W - 1) / W);
+    const int ww = w1 - w0, cnt = (h1 - h0) * ww;
     float sum = 0.f;
-    for (int y = h0; y < h1; y++)
-      for (int x = w0; x < w1; x++) sum += (float)seg[((long)n * IH + y) * IW + x];
-    const float avg = sum / (float)((h1 - h0) * (w1 - w0));
-    m[i] = avg > 0.5f ? 1.f : 0.f;
+    for (int k = lane; k < cnt; k += 64) {
+      const int y = h0 + k / ww, x = w0 + k % ww;
+      sum += (float)seg[((long)n * IH + y) * IW + x];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) m[i] = (sum / (float)cnt) > 0.5f ? 1.f : 0.f;
   }
 }
 
 extern "C" int mmt_mask_pool(const int32_t* seg, int N, int IH, int IW, int H, int W, float* m, void* stream) {
   const long total = (long)N * H * W;
   if (total == 0) return 0;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (int)((total + 3) / 4);
+  if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(mask_pool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, seg, N, IH, IW, H, W, m);
   MMT_LAUNCH_CHECK();
   return 0;

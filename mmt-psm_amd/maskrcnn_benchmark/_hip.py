@@ -58,8 +58,10 @@ _SIGS = {
 
 _lib = None
 # bench.py sets this to a list: every launch of the dominant conv kernel (128x128 tiles) is then bracketed by a pair
-# of events on the launch stream and recorded as (algorithmic FLOPs, start, stop)
+# of events on the launch stream and recorded as (algorithmic FLOPs, start, stop, shape key).  PROFILE_ALL (tuning
+# tool only) extends that to every conv / wgrad launch.
 PROFILE = None
+PROFILE_ALL = False
 
 
 def lib():
@@ -222,13 +224,16 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
-    if PROFILE is not None and lib().mmt_conv_variant(ctypes.byref(a)) == 1:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
-        e1.record()
-        PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1))
-        return y
+    if PROFILE is not None:
+        var = lib().mmt_conv_variant(ctypes.byref(a))
+        if var == 1 or PROFILE_ALL:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
+            e1.record()
+            PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1,
+                            ("fwd%d" % var, N, H, W, Cin, Cout, KH, stride, out_stride)))
+            return y
     _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
     return y
 
@@ -244,6 +249,13 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
     a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
     a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
     a.out_stride = 1
+    if PROFILE is not None and PROFILE_ALL:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _stream()), "mmt_conv_wgrad")
+        e1.record()
+        PROFILE.append((2.0 * N * a.Ho * a.Wo * Cout * Cin * KH * KW, e0, e1, ("wgrad", N, H, W, Cin, Cout, KH, stride, 1)))
+        return
     _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _stream()), "mmt_conv_wgrad")
 
 

@@ -94,9 +94,21 @@ class MTtrainer(object):
 
     # ---- one iteration (the unit bench.py times)
     def train_step(self, iteration, data_s, target_s, data_u_list=None):
-        loss_dict = self.forward_source(data_s, target_s)
-        if iteration > self.start_mt and self.lambda_value > 0 and data_u_list is not None:
-            loss_dict.update(self.forward_unlabel(data_u_list))
+        use_mt = iteration > self.start_mt and self.lambda_value > 0 and data_u_list is not None
+        feats_s = feats_u = None
+        if use_mt and self.student_bs == 1:
+            # one student backbone pass over [labeled crops ; unlabeled student view] (same per-image arithmetic,
+            # larger GEMMs forward and backward); the two forwards below consume their slice of the pyramid
+            xs = data_s.tensors.to(self.device)
+            xu = data_u_list[-1].tensors.to(self.device)
+            if xs.shape[1:] == xu.shape[1:]:
+                pyr = self.student.backbone(torch.cat([xs, xu], 0))
+                n = xs.shape[0]
+                feats_s = tuple(l[:n] for l in pyr)
+                feats_u = [tuple(l[n:] for l in pyr)]
+        loss_dict = self.forward_source(data_s, target_s, feats_s)
+        if use_mt:
+            loss_dict.update(self.forward_unlabel(data_u_list, feats_u))
         self.scheduler.step()
         losses_dict = self.weight_sum_loss(loss_dict, iteration)
         losses = sum(v for v in losses_dict.values())
@@ -141,10 +153,10 @@ class MTtrainer(object):
         if iteration > self.start_mt and self.ckpt_t is not None:
             self.ckpt_t.save("t_" + name)
 
-    def forward_source(self, image, target):
-        return self.student(image.to(self.device), [t.to(self.device) for t in target])
+    def forward_source(self, image, target, features=None):
+        return self.student(image.to(self.device), [t.to(self.device) for t in target], features=features)
 
-    def forward_unlabel(self, data_u_list):
+    def forward_unlabel(self, data_u_list, features=None):
         """MTtrainer.py:247-275 (N_STEP_UNLABEL = 1)"""
         teacher_list = [f.to(self.device) for f in data_u_list[:self.teacher_bs]]
         student = [s.to(self.device) for s in data_u_list[-self.student_bs:]]
@@ -154,7 +166,7 @@ class MTtrainer(object):
             except ValueError as e:  # no pseudo boxes for an image: the reference skips the pair (bare except)
                 self.logger.info("teacher produced no boxes (%s), skip this pair", e)
                 return {}
-        return self.student.forward_student(student, teacher_results)
+        return self.student.forward_student(student, teacher_results, features=features)
 
     def update_teacher(self, it):
         """MTtrainer.py:277-281 as one launch over the flat parameter buffers"""

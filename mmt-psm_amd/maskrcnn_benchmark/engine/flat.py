@@ -44,6 +44,8 @@ class FlatParams(object):
             p.data = view
             if p.requires_grad:
                 p.grad = self._view_like(self.grad[o:o + k], p)
+                # fused backward nodes accumulate weight gradients straight into this slot (layers/fused.py)
+                p._flat_grad = p.grad
 
     @staticmethod
     def _view_like(flat, p):

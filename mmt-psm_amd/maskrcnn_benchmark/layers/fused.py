@@ -7,9 +7,9 @@ of costing an elementwise HBM pass per activation):
     by (tensor > 0).  Every consumer of such a tensor is one of the nodes below and is told so with
     `input_relu=True`; it applies the mask in the epilogue of its data-gradient GEMM (mask = its saved input).
 
-Weight gradients are returned to autograd as fresh tensors (fp32-atomic split-K accumulation inside
-`mmt_conv_wgrad`), so shared weights (RPN head over 5 levels, box head over sup/unsup passes) are summed
-by autograd into the flat gradient buffer.
+Weight gradients: fp32-atomic split-K accumulation inside `mmt_conv_wgrad`, straight into the flat gradient
+buffer when the model is flattened (engine/flat.py), else returned to autograd as fresh tensors; either way
+shared weights (RPN head over 5 levels, box head over sup/unsup passes) sum up.
 
 Reference ops replaced: layers/misc.py:30-64 (Conv2d / ConvTranspose2d), layers/batch_norm.py:19-24,
 backbone/resnet.py:254-274 (bottleneck), backbone/fpn.py:43-69, layers/roi_align.py:11-44,
@@ -20,11 +20,21 @@ import torch
 from .. import _hip as H
 
 
-def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False):
-    dw = torch.zeros_like(H.nhwc(w))
-    db = torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device) if with_bias else None
+def _dst(t):
+    """the parameter's slot in the flat gradient buffer (engine/flat.py), if the model has been flattened"""
+    return getattr(t, "_flat_grad", None) if t is not None else None
+
+
+def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst_b=None):
+    """weight (and bias) gradient.  With flat storage the split-K atomics of `mmt_conv_wgrad` accumulate straight
+    into the gradient buffer and None is returned to autograd (no zero-fill, no `grad += dw` pass); otherwise a
+    fresh tensor is returned."""
+    dw = dst_w if dst_w is not None else torch.zeros_like(H.nhwc(w))
+    db = None
+    if with_bias:
+        db = dst_b if dst_b is not None else torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
     H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
-    return dw, db
+    return (None if dst_w is not None else dw), (None if (dst_b is not None or not with_bias) else db)
 
 
 def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, res=None, res_mode=0):
@@ -49,6 +59,7 @@ class ConvFn(torch.autograd.Function):
         y = H.conv_forward(x, w, None, b, stride, pad, relu=relu)
         ctx.save_for_backward(x, w)
         ctx.cfgv = (stride, pad, input_relu, b is not None)
+        ctx.dst = (_dst(w), _dst(b))
         return y
 
     @staticmethod
@@ -58,7 +69,7 @@ class ConvFn(torch.autograd.Function):
         g = H.nhwc(g)
         dx = dw = db = None
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
-            dw, db = _wgrad(x, g, w, stride, pad, None, has_b)
+            dw, db = _wgrad(x, g, w, stride, pad, None, has_b, *ctx.dst)
         if ctx.needs_input_grad[0]:
             dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None)
         return dx, dw, db, None, None, None, None
@@ -80,6 +91,8 @@ class LinearFn(torch.autograd.Function):
         y = H.conv_forward(x4, w4, None, b, relu=relu, mul=None if mul is None else mul.view(R, O, 1, 1))
         ctx.save_for_backward(x4, w4)
         ctx.cfgv = (input_relu, in_mask_scale, b is not None)
+        dw_ = _dst(w)
+        ctx.dst = (dw_.view(O, K, 1, 1) if dw_ is not None else None, _dst(b))
         return y.view(R, O)
 
     @staticmethod
@@ -91,8 +104,8 @@ class LinearFn(torch.autograd.Function):
         g4 = g.contiguous().view(R, O, 1, 1)
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
-            dw, db = _wgrad(x4, g4, w4, 1, 0, None, has_b)
-            dw = dw.view(O, K)
+            dw, db = _wgrad(x4, g4, w4, 1, 0, None, has_b, *ctx.dst)
+            dw = dw.view(O, K) if dw is not None else None
         if ctx.needs_input_grad[0]:
             dx = _dgrad(g4, w4, x4.shape, 1, 0, None, x4 if input_relu else None, in_mask_scale).view(R, K)
         return dx, dw, db, None, None, None, None
@@ -118,6 +131,7 @@ class BottleneckFn(torch.autograd.Function):
         ctx.bn = (s1, s2, s3, sd)
         ctx.stride = stride
         ctx.has_ds = wd is not None
+        ctx.dst = (_dst(w1), _dst(w2), _dst(w3), _dst(wd))
         return out
 
     @staticmethod
@@ -126,14 +140,15 @@ class BottleneckFn(torch.autograd.Function):
         s1, s2, s3, sd = ctx.bn
         stride = ctx.stride
         g = H.nhwc(g)  # masked by (out > 0) by the consumer
-        dw3, _ = _wgrad(o2, g, w3, 1, 0, s3)
+        d1, d2, d3, dd = ctx.dst
+        dw3, _ = _wgrad(o2, g, w3, 1, 0, s3, dst_w=d3)
         d_o2 = _dgrad(g, w3, o2.shape, 1, 0, s3, mask=o2)
-        dw2, _ = _wgrad(o1, d_o2, w2, 1, 1, s2)
+        dw2, _ = _wgrad(o1, d_o2, w2, 1, 1, s2, dst_w=d2)
         d_o1 = _dgrad(d_o2, w2, o1.shape, 1, 1, s2, mask=o1)
-        dw1, _ = _wgrad(x, d_o1, w1, stride, 0, s1)
+        dw1, _ = _wgrad(x, d_o1, w1, stride, 0, s1, dst_w=d1)
         dwd = dx = None
         if ctx.has_ds:
-            dwd, _ = _wgrad(x, g, wd, stride, 0, sd)
+            dwd, _ = _wgrad(x, g, wd, stride, 0, sd, dst_w=dd)
         if ctx.needs_input_grad[0]:
             if ctx.has_ds:
                 t = _dgrad(d_o1, w1, (x.shape[0], x.shape[1], g.shape[2], g.shape[3]), 1, 0, s1)  # compact Ho x Wo
@@ -159,6 +174,7 @@ class FPNFn(torch.autograd.Function):
             inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2)
         outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1) for k in range(4)]
         ctx.save_for_backward(*cs, *inner, *wi, *wl)
+        ctx.dst = ([(_dst(wi[k]), _dst(bi[k])) for k in range(4)], [(_dst(wl[k]), _dst(bl[k])) for k in range(4)])
         return tuple(outs)
 
     @staticmethod
@@ -170,11 +186,11 @@ class FPNFn(torch.autograd.Function):
         d_in = [None] * 4
         dwl, dbl, dwi, dbi, dcs = [None] * 4, [None] * 4, [None] * 4, [None] * 4, [None] * 4
         for k in range(4):  # finest first: d_inner_k = dgrad(layer_k) + 2x2-sum(d_inner_{k-1})
-            dwl[k], dbl[k] = _wgrad(inner[k], gs[k], wl[k], 1, 1, None, True)
+            dwl[k], dbl[k] = _wgrad(inner[k], gs[k], wl[k], 1, 1, None, True, *ctx.dst[1][k])
             d_in[k] = _dgrad(gs[k], wl[k], inner[k].shape, 1, 1, None, res=d_in[k - 1] if k > 0 else None,
                              res_mode=3 if k > 0 else 0)
         for k in range(4):
-            dwi[k], dbi[k] = _wgrad(cs[k], d_in[k], wi[k], 1, 0, None, True)
+            dwi[k], dbi[k] = _wgrad(cs[k], d_in[k], wi[k], 1, 0, None, True, *ctx.dst[0][k])
             if ctx.needs_input_grad[k]:
                 dcs[k] = _dgrad(d_in[k], wi[k], cs[k].shape, 1, 0, None, mask=cs[k])  # C_k is a ReLU output
         out = list(dcs)
@@ -193,6 +209,7 @@ class DeconvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, relu, input_relu):
         x = H.nhwc(x)
+        w_in = w
         w = H.nhwc(w)
         P, Cin, h, wd_ = x.shape
         Cout = w.shape[1]
@@ -204,6 +221,7 @@ class DeconvFn(torch.autograd.Function):
                                out_hw=(2 * h, 2 * wd_), y_out=y, y_offset=(kh * 2 * wd_ + kw) * Cout)
         ctx.save_for_backward(x, w)
         ctx.cfgv = (input_relu, b is not None)
+        ctx.dst = (_dst(w_in), _dst(b))
         return y
 
     @staticmethod
@@ -213,11 +231,14 @@ class DeconvFn(torch.autograd.Function):
         g = H.nhwc(g)
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
+            dst_w, dst_b = ctx.dst
+            dw = dst_w if dst_w is not None else torch.zeros_like(w)
             H.conv_wgrad(g, x, tuple(w.shape), 2, 0, dw)  # 'input' = g (28x28), 'dy' = x (14x14)
             if has_b:
-                db = torch.zeros((w.shape[1],), dtype=torch.float32, device=w.device)
+                db = dst_b if dst_b is not None else torch.zeros((w.shape[1],), dtype=torch.float32, device=w.device)
                 H.colsum(g, db)
+                db = None if dst_b is not None else db
+            dw = None if dst_w is not None else dw
         if ctx.needs_input_grad[0]:
             dx = H.conv_forward(g, w, stride=2, pad=0, mask=x if input_relu else None)
         return dx, dw, db, None, None

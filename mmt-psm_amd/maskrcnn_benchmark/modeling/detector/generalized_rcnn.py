@@ -17,6 +17,13 @@ from ..roi_heads.roi_heads import box_roi_heads, mask_roi_heads
 from ..roi_heads.box_head.box_head import MaskRCNNFPNAdaptor
 
 
+class ImageListView(object):
+    """an ImageList snapshot that is not affected by the in-place hflip() of extract_aug_feat"""
+
+    def __init__(self, il):
+        self.tensors, self.image_sizes = il.tensors, list(il.image_sizes)
+
+
 class GeneralizedRCNN(nn.Module):
     def __init__(self, cfg, is_teacher=False, is_student=False):
         super().__init__()
@@ -67,11 +74,14 @@ class GeneralizedRCNN(nn.Module):
         self.box_heads.box.set_teacher_mode(mode)
         self.mask_heads.mask.set_teacher_mode(mode)
 
-    def forward(self, images, targets=None, tta=None):
+    def forward(self, images, targets=None, tta=None, features=None):
+        """`features`: optional precomputed backbone(images.tensors) pyramid (the engine batches the backbone pass of
+        the labeled and unlabeled student crops; the teacher reuses view 0's pyramid for its coarse inference)."""
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
         images = to_image_list(images)
-        features = self.backbone(images.tensors)
+        if features is None:
+            features = self.backbone(images.tensors)
         proposals, proposal_losses = self.rpn(images, features, targets)
         proposals = self._tap("rpn_proposals" if self.training else "infer_proposals", proposals)
         x, result, losses, class_logits, box_regression = self.box_heads(features, proposals, targets)
@@ -89,16 +99,19 @@ class GeneralizedRCNN(nn.Module):
         if targets is not None:
             raise NotImplementedError("forward_teacher with ground-truth targets is not used by MTtrainer")
         integral = []
+        images = [to_image_list(im) for im in images]
+        # all AUG_K x {plain, mirrored} views go through the backbone as ONE batch; the coarse inference of the
+        # reference (a second, identical backbone pass on view 0, generalized_rcnn.py:126-127) reuses pyramid 0
+        first = ImageListView(images[0])
+        aug_features = self.extract_aug_feat(images)
         self.set_module_mode("test")
-        teacher_infer = self.forward(images[0])
+        teacher_infer = self.forward(first, features=aug_features[0])
         if self.mt_fg_hint > 0:
             for t in teacher_infer:
                 integral.append(t.get_field("mask").sum(0)[0])
             for t in teacher_infer:
                 t.remove_field("mask")
         self.set_module_mode("train")
-        images = [to_image_list(im) for im in images]
-        aug_features = self.extract_aug_feat(images)
         _, _, _, _, proposals, _, ffi_boxes = self.rpn.forward_teacher(images[0], aug_features[0], teacher_infer)
         proposals = self._tap("teacher_proposals", proposals)
         embeddings = self.get_emb_feature(aug_features) if self.cfg.MT.FG_HINT else None
@@ -108,9 +121,9 @@ class GeneralizedRCNN(nn.Module):
         return {"result_t": result, "class_logit_t": class_logits, "embedding": embeddings, "seg_mask": integral,
                 "ffi_boxes": ffi_boxes}
 
-    def forward_student(self, images, result_t):
+    def forward_student(self, images, result_t, features=None):
         images = [to_image_list(im) for im in images] if isinstance(images, list) else [to_image_list(images)]
-        feat_list = self.extract_aug_feat(images, teacher=False)
+        feat_list = features if features is not None else self.extract_aug_feat(images, teacher=False)
         loss_dict = {}
         if self.cfg.MT.FG_HINT:
             loss_dict.update(mt_fg_loss=self.get_fg_feature_loss(feat_list, result_t["seg_mask"], result_t["embedding"]))
@@ -122,10 +135,17 @@ class GeneralizedRCNN(nn.Module):
         """generalized_rcnn.py:201-215 (ImageList.hflip mutates in place, as in the reference)"""
         feats = []
         if teacher:
+            views = []
             for img in imglist:
-                f = self.backbone(img.tensors)
+                views.append(img.tensors)
                 img.hflip()
-                feats.extend([f, self.backbone(img.tensors)])
+                views.append(img.tensors)
+            n = views[0].shape[0]
+            if all(v.shape == views[0].shape for v in views):
+                pyr = self.backbone(torch.cat(views, 0))
+                feats = [tuple(level[i * n:(i + 1) * n] for level in pyr) for i in range(len(views))]
+            else:
+                feats = [self.backbone(v) for v in views]
         else:
             for i, img in enumerate(imglist):
                 if i % 2 == 1:

@@ -27,7 +27,7 @@ class ImageList(object):
 def to_image_list(tensors, size_divisible=0):
     if isinstance(tensors, torch.Tensor) and size_divisible > 0:
         tensors = [tensors] if tensors.dim() == 3 else list(tensors)
-    if isinstance(tensors, ImageList):
+    if isinstance(tensors, ImageList) or (hasattr(tensors, "tensors") and hasattr(tensors, "image_sizes")):
         return tensors
     if isinstance(tensors, torch.Tensor):
         assert tensors.dim() == 4
