@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
   // ---- staging geometry
   const int c4 = tid & 7;       // which 16-byte slot of the 32-float k-chunk
   const int r8 = tid >> 3;      // row within a 32-row group
-  long abase[NA];               // image base offset of each A row
+  unsigned abase[NA];           // image base offset of each A row (element offsets fit 32 bits, checked on the host)
   int aih0[NA], aiw0[NA];
   bool aok[NA];
   const int HoWo = p.Ho * p.Wo;
@@ -79,15 +79,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     aih0[j] = ho * p.stride - p.pad;
     aiw0[j] = wo * p.stride - p.pad;
-    abase[j] = (long)img * p.H * p.W * p.Cin;
+    abase[j] = (unsigned)img * (unsigned)(p.H * p.W * p.Cin);
   }
-  long bbase[NB];
+  unsigned bbase[NB];
   bool bok[NB];
 #pragma unroll
   for (int j = 0; j < NB; j++) {
     const int n = n0 + r8 + 32 * j;
     bok[j] = n < p.Cout;
-    bbase[j] = (long)(bok[j] ? n : 0) * p.K;
+    bbase[j] = (unsigned)(bok[j] ? n : 0) * (unsigned)p.K;
   }
   // LDS write offsets (floats) for this thread's slots
   int awoff[NA], bwoff[NB];
@@ -111,6 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
 
   const int nkt = (p.K + 31) / 32;
   f32x4 ra[NA], rb[NB];
+  bool pa[NA], pb[NB];  // validity of the staged values; the zero-select happens at LDS-store time, so that the
+                        // loads stay in flight across the MFMA block (a select right after the load would wait)
   // scalar tap state for the Cin%32==0 fast path
   int s_kh = 0, s_kw = 0, s_ci = 0;
 
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
       // slow generic path (Cin % 4 != 0: data-gradients of the 3/12/15-channel predictor convs): every k
       // element of this thread's 16-byte slot has its own (tap, ci) and is fetched with a scalar load
 #pragma unroll
-      for (int j = 0; j < NA; j++) ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NA; j++) { ra[j] = f32x4{0.f, 0.f, 0.f, 0.f}; pa[j] = true; }
 #pragma unroll
-      for (int j = 0; j < NB; j++) rb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NB; j++) { rb[j] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[j] = true; }
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int kidx = k0 + c4 * 4 + e;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
         for (int j = 0; j < NA; j++) {
           const int ih = aih0[j] + kh, iw = aiw0[j] + kw;
           if (aok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-            ra[j][e] = p.x[abase[j] + ((long)ih * p.W + iw) * p.Cin + ci];
+            ra[j][e] = p.x[abase[j] + (unsigned)((ih * p.W + iw) * p.Cin + ci)];
         }
 #pragma unroll
         for (int j = 0; j < NB; j++)
@@ -154,29 +156,32 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
       ci = kidx - tap * p.Cin;
       kh = tap / p.KW; kw = tap - kh * p.KW;
     }
+    // branch-free: an invalid lane reads element 0 of the tensor and the value is discarded by a select, so the
+    // compiler emits straight-line loads (no exec-mask branch + vmcnt(0) per row)
 #pragma unroll
     for (int j = 0; j < NA; j++) {
       const int ih = aih0[j] + kh, iw = aiw0[j] + kw;
       const bool ok = kok && aok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = ldg4(p.x + abase[j] + ((long)ih * p.W + iw) * p.Cin + ci);
-      ra[j] = v;
+      const unsigned off = ok ? abase[j] + (unsigned)((ih * p.W + iw) * p.Cin + ci) : 0u;
+      ra[j] = ldg4(p.x + off);
+      pa[j] = ok;
     }
     const int kidx = k0 + c4 * 4;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (bok[j] && kidx < p.K) v = ldg4(p.w + bbase[j] + kidx);
-      rb[j] = v;
+      const bool ok = bok[j] && kidx < p.K;
+      rb[j] = ldg4(p.w + (ok ? bbase[j] + (unsigned)kidx : 0u));
+      pb[j] = ok;
     }
   };
   auto store_tile = [&](int buf) {
     float* A = ldsA + buf * BM * 32;
     float* B = ldsB + buf * BN * 32;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < NA; j++) *(f32x4*)(A + awoff[j]) = ra[j];
+    for (int j = 0; j < NA; j++) *(f32x4*)(A + awoff[j]) = pa[j] ? ra[j] : zero4;
 #pragma unroll
-    for (int j = 0; j < NB; j++) *(f32x4*)(B + bwoff[j]) = rb[j];
+    for (int j = 0; j < NB; j++) *(f32x4*)(B + bwoff[j]) = pb[j] ? rb[j] : zero4;
   };
 
   load_tile(0);
@@ -297,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
 // images are [k][128] and fragments are single ds_read_b32 (lanes along the 128 => conflict-free).
 // K' is split across blockIdx.z; partial tiles are combined with fp32 atomics straight into the
 // caller's gradient buffer (which also sums the contributions of every use of a shared weight).
+template <bool FAST>  // FAST: Cout % 4 == 0 and Ho, Wo >= 8 -> straight-line vector loads, carry-select row decode
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvP p, const float* __restrict__ dy,
                                                          const float* __restrict__ rowscale,
                                                          float* __restrict__ dw, int m_per_split) {
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvP p, const fl
   const int kr = tid >> 5;   // row 0..7 (+8*j)
   // A (dy) column validity
   const int aco = co0 + c4 * 4;
-  const bool avec = (p.Cout & 3) == 0;
+  const bool avec = FAST || (p.Cout & 3) == 0;
   // B column -> (tap, ci) fixed for the whole K' loop
   const int ncol = n0 + c4 * 4;
   const bool bcol_ok = ncol < NP;
@@ -334,6 +340,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvP p, const fl
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   f32x4 ra[4], rb[4];
+  bool pa[4], pb[4];
   // (img, ho, wo) of this thread's 4 rows, advanced by 32 rows per tile with carries instead of divisions
   int r_img[4], r_ho[4], r_wo[4];
 #pragma unroll
@@ -344,44 +351,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvP p, const fl
     r_ho[j] = rem / p.Wo;
     r_wo[j] = rem - r_ho[j] * p.Wo;
   }
-  const bool inc_ok = p.Wo >= 8;
+  const bool inc_ok = FAST;
+  const int step_q = 32 / p.Wo, step_r = 32 - step_q * p.Wo;  // +32 rows = +step_q image rows, +step_r columns
   auto load_tile = [&](int mt) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int m = mt + kr + 8 * j;
       const bool mok = m < me;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (mok) {
-        const float* src = dy + (long)m * p.Cout + aco;
-        if (avec) { if (aco < p.Cout) v = ldg4(src); }
-        else {
+      if (FAST || avec) {  // uniform; the loads are branch-free (invalid lanes read element 0, select 0)
+        const bool ok = mok && aco < p.Cout;
+        ra[j] = ldg4(dy + (ok ? (unsigned)m * (unsigned)p.Cout + (unsigned)aco : 0u));
+        pa[j] = ok;
+      } else {
+        f32x4 v = zero4;
+        if (mok) {
+          const float* src = dy + (long)m * p.Cout + aco;
 #pragma unroll
           for (int e = 0; e < 4; e++) if (aco + e < p.Cout) v[e] = src[e];
         }
+        ra[j] = v;
+        pa[j] = true;
       }
-      ra[j] = v;
-      f32x4 u = {0.f, 0.f, 0.f, 0.f};
-      if (mok && bcol_ok) {
-        int img, ho, wo;
-        if (inc_ok) { img = r_img[j]; ho = r_ho[j]; wo = r_wo[j]; }
-        else { img = m / HoWo; const int rem = m - img * HoWo; ho = rem / p.Wo; wo = rem - ho * p.Wo; }
-        const int ih = ho * p.stride - p.pad + bkh, iw = wo * p.stride - p.pad + bkw;
-        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-          u = ldg4(p.x + (((long)img * p.H + ih) * p.W + iw) * p.Cin + bci);
-      }
-      rb[j] = u;
-      if (inc_ok) {
-        r_wo[j] += 32;
-        while (r_wo[j] >= p.Wo) { r_wo[j] -= p.Wo; r_ho[j]++; }
-        while (r_ho[j] >= p.Ho) { r_ho[j] -= p.Ho; r_img[j]++; }
+      int img, ho, wo;
+      if (inc_ok) { img = r_img[j]; ho = r_ho[j]; wo = r_wo[j]; }
+      else { const int mm = mok ? m : 0; img = mm / HoWo; const int rem = mm - img * HoWo; ho = rem / p.Wo; wo = rem - ho * p.Wo; }
+      const int ih = ho * p.stride - p.pad + bkh, iw = wo * p.stride - p.pad + bkw;
+      const bool okb = mok && bcol_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      rb[j] = ldg4(p.x + (okb ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + bci) : 0u));
+      pb[j] = okb;
+      if (inc_ok) {  // carries as selects (step_q + 1 <= 5 < Ho): no divergent loops, no divisions
+        int wo2 = r_wo[j] + step_r, ho2 = r_ho[j] + step_q;
+        const bool cw = wo2 >= p.Wo;
+        wo2 = cw ? wo2 - p.Wo : wo2;
+        ho2 = cw ? ho2 + 1 : ho2;
+        const bool ch = ho2 >= p.Ho;
+        r_wo[j] = wo2;
+        r_ho[j] = ch ? ho2 - p.Ho : ho2;
+        r_img[j] = ch ? r_img[j] + 1 : r_img[j];
       }
     }
   };
   auto store_tile = [&](int buf) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      *(f32x4*)(ldsA + buf * 4096 + (kr + 8 * j) * 128 + c4 * 4) = ra[j];
-      *(f32x4*)(ldsB + buf * 4096 + (kr + 8 * j) * 128 + c4 * 4) = rb[j];
+      *(f32x4*)(ldsA + buf * 4096 + (kr + 8 * j) * 128 + c4 * 4) = pa[j] ? ra[j] : zero4;
+      *(f32x4*)(ldsB + buf * 4096 + (kr + 8 * j) * 128 + c4 * 4) = pb[j] ? rb[j] : zero4;
     }
   };
   const int lr = lane & 31, kh2 = lane >> 5;
@@ -497,6 +513,8 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.relu = a->relu; p.res_mode = a->res_mode; p.out_stride = a->out_stride < 1 ? 1 : a->out_stride;
   p.out_H = a->out_H; p.out_W = a->out_W; p.mask_scale = a->mask_scale;
   if ((long)p.N * p.Ho * p.Wo > 0x7fffffffL) return MMT_EINVAL;
+  if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL || (long)p.N * p.Ho * p.Wo * p.Cout >= 0x7fffffffL ||
+      (long)p.Cout * p.KH * p.KW * p.Cin >= 0x7fffffffL) return MMT_EINVAL;  // kernels use 32-bit element offsets
   p.M = p.N * p.Ho * p.Wo;
   p.K = p.KH * p.KW * p.Cin;
   p.cin32 = (p.Cin % 32) == 0;
@@ -561,8 +579,13 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   int mps = mmt_cdiv(p.M, split);
   mps = (mps + 31) / 32 * 32;
   split = mmt_cdiv(p.M, mps);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tx, ty, split), dim3(256), (size_t)4 * 4096 * sizeof(float), s, p, dy,
-                     rowscale, dw, mps);
+  const bool fast = (p.Cout & 3) == 0 && p.Wo >= 8 && p.Ho >= 8;
+  if (fast)
+    hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(tx, ty, split), dim3(256), (size_t)4 * 4096 * sizeof(float), s, p,
+                       dy, rowscale, dw, mps);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(tx, ty, split), dim3(256), (size_t)4 * 4096 * sizeof(float), s, p,
+                       dy, rowscale, dw, mps);
   MMT_LAUNCH_CHECK();
   if (dbias) {
     int rpb = 1024;
