@@ -30,16 +30,19 @@ class BalancedPositiveNegativeSampler(object):
                 num_pos_t = torch.clamp(n_pos_avail, max=num_pos)
                 num_neg_t = torch.minimum(neg.sum(), self.batch_size_per_image - num_pos_t)
                 key = torch.rand(m.shape, device=m.device)
-                pm = self._take(key, pos, num_pos_t)
-                nm = self._take(key, neg, num_neg_t)
+                pm = self._take(key, pos, num_pos_t, num_pos)
+                nm = self._take(key, neg, num_neg_t, self.batch_size_per_image)
             pos_out.append(pm)
             neg_out.append(nm)
         return pos_out, neg_out
 
     @staticmethod
-    def _take(key, member, count):
+    def _take(key, member, count, kmax):
+        """the `count` (device scalar, <= kmax) members with the smallest keys: one top-k, no sort, no sync"""
         k = torch.where(member, key, torch.full_like(key, 2.0))
-        order = torch.argsort(k)
-        rank = torch.empty_like(order)
-        rank[order] = torch.arange(order.numel(), device=order.device)
-        return member & (rank < count)
+        kk = min(int(kmax), k.numel())
+        vals, idx = torch.topk(k, kk, largest=False, sorted=True)
+        ok = (vals < 1.5) & (torch.arange(kk, device=k.device) < count)
+        out = torch.zeros_like(member)
+        out[idx] = ok
+        return out

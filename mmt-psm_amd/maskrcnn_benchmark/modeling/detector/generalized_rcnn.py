@@ -143,6 +143,7 @@ class GeneralizedRCNN(nn.Module):
             n = views[0].shape[0]
             if all(v.shape == views[0].shape for v in views):
                 pyr = self.backbone(torch.cat(views, 0))
+                self._batched_pyr = (pyr, n, len(views))
                 feats = [tuple(level[i * n:(i + 1) * n] for level in pyr) for i in range(len(views))]
             else:
                 feats = [self.backbone(v) for v in views]
@@ -154,6 +155,13 @@ class GeneralizedRCNN(nn.Module):
         return feats
 
     def get_emb_feature(self, feature_list):
+        bp = getattr(self, "_batched_pyr", None)
+        if bp is not None and len(feature_list) == bp[2] and feature_list[0][0].data_ptr() == bp[0][0].data_ptr():
+            # the views came out of one batched backbone pass: run the 5 adaptor convs once on the batched levels
+            pyr, n, nv = bp
+            self._batched_pyr = None
+            emb = self.hint_adaptor(pyr)
+            return [[e[i * n:(i + 1) * n] for e in emb] for i in range(nv)]
         return [self.hint_adaptor(f) for f in feature_list]
 
     def get_fg_feature_loss(self, feature_list, seg_mask, teacher_feat):

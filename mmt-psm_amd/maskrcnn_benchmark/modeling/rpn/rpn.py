@@ -206,8 +206,9 @@ class RPNLossComputation(object):
     def teacher_sample_selection(self, anchors, objectness, box_regression, targets):
         """rpn/loss.py:85-136 -- its outputs are unused downstream (generalized_rcnn.py:146-148); only the RNG
         draw matters for seed-for-seed parity, so the device sampler is exercised and nothing else."""
-        labels, _ = self.prepare_targets(self._cat_anchors(anchors), targets)
-        self.fg_bg_sampler(labels, tag="teacher_rpn_sampler")
+        rp = self.fg_bg_sampler.replay
+        if rp is not None:
+            rp("teacher_rpn_sampler")  # consume the recorded draw; the labels/samples themselves are never used
 
     def __call__(self, anchors, objectness, box_regression, targets):
         labels, regt = self.prepare_targets(self._cat_anchors(anchors), targets)
