@@ -7,7 +7,7 @@
 
 One "step" = one full iteration of engine/MTtrainer.py on ONE per-GPU batch of synthetic crops already resident
 in HBM: [A] supervised student forward on 2 labeled 1000x1000 crops, [B] teacher.forward_teacher on 2 unlabeled
-crops x AUG_K=2 views x flip (+ coarse inference), [C] student.forward_student on the AUG_S=1 view (MGD + PSM),
+crops x AUG_K=2 views x flip (+ coarse inference on view 0's pyramid), [C] student.forward_student on the AUG_S=1 view (MGD + PSM),
 [D] weighted loss, backward, (RCCL all-reduce of the flat student gradient when N > 1), SGD, [E] EMA teacher.
 img = one source crop consumed per step (2 labeled + 2 unlabeled = 4 per GPU per step); weak scaling.
 
@@ -172,6 +172,14 @@ def main():
         flops = sum(p[0] for p in prof)
         ms = sum(p[1].elapsed_time(p[2]) for p in prof)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # algorithmic HBM bytes of those launches: input + weights + output once
+        alg_bytes = sum(4.0 * (k[1] * k[2] * k[3] * k[4] + k[5] * k[4] * k[6] * k[6]
+                               + k[1] * (k[2] // k[7]) * (k[3] // k[7]) * k[5]) for k in (p[3] for p in prof))
+        traffic = None
+        try:  # HBM/fabric bytes per launch of this kernel from the committed PMC passes (not measurable live)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "imgs/sec (student+teacher step, 1000x1000, AUG_K=2)",
             "value": round(value, 4), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -180,11 +188,13 @@ def main():
             "config": {"workload": "MMT-PSM mean-teacher step (BASELINE configs[2]; configs[3] when n_gpus>1): per GPU 2 "
                                    "labeled + 2 unlabeled 1000x1000x3 crops, AUG_K=2 + flip, AUG_S=1, MT.LAMBDA 5, "
                                    "PSM+MGD, EMA teacher, fwd+bwd+SGD, R50-FPN fp32, IR-Net off",
-                       "image_forwards_per_step_per_gpu": 14, "parallelism": "dp%d" % world,
+                       "image_forwards_per_step_per_gpu": 12, "parallelism": "dp%d" % world,
                        "losses": {k: round(float(v), 5) for k, v in losses.items()}},
             "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)",
                          "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(alg_bytes / max(len(prof), 1), 1),
+                         "algorithmic_flop_per_launch": round(flops / max(len(prof), 1), 1),
                          "launches_per_step": len(prof) // max(args.steps, 1),
                          "avg_launch_ms": round(ms / max(len(prof), 1), 4),
                          "share_of_step_time": round(ms / (dt * 1e3), 4)},

@@ -94,10 +94,14 @@ int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
 int mmt_conv_variant(const mmt_conv_args* a /*[host]*/);
 
 /* weight gradient: dw[co,kh,kw,ci] += rowscale[co] * sum_{n,ho,wo} dy[n,ho,wo,co] * x[n,ho*s+kh-p,wo*s+kw-p,ci]
- * accumulated with fp32 atomics into dw (the caller's flat gradient buffer); optional
- * dbias[co] += sum dy[..,co] (bias_scale applied).  Uses N,H,W,Cin,Cout,KH,KW,stride,pad,Ho,Wo of a. */
+ * (dw = the caller's gradient buffer, same layout as the weight; Cin % 4 == 0); optional dbias[co] += sum dy[..,co].
+ * The pixel dimension is split over `mmt_conv_wgrad_splits(a)` blocks; when that is > 1 the caller passes a
+ * workspace of splits * Cout*KH*KW*Cin floats (partial tiles are stored there and summed by a second kernel --
+ * fp32 atomics measured 1.6x slower on mid-size layers).  Uses N,H,W,Cin,Cout,KH,KW,stride,pad,Ho,Wo of a. */
+int mmt_conv_wgrad_splits(const mmt_conv_args* a /*[host]*/);
 int mmt_conv_wgrad(const mmt_conv_args* a /*[host]; x = input, mask/mul/res unused*/, const float* dy,
-                   const float* rowscale /*[Cout] or NULL*/, float* dw, float* dbias /*or NULL*/, void* stream);
+                   const float* rowscale /*[Cout] or NULL*/, float* dw, float* dbias /*or NULL*/,
+                   float* workspace /*or NULL when splits == 1*/, void* stream);
 
 /* bias gradient: out[c] += sum_m dy[m][c]  (dy [M,C] row-major, out zeroed or accumulated by the caller) */
 int mmt_colsum(const float* dy, int M, int C, float* out, void* stream);

@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
 template <bool FAST>  // FAST: Cout % 4 == 0 and Ho, Wo >= 8 -> straight-line vector loads, carry-select row decode
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvP p, const float* __restrict__ dy,
                                                          const float* __restrict__ rowscale,
-                                                         float* __restrict__ dw, int m_per_split) {
+                                                         float* __restrict__ dw, int m_per_split,
+                                                         float* __restrict__ ws) {
   constexpr int BM = 128, BN = 128;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldsA = lds;               // [2][32][128]  dy
@@ -427,20 +428,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvP p, const fl
     if (t + 1 < ntile) store_tile(buf ^ 1);
     __syncthreads();
   }
-  const int rq = lane >> 5;
-#pragma unroll
-  for (int b = 0; b < 2; b++) {
-    const int n = n0 + (wn * 2 + b) * 32 + lr;
-    if (n >= NP) continue;
+  // ---- epilogue.  fp32 atomics from every split-K block cost ~20 us per block (measured: mid-size layers ran at
+  // 62 TFLOP/s with them, 100 without), so the partial tile goes through LDS and is written with plain, fully
+  // coalesced float4 stores: to workspace slab `blockIdx.z` when K' is split (wgrad_reduce_kernel then sums the slabs
+  // into dw), or read-modify-written into dw directly when there is a single split.
+  {
+    float* ct = lds;  // [128][128]
+    const int rq = lane >> 5;
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int co = co0 + (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-        if (co >= p.Cout) continue;
-        const float s = rowscale ? rowscale[co] : 1.f;
-        atomicAdd(dw + (long)co * NP + n, acc[a][b][r] * s);
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+          ct[row * 128 + (wn * 2 + b) * 32 + lr] = acc[a][b][r];
+        }
+    __syncthreads();
+    const int cc = tid & 31, r0 = tid >> 5;
+    const int n = n0 + cc * 4;
+    if (n < NP) {
+      const bool direct = ws == nullptr;
+      float* dst = direct ? dw : ws + (long)blockIdx.z * p.Cout * NP;
+      for (int row = r0; row < 128; row += 8) {
+        const int co = co0 + row;
+        if (co >= p.Cout) break;
+        f32x4 v = *(const f32x4*)(ct + row * 128 + cc * 4);
+        float* q = dst + (long)co * NP + n;
+        if (direct) {
+          const float sc = rowscale ? rowscale[co] : 1.f;
+          const f32x4 o = *(const f32x4*)q;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = o[e] + v[e] * sc;
+        }
+        *(f32x4*)q = v;
       }
+    }
+  }
+}
+
+// dw[co][n] += rowscale[co] * sum_s ws[s][co][n]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Cout, int NP,
+                                                           const float* __restrict__ rowscale,
+                                                           float* __restrict__ dw) {
+  const long n4 = (long)Cout * NP / 4;
+  const long slab = (long)Cout * NP;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 a = ((const f32x4*)ws)[i];
+    for (int s = 1; s < splits; s++) {
+      const f32x4 b = *(const f32x4*)(ws + s * slab + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) a[e] += b[e];
+    }
+    const float sc = rowscale ? rowscale[(int)((i * 4) / NP)] : 1.f;
+    f32x4 o = ((f32x4*)dw)[i];
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] += a[e] * sc;
+    ((f32x4*)dw)[i] = o;
   }
 }
 
@@ -567,8 +611,24 @@ extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   }
 }
 
+extern "C" int mmt_conv_wgrad_splits(const mmt_conv_args* a) {
+  ConvP p;
+  int e = fill(p, a);
+  if (e) return e;
+  if (p.M == 0 || p.Cout == 0) return 1;
+  const int NP = p.KH * p.KW * p.Cin;
+  const int tx = mmt_cdiv(NP, 128), ty = mmt_cdiv(p.Cout, 128);
+  int split = mmt_cdiv(640, (long)tx * ty);  // ~1.25 resident rounds of 2 blocks x 256 CUs
+  const int max_split = mmt_cdiv(p.M, 512);  // at least 16 k-tiles per block
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  int mps = mmt_cdiv(p.M, split);
+  mps = (mps + 31) / 32 * 32;
+  return mmt_cdiv(p.M, mps);
+}
+
 extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const float* rowscale, float* dw,
-                              float* dbias, void* stream) {
+                              float* dbias, float* workspace, void* stream) {
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
@@ -577,21 +637,26 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   hipStream_t s = (hipStream_t)stream;
   const int NP = p.KH * p.KW * p.Cin;
   const int tx = mmt_cdiv(NP, 128), ty = mmt_cdiv(p.Cout, 128);
-  int split = mmt_cdiv(1024, (long)tx * ty);
-  const int max_split = mmt_cdiv(p.M, 256);
-  if (split > max_split) split = max_split;
-  if (split < 1) split = 1;
+  const int split = mmt_conv_wgrad_splits(a);
   int mps = mmt_cdiv(p.M, split);
   mps = (mps + 31) / 32 * 32;
-  split = mmt_cdiv(p.M, mps);
+  if (split > 1 && !workspace) return MMT_EINVAL;
+  float* ws = split > 1 ? workspace : nullptr;
   const bool fast = (p.Cout & 3) == 0 && p.Wo >= 8 && p.Ho >= 8;
   if (fast)
     hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(tx, ty, split), dim3(256), (size_t)4 * 4096 * sizeof(float), s, p,
-                       dy, rowscale, dw, mps);
+                       dy, rowscale, dw, mps, ws);
   else
     hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(tx, ty, split), dim3(256), (size_t)4 * 4096 * sizeof(float), s, p,
-                       dy, rowscale, dw, mps);
+                       dy, rowscale, dw, mps, ws);
   MMT_LAUNCH_CHECK();
+  if (split > 1) {
+    const long n4 = (long)p.Cout * NP / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, split, p.Cout, NP, rowscale, dw);
+    MMT_LAUNCH_CHECK();
+  }
   if (dbias) {
     int rpb = 1024;
     hipLaunchKernelGGL(colsum_kernel, dim3(mmt_cdiv(p.Cout, 64), mmt_cdiv(p.M, rpb)), dim3(256), 0, s, dy, p.M,

@@ -40,7 +40,8 @@ _SIGS = {
     "mmt_nms_batched": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_conv_forward": [ctypes.POINTER(ConvArgs), c_void_p],
     "mmt_conv_variant": [ctypes.POINTER(ConvArgs)],
-    "mmt_conv_wgrad": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_conv_wgrad_splits": [ctypes.POINTER(ConvArgs)],
+    "mmt_conv_wgrad": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_colsum": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "mmt_weight_flip_transpose": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -249,14 +250,16 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
     a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
     a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
     a.out_stride = 1
+    splits = lib().mmt_conv_wgrad_splits(ctypes.byref(a))
+    ws = torch.empty((splits * Cout * KH * KW * Cin,), dtype=torch.float32, device=x.device) if splits > 1 else None
     if PROFILE is not None and PROFILE_ALL:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _stream()), "mmt_conv_wgrad")
+        _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _p(ws), _stream()), "mmt_conv_wgrad")
         e1.record()
         PROFILE.append((2.0 * N * a.Ho * a.Wo * Cout * Cin * KH * KW, e0, e1, ("wgrad", N, H, W, Cin, Cout, KH, stride, 1)))
         return
-    _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _stream()), "mmt_conv_wgrad")
+    _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _p(ws), _stream()), "mmt_conv_wgrad")
 
 
 def colsum(dy2d, out):

@@ -57,6 +57,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
 ka = prof.key_averages()
 cnt = sum(e.count for e in ka if e.device_type == torch.autograd.DeviceType.CUDA) if hasattr(torch.autograd, "DeviceType") else -1
 print("kernel launches in one step:", cnt)
-rows = sorted([e for e in ka if e.self_cpu_time_total > 0], key=lambda e: -e.self_cpu_time_total)[:25]
+rows = sorted([e for e in ka if e.self_device_time_total > 0 and not e.key.startswith("void") and "kernel" not in e.key.lower()],
+              key=lambda e: -e.self_device_time_total)[:40]
 for e in rows:
-    print("%-50s calls %5d  self cpu %8.2f ms" % (e.key[:50], e.count, e.self_cpu_time_total / 1e3))
+    print("%-44s calls %5d  self GPU %8.3f ms  self cpu %7.2f ms" % (e.key[:44], e.count, e.self_device_time_total / 1e3,
+                                                                   e.self_cpu_time_total / 1e3))
