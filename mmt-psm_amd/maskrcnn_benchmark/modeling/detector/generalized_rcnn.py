@@ -104,6 +104,9 @@ class GeneralizedRCNN(nn.Module):
         # reference (a second, identical backbone pass on view 0, generalized_rcnn.py:126-127) reuses pyramid 0
         first = ImageListView(images[0])
         aug_features = self.extract_aug_feat(images)
+        batched = getattr(self, "_batched_pyr", None)
+        # RPN head outputs and decoded+NMS'ed candidates are shared between the two selector passes on pyramid 0
+        self.rpn.shared = {"pre": max(self.rpn.box_selector_train.pre_nms_top_n, self.rpn.box_selector_test.pre_nms_top_n)}
         self.set_module_mode("test")
         teacher_infer = self.forward(first, features=aug_features[0])
         if self.mt_fg_hint > 0:
@@ -113,11 +116,14 @@ class GeneralizedRCNN(nn.Module):
                 t.remove_field("mask")
         self.set_module_mode("train")
         _, _, _, _, proposals, _, ffi_boxes = self.rpn.forward_teacher(images[0], aug_features[0], teacher_infer)
+        self.rpn.shared = None
         proposals = self._tap("teacher_proposals", proposals)
         embeddings = self.get_emb_feature(aug_features) if self.cfg.MT.FG_HINT else None
         result, class_logits = None, None
         if self.cfg.MT.CLS_LOSS:
+            self.box_heads.box.batched_pyramid = batched
             _, result, _, class_logits, _ = self.box_heads.forward_teacher(aug_features, proposals, teacher_infer)
+            self.box_heads.box.batched_pyramid = None
         return {"result_t": result, "class_logit_t": class_logits, "embedding": embeddings, "seg_mask": integral,
                 "ffi_boxes": ffi_boxes}
 

@@ -293,6 +293,18 @@ class ROIBoxHead(nn.Module):
             proposals = self.loss_evaluator.subsample(proposals, targets)
         proposals_b = batch_boxlist_hflip(proposals)
         feats, logits, regs = [], [], []
+        bp = getattr(self, "batched_pyramid", None)
+        if bp is not None and len(feats_list) == bp[2] and feats_list[0][0].data_ptr() == bp[0][0].data_ptr():
+            # all views came out of one batched backbone pass: ONE 4-level ROIAlign + fc6/fc7/predictor over the
+            # ROIs of every view (image index = view * n + image), then split per view
+            pyr, n, nv = bp
+            boxes = []
+            for i in range(nv):
+                boxes += list(proposals if i % 2 == 0 else proposals_b)
+            x = self.feature_extractor(pyr, boxes, istrain=istrain)
+            cl, br = self.predictor(x, self._scale(istrain))
+            R = x.shape[0] // nv
+            return (list(x.split(R, 0)), list(cl.split(R, 0)), list(br.split(R, 0)), proposals)
         for i, feat in enumerate(feats_list):
             x = self.feature_extractor(feat, proposals if i % 2 == 0 else proposals_b, istrain=istrain)
             cl, br = self.predictor(x, self._scale(istrain))

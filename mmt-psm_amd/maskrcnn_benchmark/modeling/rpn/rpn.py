@@ -66,8 +66,22 @@ class RPNPostProcessor(nn.Module):
         self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
         self.is_teacher = is_teacher
 
-    def forward(self, anchors, objectness, box_regression, targets=None):
-        """anchors: list[image] of list[level] BoxList -> list[BoxList] (rpn/inference.py:139-172)"""
+    def forward(self, anchors, objectness, box_regression, targets=None, shared=None):
+        """anchors: list[image] of list[level] BoxList -> list[BoxList] (rpn/inference.py:139-172).
+        `shared` (dict or None): the teacher runs its TEST-config and TRAIN-config selectors on the same head outputs
+        (generalized_rcnn.py:126,146); decode + NMS are then done once on the larger pre-NMS top-k and each selector
+        picks its own prefix -- greedy NMS on a score-sorted list restricted to a prefix IS the NMS of the prefix."""
+        pre = self.pre_nms_top_n if shared is None else max(self.pre_nms_top_n, shared.get("pre", 0))
+        key = "cands%d" % pre
+        if shared is not None and key in shared:
+            c = shared[key]
+        else:
+            c = self.compute_candidates(anchors, objectness, box_regression, pre)
+            if shared is not None:
+                shared[key] = c
+        return self.select(c, targets)
+
+    def compute_candidates(self, anchors, objectness, box_regression, pre_n):
         N, L = len(anchors), len(objectness)
         dev = objectness[0].device
         sizes = [a[0].size for a in anchors]  # (W,H) per image
@@ -76,7 +90,7 @@ class RPNPostProcessor(nn.Module):
         for lvl in range(L):
             o, r = _flat(objectness[lvl].detach(), box_regression[lvl].detach())
             o = o.sigmoid()
-            k = min(self.pre_nms_top_n, o.shape[1])
+            k = min(pre_n, o.shape[1])
             sc, idx = o.topk(k, dim=1, sorted=True)
             r = torch.gather(r, 1, idx[:, :, None].expand(-1, -1, 4))
             anc = anchors[0][lvl].bbox[idx.reshape(-1)].view(N, k, 4)  # same grid for every image
@@ -88,24 +102,32 @@ class RPNPostProcessor(nn.Module):
                 sc = torch.where((ws >= self.min_size) & (hs >= self.min_size), sc, torch.full_like(sc, -1.0))
             cand_box.append(props)
             cand_score.append(sc)
-            cand_extra.append((r, idx, lvl))
+            cand_extra.append((r, idx))
             ks.append(k)
         kmax = max(ks)
         # one batched NMS over all (image, level) segments, image-major so that per-image lists are contiguous
         boxes = torch.cat([torch.cat([cand_box[l][n] for l in range(L)], 0) for n in range(N)], 0)
         scores = torch.cat([torch.cat([cand_score[l][n] for l in range(L)], 0) for n in range(N)], 0)
-        per_img = sum(ks)
         offs = [0]
         for n in range(N):
             for l in range(L):
                 offs.append(offs[-1] + ks[l])
         seg_off = torch.tensor(offs, dtype=torch.int32, device=dev)
         keep, cnt = H.nms_batched(boxes, seg_off, kmax, self.nms_thresh)
-        if self.post_nms_top_n > 0:
-            cnt = cnt.clamp(max=self.post_nms_top_n)
+        return dict(N=N, L=L, ks=ks, kmax=kmax, sizes=sizes, boxes=boxes, scores=scores, seg_off=seg_off, keep=keep,
+                    cnt=cnt, extra_src=cand_extra, dev=dev)
+
+    def select(self, c, targets=None):
+        N, L, ks, kmax, dev = c["N"], c["L"], c["ks"], c["kmax"], c["dev"]
+        boxes, scores, seg_off, keep, cnt, sizes = c["boxes"], c["scores"], c["seg_off"], c["keep"], c["cnt"], c["sizes"]
+        per_img = sum(ks)
         total = N * per_img
+        # this selector's own pre-NMS prefix per segment and post-NMS cap
+        own_pre = torch.tensor([min(self.pre_nms_top_n, k) for _ in range(N) for k in ks], dtype=torch.int32, device=dev)
         pos = seg_off[:-1, None].long() + keep.long()
-        valid = torch.arange(kmax, device=dev)[None, :] < cnt[:, None]
+        valid = (torch.arange(kmax, device=dev)[None, :] < cnt[:, None]) & (keep < own_pre[:, None])
+        if self.post_nms_top_n > 0:
+            valid = valid & (torch.cumsum(valid.to(torch.int32), 1) <= self.post_nms_top_n)
         kept = torch.zeros(total + 1, dtype=torch.bool, device=dev)
         kept[torch.where(valid, pos, torch.full_like(pos, total)).reshape(-1)] = True
         kept = kept[:total] & (scores >= 0)
@@ -127,9 +149,10 @@ class RPNPostProcessor(nn.Module):
             order = None
         extra = None
         if self.is_teacher:
+            src = c["extra_src"]
             extra = {
-                "box_reg": torch.cat([torch.cat([cand_extra[l][0][n] for l in range(L)], 0) for n in range(N)], 0),
-                "rpn_topk": torch.cat([torch.cat([cand_extra[l][1][n] for l in range(L)], 0) for n in range(N)], 0),
+                "box_reg": torch.cat([torch.cat([src[l][0][n] for l in range(L)], 0) for n in range(N)], 0),
+                "rpn_topk": torch.cat([torch.cat([src[l][1][n] for l in range(L)], 0) for n in range(N)], 0),
                 "rpn_ancher_level": torch.cat([torch.cat([torch.full((ks[l],), l, dtype=torch.int64, device=dev)
                                                           for l in range(L)], 0) for n in range(N)], 0),
             }
@@ -257,8 +280,19 @@ class RPNModule(nn.Module):
     def set_teacher_mode(self, mode):
         self.mode = mode
 
+    def _head(self, features):
+        """head outputs, shared between the coarse inference and forward_teacher of ONE forward_teacher call (both
+        run on pyramid 0; the reference recomputes them, generalized_rcnn.py:126 vs :146)"""
+        sh = getattr(self, "shared", None)
+        if sh is not None and sh.get("feat_id") == id(features[0]):
+            return sh["head"]
+        out = self.head(features)
+        if sh is not None:
+            sh["feat_id"], sh["head"], sh["keepalive"] = id(features[0]), out, features[0]
+        return out
+
     def forward(self, images, features, targets=None):
-        objectness, rpn_box_regression = self.head(features)
+        objectness, rpn_box_regression = self._head(features)
         anchors = self.anchor_generator(images, features)
         if self.training or self.mode == "train":
             with torch.no_grad():
@@ -266,15 +300,16 @@ class RPNModule(nn.Module):
             lo, lb = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
             return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}
         with torch.no_grad():
-            boxes = self.box_selector_test(anchors, objectness, rpn_box_regression)
+            boxes = self.box_selector_test(anchors, objectness, rpn_box_regression, shared=getattr(self, "shared", None))
         return boxes, {}
 
     def forward_teacher(self, images, features, targets=None):
         """rpn/rpn.py:146-177 (single pyramid branch; FFI imitation boxes are a compared method, off)"""
-        objectness, rpn_box_regression = self.head(features)
+        objectness, rpn_box_regression = self._head(features)
         anchors = self.anchor_generator(images, features)
         with torch.no_grad():
-            boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
+            boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets,
+                                            shared=getattr(self, "shared", None))
             self.loss_evaluator.teacher_sample_selection(anchors, objectness, rpn_box_regression, targets)
         return None, None, None, None, boxes, {}, None
 
