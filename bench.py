@@ -132,7 +132,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MMT_FORCE_DIST") == "1"  # the latter: exercise RCCL on a 1-GPU box
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
@@ -143,7 +144,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -161,7 +162,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof, _hip.PROFILE = [p for p in _hip.PROFILE if p[3][0] == 'fwd1'], None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -189,7 +190,7 @@ def main():
                                    "labeled + 2 unlabeled 1000x1000x3 crops, AUG_K=2 + flip, AUG_S=1, MT.LAMBDA 5, "
                                    "PSM+MGD, EMA teacher, fwd+bwd+SGD, R50-FPN fp32, IR-Net off",
                        "image_forwards_per_step_per_gpu": 12, "parallelism": "dp%d" % world,
-                       "losses": {k: round(float(v), 5) for k, v in losses.items()}},
+                       "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}},
             "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)",
                          "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -202,7 +203,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

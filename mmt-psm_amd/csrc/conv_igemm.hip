@@ -584,9 +584,13 @@ static int pick_variant(const ConvP& p) {
   // dominate; the 64x64 configuration keeps ~4x more blocks resident to overlap them (measured +10..25 %)
   static const int lowk = getenv("MMT_LOWK") ? atoi(getenv("MMT_LOWK")) : 256;
   if (p.K <= lowk) return 2;
-  // enough 128x128 tiles to fill 256 CUs twice, else go to 64x64 tiles (4x the blocks)
+  // enough 128x128 tiles to fill 256 CUs (2 resident blocks each) -> 128x128; else 128x64 (twice the blocks, A tile
+  // still reused across 64 output channels); else 64x64 (4x the blocks)
   const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
   if (t128 >= 384 && p.Cout > 64) return 1;
+  static const int mid = getenv("MMT_MID") ? atoi(getenv("MMT_MID")) : 1;
+  const long t12864 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 64);
+  if (mid && t12864 >= 256 && p.Cout >= 64) return 3;
   return 2;
 }
 
@@ -607,6 +611,7 @@ extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   switch (pick_variant(p)) {
     case 0: return launch_fwd<128, 32, 4, 1>(p, s);
     case 1: return launch_fwd<128, 128, 2, 2>(p, s);
+    case 3: return launch_fwd<128, 64, 2, 2>(p, s);
     default: return launch_fwd<64, 64, 2, 2>(p, s);
   }
 }

@@ -62,9 +62,10 @@ def init_teacher_weight(model_s, model_t):
 def allreduce_gradients(flat):
     """data-parallel exchange step: average the flat student gradient over ranks (RCCL over xGMI)"""
     ws = get_world_size()
-    if ws > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM)
-        flat.grad.mul_(1.0 / ws)
+        if ws > 1:
+            flat.grad.mul_(1.0 / ws)
 
 
 class MTtrainer(object):
@@ -102,10 +103,12 @@ class MTtrainer(object):
             xs = data_s.tensors.to(self.device)
             xu = data_u_list[-1].tensors.to(self.device)
             if xs.shape[1:] == xu.shape[1:]:
+                from maskrcnn_benchmark.layers import fused
                 pyr = self.student.backbone(torch.cat([xs, xu], 0))
                 n = xs.shape[0]
-                feats_s = tuple(l[:n] for l in pyr)
-                feats_u = [tuple(l[n:] for l in pyr)]
+                parts = [fused.split_batch(l, n) for l in pyr]
+                feats_s = tuple(p[0] for p in parts)
+                feats_u = [tuple(p[1] for p in parts)]
         loss_dict = self.forward_source(data_s, target_s, feats_s)
         if use_mt:
             loss_dict.update(self.forward_unlabel(data_u_list, feats_u))

@@ -317,3 +317,31 @@ class MGDLossFn(torch.autograd.Function):
             coef = (g / ctx.n_terms / den).expand(len(ts)).contiguous()
             grads.append(H.mgd_level_backward(s, ts, ctx.flips, m, coef))
         return (None, None, None) + tuple(grads) + (None,) * (len(ctx.teachers[0]) * len(ctx.students))
+
+
+class SplitBatchFn(torch.autograd.Function):
+    """x[:n], x[n:] along the batch dimension.  Plain slicing would make autograd materialise two zero-filled
+    full-size gradients and add them; here the backward is one concatenation (a single pass over the gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = n, x.shape
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n, shape = ctx.n, ctx.shape
+        out = H.empty_nhwc(shape[0], shape[1], shape[2], shape[3], (ga if ga is not None else gb).device)
+        if ga is not None:
+            out[:n].copy_(ga)
+        else:
+            out[:n].zero_()
+        if gb is not None:
+            out[n:].copy_(gb)
+        else:
+            out[n:].zero_()
+        return out, None
+
+
+def split_batch(x, n):
+    return SplitBatchFn.apply(x, n)
