@@ -1,0 +1,245 @@
+"""IR-Net relation NMS (reference: modeling/relation/relation_module.py:13-682) -- SURVEY.md row a26.
+
+`DuplicationRemovalNetwork` ranks the top FIRST_N (90) boxes per foreground class, embeds rank + appearance,
+runs one multi-head geometric relation attention (`RelationModule`) and regresses each box's IoU with its
+ground truth (REG_IOU); at inference those scores replace greedy NMS.  Same parameter names as the reference
+(`relation_nms.{nms_rank_fc,roi_feat_embedding_fc,classifier}`, `relation_nms.relation_module.{WG,WK,WQ,conv1}`).
+
+Shipped configuration only (configs/pap/e2e_mask_rcnn_R_50_FPN_1x.yaml + scripts/train_mt.sh): REG_IOU True,
+USE_IOU False, CLASS_AGNOSTIC False, CLS_WISE_RELATION False, MERGE_METHOD 0.
+
+Execution: the Linear layers run on the fp32 MFMA GEMM (layers.Linear); the attention itself is <= 90 boxes
+(batched 90x64x90 products, top-40 softmax, a 16-group 1x1 conv = 16 tiny GEMMs) and is expressed with batched
+library GEMMs (torch.bmm) plus device elementwise ops; the numpy label preparation of the reference
+(relation_module.py:323-391, a D2H copy + host loops per class) is tensor arithmetic on the device here.
+"""
+import math
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from maskrcnn_benchmark.layers import Linear, nms as _box_nms
+from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+from maskrcnn_benchmark.structures.bounding_box import BoxList
+from maskrcnn_benchmark.structures.boxlist_ops import cat_boxlist
+
+
+def extract_rank_embedding(rank_dim, feat_dim, wave_length=1000, device="cpu"):
+    rank_range = torch.arange(0, rank_dim, device=device).float()
+    feat_range = torch.arange(feat_dim / 2, device=device)
+    dim_mat = 1. / (torch.pow(wave_length, feat_range / (feat_dim / 2)))
+    mul = rank_range.view(-1, 1) * dim_mat.view(1, -1)
+    return torch.cat((torch.sin(mul), torch.cos(mul)), -1)
+
+
+def extract_multi_position_matrix(boxes, iou, dim_g, wave_len, clswise=False):
+    if iou is not None or clswise:
+        raise NotImplementedError("USE_IOU / CLS_WISE_RELATION are off in the shipped configuration")
+    boxes = boxes.permute(1, 0, 2)
+    x_min, y_min, x_max, y_max = torch.chunk(boxes, 4, dim=2)
+    cx, cy = (x_min + x_max) * 0.5, (y_min + y_max) * 0.5
+    w, h = (x_max - x_min) + 1., (y_max - y_min) + 1.
+    dx = torch.log(torch.clamp(torch.abs((cx - cx.permute(0, 2, 1)) / w), min=1e-3))
+    dy = torch.log(torch.clamp(torch.abs((cy - cy.permute(0, 2, 1)) / h), min=1e-3))
+    dw = torch.log(w / w.permute(0, 2, 1))
+    dh = torch.log(h / h.permute(0, 2, 1))
+    size = dh.size()
+    pm = torch.stack((dx.view(size), dy.view(size), dw.view(size), dh.view(size)), -1)
+    feat_range = torch.arange(dim_g / 8, device=boxes.device)
+    dim_mat = 1. / (torch.pow(wave_len, feat_range / (dim_g / 8)))
+    mul = (100. * pm[..., None] * dim_mat.view(1, 1, 1, 1, -1)).view(size[0], size[1], size[2], -1)
+    return torch.cat((torch.sin(mul), torch.cos(mul)), -1)
+
+
+class _GroupedPointwise(nn.Module):
+    """nn.Conv2d(in, out, 1, groups=g) of RelationModule.conv1 (parameter shapes kept) as g small GEMMs"""
+
+    def __init__(self, in_ch, out_ch, groups):
+        super().__init__()
+        self.groups = groups
+        self.weight = nn.Parameter(torch.empty(out_ch, in_ch // groups, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(out_ch))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+
+    def forward(self, x):  # x (1, in, N, M) -> (1, out, N, M)
+        g = self.groups
+        _, cin, n, m = x.shape
+        o = self.weight.shape[0]
+        xw = x.view(g, cin // g, n * m)
+        y = torch.bmm(self.weight.view(g, o // g, cin // g), xw) + self.bias.view(g, o // g, 1)
+        return y.view(1, o, n, m)
+
+
+class RelationModule(nn.Module):
+    def __init__(self, appearance_feature_dim=1024, geo_feature_dim=64, fc_dim=(64, 16), group=16,
+                 dim=(1024, 1024, 1024), topk=10, iou_method="b"):
+        super().__init__()
+        assert fc_dim[1] == group, "Check the dimensions in attention!"
+        self.fc_dim, self.dim, self.group, self.topk = fc_dim, dim, group, topk
+        self.dim_group = (dim[0] // group, dim[1] // group, dim[2] // group)
+        self.WG = Linear(geo_feature_dim, fc_dim[1])
+        self.WK = Linear(appearance_feature_dim, dim[1])
+        self.WQ = Linear(appearance_feature_dim, dim[0])
+        self.conv1 = _GroupedPointwise(fc_dim[1] * appearance_feature_dim, dim[2], group)
+
+    def forward(self, f_a, position_embedding, iou=None):
+        N, ncls, feat_dim = f_a.size()
+        g = self.group
+        f_a = f_a.permute(1, 0, 2)
+        fr = f_a.contiguous().view(N * ncls, feat_dim)
+        w_g = self.WG(position_embedding.reshape(-1, self.fc_dim[0]), relu=True)
+        w_k = self.WK(fr).view(-1, N, g, self.dim_group[1]).permute(0, 2, 3, 1).contiguous().view(-1, self.dim_group[1], N)
+        w_q = self.WQ(fr).view(-1, N, g, self.dim_group[0]).transpose(1, 2).contiguous().view(-1, N, self.dim_group[0])
+        aff = (1.0 / math.sqrt(float(self.dim_group[1]))) * torch.bmm(w_q, w_k)
+        w_g = w_g.view(-1, N, N, self.fc_dim[1]).permute(0, 3, 1, 2).contiguous().view(-1, N, N)
+        w_mn = torch.log(torch.clamp(w_g, min=1e-6)) + aff
+        k = min(N, self.topk)
+        tv, ti = torch.topk(w_mn, k, dim=2, largest=True, sorted=True)
+        w = torch.zeros_like(w_mn).scatter(2, ti, F.softmax(tv, dim=2)).view(ncls, -1, N)
+        out = torch.bmm(w, f_a).view(ncls, self.fc_dim[1], N, feat_dim).permute(1, 3, 2, 0).contiguous()
+        out = self.conv1(out.view(1, self.fc_dim[1] * feat_dim, N, -1))
+        return out.squeeze(0).permute(1, 2, 0)
+
+
+def _first_argmax(x, dim):
+    """numpy.argmax semantics (FIRST maximal index) on the device, whatever the reduction order"""
+    mx = x.max(dim=dim, keepdim=True)[0]
+    n = x.shape[dim]
+    shape = [1] * x.dim()
+    shape[dim] = n
+    ar = torch.arange(n, device=x.device).view(shape).expand_as(x)
+    return torch.where(x == mx, ar, torch.full_like(ar, n)).min(dim=dim)[0]
+
+
+class DuplicationRemovalNetwork(nn.Module):
+    def __init__(self, cfg, is_teacher=False):
+        super().__init__()
+        self.cfg = cfg.clone()
+        r = cfg.MODEL.RELATION_NMS
+        if not r.REG_IOU or r.USE_IOU or r.CLASS_AGNOSTIC or r.CLS_WISE_RELATION:
+            raise NotImplementedError("relation NMS: only the shipped REG_IOU / per-class configuration is built")
+        self.first_n = r.FIRST_N
+        self.target_thresh = tuple(r.THREAD)
+        self.geo_feature_dim = r.GEO_FEAT_DIM
+        self.nms_rank_fc = Linear(r.ROI_FEAT_DIM, r.APPEARANCE_FEAT_DIM)
+        self.roi_feat_embedding_fc = Linear(r.ROI_FEAT_DIM, r.APPEARANCE_FEAT_DIM)
+        self.relation_module = RelationModule(r.APPEARANCE_FEAT_DIM, geo_feature_dim=self.geo_feature_dim,
+                                              fc_dim=(self.geo_feature_dim, 16), group=r.GROUP, dim=tuple(r.HID_DIM),
+                                              topk=r.TOPK, iou_method=r.IOU_METHOD)
+        self.classifier = Linear(128, len(self.target_thresh))
+        self.boxcoder = BoxCoder(weights=(10., 10., 5., 5.))
+        self.fg_class = cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES - 1
+        self.fg_thread = r.FG_THREAD
+        self.detections_per_img = cfg.MODEL.ROI_HEADS.DETECTIONS_PER_IMG
+        self.nms = r.POS_NMS
+        self.merge_method = r.MERGE_METHOD
+        self.roi_feat_dim, self.app_dim = r.ROI_FEAT_DIM, r.APPEARANCE_FEAT_DIM
+        self.mode = None
+
+    def set_teacher_mode(self, mode):
+        self.mode = mode
+
+    # ---- label preparation on the device (relation_module.py:323-391)
+    def prepare_reg_label(self, sorted_boxes, sorted_score, targets):
+        labels = targets.get_field("labels")
+        n = sorted_boxes.shape[0]
+        dev = sorted_boxes.device
+        per_cls = []
+        for i in range(self.fg_class):
+            tb = targets.bbox[labels == (i + 1)]
+            G = tb.shape[0]
+            if G == 0:
+                per_cls.append(torch.zeros((n, len(self.target_thresh)), device=dev))
+                continue
+            score = sorted_score[:, i:i + 1]
+            boxes = sorted_boxes[:, i, :]
+            a1 = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
+            a2 = (tb[:, 2] - tb[:, 0] + 1) * (tb[:, 3] - tb[:, 1] + 1)
+            lt = torch.max(boxes[:, None, :2], tb[:, :2])
+            rb = torch.min(boxes[:, None, 2:], tb[:, 2:])
+            wh = (rb - lt + 1).clamp(min=0)
+            inter = wh[:, :, 0] * wh[:, :, 1]
+            iou = inter / (a1[:, None] + a2 - inter)
+            best_gt = F.one_hot(_first_argmax(iou, 1), G).to(iou.dtype)  # eye[argmax(iou, axis=1)]
+            outs = []
+            for th in self.target_thresh:
+                mask = (iou > th).to(iou.dtype)
+                osc = score * mask * best_gt
+                oiou = iou * mask * best_gt
+                msi = _first_argmax(osc, 0)                       # best-scoring box of every gt   [G]
+                moi = oiou[msi, torch.arange(G, device=dev)]       # its IoU                        [G]
+                valid = mask.sum(1) > 0                            # boxes overlapping any gt
+                # np.intersect1d(msi, valid, return_indices=True): for a box chosen by several gts the FIRST gt wins
+                first = torch.full((n,), G, dtype=torch.long, device=dev)
+                first = first.scatter_reduce(0, msi, torch.arange(G, device=dev), reduce="amin", include_self=True)
+                take = valid & (first < G)
+                reg = torch.where(take, moi[first.clamp(max=G - 1)], torch.zeros((), device=dev))
+                outs.append(reg)
+            per_cls.append(torch.stack(outs, -1))
+        return torch.stack(per_cls, 1).float()
+
+    def filter_results(self, boxes, targets, scores, image_shape, num_classes, obj):
+        """rank the boxes of one image per class (relation_module.py:503-587)"""
+        fg = num_classes - 1
+        boxes = boxes.reshape(-1, 4 * num_classes)
+        bx = torch.stack([boxes[:, j * 4:(j + 1) * 4] for j in range(1, num_classes)], dim=2)  # [R,4,fg]
+        sc = scores.reshape(-1, num_classes)[:, 1:]
+        first_n = min(bx.shape[0], self.first_n)
+        ss, ind = torch.topk(sc, first_n, dim=0, largest=True, sorted=True)
+        ori = sc[ind]
+        sobj = obj[ind]
+        sb = bx[ind]  # [n, fg, 4, fg]
+        m = torch.arange(0, fg, device=boxes.device).view(1, -1, 1, 1).expand(first_n, fg, 4, 1)
+        sb = torch.gather(sb, 3, m).squeeze(3)
+        b = BoxList(sb.reshape(first_n * fg, 4), image_shape, mode="xyxy")
+        b.add_field("sorted_idx", ind)
+        b.add_field("objectness", sobj.reshape(first_n * fg))
+        b.add_field("scores", ss)
+        b.add_field("all_scores", ori)
+        if self.training:
+            b.add_field("labels_iou_reg", self.prepare_reg_label(sb, ss, targets))
+        return b.clip_to_image(remove_empty=False)
+
+    def forward(self, x):
+        appearance_feature, proposals, cls_score, box_reg, targets = x
+        assert len(proposals) == 1, "called per image (generalized_rcnn.py:74-85)"
+        p, t = proposals[0], targets[0]
+        fg = self.fg_class
+        with torch.no_grad():
+            dec = self.boxcoder.decode(box_reg.detach().view(len(p), -1), p.bbox)
+            sbl = self.filter_results(dec, t, cls_score.detach(), p.size, fg + 1, p.get_field("objectness"))
+        ind, scores = sbl.get_field("sorted_idx"), sbl.get_field("scores")
+        bboxes = sbl.bbox.reshape(-1, fg, 4)
+        n = ind.shape[0]
+        app = self.roi_feat_embedding_fc(appearance_feature)[ind]
+        rank = self.nms_rank_fc(extract_rank_embedding(n, self.roi_feat_dim, device=app.device))
+        sf = app + rank[:, None, :]
+        pos = extract_multi_position_matrix(bboxes, None, self.geo_feature_dim, 1000)
+        sf = F.relu(sf + self.relation_module(sf, pos, None))
+        sf = self.classifier(sf.reshape(-1, self.app_dim).contiguous()).view(-1, fg, len(self.target_thresh))
+        sc3 = torch.cat([scores[:, :, None]] * len(self.target_thresh), dim=-1)
+        if self.training:
+            return None, {"nms_loss": F.mse_loss(sbl.get_field("labels_iou_reg"), sf)}
+        with torch.no_grad():
+            s = (sf * (sc3 > self.fg_thread).float())[:, :, min(max(self.merge_method, 0), len(self.target_thresh) - 1)]
+            objectness = sbl.get_field("objectness").reshape(-1, fg)
+            all_scores = sbl.get_field("all_scores")
+            parts = []
+            for cls, lab, thr in ((1, 2, 0.5), (0, 1, self.nms)):  # nuclei first, then cytoplasm (:261-312)
+                index = (s[:, cls] >= self.fg_thread).nonzero()[:, 0]
+                b = BoxList(bboxes[index, cls, :], p.size, mode="xyxy")
+                cs = s[index, cls]
+                b.add_field("scores", cs)
+                b.add_field("objectness", objectness[index, cls])
+                b.add_field("all_scores", all_scores[index, cls])
+                if thr and len(b):
+                    b = b[_box_nms(b.bbox, cs, thr)]
+                b.add_field("labels", torch.full((len(b),), lab, dtype=torch.int64, device=s.device))
+                parts.append(b)
+            r = cat_boxlist(parts)
+            nd = len(r)
+            if nd > self.detections_per_img > 0:
+                thr_v = torch.kthvalue(r.get_field("scores"), nd - self.detections_per_img + 1)[0]
+                r = r[torch.nonzero(r.get_field("scores") >= thr_v).squeeze(1)]
+        return [r], {}

@@ -37,6 +37,7 @@ def default_cfg(**over):
         mt_temp=0.5, mt_sharpen=True, mt_hard_neg=True, mt_cls_balance=1.5, mt_rank_filter=0.2,
         mt_cls_loss_type="bce", mt_cls_loss=0.2, mt_fg_hint=1.0, mt_lambda=5.0, mt_start=1000,
         mt_alpha=0.99, mt_rampup=250, mt_rampdown=250, nms_loss_w=1.0, mask_thresh=0.5,
+        relation=False,  # IR-Net (RELATION_NMS + RELATION_MASK), oracle/irnet.py
     )
     c.update(over)
     return SimpleNamespace(**c)
@@ -657,18 +658,34 @@ def forward_supervised(sd, cfg, images, targets, taps=None):
     xf = box_feature(sd, cfg, feats, samp, True, taps)
     cl, br = box_predictor(sd, xf)
     l_cls, l_box = fastrcnn_loss(cl, br, samp)
+    extra = {}
+    if cfg.relation:  # generalized_rcnn.py:63-95
+        from . import irnet
+        per = [len(s_) for s_ in samp]
+        probs = F.softmax(cl, dim=1)
+        nl = [irnet.dup_removal(sd, cfg, xi, si, ci, bi, ti, True)[1]
+              for xi, si, ci, bi, ti in zip(xf.split(per), samp, probs.split(per), br.split(per), targets)]
+        extra["nms_loss"] = torch.mean(torch.stack(nl))
     pos = [s.index(torch.nonzero(s.fields["labels"] > 0).squeeze(1)) for s in samp]
     mx = mask_feature(sd, cfg, feats, pos)
     ml = mask_predictor(sd, mx)
     l_seg = mask_loss(cfg, pos, ml, targets, taps)
+    if cfg.relation:  # mask_head.py:96-147 (DEEP_SUPER)
+        from . import irnet
+        perp = [len(p) for p in pos]
+        outs = [irnet.mask_relation(sd, cfg, f, m, p) for f, m, p in zip(mx.split(perp), ml.split(perp), pos)]
+        ml2 = torch.cat([o[0] for o in outs])
+        l_seg = 0.5 * (l_seg + mask_loss(cfg, [o[1] for o in outs], ml2, targets))
     if taps is not None:
         taps["class_logits"] = cl.detach()
         taps["box_regression"] = br.detach()
         taps["mask_logits"] = ml.detach()
         taps["sampled"] = [(s.bbox.clone(), s.fields["labels"].clone(), s.fields["regression_targets"].clone())
                            for s in samp]
-    return {"loss_classifier": l_cls, "loss_box_reg": l_box, "loss_seg": l_seg,
-            "loss_objectness": l_obj, "loss_rpn_box_reg": l_rpn}
+    out = {"loss_classifier": l_cls, "loss_box_reg": l_box, "loss_seg": l_seg,
+           "loss_objectness": l_obj, "loss_rpn_box_reg": l_rpn}
+    out.update(extra)
+    return out
 
 
 def inference(sd, cfg, x, sizes, taps=None):
@@ -680,8 +697,21 @@ def inference(sd, cfg, x, sizes, taps=None):
     props = rpn_postprocess(cfg, anchors, obj, reg, False, False)
     xf = box_feature(sd, cfg, feats, props, False)
     cl, br = box_predictor(sd, xf)
-    dets = box_postprocess(cfg, cl, br, props)
-    ml = mask_predictor(sd, mask_feature(sd, cfg, feats, dets))
+    if cfg.relation:
+        from . import irnet
+        per = [len(p) for p in props]
+        probs = F.softmax(cl, dim=1)
+        dets = [irnet.dup_removal(sd, cfg, xi, pi, ci, bi, None, False)[0]
+                for xi, pi, ci, bi in zip(xf.split(per), props, probs.split(per), br.split(per))]
+    else:
+        dets = box_postprocess(cfg, cl, br, props)
+    mx = mask_feature(sd, cfg, feats, dets)
+    ml = mask_predictor(sd, mx)
+    if cfg.relation:
+        perd = [len(d) for d in dets]
+        outs = [irnet.mask_relation(sd, cfg, f, m, d) for f, m, d in zip(mx.split(perd), ml.split(perd), dets)]
+        ml = torch.cat([o[0] for o in outs])
+        dets = [o[1] for o in outs]
     seg = mask_generate(cfg, ml, dets)
     if taps is not None:
         taps["infer_proposals"] = [(p.bbox.clone(), p.fields["objectness"].clone()) for p in props]

@@ -295,15 +295,15 @@ def to_ref_targets(tgs):
     return res
 
 
-def gen_model(size=160, n_inst=4, tag="model160"):
+def gen_model(size=160, n_inst=4, tag="model160", relation=False):
     from maskrcnn_benchmark.modeling.detector import build_detection_model
     from maskrcnn_benchmark.structures.image_list import to_image_list
-    cfg = make_cfg()
+    cfg = make_cfg(relation=relation)
     torch.manual_seed(0)
     student = build_detection_model(cfg, is_student=True)
     teacher = build_detection_model(cfg, is_teacher=True)
     shapes = {k: tuple(v.shape) for k, v in student.state_dict().items()}
-    with open(os.path.join(HERE, "state_shapes.json"), "w") as f:
+    with open(os.path.join(HERE, "state_shapes_irnet.json" if relation else "state_shapes.json"), "w") as f:
         json.dump({"shapes": {k: list(v) for k, v in shapes.items()},
                    "param_order": [k for k, _ in student.named_parameters()],
                    "trainable": [k for k, p in student.named_parameters() if p.requires_grad]}, f)
@@ -356,3 +356,5 @@ if __name__ == "__main__":
         gen_masks()
     if "model" in which:
         gen_model()
+    if "irnet" in which:
+        gen_model(tag="model160_irnet", relation=True)

@@ -158,3 +158,31 @@ def test_model_end_to_end_golden(synth, weights):
     for k, v in sl.items():
         assert v.item() == pytest.approx(float(g["stu_" + k]), rel=1e-5), k
     assert float(g["stu_mt_fg_loss"]) > 1e-3  # non-degenerate MGD
+
+
+def test_irnet_end_to_end_golden(synth):
+    """IR-Net on (RELATION_NMS + RELATION_MASK, BASELINE config 5 in fp32): oracle/irnet.py against the reference."""
+    import json, os
+    from conftest import GOLD
+    g = gold("model160_irnet")
+    shapes = json.load(open(os.path.join(GOLD, "state_shapes_irnet.json")))["shapes"]
+    sd = synth.make_weights(shapes, seed=0)
+    cfg = om.default_cfg(relation=True)
+    imgs, tgs = synth.make_labeled(2, 160, 4, seed=1234)
+    unl = synth.make_unlabeled(2, 160, 3, seed=4321)
+    torch.manual_seed(99)
+    ld = om.forward_supervised(sd, cfg, imgs, _targets(tgs))
+    assert "nms_loss" in ld
+    for k, v in ld.items():
+        assert v.item() == pytest.approx(float(g["sup_" + k]), rel=1e-5), k
+    torch.manual_seed(100)
+    tr = om.forward_teacher(sd, cfg, unl[:2])
+    for i, r in enumerate(tr["result_t"]):
+        np.testing.assert_allclose(r.bbox.numpy(), g["t_res%d_bbox" % i], rtol=0, atol=1e-4)
+        np.testing.assert_array_equal(r.fields["labels"].numpy(), g["t_res%d_labels" % i])
+    np.testing.assert_allclose(torch.stack(tr["class_logit_t"]).numpy(), g["t_logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(torch.stack(tr["seg_mask"]).numpy(), g["t_seg"].astype(np.int64))
+    torch.manual_seed(101)
+    sl = om.forward_student(sd, cfg, unl[-1:], tr)
+    for k, v in sl.items():
+        assert v.item() == pytest.approx(float(g["stu_" + k]), rel=1e-5), k
