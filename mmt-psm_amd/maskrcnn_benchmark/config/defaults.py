@@ -116,8 +116,22 @@ _DEFAULTS = {
                           "POOLER_SCALES": (0.25, 0.125, 0.0625, 0.03125), "CONV_LAYERS": (256, 256, 256, 256),
                           "RESOLUTION": 28, "SHARE_BOX_FEATURE_EXTRACTOR": False, "POSTPROCESS_MASKS": False,
                           "POSTPROCESS_MASKS_THRESHOLD": 0.5},
-        "RELATION_NMS": {"USE_RELATION_NMS": False, "LOSS": 1.0, "DO": 0.5},
-        "RELATION_MASK": {"USE_RELATION": False},
+        # IR-Net (config/defaults.py:247-305 + configs/pap/e2e_mask_rcnn_R_50_FPN_1x.yaml:35-85 + train_mt.sh);
+        # the two USE_* switches default to off here (BASELINE configs 1-4), config 5 turns them on
+        "RELATION_NMS": {"USE_RELATION_NMS": False, "LOSS": 1.0, "DO": 0.5, "FIRST_N": 90, "THREAD": (0.1,),
+                         "ROI_FEAT_DIM": 1024, "APPEARANCE_FEAT_DIM": 128, "GEO_FEAT_DIM": 64, "FC_DIM": (64, 16),
+                         "GROUP": 16, "HID_DIM": (1024, 1024, 128), "CLASS_AGNOSTIC": False, "MERGE_METHOD": 0,
+                         "FG_THREAD": 0.1, "POS_NMS": 0.55, "CLS_WISE_RELATION": False, "MUTRELATION": False,
+                         "TAG": "CIAM", "CONCAT": False, "TOPK": 40, "APPEARANCE_INTER": True, "USE_IOU": False,
+                         "IOU_METHOD": "n", "WEIGHT": 1.0, "ALPHA": 0.2, "GAMMA": 1.0, "REG_IOU": True,
+                         "REG_IOU_MSK": False, "D_LOSS": 0.0},
+        "RELATION_MASK": {"USE_RELATION": False, "BINARY": False, "USE_PRE_FEATURE": False, "PRE_NORM": False,
+                          "NORM": -1, "TYPE": "CIAM", "SAME_PREDICTOR": False, "DEEP_SUPER": True, "CAM": False,
+                          "CIAM": True, "TRAIN_CENTER_ONLY": False, "PROTO": False, "ALPHA": 0.5, "CENTER_TOPK": 20,
+                          "CENTER_PER_CLASS": 8, "APPEARANCE_FEAT_DIM": 128, "GEO_FEAT_DIM": 64, "FC_DIM": (64, 16),
+                          "GROUP": 16, "HID_DIM": (1024, 1024), "TOPK": 128, "EXTRACTOR_CHANNEL": 16,
+                          "FEATURE_EXTRACTOR": "RoiAlignMaskFeatureExtractor", "RANK": True, "CLSWIZE": True,
+                          "XY_COOR": True, "IOU_COOR": False},
     },
     "DATALOADER": {"SIZE_DIVISIBILITY": 32},
     "DATASETS": {"NO_LABEL": True, "SYN": False},

@@ -319,6 +319,25 @@ class MGDLossFn(torch.autograd.Function):
         return (None, None, None) + tuple(grads) + (None,) * (len(ctx.teachers[0]) * len(ctx.students))
 
 
+class ReluGradMaskFn(torch.autograd.Function):
+    """identity whose backward applies (x > 0): the adapter between a fused-ReLU output and consumers that are
+    NOT nodes of this file (index / cat / library ops), so that the producer still receives a pre-masked gradient"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return g * (x > 0).to(g.dtype)
+
+
+def relu_grad_mask(x):
+    return ReluGradMaskFn.apply(x) if x.requires_grad else x
+
+
 class SplitBatchFn(torch.autograd.Function):
     """x[:n], x[n:] along the batch dimension.  Plain slicing would make autograd materialise two zero-filled
     full-size gradients and add them; here the backward is one concatenation (a single pass over the gradient)."""

@@ -4,8 +4,8 @@ forward(images, targets)            supervised student step -> loss dict / eval 
 forward_teacher(images)             coarse inference -> pseudo labels + masks; K-aug x flip pyramids; per-view logits
 forward_student(images, result_t)   MGD (mt_fg_loss) + PSM (mt_classifier)
 
-Same attribute tree (backbone, rpn, box_heads, mask_heads, hint_adaptor), same dict keys.  IR-Net branches
-(relation_nms / mask relation) are BASELINE config 5 and not built yet (out-of-scope list)."""
+Same attribute tree (backbone, rpn, box_heads, mask_heads, relation_nms, hint_adaptor), same dict keys.  The IR-Net
+branches (relation_nms here, mask relation inside the mask head) follow generalized_rcnn.py:62-96."""
 import torch
 from torch import nn
 
@@ -15,6 +15,7 @@ from ..backbone import build_backbone
 from ..rpn.rpn import build_rpn
 from ..roi_heads.roi_heads import box_roi_heads, mask_roi_heads
 from ..roi_heads.box_head.box_head import MaskRCNNFPNAdaptor
+from ..relation.relation_module import DuplicationRemovalNetwork
 
 
 class ImageListView(object):
@@ -27,15 +28,13 @@ class ImageListView(object):
 class GeneralizedRCNN(nn.Module):
     def __init__(self, cfg, is_teacher=False, is_student=False):
         super().__init__()
-        if cfg.MODEL.RELATION_NMS.USE_RELATION_NMS or cfg.MODEL.RELATION_MASK.USE_RELATION:
-            raise NotImplementedError("IR-Net (RELATION_NMS / RELATION_MASK) is BASELINE config 5: not on the "
-                                      "MI355X path yet; set both to False")
         self.cfg = cfg
         self.backbone = build_backbone(cfg)
         self.rpn = build_rpn(cfg, is_teacher)
         self.box_heads = box_roi_heads(cfg)
         self.mask_heads = mask_roi_heads(cfg, is_student)
-        self.relation_nms = None
+        # generalized_rcnn.py:25-30 (module order = parameter order = the order the EMA zips by)
+        self.relation_nms = DuplicationRemovalNetwork(cfg, is_teacher) if cfg.MODEL.RELATION_NMS.USE_RELATION_NMS else None
         self.mt_fg_hint = cfg.MT.FG_HINT
         self.mt_cls = cfg.MT.CLS_LOSS
         self.hint_adaptor = MaskRCNNFPNAdaptor(cfg)
@@ -59,7 +58,7 @@ class GeneralizedRCNN(nn.Module):
                 b = BoxList(r[0].to(old.bbox.device), old.size, "xyxy")
                 if name == "detections":
                     b.add_field("scores", r[1].to(old.bbox.device))
-                    b.add_field("objectness", r[1].to(old.bbox.device))
+                    b.add_field("objectness", r[3 if len(r) > 3 else 1].to(old.bbox.device))
                     b.add_field("labels", r[2].to(old.bbox.device))
                 else:
                     b.add_field("objectness", r[1].to(old.bbox.device))
@@ -72,6 +71,8 @@ class GeneralizedRCNN(nn.Module):
     def set_module_mode(self, mode):
         self.rpn.set_teacher_mode(mode)
         self.box_heads.box.set_teacher_mode(mode)
+        if self.relation_nms is not None:
+            self.relation_nms.set_teacher_mode(mode)
         self.mask_heads.mask.set_teacher_mode(mode)
 
     def forward(self, images, targets=None, tta=None, features=None):
@@ -85,15 +86,38 @@ class GeneralizedRCNN(nn.Module):
         proposals, proposal_losses = self.rpn(images, features, targets)
         proposals = self._tap("rpn_proposals" if self.training else "infer_proposals", proposals)
         x, result, losses, class_logits, box_regression = self.box_heads(features, proposals, targets)
+        nms_loss = None
+        if self.relation_nms is not None:
+            result, nms_loss = self._relation_nms(x, result, class_logits, box_regression, targets)
         if not self.training:
+            if self.taps is not None:
+                self.taps["detections_own"] = result  # before any replay: what this model itself detected
             result = self._tap("detections", result)
         result, detector_losses = self.mask_heads(losses, features, result, targets, images)
         if self.training:
             out = {}
             out.update(detector_losses)
             out.update(proposal_losses)
+            if nms_loss is not None:
+                out.update(nms_loss)
             return out
         return result
+
+    def _relation_nms(self, x, result, class_logits, box_regression, targets):
+        """generalized_rcnn.py:62-96: per image, learned duplicate removal on the (un-NMS'ed) box-head output"""
+        prob = torch.softmax(class_logits, dim=1)
+        sizes = [len(r) for r in result]
+        # `x` is the fused ReLU(+dropout) output of fc7: its consumers mask the gradient (layers/fused.py convention)
+        self.relation_nms.in_mask_scale = self.box_heads.box._scale(self.training)
+        outs, losses = [], []
+        tg = targets if targets is not None else [None] * len(sizes)
+        for xi, re, cl, br, t in zip(x.split(sizes), result, prob.split(sizes), box_regression.split(sizes), tg):
+            r, l = self.relation_nms((xi, [re], cl, br, [t]))
+            outs.append(r)
+            losses.append(l)
+        if self.training:
+            return result, {"nms_loss": torch.mean(torch.stack([l["nms_loss"] for l in losses]))}
+        return [r[0] for r in outs], None
 
     def forward_teacher(self, images, targets=None):
         if targets is not None:

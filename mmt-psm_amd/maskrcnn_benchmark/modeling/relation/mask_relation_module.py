@@ -37,7 +37,8 @@ class RoiAlignMaskFeatureExtractor(nn.Module):
         x = fused.conv(x, w1.contiguous(memory_format=torch.channels_last), self.mask_fcn1.bias, 1, 1, True, False)
         x = self.mask_fcn2(x, relu=True, input_relu=True)
         x = self.mask_fcn3(x, relu=True, input_relu=True)
-        return self.conv5_mask(x, relu=True, input_relu=True)
+        # the ReLU after conv5_mask feeds CIAM (library ops, not fused nodes) -> a plain elementwise ReLU here
+        return F.relu(self.conv5_mask(x, relu=False, input_relu=True))
 
 
 class CIAM_Module(nn.Module):
@@ -88,7 +89,7 @@ class MaskRelationRefineNet(nn.Module):
         sel = sorted_mask[torch.arange(order.numel(), device=order.device), labels[order]]
         feat = self.appearance_feature_extractor((feat_roi[order], torch.sigmoid(sel)[:, None, :, :]))
         rel = torch.cat([self.relation_module(f) for f in torch.split(feat, cls_len) if f.shape[0] != 0])
-        rel = self.deconv_1(rel, relu=True, input_relu=True)
+        rel = self.deconv_1(rel, relu=True, input_relu=False)
         rel = self.classifier(rel, relu=False, input_relu=True)
         sorted_fields = proposal.copy_with_fields([f for f in proposal.fields() if f != "mask"])[order]
         return rel, [sorted_fields], target, None

@@ -67,7 +67,7 @@ class _GroupedPointwise(nn.Module):
         _, cin, n, m = x.shape
         o = self.weight.shape[0]
         xw = x.view(g, cin // g, n * m)
-        y = torch.bmm(self.weight.view(g, o // g, cin // g), xw) + self.bias.view(g, o // g, 1)
+        y = torch.bmm(self.weight.reshape(g, o // g, cin // g), xw) + self.bias.view(g, o // g, 1)
         return y.view(1, o, n, m)
 
 
@@ -88,7 +88,7 @@ class RelationModule(nn.Module):
         g = self.group
         f_a = f_a.permute(1, 0, 2)
         fr = f_a.contiguous().view(N * ncls, feat_dim)
-        w_g = self.WG(position_embedding.reshape(-1, self.fc_dim[0]), relu=True)
+        w_g = F.relu(self.WG(position_embedding.reshape(-1, self.fc_dim[0]).contiguous()))
         w_k = self.WK(fr).view(-1, N, g, self.dim_group[1]).permute(0, 2, 3, 1).contiguous().view(-1, self.dim_group[1], N)
         w_q = self.WQ(fr).view(-1, N, g, self.dim_group[0]).transpose(1, 2).contiguous().view(-1, N, self.dim_group[0])
         aff = (1.0 / math.sqrt(float(self.dim_group[1]))) * torch.bmm(w_q, w_k)
@@ -212,7 +212,8 @@ class DuplicationRemovalNetwork(nn.Module):
         ind, scores = sbl.get_field("sorted_idx"), sbl.get_field("scores")
         bboxes = sbl.bbox.reshape(-1, fg, 4)
         n = ind.shape[0]
-        app = self.roi_feat_embedding_fc(appearance_feature)[ind]
+        app = self.roi_feat_embedding_fc(appearance_feature, input_relu=True,
+                                         in_mask_scale=getattr(self, "in_mask_scale", 1.0))[ind]
         rank = self.nms_rank_fc(extract_rank_embedding(n, self.roi_feat_dim, device=app.device))
         sf = app + rank[:, None, :]
         pos = extract_multi_position_matrix(bboxes, None, self.geo_feature_dim, 1000)

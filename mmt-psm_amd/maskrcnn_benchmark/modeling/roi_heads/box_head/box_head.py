@@ -265,6 +265,7 @@ class ROIBoxHead(nn.Module):
         self.predictor = FPNPredictor(cfg)
         self.post_processor = make_roi_box_post_processor(cfg)
         self.loss_evaluator = make_roi_box_loss_evaluator(cfg)
+        self.use_realation_nms = relation and cfg.MODEL.RELATION_NMS.USE_RELATION_NMS  # (sic) box_head.py:24
         self.cfg = cfg
         self.mode = None
 
@@ -282,8 +283,9 @@ class ROIBoxHead(nn.Module):
         x = self.feature_extractor(features, proposals, istrain=self.training)
         class_logits, box_regression = self.predictor(x, self._scale(self.training))
         if not self.training:
-            with torch.no_grad():
-                proposals = self.post_processor((class_logits, box_regression), proposals)
+            if not self.use_realation_nms:  # with IR-Net the relation module replaces score-threshold + greedy NMS
+                with torch.no_grad():
+                    proposals = self.post_processor((class_logits, box_regression), proposals)
             return x, proposals, {}, class_logits, box_regression
         lc, lb = self.loss_evaluator([class_logits], [box_regression])
         return x, proposals, dict(loss_classifier=lc, loss_box_reg=lb), class_logits, box_regression

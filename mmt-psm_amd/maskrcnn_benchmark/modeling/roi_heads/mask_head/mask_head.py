@@ -15,6 +15,7 @@ from maskrcnn_benchmark.modeling.matcher import Matcher
 from maskrcnn_benchmark.modeling.poolers import Pooler
 from maskrcnn_benchmark.structures.bounding_box import BoxList
 from maskrcnn_benchmark.structures.boxlist_ops import boxlist_iou
+from maskrcnn_benchmark.modeling.relation.mask_relation_module import MaskRelationRefineNet
 
 
 def keep_only_positive_boxes(boxes):
@@ -176,6 +177,12 @@ class ROIMaskHead(nn.Module):
         self.post_processor = make_roi_mask_post_processor(cfg)
         self.mask_generator = make_roi_mask_generator(cfg)
         self.loss_evaluator = make_roi_mask_loss_evaluator(cfg)
+        # mask_head.py:49-50 builds the module whatever USE_RELATION says (`if cfg.MODEL.RELATION_MASK:` is a CfgNode),
+        # so its keys are in every checkpoint; when unused it never gets a gradient there -> frozen here
+        self.use_relation = cfg.MODEL.RELATION_MASK.USE_RELATION
+        self.mask_relation_module = MaskRelationRefineNet(cfg, self.predictor)
+        if not self.use_relation:
+            self.mask_relation_module.requires_grad_(False)
         self.mode = None
 
     def set_teacher_mode(self, mode):
@@ -187,8 +194,28 @@ class ROIMaskHead(nn.Module):
             proposals, _ = keep_only_positive_boxes(proposals)
         x, _ = self.feature_extractor(features, proposals)
         mask_logits = self.predictor(x)
+        loss_1 = self.loss_evaluator(proposals, mask_logits, targets) if self.training else None
+        if self.use_relation:
+            # mask_head.py:98-127: per image, instances sorted per class by objectness, second logits from CIAM
+            sizes = [len(p) for p in proposals]
+            xr = fused.relu_grad_mask(x)  # x is a fused-ReLU output read by non-fused ops below
+            tg = targets if targets is not None else [None] * len(sizes)
+            logits2, sorted_props = [], []
+            for f, m, p, t in zip(xr.split(sizes), mask_logits.split(sizes), proposals, tg):
+                if len(p) == 0:
+                    logits2.append(m)
+                    sorted_props.append(p)
+                    continue
+                l2, sp, _, _ = self.mask_relation_module((f, m, p, t))
+                logits2.append(l2)
+                sorted_props.extend(sp)
+            mask_logits = torch.cat(logits2) if len(logits2) > 1 else logits2[0]
+            proposals = sorted_props
         if self.training:
-            return x, all_proposals, dict(loss_seg=self.loss_evaluator(proposals, mask_logits, targets))
+            if self.use_relation:
+                loss_2 = self.loss_evaluator(proposals, mask_logits, targets)
+                loss_1 = 0.5 * (loss_1 + loss_2) if self.cfg.MODEL.RELATION_MASK.DEEP_SUPER else loss_2
+            return x, all_proposals, dict(loss_seg=loss_1)
         # D8 of SURVEY.md: the reference hands a tuple to the post-processor here; the only semantics under which
         # the teacher produces a pseudo-mask is the concatenated logits, which is what `mask_logits` already is
         with torch.no_grad():

@@ -705,6 +705,7 @@ def inference(sd, cfg, x, sizes, taps=None):
                 for xi, pi, ci, bi in zip(xf.split(per), props, probs.split(per), br.split(per))]
     else:
         dets = box_postprocess(cfg, cl, br, props)
+    dets_in = dets  # what the mask head receives (before the per-class objectness sort of the mask relation)
     mx = mask_feature(sd, cfg, feats, dets)
     ml = mask_predictor(sd, mx)
     if cfg.relation:
@@ -715,7 +716,9 @@ def inference(sd, cfg, x, sizes, taps=None):
     seg = mask_generate(cfg, ml, dets)
     if taps is not None:
         taps["infer_proposals"] = [(p.bbox.clone(), p.fields["objectness"].clone()) for p in props]
-        taps["detections"] = [(d.bbox.clone(), d.fields["scores"].clone(), d.fields["labels"].clone()) for d in dets]
+        taps["detections"] = [(d.bbox.clone(), d.fields["scores"].clone(), d.fields["labels"].clone(),
+                               d.fields.get("objectness", d.fields["scores"]).clone()) for d in dets_in]
+        taps["detections_out"] = [(d.bbox.clone(), d.fields["labels"].clone()) for d in dets]
         taps["infer_mask_logits"] = ml.detach().clone()
     return dets, seg
 

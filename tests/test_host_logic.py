@@ -147,18 +147,30 @@ def test_config_surface():
     assert cfg.MODEL.ROI_HEADS.BBOX_REG_WEIGHTS == (10.0, 10.0, 5.0, 5.0)
 
 
-def test_model_state_dict_keys_match_reference(state_shapes):
+@pytest.mark.parametrize("irnet", [False, True])
+def test_model_state_dict_keys_match_reference(state_shapes, irnet):
+    import json, os
+    from conftest import GOLD
     from maskrcnn_benchmark.config import make_default_cfg
     from maskrcnn_benchmark.modeling.detector import build_detection_model
-    m = build_detection_model(make_default_cfg())
+    cfg = make_default_cfg()
+    if irnet:  # BASELINE config 5: relation NMS + mask relation on
+        cfg.merge_from_list(["MODEL.RELATION_NMS.USE_RELATION_NMS", True, "MODEL.RELATION_MASK.USE_RELATION", True])
+        state_shapes = json.load(open(os.path.join(GOLD, "state_shapes_irnet.json")))
+    m = build_detection_model(cfg)
     sd = m.state_dict()
     ref = state_shapes["shapes"]
     assert all(list(v.shape) == ref[k] for k, v in sd.items())
-    assert sorted(k for k in ref if k not in sd) == sorted(k for k in ref if "mask_relation_module" in k)  # IR-Net: next
+    assert sorted(ref) == sorted(sd)
     order = [k for k, _ in m.named_parameters()]
-    assert order == [k for k in state_shapes["param_order"] if "mask_relation_module" not in k]  # EMA zips by order
+    assert order == state_shapes["param_order"]  # the EMA zips teacher and student parameters by order
     frozen = {k for k, p in m.named_parameters() if not p.requires_grad}
-    assert frozen == {k for k in order if k not in state_shapes["trainable"]}
+    ref_frozen = {k for k in order if k not in state_shapes["trainable"]}
+    if not irnet:
+        # the reference builds mask_relation_module even when it is off (mask_head.py:49); it never receives a
+        # gradient there, so torch SGD skips it -- the flat SGD gets the same effect by freezing it
+        ref_frozen |= {k for k in order if "mask_relation_module" in k}
+    assert frozen == ref_frozen
 
 
 _DP_SCRIPT = r"""

@@ -1,0 +1,116 @@
+"""IR-Net (relation NMS + mask relation, BASELINE config 5 in fp32) on the MI355X against the CPU
+oracle (oracle/irnet.py, itself pinned to the reference by tests/golden/model160_irnet.npz).  Sampler sets, dropout
+masks and proposal lists are replayed from the oracle run as in test_model_gpu.py; the relation modules -- ranking,
+label preparation, attention, CIAM, second mask logits -- are computed by the product."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold, GOLD
+from test_model_gpu import _targets_oracle, _targets_product
+
+pytestmark = pytest.mark.gpu
+SIZE = 160
+
+
+@pytest.fixture(scope="module")
+def setup(synth):
+    from maskrcnn_benchmark.config import make_default_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    shapes = json.load(open(os.path.join(GOLD, "state_shapes_irnet.json")))["shapes"]
+    weights = synth.make_weights(shapes, seed=0)
+    cfg = make_default_cfg()
+    cfg.merge_from_list(["MODEL.RELATION_NMS.USE_RELATION_NMS", True, "MODEL.RELATION_MASK.USE_RELATION", True])
+    student = build_detection_model(cfg, is_student=True).cuda()
+    teacher = build_detection_model(cfg, is_teacher=True).cuda()
+    missing, unexpected = student.load_state_dict(weights, strict=False)
+    assert all("cell_anchors" in k for k in missing), missing
+    assert all("cell_anchors" in k for k in unexpected), unexpected
+    teacher.load_state_dict(weights, strict=False)
+    student.train()
+    teacher.eval()
+    return cfg, student, teacher, weights
+
+
+def test_irnet_supervised_forward_backward(setup, synth):
+    from oracle import model as om
+    from maskrcnn_benchmark.utils.replay import Replay
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    cfg, student, _, weights = setup
+    ocfg = om.default_cfg(relation=True)
+    imgs, tgs = synth.make_labeled(2, SIZE, 4, seed=1234)
+    sd = {k: v.clone().requires_grad_(v.dtype == torch.float32 and "bn" not in k and "downsample.1" not in k)
+          for k, v in weights.items()}
+    taps = {}
+    torch.manual_seed(99)
+    ref = om.forward_supervised(sd, ocfg, imgs, _targets_oracle(om, tgs), taps)
+    g = gold("model160_irnet")
+    # nms_loss: the top-40 attention selection and the per-gt argmax labels are discrete, and with the synthetic
+    # weights the regressed values are O(5), so the loss moves by ~1e-4 relative between hosts' CPU GEMMs already
+    # (20.0466 on the GPU box's host vs 20.0447 in the build container); 1e-3 for that key, 1e-4 for the others
+    tol = lambda k, base: 1e-3 if k == "nms_loss" else base
+    for k, v in ref.items():
+        assert v.item() == pytest.approx(float(g["sup_" + k]), rel=tol(k, 1e-5))
+    sum(ref.values()).backward()
+
+    student.set_replay(Replay(taps))
+    for p in student.parameters():
+        p.grad = None
+    out = student(to_image_list(list(imgs.cuda()), 32), _targets_product(tgs, "cuda"))
+    student.set_replay(None)
+    assert set(out) == set(ref) and "nms_loss" in out
+    for k in ref:
+        assert out[k].item() == pytest.approx(ref[k].item(), rel=tol(k, 1e-4)), k
+    sum(out.values()).backward()
+    named = dict(student.named_parameters())
+    for k in ("relation_nms.roi_feat_embedding_fc.weight", "relation_nms.nms_rank_fc.weight",
+              "relation_nms.relation_module.WG.weight", "relation_nms.relation_module.WK.weight",
+              "relation_nms.relation_module.WQ.bias", "relation_nms.relation_module.conv1.weight",
+              "relation_nms.classifier.weight", "relation_nms.classifier.bias",
+              "mask_heads.mask.mask_relation_module.appearance_feature_extractor.mask_fcn1.weight",
+              "mask_heads.mask.mask_relation_module.appearance_feature_extractor.conv5_mask.weight",
+              "mask_heads.mask.mask_relation_module.relation_module.gamma",
+              "mask_heads.mask.mask_relation_module.deconv_1.weight",
+              "mask_heads.mask.mask_relation_module.classifier.weight",
+              "mask_heads.mask.feature_extractor.mask_fcn4.weight",   # receives gradient from BOTH mask losses
+              "box_heads.box.feature_extractor.fc7.weight",          # ... and from nms_loss through fc7's output
+              "backbone.fpn.fpn_layer1.weight"):
+        gr, pg = sd[k].grad, named[k].grad.detach().cpu()
+        scale = gr.abs().max().item() + 1e-12
+        # relation_nms: d/dw of log(clamp(relu(WG x), 1e-6)) carries 1/w_g factors -> a little looser than 2e-3
+        assert (pg - gr).abs().max().item() / scale < (5e-3 if k.startswith("relation_nms") else 2e-3), k
+
+
+def test_irnet_teacher_inference(setup, synth):
+    """eval path: learned duplicate removal + per-class NMS + second mask logits -> pseudo labels and pseudo masks"""
+    from oracle import model as om
+    from maskrcnn_benchmark.utils.replay import Replay
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    cfg, _, teacher, weights = setup
+    ocfg = om.default_cfg(relation=True)
+    unl = synth.make_unlabeled(2, SIZE, 3, seed=4321)
+    taps = {}
+    torch.manual_seed(100)
+    tr = om.forward_teacher(weights, ocfg, unl[:2], taps)
+    teacher.taps = {}
+    teacher.set_replay(Replay({k: v for k, v in taps.items() if k != "detections"}))  # detections: the product's own
+    with torch.no_grad():
+        out = teacher.forward_teacher([to_image_list(list(u.cuda()), 32) for u in unl[:2]])
+    teacher.set_replay(None)
+    own = teacher.taps["detections_own"]
+    teacher.taps = None
+    for (rb, rs, rl, ro), o in zip(taps["detections"], own):  # relation-NMS output, before the mask-relation sort
+        assert len(o) == rb.shape[0] and len(o) > 0
+        np.testing.assert_allclose(o.bbox.cpu().numpy(), rb.numpy(), atol=1e-3)
+        np.testing.assert_array_equal(o.get_field("labels").cpu().numpy(), rl.numpy())
+        np.testing.assert_allclose(o.get_field("scores").cpu().numpy(), rs.numpy(), rtol=1e-3, atol=1e-5)
+    for r, o in zip(tr["result_t"], out["result_t"]):
+        np.testing.assert_allclose(o.bbox.cpu().numpy(), r.bbox.numpy(), atol=1e-3)
+        np.testing.assert_array_equal(o.get_field("labels").cpu().numpy(), r.fields["labels"].numpy())
+    a, b = torch.stack(tr["class_logit_t"]), torch.stack(out["class_logit_t"]).cpu()
+    assert (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
+    for s_r, s_o in zip(tr["seg_mask"], out["seg_mask"]):
+        assert (s_r != s_o.cpu().long()).float().mean().item() < 1e-4
