@@ -32,7 +32,7 @@ CROP = 1000
 N_LAB, N_UNLAB, N_INST = 2, 2, 12
 
 
-def build(device, rank):
+def build(device, rank, irnet=False):
     import synthetic
     from maskrcnn_benchmark.config import make_default_cfg
     from maskrcnn_benchmark.modeling.detector import build_detection_model
@@ -43,11 +43,24 @@ def build(device, rank):
     from maskrcnn_benchmark.structures.image_list import to_image_list
 
     cfg = make_default_cfg()
+    if irnet:  # BASELINE configs[4] (in fp32): learned duplicate removal + mask relation on
+        # RELATION_NMS.LOSS 0.01 (shipped: 1.0): the synthetic fc7 features have |x|^2 ~ 1e3, so an MSE head on top of
+        # them is unstable at BASE_LR 0.005 with weight 1 (lr * |x|^2 > 2) and the run turns NaN within 4 steps;
+        # the loss weight only scales the gradient -- the launches per step are the same
+        cfg.merge_from_list(["MODEL.RELATION_NMS.USE_RELATION_NMS", True, "MODEL.RELATION_MASK.USE_RELATION", True,
+                             "MODEL.RELATION_NMS.LOSS", 0.01])
     torch.manual_seed(0)
     student = build_detection_model(cfg, is_student=True)
     teacher = build_detection_model(cfg, is_teacher=True)
     shapes = {k: tuple(v.shape) for k, v in student.state_dict().items()}
     sd = synthetic.make_weights(shapes, seed=0)  # identical on every rank (DP replicas start equal)
+    if irnet:
+        # the relation-NMS IoU regressor keeps its own (seeded) training initialisation: with the O(1) synthetic
+        # weights its MSE loss starts at ~20 and diverges to NaN within three SGD steps at BASE_LR.  Its output bias
+        # is set to 0.5 (a regressor that predicts IoU 0.5 +- small for every ranked box) so that the teacher's
+        # learned duplicate removal keeps detections (> FG_THREAD) and the mean-teacher branch has pseudo labels
+        sd = {k: v for k, v in sd.items() if not k.startswith("relation_nms.")}
+        torch.nn.init.constant_(student.relation_nms.classifier.bias, 0.5)
     student.load_state_dict(sd, strict=False)
     teacher.load_state_dict(sd, strict=False)
     student.to(device)
@@ -123,6 +136,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--irnet", action="store_true", help="IR-Net on (BASELINE configs[4] in fp32); not the headline line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,7 +153,7 @@ def main():
 
     from maskrcnn_benchmark import _hip
     _hip.lib()
-    cfg, trainer, batch = build(device, rank)
+    cfg, trainer, batch = build(device, rank, args.irnet)
     it0 = cfg.MT.START_MT + cfg.MT.RAMPUP_STEP + 100  # mean-teacher branch active, consistency weight = lambda
 
     def sync():
@@ -188,7 +202,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MMT-PSM mean-teacher step (BASELINE configs[2]; configs[3] when n_gpus>1): per GPU 2 "
                                    "labeled + 2 unlabeled 1000x1000x3 crops, AUG_K=2 + flip, AUG_S=1, MT.LAMBDA 5, "
-                                   "PSM+MGD, EMA teacher, fwd+bwd+SGD, R50-FPN fp32, IR-Net off",
+                                   "PSM+MGD, EMA teacher, fwd+bwd+SGD, R50-FPN fp32, IR-Net %s" % (
+                                       "ON (relation NMS + mask relation; RELATION_NMS.LOSS 0.01)" if args.irnet else "off"),
                        "image_forwards_per_step_per_gpu": 12, "parallelism": "dp%d" % world,
                        "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}},
             "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)",

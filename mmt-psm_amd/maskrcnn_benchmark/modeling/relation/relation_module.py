@@ -109,7 +109,8 @@ def _first_argmax(x, dim):
     shape = [1] * x.dim()
     shape[dim] = n
     ar = torch.arange(n, device=x.device).view(shape).expand_as(x)
-    return torch.where(x == mx, ar, torch.full_like(ar, n)).min(dim=dim)[0]
+    # (all-NaN slices have no maximal element; clamp so that a diverged model fails with NaN losses, not an index fault)
+    return torch.where(x == mx, ar, torch.full_like(ar, n)).min(dim=dim)[0].clamp(max=n - 1)
 
 
 class DuplicationRemovalNetwork(nn.Module):

@@ -144,3 +144,30 @@ def test_teacher_student(setup, synth, weights):
     for k in sref:
         assert sout[k].item() == pytest.approx(sref[k].item(), rel=2e-4), k
     assert sref["mt_fg_loss"].item() > 1e-3
+
+
+def test_teacher_without_detections(setup, synth):
+    """An unlabeled image on which the teacher detects nothing: the coarse inference returns empty BoxLists (with an
+    all-zero pseudo mask) and forward_teacher raises the Matcher's ValueError exactly like the reference
+    (modeling/matcher.py:55-62 via box_head/loss.py subsample) -- never a device fault."""
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    cfg, _, teacher = setup
+    unl = synth.make_unlabeled(2, SIZE, 3, seed=77)
+    pp = teacher.box_heads.box.post_processor
+    old = pp.score_thresh
+    pp.score_thresh = 2.0
+    try:
+        teacher.set_module_mode("test")
+        with torch.no_grad():
+            res = teacher(to_image_list(list(unl[0].cuda()), 32))
+        assert [len(r) for r in res] == [0, 0]
+        for r in res:
+            assert int(r.get_field("mask").sum(0)[0].sum()) == 0
+        with pytest.raises(ValueError, match="No ground-truth boxes"):
+            with torch.no_grad():
+                teacher.forward_teacher([to_image_list(list(u.cuda()), 32) for u in unl[:2]])
+        torch.cuda.synchronize()
+    finally:
+        pp.score_thresh = old
+        teacher.set_module_mode("train")
+        teacher.rpn.shared = None
