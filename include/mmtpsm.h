@@ -86,12 +86,41 @@ typedef struct {
   int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
   int relu, res_mode, out_stride, out_H, out_W; /* out_H/out_W: full dims of y when out_stride>1 */
   float mask_scale;
+  /* optional (split-bf16 modes, see mmt_set_conv_precision): the weight tensor packed by mmt_pack_weight(s) --
+   * plane q (q = 0..2) at w_planes + q * w_plane_stride bf16 elements.  16-byte aligned, stride % 8 == 0.
+   * NULL: the kernel splits the fp32 weights itself (slower). */
+  const void* w_planes;
+  long w_plane_stride;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
 /* which tile configuration mmt_conv_forward picks for these shapes: 0 = 128x32, 1 = 128x128 (the dominant
  * kernel of the step, conv_fwd_kernel<128,128,2,2>), 2 = 64x64.  Used by bench.py for the roofline line. */
 int mmt_conv_variant(const mmt_conv_args* a /*[host]*/);
+/* arithmetic of the convolution GEMMs (process-wide; initial value from the environment variable
+ * MMT_CONV_PRECISION, default 0):
+ *   0  fp32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products, the reference's arithmetic (ATen fp32 conv)
+ *   3  fp32 operands split into three bf16 terms on the fly, 6 bf16 MFMAs per product block: fp32-grade results
+ *      (dropped terms <= 3*2^-27 of a product) at up to 2.6x the fp32-MFMA rate
+ *   2  two-term split, 3 bf16 MFMAs (~2^-17 per product)
+ *   1  plain bf16 inputs, fp32 accumulate (torch.autocast(bfloat16)-class arithmetic; BASELINE config 5)
+ * Tensors stay fp32 in HBM in every mode.  Shapes the split kernels do not cover (Cin % 16 != 0, Cout <= 32) always
+ * run in mode 0.  Returns MMT_EINVAL for an unknown mode. */
+int mmt_set_conv_precision(int mode);
+int mmt_get_conv_precision(void);
+/* Packed bf16 planes of a weight matrix w[Cout][K] (K = KH*KW*Cin in the weight's own memory order, K % 16 == 0) for
+ * the split-bf16 modes.  Plane q (q = 0..2, at planes + q*plane_stride bf16 elements) holds the q-th term of the
+ * round-to-nearest bf16 expansion w = w0 + w1 + w2 (exact to 2^-27 |w|), tiled as
+ * [K/16][ceil(Cout/32)][32 rows][2 halves][8] -- the LDS image of the kernels, so that their global->LDS DMA reads
+ * 1 KiB of consecutive memory per instruction.  mmt_packed_weight_elems = elements per plane (-1 if unsupported).
+ * mmt_pack_weights packs many matrices of one fp32 buffer in a single launch (engine/flat.py: once per SGD / EMA step):
+ * descs[] (device) gives per matrix its offset in `base`, its offset inside a plane, Cout, K and its first unit index
+ * (unit = one 1 KiB tile = 512 elements); unit_desc[u] (device) = index of the matrix unit u belongs to. */
+typedef struct { long src_off, dst_off; int Cout, K, unit0, pad; } mmt_pack_desc;
+long mmt_packed_weight_elems(int Cout, int K);
+int mmt_pack_weight(const float* w, void* planes, long plane_stride, int Cout, int K, void* stream);
+int mmt_pack_weights(const float* base, void* planes, long plane_stride, const mmt_pack_desc* descs /*[dev]*/,
+                     const int* unit_desc /*[dev]*/, int n_units, void* stream);
 
 /* weight gradient: dw[co,kh,kw,ci] += rowscale[co] * sum_{n,ho,wo} dy[n,ho,wo,co] * x[n,ho*s+kh-p,wo*s+kw-p,ci]
  * (dw = the caller's gradient buffer, same layout as the weight; Cin % 4 == 0); optional dbias[co] += sum dy[..,co].

@@ -35,9 +35,100 @@ struct ConvP {
   int relu, res_mode, out_stride, out_H, out_W;
   float mask_scale;
   int M, K, cin32, cin4;  // derived
+  const unsigned short* wpl; long wpl_stride;  // pre-split bf16 planes of w (or null)
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
+
+// ---- shared epilogue of the forward kernels: accumulators -> LDS (the operand ring is free by then) -> row-major
+// float4 rows, so that stores and residual / mask / mul loads are all 16 B per lane and fully coalesced (a 128-wide
+// tile row = 512 B), and the (img,ho,wo) decode is per row instead of per element.  Matters for the low-K 1x1
+// layers, which are store-bound: their whole runtime is this epilogue.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)], float* lds,
+                                              const int m0, const int n0, const int tid, const int lane,
+                                              const int wm, const int wn, const int HoWo) {
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  {
+    float* ct = lds;  // [BM][BN]
+    const int col_l = lane & 31, rq = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+      for (int b = 0; b < TN; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+          ct[row * BN + (wn * TN + b) * 32 + col_l] = acc[a][b][r];
+        }
+    __syncthreads();
+    constexpr int C4 = BN / 4, RPP = 256 / C4;
+    const int cc = tid % C4, r0 = tid / C4;
+    const int c = n0 + cc * 4;
+    if (c < p.Cout) {
+      const bool vec = (p.Cout & 3) == 0;
+      const int nv = vec ? 4 : min(4, p.Cout - c);
+      float sc[4], sh[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        sc[e] = (p.scale && e < nv) ? p.scale[c + e] : 1.f;
+        sh[e] = (p.shift && e < nv) ? p.shift[c + e] : 0.f;
+      }
+      auto ld = [&](const float* q, float* o) {
+        if (vec) { const f32x4 t = ldg4(q); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
+        else { for (int e = 0; e < 4; e++) o[e] = e < nv ? q[e] : 0.f; }
+      };
+      for (int row = r0; row < BM; row += RPP) {
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        const f32x4 t = *(const f32x4*)(ct + row * BN + cc * 4);
+        float v[4] = {t[0] * sc[0] + sh[0], t[1] * sc[1] + sh[1], t[2] * sc[2] + sh[2], t[3] * sc[3] + sh[3]};
+        long oidx = (long)m * p.Cout + c;
+        float u[4];
+        if (p.res_mode >= 2 || p.out_stride > 1) {
+          const int img = m / HoWo, rem = m - img * HoWo;
+          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+          if (p.res_mode == 2) {
+            const int h2 = p.Ho >> 1, w2 = p.Wo >> 1;
+            ld(p.res + (((long)img * h2 + (ho >> 1)) * w2 + (wo >> 1)) * p.Cout + c, u);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += u[e];
+          } else if (p.res_mode == 3) {
+            const int h2 = p.Ho * 2, w2 = p.Wo * 2;
+            const float* rp = p.res + (((long)img * h2 + 2 * ho) * w2 + 2 * wo) * p.Cout + c;
+            float u1[4], u2[4], u3[4];
+            ld(rp, u); ld(rp + p.Cout, u1); ld(rp + (long)w2 * p.Cout, u2); ld(rp + (long)w2 * p.Cout + p.Cout, u3);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += (u[e] + u1[e]) + (u2[e] + u3[e]);
+          }
+          if (p.out_stride > 1)
+            oidx = (((long)img * p.out_H + ho * p.out_stride) * p.out_W + wo * p.out_stride) * p.Cout + c;
+        }
+        if (p.res_mode == 1) {
+          ld(p.res + (long)m * p.Cout + c, u);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += u[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.mask) {
+          ld(p.mask + oidx, u);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = u[e] > 0.f ? v[e] * p.mask_scale : 0.f;
+        }
+        if (p.mul) {
+          ld(p.mul + (long)m * p.Cout + c, u);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] *= u[e];
+        }
+        if (vec) *(f32x4*)(p.y + oidx) = f32x4{v[0], v[1], v[2], v[3]};
+        else for (int e = 0; e < nv; e++) p.y[oidx + e] = v[e];
+      }
+    }
+  }
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
@@ -212,89 +303,443 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: accumulators -> LDS (the operand ring is free now) -> row-major float4 rows, so that stores,
-  // residual / mask / mul loads are all 16 B per lane and fully coalesced (a 128-wide tile row = 512 B), and the
-  // (img,ho,wo) decode is per row instead of per element.  Matters for the low-K 1x1 layers, which are
-  // store-bound: their whole runtime is this epilogue.
-  {
-    float* ct = lds;  // [BM][BN]
-    const int col_l = lane & 31, rq = lane >> 5;
+  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tid, lane, wm, wn, HoWo);
+}
+
+// ------------------------------------------------------------------------------------ split-bf16 forward
+// The same implicit GEMM on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate) with fp32
+// operands in HBM: while a tile is staged into LDS every fp32 value x is split into NS bf16 terms (round-to-nearest at
+// each level, residuals exact in fp32):   x = x0 + x1 (+ x2),  |x1| <= 2^-9 |x|,  |x2| <= 2^-18 |x|.
+//   NS = 3: a*b ~= a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0); dropped terms <= 3 * 2^-27 |ab|, i.e. below the fp32
+//           rounding of the product itself -> fp32-grade results (accumulation is fp32, small terms first) at 6 MFMAs
+//           per 16-k step = 2500/6 = 417 TFLOP/s effective peak vs 157 for the fp32-input MFMA
+//   NS = 2: 3 products, ~2^-17 relative per product;   NS = 1: plain bf16 inputs (BASELINE config 5's "bf16 MFMA path")
+// LDS image per plane: [row][16 bf16] (32 B rows); the 16-byte half holding k 0..7 / 8..15 is XOR-ed with (row>>3)&1,
+// which makes the ds_read_b128 fragment reads conflict-free for the four 16-lane service groups; A and B use the same
+// lane->k assignment, so the k order inside the instruction does not matter.  Tile = BM x BN x 16, 2-deep LDS ring.
+// Requires Cin % 16 == 0 (every heavy layer of the path); other shapes run on the fp32 kernel above.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
+}
+
+template <int NS>
+__device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]) {
+  float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
 #pragma unroll
-    for (int a = 0; a < TM; a++)
-#pragma unroll
-      for (int b = 0; b < TN; b++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-          ct[row * BN + (wn * TN + b) * 32 + col_l] = acc[a][b][r];
-        }
-    __syncthreads();
-    constexpr int C4 = BN / 4, RPP = 256 / C4;
-    const int cc = tid % C4, r0 = tid / C4;
-    const int c = n0 + cc * 4;
-    if (c < p.Cout) {
-      const bool vec = (p.Cout & 3) == 0;
-      const int nv = vec ? 4 : min(4, p.Cout - c);
-      float sc[4], sh[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        sc[e] = (p.scale && e < nv) ? p.scale[c + e] : 1.f;
-        sh[e] = (p.shift && e < nv) ? p.shift[c + e] : 0.f;
-      }
-      auto ld = [&](const float* q, float* o) {
-        if (vec) { const f32x4 t = ldg4(q); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
-        else { for (int e = 0; e < 4; e++) o[e] = e < nv ? q[e] : 0.f; }
-      };
-      for (int row = r0; row < BM; row += RPP) {
-        const int m = m0 + row;
-        if (m >= p.M) break;
-        const f32x4 t = *(const f32x4*)(ct + row * BN + cc * 4);
-        float v[4] = {t[0] * sc[0] + sh[0], t[1] * sc[1] + sh[1], t[2] * sc[2] + sh[2], t[3] * sc[3] + sh[3]};
-        long oidx = (long)m * p.Cout + c;
-        float u[4];
-        if (p.res_mode >= 2 || p.out_stride > 1) {
-          const int img = m / HoWo, rem = m - img * HoWo;
-          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-          if (p.res_mode == 2) {
-            const int h2 = p.Ho >> 1, w2 = p.Wo >> 1;
-            ld(p.res + (((long)img * h2 + (ho >> 1)) * w2 + (wo >> 1)) * p.Cout + c, u);
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += u[e];
-          } else if (p.res_mode == 3) {
-            const int h2 = p.Ho * 2, w2 = p.Wo * 2;
-            const float* rp = p.res + (((long)img * h2 + 2 * ho) * w2 + 2 * wo) * p.Cout + c;
-            float u1[4], u2[4], u3[4];
-            ld(rp, u); ld(rp + p.Cout, u1); ld(rp + (long)w2 * p.Cout, u2); ld(rp + (long)w2 * p.Cout + p.Cout, u3);
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += (u[e] + u1[e]) + (u2[e] + u3[e]);
-          }
-          if (p.out_stride > 1)
-            oidx = (((long)img * p.out_H + ho * p.out_stride) * p.out_W + wo * p.out_stride) * p.Cout + c;
-        }
-        if (p.res_mode == 1) {
-          ld(p.res + (long)m * p.Cout + c, u);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += u[e];
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (p.mask) {
-          ld(p.mask + oidx, u);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = u[e] > 0.f ? v[e] * p.mask_scale : 0.f;
-        }
-        if (p.mul) {
-          ld(p.mul + (long)m * p.Cout + c, u);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] *= u[e];
-        }
-        if (vec) *(f32x4*)(p.y + oidx) = f32x4{v[0], v[1], v[2], v[3]};
-        else for (int e = 0; e < nv; e++) p.y[oidx + e] = v[e];
-      }
+  for (int q = 0; q < NS; q++) {
+    const unsigned a = pk_bf16(r0, r1), b = pk_bf16(r2, r3);
+    o[q] = uint2{a, b};
+    if (q + 1 < NS) {
+      r0 -= __builtin_bit_cast(float, a << 16);
+      r1 -= __builtin_bit_cast(float, a & 0xffff0000u);
+      r2 -= __builtin_bit_cast(float, b << 16);
+      r3 -= __builtin_bit_cast(float, b & 0xffff0000u);
     }
   }
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvP p) {
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int NA = BM / 64, NB = BN / 64;  // float4 loads per thread per 16-k tile
+  constexpr int PA = BM * 32, PB = BN * 32;  // bytes per bf16 plane
+  constexpr int STAGE = NS * (PA + PB);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ring = (char*)lds;  // [2][NS planes of A | NS planes of B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int c4 = tid & 3;    // which float4 of the 16-float k-chunk
+  const int r64 = tid >> 2;  // row within a 64-row group
+  unsigned abase[NA];
+  int aih0[NA], aiw0[NA];
+  bool aok[NA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int j = 0; j < NA; j++) {
+    const int m = m0 + r64 + 64 * j;
+    aok[j] = m < p.M;
+    const int mm = aok[j] ? m : 0;
+    const int img = mm / HoWo, rem = mm - img * HoWo;
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    aih0[j] = ho * p.stride - p.pad;
+    aiw0[j] = wo * p.stride - p.pad;
+    abase[j] = (unsigned)img * (unsigned)(p.H * p.W * p.Cin);
+  }
+  unsigned bbase[NB];
+  bool bok[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const int n = n0 + r64 + 64 * j;
+    bok[j] = n < p.Cout;
+    bbase[j] = (unsigned)(bok[j] ? n : 0) * (unsigned)p.K;
+  }
+  // byte offset of this thread's 8-byte slot inside a plane (rows r64 + 64 j: (row>>3)&1 does not depend on j)
+  const int woff = r64 * 32 + ((((c4 >> 1) ^ (r64 >> 3)) & 1) << 4) + ((c4 & 1) << 3);
+  const int lr = lane & 31, kh2 = lane >> 5;
+  const int froff = lr * 32 + (((kh2 ^ (lr >> 3)) & 1) << 4);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int nkt = p.K >> 4;
+  f32x4 ra[NA], rb[NB];
+  bool pa[NA], pb[NB];
+  int s_kh = 0, s_kw = 0, s_ci = 0;
+
+  auto load_tile = [&](int kt) {
+    const int kh = s_kh, kw = s_kw, ci = s_ci + c4 * 4;
+    s_ci += 16;
+    if (s_ci >= p.Cin) { s_ci = 0; if (++s_kw == p.KW) { s_kw = 0; ++s_kh; } }
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+      const int ih = aih0[j] + kh, iw = aiw0[j] + kw;
+      const bool ok = aok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned off = ok ? abase[j] + (unsigned)((ih * p.W + iw) * p.Cin + ci) : 0u;
+      if (DBG & 2) ra[j] = f32x4{(float)off, 1.f, 2.f, 3.f}; else
+      ra[j] = ldg4(p.x + off);
+      pa[j] = ok;
+    }
+    const int kidx = kt * 16 + c4 * 4;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      if (DBG & 2) rb[j] = f32x4{(float)kidx, 1.f, 2.f, 3.f}; else
+      rb[j] = ldg4(p.w + (bok[j] ? bbase[j] + (unsigned)kidx : 0u));
+      pb[j] = bok[j];
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* A = ring + buf * STAGE + woff;
+    char* B = A + NS * PA;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+      uint2 o[NS];
+      if (DBG & 4) { const f32x4 v = pa[j] ? ra[j] : zero4; for (int q = 0; q < NS; q++) o[q] = uint2{__builtin_bit_cast(unsigned, v[0]) + q, __builtin_bit_cast(unsigned, v[2])}; } else
+      split4<NS>(pa[j] ? ra[j] : zero4, o);
+#pragma unroll
+      for (int q = 0; q < NS; q++) *(uint2*)(A + q * PA + j * 64 * 32) = o[q];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      uint2 o[NS];
+      if (DBG & 4) { const f32x4 v = pb[j] ? rb[j] : zero4; for (int q = 0; q < NS; q++) o[q] = uint2{__builtin_bit_cast(unsigned, v[0]) + q, __builtin_bit_cast(unsigned, v[2])}; } else
+      split4<NS>(pb[j] ? rb[j] : zero4, o);
+#pragma unroll
+      for (int q = 0; q < NS; q++) *(uint2*)(B + q * PB + j * 64 * 32) = o[q];
+    }
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const char* A = ring + buf * STAGE + (wm * TM * 32) * 32 + froff;
+    const char* B = ring + buf * STAGE + NS * PA + (wn * TN * 32) * 32 + froff;
+    bf16x8 fa[NS][TM], fb[NS][TN];
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+#pragma unroll
+      for (int a = 0; a < TM; a++) fa[q][a] = *(const bf16x8*)(A + q * PA + a * 32 * 32);
+#pragma unroll
+      for (int b = 0; b < TN; b++) fb[q][b] = *(const bf16x8*)(B + q * PB + b * 32 * 32);
+    }
+    // smallest terms first: order s = qa + qb descending
+#pragma unroll
+    for (int sum = 2 * (NS - 1) > NS - 1 ? NS - 1 : 0; sum >= 0; sum--)
+#pragma unroll
+      for (int qa = 0; qa <= sum; qa++) {
+        const int qb = sum - qa;
+        if (qa < NS && qb < NS) {
+#pragma unroll
+          for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int b = 0; b < TN; b++)
+              if (DBG & 1) acc[a][b][(qa + qb) & 15] += (float)fa[qa][a][0] * (float)fb[qb][b][0]; else
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
+        }
+      }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tid, lane, wm, wn, HoWo);
+}
+
+// ------------------------------------------------------------------------------------ split-bf16 forward, DMA-fed
+// Same arithmetic as conv_fwd_split_kernel, restructured around what that kernel measured as its limit (ds_write
+// bandwidth of ~80 B/clk/CU and one store-phase + barrier per 16-k step; the split VALU work itself was free):
+//   * B (weights) arrives PRE-SPLIT: NS bf16 planes of the weight tensor in HBM (mmt_pack_weights, refreshed once per
+//     optimiser / EMA step), copied global -> LDS by the DMA path (global_load_lds_dwordx4: no VGPR staging, no ds_write);
+//   * A (activations) is DMA-copied as raw fp32 and split in registers AFTER the fragment read; with the 4x1 wave grid
+//     the rows of a wave are private to it, so every activation value is split once per block (8 values per lane per
+//     16-k step);
+//   * 3-deep LDS ring, one raw s_barrier per step, counted vmcnt: the DMA of step t+2 is issued right after the barrier
+//     of step t and stays in flight across the next barrier.
+// LDS images are lane-linear per DMA instruction (hardware: dest = base + 16 * lane); the bank swizzles are applied on
+// the SOURCE address and again on the fragment read (A: 16-B chunk ^= (row>>2)&3 of a 64-B row; B: half ^= (row>>3)&1).
+__device__ __attribute__((aligned(16))) const float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};  // source of halo / OOB lanes
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void dma16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_ptr_t)l, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, const unsigned short* __restrict__ wpl,
+                                                               const long wpl_stride) {
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int A_BYTES = BM * 64;           // [BM][16] fp32
+  constexpr int PB = BN * 32;                // one bf16 plane [BN][16]
+  constexpr int STAGE = A_BYTES + NS * PB;
+  constexpr int NIA = BM / 64;               // A DMA instructions per wave per step (16 rows each)
+  constexpr int NIB_TOT = NS * BN / 32;      // B DMA instructions per step (32 rows of one plane each)
+  constexpr int NIB = (NIB_TOT + 3) / 4;     // per wave (the tail wraps around: same data written twice, harmless)
+  constexpr int NI = NIA + NIB;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ring = (char*)lds;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HoWo = p.Ho * p.Wo;
+
+  // ---- DMA source geometry.  A instruction i of this wave covers rows (wave + 4 i) * 16 + (lane >> 2), 16-B chunk
+  // (lane & 3) of the LDS row, which holds logical chunk (lane & 3) ^ ((row >> 2) & 3).
+  unsigned abase[NIA];
+  int aih0[NIA], aiw0[NIA], achunk[NIA];
+  bool aok[NIA];
+#pragma unroll
+  for (int i = 0; i < NIA; i++) {
+    const int row = (wave + 4 * i) * 16 + (lane >> 2);
+    const int m = m0 + row;
+    aok[i] = m < p.M;
+    const int mm = aok[i] ? m : 0;
+    const int img = mm / HoWo, rem = mm - img * HoWo;
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    aih0[i] = ho * p.stride - p.pad;
+    aiw0[i] = wo * p.stride - p.pad;
+    abase[i] = (unsigned)img * (unsigned)(p.H * p.W * p.Cin);
+    achunk[i] = ((lane & 3) ^ ((row >> 2) & 3)) * 4;
+  }
+  // B instruction t = wave + 4 i (mod NIB_TOT): plane t / (BN/32), 32-row block t % (BN/32).  The packed weight planes
+  // (mmt_pack_weights) hold, for every 16-k step and 32-channel block, the 1 KiB LDS image itself (swizzle included),
+  // so a DMA instruction reads 1 KiB of consecutive memory: 8 full cache lines instead of 32 quarter-used ones
+  const int nb32 = (p.Cout + 31) >> 5;
+  const long kt_stride = (long)nb32 * 512;  // bf16 elements per 16-k step
+  const unsigned short* bsrc[NIB];
+  int bdst[NIB];
+#pragma unroll
+  for (int i = 0; i < NIB; i++) {
+    const int t = (wave + 4 * i) % NIB_TOT;
+    const int q = t / (BN / 32), rb = t % (BN / 32);
+    int nb = n0 / 32 + rb;
+    if (nb >= nb32) nb = nb32 - 1;  // tile hanging over Cout: any valid block (those columns are never stored)
+    bsrc[i] = wpl + q * wpl_stride + (long)nb * 512 + lane * 8;
+    bdst[i] = A_BYTES + q * PB + rb * 1024;
+  }
+  int s_kh = 0, s_kw = 0, s_ci = 0;
+  auto issue_a = [&](int stage) {  // next 16-k chunk of the activations (tap-major, channels inside the tap)
+    char* st = ring + stage * STAGE;
+    const int kh = s_kh, kw = s_kw, ci = s_ci;
+    s_ci += 16;
+    if (s_ci >= p.Cin) { s_ci = 0; if (++s_kw == p.KW) { s_kw = 0; ++s_kh; } }
+#pragma unroll
+    for (int i = 0; i < NIA; i++) {
+      const int ih = aih0[i] + kh, iw = aiw0[i] + kw;
+      const bool ok = aok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const float* src = ok ? p.x + (abase[i] + (unsigned)((ih * p.W + iw) * p.Cin + ci + achunk[i])) : g_zero16;
+      dma16(src, st + (wave + 4 * i) * 1024);
+    }
+  };
+  auto issue_b = [&](int kt, int stage) {
+    char* st = ring + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < NIB; i++) dma16(bsrc[i] + (long)kt * kt_stride, st + bdst[i]);
+  };
+
+  // ---- fragment read offsets
+  const int lr = lane & 31, kh2 = lane >> 5;
+  int aoff[TM][2];
+#pragma unroll
+  for (int a = 0; a < TM; a++) {
+    const int row = (wm * TM + a) * 32 + lr;
+#pragma unroll
+    for (int h = 0; h < 2; h++) aoff[a][h] = row * 64 + (((2 * kh2 + h) ^ ((row >> 2) & 3)) << 4);
+  }
+  const int boff = A_BYTES + (wn * TN * 32 + lr) * 32 + (((kh2 ^ (lr >> 3)) & 1) << 4);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int nkt = p.K >> 4;
+  f32x4 va[TM][2];  // raw fp32 A fragments of the next step, between their ds_read and their split
+  auto read_frags = [&](int stage, bf16x8 (&fb)[NS][TN]) {
+    const char* st = ring + stage * STAGE;
+#pragma unroll
+    for (int a = 0; a < TM; a++) {
+      va[a][0] = *(const f32x4*)(st + aoff[a][0]);
+      va[a][1] = *(const f32x4*)(st + aoff[a][1]);
+    }
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+      for (int b = 0; b < TN; b++) fb[q][b] = *(const bf16x8*)(st + boff + q * PB + b * 1024);
+  };
+  auto split_frags = [&](bf16x8 (&fa)[NS][TM]) {
+#pragma unroll
+    for (int a = 0; a < TM; a++) {
+      uint2 o0[NS], o1[NS];
+      split4<NS>(va[a][0], o0);
+      split4<NS>(va[a][1], o1);
+#pragma unroll
+      for (int q = 0; q < NS; q++) {
+        const uint4 u = {o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+        fa[q][a] = __builtin_bit_cast(bf16x8, u);
+      }
+    }
+  };
+  // One pipeline step.  The wave's own work for the FUTURE steps is spread between the MFMA groups of step kt so that
+  // the memory pipe is fed while the matrix pipe runs (issued as one burst, the DMAs of the two resident blocks and
+  // their MFMA phases fell into lockstep: measured time = fill time + MFMA time, no overlap):
+  //   after group 0: DMA of A for step kt+3     after group 1: DMA of B for step kt+3
+  //   after group 2: ds_read of the fragments of step kt+1     after group 3: split of A for step kt+1
+  auto step = [&](int kt, int stage_next, int stage_free, const bf16x8 (&fa)[NS][TM], const bf16x8 (&fb)[NS][TN],
+                  bf16x8 (&fan)[NS][TM], bf16x8 (&fbn)[NS][TN]) {
+    const bool more = kt + 1 < nkt, fill = kt + 3 < nkt;
+    if (more) {
+      // this wave's DMAs of step kt+1 have landed (those of step kt+2 may stay in flight) and its own fragment reads of
+      // step kt are complete ...
+      if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      // ... and so are everybody else's: step kt+1 is readable, the buffer of step kt is free
+      __builtin_amdgcn_s_barrier();
+    }
+    auto filler = [&](int g) {
+      if (g == 0) { if (fill) issue_a(stage_free); }
+      else if (g == 1) { if (fill) issue_b(kt + 3, stage_free); }
+      else if (g == 2) { if (more) read_frags(stage_next, fbn); }
+      else if (g == 3) { if (more) split_frags(fan); }
+    };
+    int g = 0;
+#pragma unroll
+    for (int sum = NS - 1; sum >= 0; sum--)
+#pragma unroll
+      for (int qa = 0; qa <= sum; qa++) {
+        const int qb = sum - qa;
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+          for (int b = 0; b < TN; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        filler(g++);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (r >= g) filler(r);
+  };
+  issue_a(0); issue_b(0, 0);
+  if (nkt > 1) { issue_a(1); issue_b(1, 1); }
+  if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (nkt > 2) { issue_a(2); issue_b(2, 2); }
+  bf16x8 fa0[NS][TM], fb0[NS][TN], fa1[NS][TM], fb1[NS][TN];
+  read_frags(0, fb0);
+  split_frags(fa0);
+  int stage = 0;  // buffer of step kt
+  for (int kt = 0; kt < nkt; kt += 2) {
+    const int s1 = stage == 2 ? 0 : stage + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+    step(kt, s1, stage, fa0, fb0, fa1, fb1);
+    if (kt + 1 < nkt) step(kt + 1, s2, s1, fa1, fb1, fa0, fb0);
+    stage = s2;
+  }
+  __syncthreads();
+  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tid, lane, wm, wn, HoWo);
+}
+
+// Weight packing for the DMA-fed kernels.  For a weight matrix [Cout][K] (K % 16 == 0) plane q of the packed form is
+//   [K/16 steps][ceil(Cout/32) blocks][32 rows][2 halves][8 bf16]
+// where (row r, physical half h) holds the q-th bf16 term of w[32 blk + r][16 step + 8 (h ^ ((r>>3)&1)) + 0..7]
+// (zeros for rows >= Cout).  One wave produces one 1 KiB unit of each plane: lane = (row, half).
+struct PackDesc { long src_off, dst_off; int Cout, K, unit0, pad; };
+
+__device__ __forceinline__ void pack_unit(const float* __restrict__ w, unsigned short* __restrict__ dst, long plane_stride,
+                                          int Cout, int K, int unit, int lane) {
+  const int nb32 = (Cout + 31) >> 5;
+  const int step = unit / nb32, blk = unit - step * nb32;
+  const int r = lane >> 1, h = lane & 1;
+  const int n = blk * 32 + r;
+  const int lh = h ^ ((r >> 3) & 1);
+  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+  if (n < Cout) {
+    const float* src = w + (long)n * K + step * 16 + lh * 8;
+    v0 = ldg4(src);
+    v1 = ldg4(src + 4);
+  }
+  uint2 o0[3], o1[3];
+  split4<3>(v0, o0);
+  split4<3>(v1, o1);
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    *(uint4*)(dst + q * plane_stride + (long)unit * 512 + lane * 8) = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+}
+
+__global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst,
+                                                       long plane_stride, int Cout, int K, int n_units) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit < n_units) pack_unit(w, dst, plane_stride, Cout, K, unit, threadIdx.x & 63);
+}
+
+__global__ __launch_bounds__(256) void pack_many_kernel(const float* __restrict__ base, unsigned short* __restrict__ dst,
+                                                        long plane_stride, const PackDesc* __restrict__ descs,
+                                                        const int* __restrict__ unit_desc, int n_units) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;
+  const PackDesc d = descs[unit_desc[unit]];
+  pack_unit(base + d.src_off, dst + d.dst_off, plane_stride, d.Cout, d.K, unit - d.unit0, threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------ weight gradient
@@ -557,6 +1002,7 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.stride = a->stride; p.pad = a->pad; p.Ho = a->Ho; p.Wo = a->Wo;
   p.relu = a->relu; p.res_mode = a->res_mode; p.out_stride = a->out_stride < 1 ? 1 : a->out_stride;
   p.out_H = a->out_H; p.out_W = a->out_W; p.mask_scale = a->mask_scale;
+  p.wpl = (const unsigned short*)a->w_planes; p.wpl_stride = a->w_plane_stride;
   if ((long)p.N * p.Ho * p.Wo > 0x7fffffffL) return MMT_EINVAL;
   if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL || (long)p.N * p.Ho * p.Wo * p.Cout >= 0x7fffffffL ||
       (long)p.Cout * p.KH * p.KW * p.Cin >= 0x7fffffffL) return MMT_EINVAL;  // kernels use 32-bit element offsets
@@ -576,7 +1022,91 @@ int launch_fwd(const ConvP& p, hipStream_t s) {
   return 0;
 }
 
+template <int BM, int BN, int WM, int WN, int NS>
+int launch_split(const ConvP& p, hipStream_t s) {
+  const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN);
+  size_t ring = (size_t)2 * NS * (BM + BN) * 32, epi = (size_t)BM * BN * sizeof(float);
+  hipLaunchKernelGGL((conv_fwd_split_kernel<BM, BN, WM, WN, NS>), dim3(tiles), dim3(256), ring > epi ? ring : epi, s, p);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+int launch_glds(const ConvP& p, hipStream_t s) {
+  const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN);
+  size_t ring = (size_t)3 * (BM * 64 + NS * BN * 32), epi = (size_t)BM * BN * sizeof(float);
+  hipLaunchKernelGGL((conv_fwd_glds_kernel<BM, BN, WM, WN, NS>), dim3(tiles), dim3(256), ring > epi ? ring : epi, s, p,
+                     p.wpl, p.wpl_stride);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int NS>
+int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
+  switch (variant) {
+    case 1: return launch_glds<128, 128, 4, 1, NS>(p, s);
+    case 3: return launch_glds<128, 64, 4, 1, NS>(p, s);
+    default: return launch_glds<64, 64, 2, 2, NS>(p, s);
+  }
+}
+
+template <int NS>
+int launch_split_variant(int variant, const ConvP& p, hipStream_t s) {
+  static const int dbg = getenv("MMT_DBG") ? atoi(getenv("MMT_DBG")) : 0;
+  if (NS == 3 && variant == 1 && dbg) {
+    const int tiles = mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
+#define DBGCASE(D) case D: hipLaunchKernelGGL((conv_fwd_split_kernel<128, 128, 2, 2, 3, D>), dim3(tiles), dim3(256), 65536, s, p); return 0;
+    switch (dbg) { DBGCASE(1) DBGCASE(2) DBGCASE(4) DBGCASE(8) DBGCASE(3) DBGCASE(6) DBGCASE(7) DBGCASE(5) }
+  }
+  switch (variant) {
+    case 1: return launch_split<128, 128, 2, 2, NS>(p, s);
+    case 3: return launch_split<128, 64, 2, 2, NS>(p, s);
+    default: return launch_split<64, 64, 2, 2, NS>(p, s);
+  }
+}
+
+// 0: fp32-input MFMA (exact fp32 products)   1: bf16   2: 2-term split (3 products)   3: 3-term split (6 products)
+int g_precision = -1;
+int precision() {
+  if (g_precision < 0) g_precision = getenv("MMT_CONV_PRECISION") ? atoi(getenv("MMT_CONV_PRECISION")) : 0;
+  return g_precision;
+}
+
 }  // namespace
+
+extern "C" int mmt_set_conv_precision(int mode) {
+  if (mode < 0 || mode > 3) return MMT_EINVAL;
+  g_precision = mode;
+  return 0;
+}
+
+extern "C" int mmt_get_conv_precision(void) { return precision(); }
+
+extern "C" long mmt_packed_weight_elems(int Cout, int K) {
+  if (Cout <= 0 || K <= 0 || (K & 15)) return -1;
+  return (long)(K / 16) * ((Cout + 31) / 32) * 512;
+}
+
+extern "C" int mmt_pack_weight(const float* w, void* planes, long plane_stride, int Cout, int K, void* stream) {
+  const long n = mmt_packed_weight_elems(Cout, K);
+  if (!w || !planes || n < 0 || plane_stride < n || (plane_stride & 7) || ((size_t)planes & 15)) return MMT_EINVAL;
+  const int units = (int)(n / 512);
+  hipLaunchKernelGGL(pack_one_kernel, dim3((units + 3) / 4), dim3(256), 0, (hipStream_t)stream, w,
+                     (unsigned short*)planes, plane_stride, Cout, K, units);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_pack_weights(const float* base, void* planes, long plane_stride, const mmt_pack_desc* descs,
+                                const int* unit_desc, int n_units, void* stream) {
+  if (!base || !planes || !descs || !unit_desc || (plane_stride & 7) || ((size_t)planes & 15)) return MMT_EINVAL;
+  if (n_units <= 0) return 0;
+  static_assert(sizeof(mmt_pack_desc) == sizeof(PackDesc), "descriptor layout");
+  hipLaunchKernelGGL(pack_many_kernel, dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream, base,
+                     (unsigned short*)planes, plane_stride, (const PackDesc*)descs, unit_desc, n_units);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
 
 static int pick_variant(const ConvP& p) {
   if (p.Cout <= 32) return 0;
@@ -608,7 +1138,21 @@ extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   if (!p.w || !p.y) return MMT_EINVAL;
   if (p.M == 0 || p.Cout == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  switch (pick_variant(p)) {
+  const int variant = pick_variant(p);
+  const int prec = precision();
+  static const int noglds = getenv("MMT_NO_GLDS") ? atoi(getenv("MMT_NO_GLDS")) : 0;
+  if (prec > 0 && variant != 0 && (p.Cin & 15) == 0 && p.wpl && !noglds) {
+    if (((size_t)p.wpl & 15) || (p.wpl_stride & 7)) return MMT_EINVAL;
+    if (prec == 1) return launch_glds_variant<1>(variant, p, s);
+    if (prec == 2) return launch_glds_variant<2>(variant, p, s);
+    return launch_glds_variant<3>(variant, p, s);
+  }
+  if (prec > 0 && variant != 0 && (p.Cin & 15) == 0) {
+    if (prec == 1) return launch_split_variant<1>(variant, p, s);
+    if (prec == 2) return launch_split_variant<2>(variant, p, s);
+    return launch_split_variant<3>(variant, p, s);
+  }
+  switch (variant) {
     case 0: return launch_fwd<128, 32, 4, 1>(p, s);
     case 1: return launch_fwd<128, 128, 2, 2>(p, s);
     case 3: return launch_fwd<128, 64, 2, 2>(p, s);

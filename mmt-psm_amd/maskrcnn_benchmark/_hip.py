@@ -26,7 +26,7 @@ class ConvArgs(ctypes.Structure):
                 ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int), ("KH", c_int),
                 ("KW", c_int), ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int),
                 ("relu", c_int), ("res_mode", c_int), ("out_stride", c_int), ("out_H", c_int), ("out_W", c_int),
-                ("mask_scale", c_float)]
+                ("mask_scale", c_float), ("w_planes", c_void_p), ("w_plane_stride", ctypes.c_long)]
 
 
 class MgdTeachers(ctypes.Structure):
@@ -40,6 +40,10 @@ _SIGS = {
     "mmt_nms_batched": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_conv_forward": [ctypes.POINTER(ConvArgs), c_void_p],
     "mmt_conv_variant": [ctypes.POINTER(ConvArgs)],
+    "mmt_set_conv_precision": [ctypes.c_int],
+    "mmt_get_conv_precision": [],
+    "mmt_pack_weight": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
+    "mmt_pack_weights": [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p],
     "mmt_conv_wgrad_splits": [ctypes.POINTER(ConvArgs)],
     "mmt_conv_wgrad": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_colsum": [c_void_p, c_int, c_int, c_void_p, c_void_p],
@@ -207,6 +211,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     a = _conv_args(x, w, stride, pad, Ho, Wo)
+    _keep = _weight_planes(w, a)  # noqa: F841  (keeps a per-call plane buffer alive until the launch is queued)
     if out_stride > 1:
         oh, ow = out_hw
         y = y_out if y_out is not None else empty_nhwc(N, Cout, oh, ow, x.device, zero=True)
@@ -237,6 +242,59 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             return y
     _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
     return y
+
+
+# pre-split bf16 planes of weight tensors (split-bf16 conv modes), keyed by the weight's device address:
+#   address -> (weakref to the owning FlatParams, element offset, numel).  engine/flat.py registers every parameter of a
+#   flattened model here (one [3, total] buffer refreshed after each SGD / EMA step); anything else -- and any parameter
+#   modified in place since the last refresh (its version counter moved) -- is split per call.
+PLANES = {}
+
+
+def packed_elems(cout, k):
+    """elements per packed bf16 plane of a [cout][k] weight matrix (include/mmtpsm.h: mmt_packed_weight_elems)"""
+    return (k // 16) * ((cout + 31) // 32) * 512
+
+
+def pack_weight(w):
+    """dense fp32 weight (Cout, ...) with K = numel/Cout, K % 16 == 0 -> packed bf16 planes [3, elems]"""
+    cout = w.shape[0]
+    k = w.numel() // cout
+    planes = torch.empty((3, packed_elems(cout, k)), dtype=torch.bfloat16, device=w.device)
+    _check(lib().mmt_pack_weight(w.data_ptr(), planes.data_ptr(), planes.stride(0), cout, k, _stream()), "mmt_pack_weight")
+    return planes
+
+
+def pack_weights(base, planes, descs, unit_desc, n_units):
+    _check(lib().mmt_pack_weights(base.data_ptr(), planes.data_ptr(), planes.stride(0), descs.data_ptr(),
+                                  unit_desc.data_ptr(), n_units, _stream()), "mmt_pack_weights")
+
+
+def _weight_planes(w, a):
+    """fill a.w_planes / a.w_plane_stride for a dense weight tensor when a split-bf16 mode is on"""
+    if get_conv_precision() == 0 or (w.shape[1] & 15) or w.shape[0] <= 32:
+        return None
+    ptr = w.data_ptr()
+    ent = PLANES.get(ptr)
+    if ent is not None:
+        flat = ent[0]()
+        if flat is None or flat.planes is None:
+            del PLANES[ptr]
+        elif ent[2] == w.numel() and flat.plane_versions.get(ptr) == w._version:
+            a.w_planes, a.w_plane_stride = flat.planes.data_ptr() + 2 * ent[1], flat.planes.stride(0)
+            return flat.planes
+    pl = pack_weight(w)
+    a.w_planes, a.w_plane_stride = pl.data_ptr(), pl.stride(0)
+    return pl
+
+
+def set_conv_precision(mode):
+    """0 fp32 MFMA | 1 bf16 | 2 bf16x2 split | 3 bf16x3 split (include/mmtpsm.h: mmt_set_conv_precision)"""
+    _check(lib().mmt_set_conv_precision(int(mode)), "mmt_set_conv_precision")
+
+
+def get_conv_precision():
+    return lib().mmt_get_conv_precision()
 
 
 def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):

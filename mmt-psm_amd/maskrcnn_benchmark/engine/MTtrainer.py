@@ -57,6 +57,7 @@ def weight_sum_losses(loss_dict, step, rampup_length, rampdown_length, total_len
 
 def init_teacher_weight(model_s, model_t):
     flatten_model(model_t).data.copy_(flatten_model(model_s).data)
+    flatten_model(model_t).refresh_planes()
 
 
 def allreduce_gradients(flat):
@@ -175,3 +176,4 @@ class MTtrainer(object):
         """MTtrainer.py:277-281 as one launch over the flat parameter buffers"""
         alpha = min(1 - 1 / (it + 1), self.alpha)
         H.ema_update(self.flat_t.data, self.flat_s.data, alpha)
+        self.flat_t.refresh_planes()

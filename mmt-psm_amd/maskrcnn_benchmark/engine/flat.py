@@ -19,7 +19,7 @@ class FlatParams(object):
         dev = named[0][1].device
 
         def pad4(n):
-            return (n + 3) // 4 * 4
+            return (n + 7) // 8 * 8  # 32-byte aligned views: float4 kernels, and 16-byte aligned bf16 plane slices
 
         self.index = {}
         off = 0
@@ -46,6 +46,41 @@ class FlatParams(object):
                 p.grad = self._view_like(self.grad[o:o + k], p)
                 # fused backward nodes accumulate weight gradients straight into this slot (layers/fused.py)
                 p._flat_grad = p.grad
+        self.planes = None
+        self.plane_versions = {}
+        self._named = named
+        self.refresh_planes()
+
+    def refresh_planes(self):
+        """split-bf16 conv modes (mmt_set_conv_precision != 0): re-pack every weight matrix of the parameter buffer into
+        its three bf16 planes (include/mmtpsm.h: mmt_pack_weights) -- ONE launch over a device descriptor table; called
+        after everything that rewrites parameters through raw pointers (SGD, EMA, teacher initialisation).
+        Convolutions look their weight up by address in _hip.PLANES."""
+        from .. import _hip as H
+        if not self.data.is_cuda or H.get_conv_precision() == 0:
+            return
+        if self.planes is None:
+            import struct
+            import weakref
+            descs, unit_desc, off, unit0 = [], [], 0, 0
+            for n, p in self._named:
+                if p.dim() < 2 or p.shape[0] <= 32 or (p.numel() // p.shape[0]) % 16:
+                    continue  # such layers always run on the fp32 kernel
+                cout, k = p.shape[0], p.numel() // p.shape[0]
+                o, _ = self.index[n]
+                elems = H.packed_elems(cout, k)
+                descs.append(struct.pack("qqiiii", o, off, cout, k, unit0, 0))
+                unit_desc += [len(descs) - 1] * (elems // 512)
+                H.PLANES[p.data_ptr()] = (weakref.ref(self), off, p.numel())
+                off += elems
+                unit0 += elems // 512
+            dev = self.data.device
+            self.planes = torch.empty((3, max(off, 8)), dtype=torch.bfloat16, device=dev)
+            self._pack_descs = torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev)
+            self._pack_units = torch.tensor(unit_desc, dtype=torch.int32, device=dev)
+            self._n_units = unit0
+        H.pack_weights(self.data, self.planes, self._pack_descs, self._pack_units, self._n_units)
+        self.plane_versions = {p.data_ptr(): p._version for _, p in self._named if p.dim() >= 2}
 
     @staticmethod
     def _view_like(flat, p):

@@ -31,6 +31,7 @@ class FlatSGD(object):
         if nb:
             H.sgd_momentum(f.data[nw:nw + nb], f.grad[nw:nw + nb], f.momentum[nw:nw + nb], lr * self.bias_lr_factor,
                            self.weight_decay_bias, self.momentum, first)
+        f.refresh_planes()
         self.steps += 1
         self.param_groups[0]["lr"] = lr
 
