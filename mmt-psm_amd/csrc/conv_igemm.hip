@@ -509,7 +509,7 @@ __device__ __forceinline__ void dma16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_ptr_t)l, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int S>
 __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, const unsigned short* __restrict__ wpl,
                                                                const long wpl_stride) {
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -613,53 +613,83 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   const int nkt = p.K >> 4;
-  f32x4 va[TM][2];  // raw fp32 A fragments of the next step, between their ds_read and their split
-  auto read_frags = [&](int stage, bf16x8 (&fb)[NS][TN]) {
+  f32x4 va[TM][2];   // raw fp32 A fragments of the next step, between their ds_read and their split
+  uint2 oa[TM][2][NS];  // ... and their bf16 terms, between the split and the hand-over to the MFMA operand registers
+  auto read_a = [&](int stage) {
     const char* st = ring + stage * STAGE;
 #pragma unroll
     for (int a = 0; a < TM; a++) {
       va[a][0] = *(const f32x4*)(st + aoff[a][0]);
       va[a][1] = *(const f32x4*)(st + aoff[a][1]);
     }
+  };
+  auto read_b = [&](int stage, bf16x8 (&fb)[NS][TN], int q0, int q1) {
+    const char* st = ring + stage * STAGE;
 #pragma unroll
     for (int q = 0; q < NS; q++)
+      if (q >= q0 && q < q1)
 #pragma unroll
-      for (int b = 0; b < TN; b++) fb[q][b] = *(const bf16x8*)(st + boff + q * PB + b * 1024);
+        for (int b = 0; b < TN; b++) fb[q][b] = *(const bf16x8*)(st + boff + q * PB + b * 1024);
   };
-  auto split_frags = [&](bf16x8 (&fa)[NS][TM]) {
+  auto split_half = [&](int h) {
 #pragma unroll
-    for (int a = 0; a < TM; a++) {
-      uint2 o0[NS], o1[NS];
-      split4<NS>(va[a][0], o0);
-      split4<NS>(va[a][1], o1);
+    for (int a = 0; a < TM; a++) split4<NS>(va[a][h], oa[a][h]);
+  };
+  auto pack_a = [&](bf16x8 (&fa)[NS][TM]) {
+#pragma unroll
+    for (int a = 0; a < TM; a++)
 #pragma unroll
       for (int q = 0; q < NS; q++) {
-        const uint4 u = {o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+        const uint4 u = {oa[a][0][q].x, oa[a][0][q].y, oa[a][1][q].x, oa[a][1][q].y};
         fa[q][a] = __builtin_bit_cast(bf16x8, u);
       }
-    }
   };
-  // One pipeline step.  The wave's own work for the FUTURE steps is spread between the MFMA groups of step kt so that
-  // the memory pipe is fed while the matrix pipe runs (issued as one burst, the DMAs of the two resident blocks and
-  // their MFMA phases fell into lockstep: measured time = fill time + MFMA time, no overlap):
-  //   after group 0: DMA of A for step kt+3     after group 1: DMA of B for step kt+3
-  //   after group 2: ds_read of the fragments of step kt+1     after group 3: split of A for step kt+1
+  auto wait_dma = [&](int steps_in_flight) {  // counted wait: the newest `steps_in_flight` steps of DMAs may stay pending
+    static_assert(S >= 3 && S <= 5 && 3 * NI < 64, "vmcnt range");
+    if (steps_in_flight <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (steps_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NI) : "memory");
+    else if (steps_in_flight == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * NI) : "memory");
+  };
+  // One pipeline step.  The staging work for the FUTURE steps is cut into six pieces that go out behind the six MFMA
+  // groups of step kt (one group = one product term over the wave's TM x TN tiles, one MFMA per accumulator), so that
+  // the memory and LDS pipes are fed while the matrix pipe runs.  Issued as one burst they were not: the DMA phases
+  // and the MFMA phases of the two resident blocks fell into lockstep (measured: time = fill time + MFMA time).
+  //   0: DMA of A for step kt+S      1: DMA of B for step kt+S      2: LDS reads of raw A + first B plane of step kt+1
+  //   3: LDS reads of the other B planes      4, 5: bf16 split of A (two halves) + operand hand-over
+  constexpr bool BF = BM >= 128;  // branch-free steps (below); the 64 x 64 low-K variant keeps the conditional form
   auto step = [&](int kt, int stage_next, int stage_free, const bf16x8 (&fa)[NS][TM], const bf16x8 (&fb)[NS][TN],
                   bf16x8 (&fan)[NS][TM], bf16x8 (&fbn)[NS][TN]) {
-    const bool more = kt + 1 < nkt, fill = kt + 3 < nkt;
-    if (more) {
-      // this wave's DMAs of step kt+1 have landed (those of step kt+2 may stay in flight) and its own fragment reads of
-      // step kt are complete ...
-      if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      // ... and so are everybody else's: step kt+1 is readable, the buffer of step kt is free
+    const bool more = kt + 1 < nkt, fill = kt + S < nkt;
+    if (BF) {
+      // this wave's DMAs of step kt+1 have landed (those of steps kt+2 .. kt+S-1 may stay in flight) and its own fragment
+      // reads of step kt are complete, and so are everybody else's: step kt+1 is readable, the buffer of step kt is free
+      wait_dma(S - 2);
+      __builtin_amdgcn_s_barrier();
+      // Straight-line body: the tail steps re-fetch the last k-chunk into a buffer nobody reads again and pre-read a
+      // stale buffer instead of branching, so that the whole step is ONE scheduling region and the DMA issue, the
+      // fragment reads of step kt+1 and the A split can be woven between the MFMAs of step kt (pipeline description
+      // below).  Issued as one burst after the barrier they were not overlapped at all: the staging phases and the
+      // MFMA phases of the two resident blocks fell into lockstep (measured: time = fill time + MFMA time).
+      issue_a(stage_free);
+      issue_b(min(kt + S, nkt - 1), stage_free);
+      read_a(stage_next);
+      read_b(stage_next, fbn, 0, NS);
+      split_half(0);
+      split_half(1);
+      pack_a(fan);
+    } else if (more) {
+      wait_dma(min(S - 2, nkt - 2 - kt));
       __builtin_amdgcn_s_barrier();
     }
-    auto filler = [&](int g) {
+    auto piece = [&](int g) {
+      if (BF) return;
       if (g == 0) { if (fill) issue_a(stage_free); }
-      else if (g == 1) { if (fill) issue_b(kt + 3, stage_free); }
-      else if (g == 2) { if (more) read_frags(stage_next, fbn); }
-      else if (g == 3) { if (more) split_frags(fan); }
+      else if (g == 1) { if (fill) issue_b(kt + S, stage_free); }
+      else if (g == 2) { if (more) { read_a(stage_next); read_b(stage_next, fbn, 0, 1); } }
+      else if (g == 3) { if (more) read_b(stage_next, fbn, 1, NS); }
+      else if (g == 4) { if (more) split_half(0); }
+      else if (g == 5) { if (more) { split_half(1); pack_a(fan); } }
     };
     int g = 0;
 #pragma unroll
@@ -672,30 +702,47 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
 #pragma unroll
           for (int b = 0; b < TN; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        filler(g++);
-        __builtin_amdgcn_sched_barrier(0);
+        if (!BF) {
+          piece(g++);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+    if (BF) {
+      constexpr int NMFMA = TM * TN * (NS * (NS + 1) / 2);
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-      if (r >= g) filler(r);
+      for (int i = 0; i < NMFMA; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            // 1 MFMA
+        if (i < NI) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                // 1 DMA (VMEM read)
+        if (i < 2 * TM + NS * TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                            // VALU (addresses, split)
+        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);                            // SALU
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+        if (r >= g) piece(r);
+    }
   };
-  issue_a(0); issue_b(0, 0);
-  if (nkt > 1) { issue_a(1); issue_b(1, 1); }
-  if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < S - 1; t++)
+    if (BF || t < nkt) { issue_a(t); issue_b(min(t, nkt - 1), t); }
+  wait_dma(BF ? S - 2 : min(S - 1, nkt) - 1);
   __builtin_amdgcn_s_barrier();
-  if (nkt > 2) { issue_a(2); issue_b(2, 2); }
+  if (BF || S - 1 < nkt) { issue_a(S - 1); issue_b(min(S - 1, nkt - 1), S - 1); }
   bf16x8 fa0[NS][TM], fb0[NS][TN], fa1[NS][TM], fb1[NS][TN];
-  read_frags(0, fb0);
-  split_frags(fa0);
+  read_a(0);
+  read_b(0, fb0, 0, NS);
+  split_half(0);
+  split_half(1);
+  pack_a(fa0);
   int stage = 0;  // buffer of step kt
   for (int kt = 0; kt < nkt; kt += 2) {
-    const int s1 = stage == 2 ? 0 : stage + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+    const int s1 = stage == S - 1 ? 0 : stage + 1, s2 = s1 == S - 1 ? 0 : s1 + 1;
     step(kt, s1, stage, fa0, fb0, fa1, fb1);
     if (kt + 1 < nkt) step(kt + 1, s2, s1, fa1, fb1, fa0, fb0);
     stage = s2;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (branch-free form: the surplus DMAs of the tail steps)
   __syncthreads();
   conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tid, lane, wm, wn, HoWo);
 }
@@ -912,6 +959,192 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvP p, const fl
   }
 }
 
+// ------------------------------------------------------------------------------------ split-bf16 weight gradient
+// Same GEMM as conv_wgrad_kernel (M' = Cout, N' = KH*KW*Cin, K' = pixels) on the bf16 matrix pipe with the fp32
+// operands split into NS bf16 terms while they are staged.  The reduction index (pixels) is the STRIDED index of both
+// operands in memory (dy[m][co], x[m][ci]) while the MFMA wants 8 consecutive k per lane, so the staging transposes:
+// a thread owns a 4-pixel x 4-channel block (4 float4 loads, lanes along channels -> 256 B contiguous per pixel), splits
+// it, and writes per channel one 8-byte group of 4 consecutive pixels.  LDS image per operand and plane:
+//   [k/8][row][8 k] bf16 with row = (c % 4) * 32 + c / 4  for channel c of the 128-wide tile
+// (a thread's four channels land in four different 32-row MFMA tiles; consecutive lanes write consecutive rows: 2-way
+// bank conflict on the ds_write_b64 instead of 8-way for row = c).  MFMA tile T, row i therefore is channel 4 i + T;
+// the epilogue undoes the permutation when it lays the accumulators out in LDS.  Fragment reads are ds_read_b128 at
+// (k/8, row), conflict-free without a swizzle.  Tile 128 x 128 x 16 pixels, 2-deep ring, waves 2 x 2 (each 64 x 64):
+// waves 0,1 stage dy, waves 2,3 stage the gathered input.
+template <int NS, bool INC>  // INC: Ho, Wo >= 8 -> carry-select pixel decode (else divisions)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p, const float* __restrict__ dy,
+                                                                  const float* __restrict__ rowscale,
+                                                                  float* __restrict__ dw, int m_per_split,
+                                                                  float* __restrict__ ws) {
+  constexpr int PL = 2 * 128 * 16;       // bytes per plane per operand: [2][128][16 B]
+  constexpr int STAGE = 2 * NS * PL;     // A planes | B planes
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ring = (char*)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int co0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int NP = p.KH * p.KW * p.Cin;
+  const int ms = blockIdx.z * m_per_split;
+  const int me = min(p.M, ms + m_per_split);
+  if (ms >= me) return;
+  const int HoWo = p.Ho * p.Wo;
+
+  // ---- staging role of this thread
+  const bool roleB = wave >= 2;                       // wave-uniform
+  const int cq = (wave & 1) * 16 + (lane & 15);       // channel quad 0..31 of the 128-wide tile
+  const int pg = lane >> 4;                           // pixel group 0..3 (4 pixels each) of the 16-pixel step
+  const int ch = (roleB ? n0 : co0) + cq * 4;         // first of this thread's 4 channels / columns
+  bool col_ok;
+  int bkh = 0, bkw = 0, bci = 0;
+  if (roleB) {
+    col_ok = ch < NP;
+    if (col_ok) { const int tap = ch / p.Cin; bci = ch - tap * p.Cin; bkh = tap / p.KW; bkw = tap - bkh * p.KW; }
+  } else {
+    col_ok = ch < p.Cout;
+  }
+  // LDS byte offset (inside a plane) of channel e = 0: k-group pg>>1, row e*32 + cq, 8-byte half pg&1
+  const int woff = (pg >> 1) * 2048 + cq * 16 + (pg & 1) * 8 + (roleB ? NS * PL : 0);
+  int r_img[4], r_ho[4], r_wo[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int m = ms + pg * 4 + j;
+    r_img[j] = m / HoWo;
+    const int rem = m - r_img[j] * HoWo;
+    r_ho[j] = rem / p.Wo;
+    r_wo[j] = rem - r_ho[j] * p.Wo;
+  }
+  const int step_q = 16 / p.Wo, step_r = 16 - step_q * p.Wo;
+  f32x4 rg[4];
+  bool pr[4];
+  auto load_tile = [&](int mt) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int m = mt + pg * 4 + j;
+      const bool mok = m < me && col_ok;
+      if (!roleB) {
+        rg[j] = ldg4(dy + (mok ? (unsigned)m * (unsigned)p.Cout + (unsigned)ch : 0u));
+        pr[j] = mok;
+      } else {
+        int img, ho, wo;
+        if (INC) { img = r_img[j]; ho = r_ho[j]; wo = r_wo[j]; }
+        else { const int mm = m < me ? m : 0; img = mm / HoWo; const int rem = mm - img * HoWo; ho = rem / p.Wo; wo = rem - ho * p.Wo; }
+        const int ih = ho * p.stride - p.pad + bkh, iw = wo * p.stride - p.pad + bkw;
+        const bool ok = mok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        rg[j] = ldg4(p.x + (ok ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + bci) : 0u));
+        pr[j] = ok;
+        if (INC) {
+          int wo2 = r_wo[j] + step_r, ho2 = r_ho[j] + step_q;
+          const bool cw = wo2 >= p.Wo;
+          wo2 = cw ? wo2 - p.Wo : wo2;
+          ho2 = cw ? ho2 + 1 : ho2;
+          const bool chh = ho2 >= p.Ho;
+          r_wo[j] = wo2;
+          r_ho[j] = chh ? ho2 - p.Ho : ho2;
+          r_img[j] = chh ? r_img[j] + 1 : r_img[j];
+        }
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* base = ring + buf * STAGE + woff;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = pr[j] ? rg[j] : zero4;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {  // channel e of the block: its 4 pixels are 4 consecutive k
+      uint2 o[NS];
+      split4<NS>(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, o);
+#pragma unroll
+      for (int q = 0; q < NS; q++) *(uint2*)(base + q * PL + e * 512) = o[q];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int lr = lane & 31, kh2 = lane >> 5;
+  const int froff = kh2 * 2048 + lr * 16;
+  const int ntile = (me - ms + 15) / 16;
+  load_tile(ms);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntile; t++) {
+    const int buf = t & 1;
+    const bool more = t + 1 < ntile;
+    const char* A = ring + buf * STAGE + froff + (wm * 2) * 512;
+    const char* B = ring + buf * STAGE + NS * PL + froff + (wn * 2) * 512;
+    bf16x8 fa[NS][2], fb[NS][2];
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+      for (int a = 0; a < 2; a++) {
+        fa[q][a] = *(const bf16x8*)(A + q * PL + a * 512);
+        fb[q][a] = *(const bf16x8*)(B + q * PL + a * 512);
+      }
+    int g = 0;
+#pragma unroll
+    for (int sum = NS - 1; sum >= 0; sum--)
+#pragma unroll
+      for (int qa = 0; qa <= sum; qa++) {
+        const int qb = sum - qa;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
+        if (g == 0) {  // the global loads of the next step go out behind the first MFMA group
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) load_tile(ms + (t + 1) * 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        g++;
+      }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  // ---- epilogue: as conv_wgrad_kernel, with the (tile, row) -> channel permutation undone while writing to LDS
+  {
+    float* ct = lds;  // [128][128]
+    const int rq = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * rq;
+          ct[(4 * i + wm * 2 + a) * 128 + 4 * lr + wn * 2 + b] = acc[a][b][r];
+        }
+    __syncthreads();
+    const int cc = tid & 31, r0 = tid >> 5;
+    const int n = n0 + cc * 4;
+    if (n < NP) {
+      const bool direct = ws == nullptr;
+      float* dst = direct ? dw : ws + (long)blockIdx.z * p.Cout * NP;
+      for (int row = r0; row < 128; row += 8) {
+        const int co = co0 + row;
+        if (co >= p.Cout) break;
+        f32x4 v = *(const f32x4*)(ct + row * 128 + cc * 4);
+        float* q = dst + (long)co * NP + n;
+        if (direct) {
+          const float sc = rowscale ? rowscale[co] : 1.f;
+          const f32x4 o = *(const f32x4*)q;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = o[e] + v[e] * sc;
+        }
+        *(f32x4*)q = v;
+      }
+    }
+  }
+}
+
 // dw[co][n] += rowscale[co] * sum_s ws[s][co][n]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Cout, int NP,
                                                            const float* __restrict__ rowscale,
@@ -1031,12 +1264,23 @@ int launch_split(const ConvP& p, hipStream_t s) {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int S>
 int launch_glds(const ConvP& p, hipStream_t s) {
   const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN);
-  size_t ring = (size_t)3 * (BM * 64 + NS * BN * 32), epi = (size_t)BM * BN * sizeof(float);
-  hipLaunchKernelGGL((conv_fwd_glds_kernel<BM, BN, WM, WN, NS>), dim3(tiles), dim3(256), ring > epi ? ring : epi, s, p,
-                     p.wpl, p.wpl_stride);
+  const size_t ring = (size_t)S * (BM * 64 + NS * BN * 32), epi = (size_t)BM * BN * sizeof(float);
+  size_t lds = ring > epi ? ring : epi;
+  static const int pad = getenv("MMT_LDS_PAD") ? atoi(getenv("MMT_LDS_PAD")) : 0;  // tuning aid: forces 1 block per CU
+  if ((size_t)pad > lds) lds = pad;
+  auto kern = conv_fwd_glds_kernel<BM, BN, WM, WN, NS, S>;
+  if (lds > 65536) {
+    static bool done = false;  // per instantiation
+    if (!done) {
+      const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, p, p.wpl, p.wpl_stride);
   MMT_LAUNCH_CHECK();
   return 0;
 }
@@ -1044,9 +1288,13 @@ int launch_glds(const ConvP& p, hipStream_t s) {
 template <int NS>
 int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
   switch (variant) {
-    case 1: return launch_glds<128, 128, 4, 1, NS>(p, s);
-    case 3: return launch_glds<128, 64, 4, 1, NS>(p, s);
-    default: return launch_glds<64, 64, 2, 2, NS>(p, s);
+    case 1: {
+      static const int st = getenv("MMT_STAGES") ? atoi(getenv("MMT_STAGES")) : 3;
+      if (st == 4) return launch_glds<128, 128, 4, 1, NS, 4>(p, s);
+      return launch_glds<128, 128, 4, 1, NS, 3>(p, s);
+    }
+    case 3: return launch_glds<128, 64, 4, 1, NS, 3>(p, s);
+    default: return launch_glds<64, 64, 2, 2, NS, 3>(p, s);
   }
 }
 
@@ -1192,7 +1440,15 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   if (split > 1 && !workspace) return MMT_EINVAL;
   float* ws = split > 1 ? workspace : nullptr;
   const bool fast = (p.Cout & 3) == 0 && p.Wo >= 8 && p.Ho >= 8;
-  if (fast)
+  const int prec = precision();
+  static const int nosplit = getenv("MMT_WGRAD_FP32") ? atoi(getenv("MMT_WGRAD_FP32")) : 0;
+  if (prec > 0 && !nosplit && (p.Cout & 3) == 0 && (mps & 15) == 0) {
+    const dim3 grid(tx, ty, split);
+#define WGS(NS, INC) hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws)
+    if (fast) { if (prec == 1) WGS(1, true); else if (prec == 2) WGS(2, true); else WGS(3, true); }
+    else { if (prec == 1) WGS(1, false); else if (prec == 2) WGS(2, false); else WGS(3, false); }
+#undef WGS
+  } else if (fast)
     hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(tx, ty, split), dim3(256), (size_t)4 * 4096 * sizeof(float), s, p,
                        dy, rowscale, dw, mps, ws);
   else
