@@ -28,6 +28,8 @@ sys.path.insert(0, os.path.join(ROOT, "mmt-psm_amd"))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: bf16 dense (v_mfma_f32_32x32x16_bf16)
+PRODUCTS = {0: 1, 1: 1, 2: 3, 3: 6}  # MFMA products per algorithmic multiply-add in each arithmetic mode
 CROP = 1000
 N_LAB, N_UNLAB, N_INST = 2, 2, 12
 
@@ -130,6 +132,33 @@ def cpu_baseline():
                       "unlabeled 1000x1000 crop (half a per-GPU batch), fp32, %.1f s" % dt}
 
 
+ARITH = {0: "fp32-input MFMA (IEEE fp32 products)",
+         3: "fp32 tensors; products on the bf16 matrix pipe as a 3-term bf16 split (6 MFMAs, fp32 accumulate): error vs fp64 "
+            "<= the fp32-input MFMA's (profiles/r01_precision.txt); MMT_CONV_PRECISION=0 selects the fp32-input MFMA",
+         2: "fp32 tensors; 2-term bf16 split (3 MFMAs)", 1: "fp32 tensors; bf16 products, fp32 accumulate"}
+
+
+def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, args):
+    """dominant kernel = the 128x128 forward tile (also runs every stride-1 data gradient).  `achieved` is algorithmic
+    FLOP/s (2*M*N*K per launch / event-bracketed launch time); `peak` is the matrix-pipe peak available to that
+    arithmetic: the fp32-input MFMA peak in mode 0, the bf16 dense peak divided by the products per multiply-add else."""
+    n = max(len(prof), 1)
+    peak = PEAK_FP32_MFMA_TFLOPS if mode == 0 else PEAK_BF16_MFMA_TFLOPS / PRODUCTS[mode]
+    kern = ("conv_fwd_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)" if mode == 0 else
+            "conv_fwd_glds_kernel<128,128,4,1,%d,3> (v_mfma_f32_32x32x16_bf16 x %d products)" % (mode, PRODUCTS[mode]))
+    r = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+         "frac": round(ach / peak, 4), "traffic": traffic,
+         "algorithmic_bytes_per_launch": round(alg_bytes / n, 1), "algorithmic_flop_per_launch": round(flops / n, 1),
+         "launches_per_step": len(prof) // max(args.steps, 1), "avg_launch_ms": round(ms / n, 4),
+         "share_of_step_time": round(ms / (dt * 1e3), 4)}
+    if mode != 0:
+        r["executed_mfma_tflops"] = round(ach * PRODUCTS[mode], 1)
+        r["peak_note"] = "%.0f TFLOP/s bf16 dense / %d products; the same work on the fp32-input MFMA is capped at %.1f" % (
+            PEAK_BF16_MFMA_TFLOPS, PRODUCTS[mode], PEAK_FP32_MFMA_TFLOPS)
+        r["vs_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,20 +195,37 @@ def main():
         il, targets, ul = batch()
         return trainer.train_step(it0 + i, il, targets, ul)
 
+    def timed(first, n):
+        sync()
+        _hip.PROFILE = []
+        t0 = time.perf_counter()
+        for i in range(n):
+            losses = step(first + i)
+        sync()
+        dt = time.perf_counter() - t0
+        prof, _hip.PROFILE = [p for p in _hip.PROFILE if p[3][0] == 'fwd1'], None
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, prof, losses
+
+    mode = _hip.get_conv_precision()
     for i in range(args.warmup):
         step(i)
-    sync()
-    _hip.PROFILE = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        losses = step(args.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
-    prof, _hip.PROFILE = [p for p in _hip.PROFILE if p[3][0] == 'fwd1'], None
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, prof, losses = timed(args.warmup, args.steps)
+    ref_fp32 = None
+    if mode != 0 and world == 1 and not os.environ.get("MMT_BENCH_NO_FP32_LEG"):
+        # the same workload on the fp32-input MFMA kernels (mode 0), reported next to the headline number
+        _hip.set_conv_precision(0)
+        step(args.warmup + args.steps)
+        n0 = max(2, args.steps // 2)
+        dt0, prof0, _ = timed(args.warmup + args.steps + 1, n0)
+        fl0, ms0 = sum(p[0] for p in prof0), sum(p[1].elapsed_time(p[2]) for p in prof0)
+        ref_fp32 = {"ms_per_step": round(dt0 / n0 * 1e3, 3), "value": round((N_LAB + N_UNLAB) * n0 / dt0, 4),
+                    "steps": n0, "dominant_kernel_tflops": round(fl0 / (ms0 * 1e-3) / 1e12, 2) if ms0 > 0 else None,
+                    "frac_of_fp32_mfma_peak": round(fl0 / (ms0 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ms0 > 0 else None}
+        _hip.set_conv_precision(mode)
 
     if rank == 0:
         imgs_per_step = (N_LAB + N_UNLAB) * world
@@ -192,7 +238,9 @@ def main():
                                + k[1] * (k[2] // k[7]) * (k[3] // k[7]) * k[5]) for k in (p[3] for p in prof))
         traffic = None
         try:  # HBM/fabric bytes per launch of this kernel from the committed PMC passes (not measurable live)
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["traffic_bytes_per_launch"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = tj["by_mode"][str(mode)]["traffic_bytes_per_launch"] if "by_mode" in tj else (
+                tj["traffic_bytes_per_launch"] if mode == 0 else None)
         except Exception:
             pass
         out = {
@@ -206,15 +254,11 @@ def main():
                                        "ON (relation NMS + mask relation; RELATION_NMS.LOSS 0.01)" if args.irnet else "off"),
                        "image_forwards_per_step_per_gpu": 12, "parallelism": "dp%d" % world,
                        "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}},
-            "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)",
-                         "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": round(alg_bytes / max(len(prof), 1), 1),
-                         "algorithmic_flop_per_launch": round(flops / max(len(prof), 1), 1),
-                         "launches_per_step": len(prof) // max(args.steps, 1),
-                         "avg_launch_ms": round(ms / max(len(prof), 1), 4),
-                         "share_of_step_time": round(ms / (dt * 1e3), 4)},
+            "roofline": roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, args),
         }
+        out["config"]["conv_arithmetic"] = ARITH[mode]
+        if ref_fp32 is not None:
+            out["fp32_mfma_mode"] = ref_fp32
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -97,15 +97,19 @@ int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
 /* which tile configuration mmt_conv_forward picks for these shapes: 0 = 128x32, 1 = 128x128 (the dominant
  * kernel of the step, conv_fwd_kernel<128,128,2,2>), 2 = 64x64.  Used by bench.py for the roofline line. */
 int mmt_conv_variant(const mmt_conv_args* a /*[host]*/);
-/* arithmetic of the convolution GEMMs (process-wide; initial value from the environment variable
- * MMT_CONV_PRECISION, default 0):
- *   0  fp32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products, the reference's arithmetic (ATen fp32 conv)
- *   3  fp32 operands split into three bf16 terms on the fly, 6 bf16 MFMAs per product block: fp32-grade results
- *      (dropped terms <= 3*2^-27 of a product) at up to 2.6x the fp32-MFMA rate
- *   2  two-term split, 3 bf16 MFMAs (~2^-17 per product)
+/* arithmetic of the convolution GEMMs -- forward, data gradient and weight gradient (process-wide; initial value from
+ * the environment variable MMT_CONV_PRECISION, default 3):
+ *   3  fp32 operands split on the fly into three bf16 terms x = x0 + x1 + x2 (round-to-nearest at each level, exact to
+ *      2^-27 |x|); a*b is evaluated as the six products a0b0, a0b1, a1b0, a0b2, a1b1, a2b0 on the bf16 matrix pipe
+ *      (v_mfma_f32_32x32x16_bf16, fp32 accumulate, small terms first).  Dropped terms <= 3*2^-27 |ab|, below the
+ *      rounding of the fp32 product itself: measured error against fp64 is equal to or lower than mode 0's
+ *      (profiles/r01_precision.txt) at 1.3-1.7x its speed -- the fp32-input MFMA runs at 1/16 of the bf16 rate.
+ *   0  fp32-input MFMA (v_mfma_f32_32x32x2_f32): IEEE fp32 products and fp32 accumulate, the arithmetic of the
+ *      reference's ATen fp32 convolution
+ *   2  two-term split, 3 bf16 MFMAs (~2^-18 relative per product)
  *   1  plain bf16 inputs, fp32 accumulate (torch.autocast(bfloat16)-class arithmetic; BASELINE config 5)
- * Tensors stay fp32 in HBM in every mode.  Shapes the split kernels do not cover (Cin % 16 != 0, Cout <= 32) always
- * run in mode 0.  Returns MMT_EINVAL for an unknown mode. */
+ * Tensors stay fp32 in HBM in every mode.  Shapes the split kernels do not cover (Cin % 16 != 0 or Cout <= 32 forward,
+ * Cout % 4 != 0 weight gradient) always run in mode 0.  Returns MMT_EINVAL for an unknown mode. */
 int mmt_set_conv_precision(int mode);
 int mmt_get_conv_precision(void);
 /* Packed bf16 planes of a weight matrix w[Cout][K] (K = KH*KW*Cin in the weight's own memory order, K % 16 == 0) for

@@ -1316,7 +1316,10 @@ int launch_split_variant(int variant, const ConvP& p, hipStream_t s) {
 // 0: fp32-input MFMA (exact fp32 products)   1: bf16   2: 2-term split (3 products)   3: 3-term split (6 products)
 int g_precision = -1;
 int precision() {
-  if (g_precision < 0) g_precision = getenv("MMT_CONV_PRECISION") ? atoi(getenv("MMT_CONV_PRECISION")) : 0;
+  if (g_precision < 0) {
+    g_precision = getenv("MMT_CONV_PRECISION") ? atoi(getenv("MMT_CONV_PRECISION")) : 3;
+    if (g_precision < 0 || g_precision > 3) g_precision = 3;
+  }
   return g_precision;
 }
 

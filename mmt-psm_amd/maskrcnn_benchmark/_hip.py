@@ -249,6 +249,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
 #   flattened model here (one [3, total] buffer refreshed after each SGD / EMA step); anything else -- and any parameter
 #   modified in place since the last refresh (its version counter moved) -- is split per call.
 PLANES = {}
+PLANES_EPOCH = 0  # bumped by set_conv_precision: planes packed before a mode switch are not trusted afterwards (steps taken
+                  # in mode 0 do not refresh them)
 
 
 def packed_elems(cout, k):
@@ -280,7 +282,7 @@ def _weight_planes(w, a):
         flat = ent[0]()
         if flat is None or flat.planes is None:
             del PLANES[ptr]
-        elif ent[2] == w.numel() and flat.plane_versions.get(ptr) == w._version:
+        elif ent[2] == w.numel() and flat.plane_versions.get(ptr) == w._version and flat.plane_epoch >= PLANES_EPOCH:
             a.w_planes, a.w_plane_stride = flat.planes.data_ptr() + 2 * ent[1], flat.planes.stride(0)
             return flat.planes
     pl = pack_weight(w)
@@ -290,7 +292,9 @@ def _weight_planes(w, a):
 
 def set_conv_precision(mode):
     """0 fp32 MFMA | 1 bf16 | 2 bf16x2 split | 3 bf16x3 split (include/mmtpsm.h: mmt_set_conv_precision)"""
+    global PLANES_EPOCH
     _check(lib().mmt_set_conv_precision(int(mode)), "mmt_set_conv_precision")
+    PLANES_EPOCH += 1
 
 
 def get_conv_precision():

@@ -48,6 +48,7 @@ class FlatParams(object):
                 p._flat_grad = p.grad
         self.planes = None
         self.plane_versions = {}
+        self.plane_epoch = -1
         self._named = named
         self.refresh_planes()
 
@@ -81,6 +82,7 @@ class FlatParams(object):
             self._n_units = unit0
         H.pack_weights(self.data, self.planes, self._pack_descs, self._pack_units, self._n_units)
         self.plane_versions = {p.data_ptr(): p._version for _, p in self._named if p.dim() >= 2}
+        self.plane_epoch = H.PLANES_EPOCH
 
     @staticmethod
     def _view_like(flat, p):

@@ -9,7 +9,7 @@ for name,N,Cin,H,W,Cout,k,s,p in [("fpn_layer1 N8", 8,256,256,256,256,3,1,1), ("
     x = cl(torch.randn(N,Cin,H,W,device='cuda')); w = cl(torch.randn(Cout,Cin,k,k,device='cuda')*0.05)
     import weakref
     class F(object): pass
-    f = F(); f.planes = hip.pack_weight(w); f.plane_versions = {w.data_ptr(): w._version}
+    f = F(); f.planes = hip.pack_weight(w); f.plane_versions = {w.data_ptr(): w._version}; f.plane_epoch = hip.PLANES_EPOCH + 10**9
     hip.PLANES[w.data_ptr()] = (weakref.ref(f), 0, w.numel())
     for _ in range(3): y = hip.conv_forward(x,w,None,None,s,p)
     torch.cuda.synchronize()

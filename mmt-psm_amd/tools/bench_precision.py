@@ -9,7 +9,7 @@ class FakeFlat(object):
     pass
 def register(w):
     import weakref
-    f = FakeFlat(); f.planes = hip.pack_weight(w); f.plane_versions = {w.data_ptr(): w._version}
+    f = FakeFlat(); f.planes = hip.pack_weight(w); f.plane_versions = {w.data_ptr(): w._version}; f.plane_epoch = hip.PLANES_EPOCH + 10**9
     hip.PLANES[w.data_ptr()] = (weakref.ref(f), 0, w.numel())
     return f
 cases = [

@@ -320,3 +320,104 @@ def test_polygon_targets_golden(hip):
                                    T(g["proj_boxes"]).cuda(), 28)
     assert int(ovf) == 0
     np.testing.assert_array_equal(out.cpu().numpy(), g["proj_out"])
+
+
+# ------------------------------------------------------------------------------------------ conv arithmetic modes
+@pytest.fixture
+def restore_mode(hip):
+    m = hip.get_conv_precision()
+    yield
+    hip.set_conv_precision(m)
+
+
+MODE_TOL = {0: 1e-5, 3: 1e-5, 2: 6e-5, 1: 2e-2}  # max |err| / max |ref| against fp64
+
+
+@pytest.mark.parametrize("case", [(2, 64, 24, 24, 96, 3, 1, 1), (3, 128, 30, 30, 160, 1, 2, 0), (1, 48, 17, 23, 64, 3, 1, 1),
+                                  (2, 256, 64, 64, 256, 3, 1, 1), (2, 16, 40, 40, 64, 1, 1, 0), (8, 32, 64, 64, 64, 1, 1, 0),
+                                  (300, 1024, 1, 1, 1024, 1, 1, 0)])
+def test_conv_arithmetic_modes_forward(hip, restore_mode, case):
+    """every arithmetic mode of mmt_conv_forward against fp64, with and without pre-packed weight planes; the 3-term
+    split (default) must be as accurate as the fp32-input MFMA"""
+    N, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x, w = cl(torch.randn(N, Cin, H, W, generator=g)), cl(torch.randn(Cout, Cin, k, k, generator=g) * 0.05)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, s, p) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    scl = ref.abs().max().item()
+    err = {}
+    for mode in (0, 3, 2, 1):
+        hip.set_conv_precision(mode)
+        y = hip.conv_forward(x, w, sc, sh, s, p, relu=True)
+        err[mode] = (y.double() - ref).abs().max().item() / scl
+        assert err[mode] < MODE_TOL[mode], (mode, err[mode])
+    assert err[3] <= 2.0 * err[0] + 2e-7, err
+    # tiles hanging over M and Cout, zero-filled halo, K = 16 (a single step) are all in the cases above
+
+
+@pytest.mark.parametrize("case", [(2, 64, 24, 24, 96, 3, 1, 1), (3, 128, 30, 30, 160, 1, 2, 0), (1, 48, 17, 23, 64, 3, 1, 1),
+                                  (1000, 256, 1, 1, 512, 1, 1, 0), (2, 20, 12, 12, 36, 3, 1, 1), (20, 256, 14, 14, 256, 3, 1, 1)])
+def test_conv_arithmetic_modes_wgrad(hip, restore_mode, case):
+    N, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = cl(torch.randn(N, Cin, H, W, generator=g))
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = cl(torch.randn(N, Cout, Ho, Wo, generator=g))
+    rs = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), dy.double(), stride=s, padding=p) * rs.double().view(-1, 1, 1, 1)
+    scl = ref.abs().max().item()
+    err = {}
+    for mode in (0, 3, 2, 1):
+        hip.set_conv_precision(mode)
+        dw = hip.nhwc(torch.zeros(Cout, Cin, k, k, device="cuda").contiguous(memory_format=torch.channels_last))
+        hip.conv_wgrad(x, dy, (Cout, Cin, k, k), s, p, dw, rowscale=rs)
+        hip.conv_wgrad(x, dy, (Cout, Cin, k, k), s, p, dw, rowscale=rs)  # accumulates
+        err[mode] = (dw.double() - 2 * ref).abs().max().item() / (2 * scl)
+        assert err[mode] < MODE_TOL[mode], (mode, err[mode])
+    assert err[3] <= 2.0 * err[0] + 2e-7, err
+
+
+def test_packed_weight_planes_bookkeeping(hip, restore_mode):
+    """engine/flat.py keeps one packed copy of all weight matrices; a convolution must never use a stale one"""
+    from torch import nn
+    from maskrcnn_benchmark.layers import Conv2d
+    from maskrcnn_benchmark.engine.flat import flatten_model
+    hip.set_conv_precision(3)
+    torch.manual_seed(3)
+    m = nn.Sequential(Conv2d(32, 64, 3, 1, 1), Conv2d(64, 48, 1, 1, 0)).cuda()
+    x = cl(torch.randn(2, 32, 20, 20))
+
+    def fwd():
+        with torch.no_grad():
+            return m[1](m[0](x, relu=True))
+
+    def ref():
+        with torch.no_grad():
+            return F.conv2d(F.relu(F.conv2d(x.double(), m[0].weight.double(), m[0].bias.double(), 1, 1)),
+                            m[1].weight.double(), m[1].bias.double())
+
+    def close(y):
+        r = ref()
+        return (y.double() - r).abs().max().item() < 1e-5 * r.abs().max().item()
+
+    y_percall = fwd()  # not flattened: packed per call
+    flat = flatten_model(m)
+    w0 = m[0].weight
+    assert hip.PLANES[w0.data_ptr()][0]() is flat and flat.planes is not None
+    assert torch.equal(fwd(), y_percall) and close(y_percall)  # same arithmetic through the cached planes
+    # (a) raw-pointer update + refresh (what FlatSGD.step / update_teacher do)
+    flat.data.mul_(1.5)
+    flat.refresh_planes()
+    assert close(fwd())
+    # (b) in-place update through torch WITHOUT a refresh: the version counter moved -> per-call packing, still right
+    with torch.no_grad():
+        m[0].weight.mul_(-0.5)
+    assert close(fwd())
+    # (c) a mode switch invalidates planes packed before it (steps taken in mode 0 do not refresh them)
+    hip.set_conv_precision(0)
+    flat.data.mul_(2.0)
+    flat.refresh_planes()  # no-op in mode 0
+    hip.set_conv_precision(3)
+    assert close(fwd())
+    flat.refresh_planes()
+    assert close(fwd())
