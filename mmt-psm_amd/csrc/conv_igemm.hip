@@ -975,7 +975,7 @@ template <int NS, bool INC>  // INC: Ho, Wo >= 8 -> carry-select pixel decode (e
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p, const float* __restrict__ dy,
                                                                   const float* __restrict__ rowscale,
                                                                   float* __restrict__ dw, int m_per_split,
-                                                                  float* __restrict__ ws) {
+                                                                  float* __restrict__ ws, float* __restrict__ dbias) {
   constexpr int PL = 2 * 128 * 16;       // bytes per plane per operand: [2][128][16 B]
   constexpr int STAGE = 2 * NS * PL;     // A planes | B planes
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1017,6 +1017,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p,
   const int step_q = 16 / p.Wo, step_r = 16 - step_q * p.Wo;
   f32x4 rg[4];
   bool pr[4];
+  // bias gradient rides along: the dy values pass through the registers of waves 0,1 anyway (first column tile only)
+  const bool do_bias = dbias != nullptr && blockIdx.x == 0 && !roleB;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   auto load_tile = [&](int mt) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -1052,6 +1055,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p,
     f32x4 v[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) v[j] = pr[j] ? rg[j] : zero4;
+    if (do_bias) bsum += (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
     for (int e = 0; e < 4; e++) {  // channel e of the block: its 4 pixels are 4 consecutive k
       uint2 o[NS];
@@ -1108,6 +1112,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p,
       }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
+  }
+  if (do_bias) {  // lanes cq + 16 * pg hold partial sums of the same 4 channels: fold the 4 pixel groups, one atomic each
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float t = bsum[e];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (pg == 0 && ch + e < p.Cout) atomicAdd(dbias + ch + e, t);
+    }
   }
   // ---- epilogue: as conv_wgrad_kernel, with the (tile, row) -> channel permutation undone while writing to LDS
   {
@@ -1447,10 +1460,11 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   static const int nosplit = getenv("MMT_WGRAD_FP32") ? atoi(getenv("MMT_WGRAD_FP32")) : 0;
   if (prec > 0 && !nosplit && (p.Cout & 3) == 0 && (mps & 15) == 0) {
     const dim3 grid(tx, ty, split);
-#define WGS(NS, INC) hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws)
+#define WGS(NS, INC) hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)
     if (fast) { if (prec == 1) WGS(1, true); else if (prec == 2) WGS(2, true); else WGS(3, true); }
     else { if (prec == 1) WGS(1, false); else if (prec == 2) WGS(2, false); else WGS(3, false); }
 #undef WGS
+    dbias = nullptr;  // summed inside the kernel
   } else if (fast)
     hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(tx, ty, split), dim3(256), (size_t)4 * 4096 * sizeof(float), s, p,
                        dy, rowscale, dw, mps, ws);
