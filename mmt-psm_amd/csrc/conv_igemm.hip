@@ -573,24 +573,44 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
     bsrc[i] = wpl + q * wpl_stride + (long)nb * 512 + lane * 8;
     bdst[i] = A_BYTES + q * PB + rb * 1024;
   }
-  int s_kh = 0, s_kw = 0, s_ci = 0;
-  auto issue_a = [&](int stage) {  // next 16-k chunk of the activations (tap-major, channels inside the tap)
-    char* st = ring + stage * STAGE;
-    const int kh = s_kh, kw = s_kw, ci = s_ci;
+  // ---- staging micro-operations.  Everything a wave does for FUTURE steps is cut into small pieces that are placed,
+  // one or two at a time, behind the individual MFMAs of the current step (hard scheduling fences in between: left to
+  // itself the compiler issues the staging code in one burst and chains MFMAs on the same accumulator).  Measured on
+  // this part: vector-ALU work hardly ever co-executes with an MFMA of the OTHER wave of the SIMD (SQ_VALU_MFMA_COEXEC
+  // 7 % of MFMA-busy), so hiding it in the MFMA shadow of the same wave is what counts.
+  int s_kh = 0, s_kw = 0, s_ci = 0;   // tap / channel position of the next A chunk to fetch
+  int c_kh = 0, c_kw = 0, c_ci = 0;   // ... latched for the DMAs of this step
+  unsigned roff[NIA];  // element offset of (row, current tap, channel 0 + this lane's chunk); valid flag
+  bool rok[NIA];
+  const float* const zsrc = g_zero16;
+  auto tap_next = [&]() {
+    c_kh = s_kh; c_kw = s_kw; c_ci = s_ci;
+    if (c_ci == 0) {  // first chunk of a tap (once per Cin/16 steps): bounds and row offsets for the whole tap
+#pragma unroll
+      for (int i = 0; i < NIA; i++) {
+        const int ih = aih0[i] + c_kh, iw = aiw0[i] + c_kw;
+        rok[i] = aok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        roff[i] = abase[i] + (unsigned)((ih * p.W + iw) * p.Cin + achunk[i]);
+      }
+    }
     s_ci += 16;
     if (s_ci >= p.Cin) { s_ci = 0; if (++s_kw == p.KW) { s_kw = 0; ++s_kh; } }
-#pragma unroll
-    for (int i = 0; i < NIA; i++) {
-      const int ih = aih0[i] + kh, iw = aiw0[i] + kw;
-      const bool ok = aok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const float* src = ok ? p.x + (abase[i] + (unsigned)((ih * p.W + iw) * p.Cin + ci + achunk[i])) : g_zero16;
-      dma16(src, st + (wave + 4 * i) * 1024);
-    }
   };
-  auto issue_b = [&](int kt, int stage) {
-    char* st = ring + stage * STAGE;
+  bool filling = true;  // false in the tail steps (nothing left to fetch): their DMAs read the 16 zero bytes instead
+  auto dma_a = [&](int i, int stage) {
+    const float* src = rok[i] && filling ? p.x + (roff[i] + (unsigned)c_ci) : zsrc;
+    dma16(src, ring + stage * STAGE + (wave + 4 * i) * 1024);
+  };
+  auto dma_b = [&](int i, int kt, int stage) {
+    const void* src = filling ? (const void*)(bsrc[i] + (long)kt * kt_stride) : (const void*)zsrc;
+    dma16(src, ring + stage * STAGE + bdst[i]);
+  };
+  auto issue_all = [&](int kt, int stage) {  // prologue form
+    tap_next();
 #pragma unroll
-    for (int i = 0; i < NIB; i++) dma16(bsrc[i] + (long)kt * kt_stride, st + bdst[i]);
+    for (int i = 0; i < NIA; i++) dma_a(i, stage);
+#pragma unroll
+    for (int i = 0; i < NIB; i++) dma_b(i, kt, stage);
   };
 
   // ---- fragment read offsets
@@ -613,27 +633,19 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   const int nkt = p.K >> 4;
-  f32x4 va[TM][2];   // raw fp32 A fragments of the next step, between their ds_read and their split
-  uint2 oa[TM][2][NS];  // ... and their bf16 terms, between the split and the hand-over to the MFMA operand registers
-  auto read_a = [&](int stage) {
-    const char* st = ring + stage * STAGE;
-#pragma unroll
-    for (int a = 0; a < TM; a++) {
-      va[a][0] = *(const f32x4*)(st + aoff[a][0]);
-      va[a][1] = *(const f32x4*)(st + aoff[a][1]);
-    }
+  f32x4 va[TM][2];        // raw fp32 A fragment halves of the next step; turned into residuals by the split levels
+  unsigned ua[TM][2][2];  // packed bf16 pairs of the level being produced
+  uint2 oa[TM][2][NS];    // bf16 terms of the A fragment halves
+  auto split_cvt = [&](int a, int h, int q) {
+    ua[a][h][0] = pk_bf16(va[a][h][0], va[a][h][1]);
+    ua[a][h][1] = pk_bf16(va[a][h][2], va[a][h][3]);
+    oa[a][h][q] = uint2{ua[a][h][0], ua[a][h][1]};
   };
-  auto read_b = [&](int stage, bf16x8 (&fb)[NS][TN], int q0, int q1) {
-    const char* st = ring + stage * STAGE;
-#pragma unroll
-    for (int q = 0; q < NS; q++)
-      if (q >= q0 && q < q1)
-#pragma unroll
-        for (int b = 0; b < TN; b++) fb[q][b] = *(const bf16x8*)(st + boff + q * PB + b * 1024);
-  };
-  auto split_half = [&](int h) {
-#pragma unroll
-    for (int a = 0; a < TM; a++) split4<NS>(va[a][h], oa[a][h]);
+  auto split_sub = [&](int a, int h) {
+    va[a][h][0] -= __builtin_bit_cast(float, ua[a][h][0] << 16);
+    va[a][h][1] -= __builtin_bit_cast(float, ua[a][h][0] & 0xffff0000u);
+    va[a][h][2] -= __builtin_bit_cast(float, ua[a][h][1] << 16);
+    va[a][h][3] -= __builtin_bit_cast(float, ua[a][h][1] & 0xffff0000u);
   };
   auto pack_a = [&](bf16x8 (&fa)[NS][TM]) {
 #pragma unroll
@@ -644,6 +656,28 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
         fa[q][a] = __builtin_bit_cast(bf16x8, u);
       }
   };
+  constexpr int SPL = 2 * NS - 1;  // split pieces per fragment half: cvt, (sub, cvt) x (NS-1)
+  constexpr int M_DMA = NIA + NIB, M_RA = 2 * TM, M_RB = NS * TN, M_SPLIT = 2 * TM * SPL;
+  constexpr int NMICRO = M_DMA + M_RA + M_RB + M_SPLIT + 1;
+  // idx is a compile-time constant wherever this is called (fully unrolled callers)
+  auto micro = [&](int idx, int kt_fill, int stage_free, int stage_next, bf16x8 (&fan)[NS][TM], bf16x8 (&fbn)[NS][TN]) {
+    if (idx < NIA) { dma_a(idx, stage_free); return; }
+    idx -= NIA;
+    if (idx < NIB) { dma_b(idx, kt_fill, stage_free); return; }
+    idx -= NIB;
+    const char* st = ring + stage_next * STAGE;
+    if (idx < M_RA) { va[idx >> 1][idx & 1] = *(const f32x4*)(st + aoff[idx >> 1][idx & 1]); return; }
+    idx -= M_RA;
+    if (idx < M_RB) { const int q = idx / TN, b = idx % TN; fbn[q][b] = *(const bf16x8*)(st + boff + q * PB + b * 1024); return; }
+    idx -= M_RB;
+    if (idx < M_SPLIT) {
+      // level-major over the 2*TM fragment halves, so that consecutive pieces are independent of each other
+      const int lvl = idx / (2 * TM), f = idx % (2 * TM), a = f >> 1, h = f & 1;
+      if (lvl & 1) split_sub(a, h); else split_cvt(a, h, lvl >> 1);
+      return;
+    }
+    pack_a(fan);
+  };
   auto wait_dma = [&](int steps_in_flight) {  // counted wait: the newest `steps_in_flight` steps of DMAs may stay pending
     static_assert(S >= 3 && S <= 5 && 3 * NI < 64, "vmcnt range");
     if (steps_in_flight <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -651,47 +685,19 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
     else if (steps_in_flight == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * NI) : "memory");
   };
-  // One pipeline step.  The staging work for the FUTURE steps is cut into six pieces that go out behind the six MFMA
-  // groups of step kt (one group = one product term over the wave's TM x TN tiles, one MFMA per accumulator), so that
-  // the memory and LDS pipes are fed while the matrix pipe runs.  Issued as one burst they were not: the DMA phases
-  // and the MFMA phases of the two resident blocks fell into lockstep (measured: time = fill time + MFMA time).
-  //   0: DMA of A for step kt+S      1: DMA of B for step kt+S      2: LDS reads of raw A + first B plane of step kt+1
-  //   3: LDS reads of the other B planes      4, 5: bf16 split of A (two halves) + operand hand-over
-  constexpr bool BF = BM >= 128;  // branch-free steps (below); the 64 x 64 low-K variant keeps the conditional form
+  // One pipeline step, branch-free: the tail steps still issue their DMAs (the counted waits stay uniform) but point
+  // them at 16 zero bytes, and pre-read a stale buffer, instead of testing for the end.
   auto step = [&](int kt, int stage_next, int stage_free, const bf16x8 (&fa)[NS][TM], const bf16x8 (&fb)[NS][TN],
                   bf16x8 (&fan)[NS][TM], bf16x8 (&fbn)[NS][TN]) {
-    const bool more = kt + 1 < nkt, fill = kt + S < nkt;
-    if (BF) {
-      // this wave's DMAs of step kt+1 have landed (those of steps kt+2 .. kt+S-1 may stay in flight) and its own fragment
-      // reads of step kt are complete, and so are everybody else's: step kt+1 is readable, the buffer of step kt is free
-      wait_dma(S - 2);
-      __builtin_amdgcn_s_barrier();
-      // Straight-line body: the tail steps re-fetch the last k-chunk into a buffer nobody reads again and pre-read a
-      // stale buffer instead of branching, so that the whole step is ONE scheduling region and the DMA issue, the
-      // fragment reads of step kt+1 and the A split can be woven between the MFMAs of step kt (pipeline description
-      // below).  Issued as one burst after the barrier they were not overlapped at all: the staging phases and the
-      // MFMA phases of the two resident blocks fell into lockstep (measured: time = fill time + MFMA time).
-      issue_a(stage_free);
-      issue_b(min(kt + S, nkt - 1), stage_free);
-      read_a(stage_next);
-      read_b(stage_next, fbn, 0, NS);
-      split_half(0);
-      split_half(1);
-      pack_a(fan);
-    } else if (more) {
-      wait_dma(min(S - 2, nkt - 2 - kt));
-      __builtin_amdgcn_s_barrier();
-    }
-    auto piece = [&](int g) {
-      if (BF) return;
-      if (g == 0) { if (fill) issue_a(stage_free); }
-      else if (g == 1) { if (fill) issue_b(kt + S, stage_free); }
-      else if (g == 2) { if (more) { read_a(stage_next); read_b(stage_next, fbn, 0, 1); } }
-      else if (g == 3) { if (more) read_b(stage_next, fbn, 1, NS); }
-      else if (g == 4) { if (more) split_half(0); }
-      else if (g == 5) { if (more) { split_half(1); pack_a(fan); } }
-    };
-    int g = 0;
+    // this wave's DMAs of step kt+1 have landed (those of steps kt+2 .. kt+S-1 may stay in flight) and its own fragment
+    // reads of step kt are complete, and so are everybody else's: step kt+1 is readable, the buffer of step kt is free
+    wait_dma(S - 2);
+    __builtin_amdgcn_s_barrier();
+    tap_next();
+    filling = kt + S < nkt;
+    const int kt_fill = min(kt + S, nkt - 1);
+    constexpr int NM = TM * TN * (NS * (NS + 1) / 2);
+    int j = 0, mi = 0;
 #pragma unroll
     for (int sum = NS - 1; sum >= 0; sum--)
 #pragma unroll
@@ -700,41 +706,37 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
 #pragma unroll
         for (int a = 0; a < TM; a++)
 #pragma unroll
-          for (int b = 0; b < TN; b++)
+          for (int b = 0; b < TN; b++) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
-        if (!BF) {
-          piece(g++);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    if (BF) {
-      constexpr int NMFMA = TM * TN * (NS * (NS + 1) / 2);
+            j++;
 #pragma unroll
-      for (int i = 0; i < NMFMA; i++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            // 1 MFMA
-        if (i < NI) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                // 1 DMA (VMEM read)
-        if (i < 2 * TM + NS * TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                            // VALU (addresses, split)
-        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);                            // SALU
+            for (int r = 0; r < (NMICRO + NM - 1) / NM; r++)
+              if (mi < (j * NMICRO + NM - 1) / NM) { micro(mi, kt_fill, stage_free, stage_next, fan, fbn); mi++; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
       }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 6; r++)
-        if (r >= g) piece(r);
-    }
   };
 #pragma unroll
-  for (int t = 0; t < S - 1; t++)
-    if (BF || t < nkt) { issue_a(t); issue_b(min(t, nkt - 1), t); }
-  wait_dma(BF ? S - 2 : min(S - 1, nkt) - 1);
+  for (int t = 0; t < S - 1; t++) { filling = t < nkt; issue_all(min(t, nkt - 1), t); }
+  wait_dma(S - 2);
   __builtin_amdgcn_s_barrier();
-  if (BF || S - 1 < nkt) { issue_a(S - 1); issue_b(min(S - 1, nkt - 1), S - 1); }
+  filling = S - 1 < nkt;
+  issue_all(min(S - 1, nkt - 1), S - 1);
   bf16x8 fa0[NS][TM], fb0[NS][TN], fa1[NS][TM], fb1[NS][TN];
-  read_a(0);
-  read_b(0, fb0, 0, NS);
-  split_half(0);
-  split_half(1);
-  pack_a(fa0);
+  {
+    const char* st = ring;
+#pragma unroll
+    for (int a = 0; a < TM; a++) { va[a][0] = *(const f32x4*)(st + aoff[a][0]); va[a][1] = *(const f32x4*)(st + aoff[a][1]); }
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+      for (int b = 0; b < TN; b++) fb0[q][b] = *(const bf16x8*)(st + boff + q * PB + b * 1024);
+#pragma unroll
+    for (int lvl = 0; lvl < SPL; lvl++)
+#pragma unroll
+      for (int f = 0; f < 2 * TM; f++) { if (lvl & 1) split_sub(f >> 1, f & 1); else split_cvt(f >> 1, f & 1, lvl >> 1); }
+    pack_a(fa0);
+  }
   int stage = 0;  // buffer of step kt
   for (int kt = 0; kt < nkt; kt += 2) {
     const int s1 = stage == S - 1 ? 0 : stage + 1, s2 = s1 == S - 1 ? 0 : s1 + 1;
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
     if (kt + 1 < nkt) step(kt + 1, s2, s1, fa1, fb1, fa0, fb0);
     stage = s2;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (branch-free form: the surplus DMAs of the tail steps)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the tail steps must land before LDS is reused
   __syncthreads();
   conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tid, lane, wm, wn, HoWo);
 }
