@@ -32,10 +32,17 @@ def _targets_product(tgs, dev):
     return out
 
 
-@pytest.fixture(scope="module")
-def setup(synth, weights):
+@pytest.fixture(scope="module", params=[3, 0], ids=["bf16x3-split", "fp32-mfma"])
+def setup(request, synth, weights):
+    """the whole model-level parity suite runs in both convolution arithmetics: the default 3-term bf16 split and the
+    fp32-input MFMA (include/mmtpsm.h: mmt_set_conv_precision) -- same tolerances"""
+    from maskrcnn_benchmark import _hip
     from maskrcnn_benchmark.config import make_default_cfg
     from maskrcnn_benchmark.modeling.detector import build_detection_model
+    _hip.lib()
+    prev = _hip.get_conv_precision()
+    _hip.set_conv_precision(request.param)
+    request.addfinalizer(lambda: _hip.set_conv_precision(prev))
     cfg = make_default_cfg()
     student = build_detection_model(cfg, is_student=True).cuda()
     teacher = build_detection_model(cfg, is_teacher=True).cuda()
