@@ -100,21 +100,25 @@ __global__ __launch_bounds__(256) void roi_align_kernel(Pyr p, const float* __re
         if (ry[a] == ry[b] && wy[a] != 0.f) { wy[b] += wy[a]; wy[a] = 0.f; }
         if (rx[a] == rx[b] && wx[a] != 0.f) { wx[b] += wx[a]; wx[a] = 0.f; }
       }
-    for (int c0 = lane * VEC; c0 < C; c0 += 64 * VEC) {
-      float g[VEC];
-      if (VEC == 4) { const f32x4 t = *(const f32x4*)(o + c0); g[0] = t[0]; g[1 % VEC] = t[1]; g[2 % VEC] = t[2]; g[3 % VEC] = t[3]; }
-      else g[0] = o[c0];
+    // lanes run over CONSECUTIVE channels (lane + 64 j): every atomic instruction then covers 256 contiguous bytes (two
+    // full cache lines at the L2 atomic units) instead of 64 four-byte pieces spread over 1 KiB
+    for (int cb = 0; cb < C; cb += 256) {
+      float g[4];
 #pragma unroll
-      for (int j = 0; j < VEC; j++) g[j] = g[j] / count;
+      for (int j = 0; j < 4; j++) {
+        const int c = cb + lane + 64 * j;
+        g[j] = c < C ? o[c] / count : 0.f;
+      }
 #pragma unroll
       for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
           const float wgt = wy[a] * wx[b];
           if (wgt != 0.f) {
-            float* dst = gfeat + ((long)ry[a] * W + rx[b]) * C + c0;
+            float* dst = gfeat + ((long)ry[a] * W + rx[b]) * C + cb + lane;
 #pragma unroll
-            for (int j = 0; j < VEC; j++) atomicAdd(dst + j, g[j] * wgt);
+            for (int j = 0; j < 4; j++)
+              if (cb + lane + 64 * j < C) atomicAdd(dst + 64 * j, g[j] * wgt);
           }
         }
     }
