@@ -1433,7 +1433,10 @@ extern "C" int mmt_conv_wgrad_splits(const mmt_conv_args* a) {
   if (p.M == 0 || p.Cout == 0) return 1;
   const int NP = p.KH * p.KW * p.Cin;
   const int tx = mmt_cdiv(NP, 128), ty = mmt_cdiv(p.Cout, 128);
-  int split = mmt_cdiv(640, (long)tx * ty);  // ~1.25 resident rounds of 2 blocks x 256 CUs
+  // all blocks of a launch run equally long: fill the 512 resident slots (256 CUs x 2 blocks) ONCE.  (640 = 1.25
+  // rounds cost a second, 20 %-full round: 92 -> 105 TFLOP/s fp32, 103 -> 136 split-bf16 on the FPN 3x3 shapes)
+  const long tiles = (long)tx * ty;
+  int split = (int)(tiles >= 512 ? 1 : 512 / tiles);
   const int max_split = mmt_cdiv(p.M, 512);  // at least 16 k-tiles per block
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
