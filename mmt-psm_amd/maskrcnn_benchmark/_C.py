@@ -9,6 +9,7 @@ raises for CPU tensors -- there is no CPU implementation in the product.
 import torch
 
 from . import _hip
+from .utils.miscellaneous import dev_const
 
 
 def nms(dets, scores, threshold):
@@ -19,7 +20,7 @@ def nms(dets, scores, threshold):
     _hip._dev(dets, "dets")
     order = torch.sort(scores, descending=True, stable=True)[1]
     n = dets.shape[0]
-    seg = torch.tensor([0, n], dtype=torch.int32, device=dets.device)
+    seg = dev_const([0, n], torch.int32, dets.device)
     keep, cnt = _hip.nms_batched(dets[order], seg, n, threshold)
     k = int(cnt[0])
     return torch.sort(order[keep[0, :k].long()])[0]

@@ -5,6 +5,8 @@ hint adaptor) and the same three entry points: forward / forward_teacher / forwa
 Execution: 4-level ROIAlign in one launch -> fc6/fc7 on the fp32 MFMA GEMM with bias+ReLU(+dropout) in the
 epilogue -> cls_score and bbox_pred as ONE 15-wide GEMM; PSM loss as two small kernels."""
 import torch
+
+from maskrcnn_benchmark.utils.miscellaneous import dev_const
 from torch import nn
 import torch.nn.functional as F
 
@@ -174,7 +176,7 @@ class FastRCNNLossComputation(object):
             S = (n_pos + n_keep).to(torch.float32)
         else:
             roww = torch.ones(labels.shape, device=labels.device)
-            S = torch.tensor(float(labels.numel()), device=labels.device)
+            S = dev_const(float(labels.numel()), torch.float32, labels.device)
         nc = teacher.shape[2]
         norm = 1.0 / (S * (3.0 if kind == 0 else float(nc)))
         losses = [fused.PSMLossFn.apply(cl, teacher, roww, norm, cfg.MT.TEMP, 1 if cfg.MT.SHARPEN else 0, kind)
@@ -209,7 +211,7 @@ class PostProcessor(nn.Module):
         segs, metas = [], []
         for pr, bx, b in zip(prob.split(per, 0), dec.split(per, 0), boxes):
             w, h = b.size
-            lim = torch.tensor([w - 1, h - 1, w - 1, h - 1], dtype=torch.float32, device=dev)
+            lim = dev_const([w - 1, h - 1, w - 1, h - 1], torch.float32, dev)
             bx = torch.minimum(bx.reshape(-1, 4).clamp(min=0), lim).reshape(-1, nc * 4)
             for j in range(1, nc):
                 sc = pr[:, j]
@@ -223,7 +225,7 @@ class PostProcessor(nn.Module):
             bl.append(s[0][:nv])
             offs.append(offs[-1] + nv)
         kmax = max(max(n_valid), 1)
-        keep, cnt = H.nms_batched(torch.cat(bl, 0), torch.tensor(offs, dtype=torch.int32, device=dev), kmax, self.nms)
+        keep, cnt = H.nms_batched(torch.cat(bl, 0), torch.tensor(offs, dtype=torch.int32, device=dev), kmax, self.nms)  # data-dependent
         cnts = cnt.tolist()
         results, si = [], 0
         for b in boxes:

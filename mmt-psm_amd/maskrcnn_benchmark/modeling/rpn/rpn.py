@@ -11,6 +11,8 @@ clip over the whole batch, then a SINGLE `mmt_nms_batched` launch pair over all 
 the greedy sweep on the device (the reference does 5*N separate NMS calls each with a D2H mask copy).
 """
 import torch
+
+from maskrcnn_benchmark.utils.miscellaneous import dev_const
 from torch import nn
 import torch.nn.functional as F
 
@@ -85,7 +87,7 @@ class RPNPostProcessor(nn.Module):
         N, L = len(anchors), len(objectness)
         dev = objectness[0].device
         sizes = [a[0].size for a in anchors]  # (W,H) per image
-        lim = torch.tensor([[s[0] - 1, s[1] - 1, s[0] - 1, s[1] - 1] for s in sizes], dtype=torch.float32, device=dev)
+        lim = dev_const([[s[0] - 1, s[1] - 1, s[0] - 1, s[1] - 1] for s in sizes], torch.float32, dev)
         cand_box, cand_score, cand_extra, ks = [], [], [], []
         for lvl in range(L):
             o, r = _flat(objectness[lvl].detach(), box_regression[lvl].detach())
@@ -112,7 +114,7 @@ class RPNPostProcessor(nn.Module):
         for n in range(N):
             for l in range(L):
                 offs.append(offs[-1] + ks[l])
-        seg_off = torch.tensor(offs, dtype=torch.int32, device=dev)
+        seg_off = dev_const(offs, torch.int32, dev)
         keep, cnt = H.nms_batched(boxes, seg_off, kmax, self.nms_thresh)
         return dict(N=N, L=L, ks=ks, kmax=kmax, sizes=sizes, boxes=boxes, scores=scores, seg_off=seg_off, keep=keep,
                     cnt=cnt, extra_src=cand_extra, dev=dev)
@@ -123,7 +125,7 @@ class RPNPostProcessor(nn.Module):
         per_img = sum(ks)
         total = N * per_img
         # this selector's own pre-NMS prefix per segment and post-NMS cap
-        own_pre = torch.tensor([min(self.pre_nms_top_n, k) for _ in range(N) for k in ks], dtype=torch.int32, device=dev)
+        own_pre = dev_const([min(self.pre_nms_top_n, k) for _ in range(N) for k in ks], torch.int32, dev)
         pos = seg_off[:-1, None].long() + keep.long()
         valid = (torch.arange(kmax, device=dev)[None, :] < cnt[:, None]) & (keep < own_pre[:, None])
         if self.post_nms_top_n > 0:

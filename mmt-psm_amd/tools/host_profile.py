@@ -1,0 +1,21 @@
+"""host-side profile (cProfile) of one mean-teacher step: where the Python/launch time goes"""
+import cProfile, pstats, sys, os, io, torch
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, ROOT)
+import bench
+cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0)
+for i in range(3):
+    il, tg, ul = batch(); trainer.train_step(1400 + i, il, tg, ul)
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+il, tg, ul = batch()
+pr.enable()
+trainer.train_step(1403, il, tg, ul)
+pr.disable()
+torch.cuda.synchronize()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(35)
+print(s.getvalue()[:6000])
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+print(s.getvalue()[:7000])
