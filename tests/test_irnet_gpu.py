@@ -114,3 +114,33 @@ def test_irnet_teacher_inference(setup, synth):
     assert (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
     for s_r, s_o in zip(tr["seg_mask"], out["seg_mask"]):
         assert (s_r != s_o.cpu().long()).float().mean().item() < 1e-4
+
+
+def test_irnet_bf16_products_mode(setup, synth):
+    """BASELINE configs[4] asks for a bf16 MFMA path with IR-Net on: arithmetic mode 1 (bf16 products, fp32 accumulate and
+    fp32 tensors).  Same forward as above against the fp32 CPU oracle, at bf16-class tolerances."""
+    from oracle import model as om
+    from maskrcnn_benchmark import _hip
+    from maskrcnn_benchmark.utils.replay import Replay
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    cfg, student, _, weights = setup
+    ocfg = om.default_cfg(relation=True)
+    imgs, tgs = synth.make_labeled(2, SIZE, 4, seed=1234)
+    taps = {}
+    torch.manual_seed(99)
+    with torch.no_grad():
+        ref = om.forward_supervised(weights, ocfg, imgs, _targets_oracle(om, tgs), taps)
+    prev = _hip.get_conv_precision()
+    _hip.set_conv_precision(1)
+    try:
+        student.set_replay(Replay(taps))
+        with torch.no_grad():
+            out = student(to_image_list(list(imgs.cuda()), 32), _targets_product(tgs, "cuda"))
+        student.set_replay(None)
+    finally:
+        _hip.set_conv_precision(prev)
+    dev = {k: abs(out[k].item() - ref[k].item()) / max(abs(ref[k].item()), 1e-6) for k in ref}
+    assert all(v == v for v in dev.values())
+    for k, v in dev.items():
+        assert v < (0.25 if k == "nms_loss" else 5e-2), dev
+    assert max(v for k, v in dev.items() if k != "nms_loss") > 1e-6  # it really ran the bf16 kernels
