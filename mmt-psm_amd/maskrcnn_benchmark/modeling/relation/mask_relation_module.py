@@ -5,7 +5,7 @@ Per image and per class the instances are sorted by objectness; their first-pass
 max-pooled 14x14) is concatenated to the 256-channel ROI feature, pushed through 3 x conv3x3(256) + conv3x3(16),
 mixed across instances by the cross-instance channel attention CIAM, then deconv(16) + 1x1(3) give the second
 mask logits.  Parameter names as in the reference (mask_heads.mask.mask_relation_module.*).  The convolutions run
-on the fp32 MFMA implicit GEMM (the 257-channel input is carried as 260 channels, weights zero-padded on the fly);
+on the MFMA implicit GEMM (the 257-channel input is carried as 272 channels, weights zero-padded on the fly);
 CIAM is two batched library GEMMs over <= 128 instances."""
 import torch
 from torch import nn
@@ -32,8 +32,9 @@ class RoiAlignMaskFeatureExtractor(nn.Module):
         x, mask = x
         from maskrcnn_benchmark.layers import fused
         pool = F.max_pool2d(mask, kernel_size=2, stride=2)
-        x = torch.cat((x, pool, pool.new_zeros((pool.shape[0], 3, pool.shape[2], pool.shape[3]))), 1)  # 257 -> 260 ch
-        w1 = F.pad(self.mask_fcn1.weight, (0, 0, 0, 0, 0, 3))
+        # 257 -> 272 channels (a multiple of 16: the DMA-fed split-bf16 kernel takes the layer; zero channels add zeros)
+        x = torch.cat((x, pool, pool.new_zeros((pool.shape[0], 15, pool.shape[2], pool.shape[3]))), 1)
+        w1 = F.pad(self.mask_fcn1.weight, (0, 0, 0, 0, 0, 15))
         x = fused.conv(x, w1.contiguous(memory_format=torch.channels_last), self.mask_fcn1.bias, 1, 1, True, False)
         x = self.mask_fcn2(x, relu=True, input_relu=True)
         x = self.mask_fcn3(x, relu=True, input_relu=True)
