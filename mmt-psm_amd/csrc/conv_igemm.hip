@@ -343,7 +343,7 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int DBG = 0>
+template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvP p) {
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int NA = BM / 64, NB = BN / 64;  // float4 loads per thread per 16-k tile
@@ -419,14 +419,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvP p) {
       const int ih = aih0[j] + kh, iw = aiw0[j] + kw;
       const bool ok = aok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       const unsigned off = ok ? abase[j] + (unsigned)((ih * p.W + iw) * p.Cin + ci) : 0u;
-      if (DBG & 2) ra[j] = f32x4{(float)off, 1.f, 2.f, 3.f}; else
       ra[j] = ldg4(p.x + off);
       pa[j] = ok;
     }
     const int kidx = kt * 16 + c4 * 4;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-      if (DBG & 2) rb[j] = f32x4{(float)kidx, 1.f, 2.f, 3.f}; else
       rb[j] = ldg4(p.w + (bok[j] ? bbase[j] + (unsigned)kidx : 0u));
       pb[j] = bok[j];
     }
@@ -438,7 +436,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvP p) {
 #pragma unroll
     for (int j = 0; j < NA; j++) {
       uint2 o[NS];
-      if (DBG & 4) { const f32x4 v = pa[j] ? ra[j] : zero4; for (int q = 0; q < NS; q++) o[q] = uint2{__builtin_bit_cast(unsigned, v[0]) + q, __builtin_bit_cast(unsigned, v[2])}; } else
       split4<NS>(pa[j] ? ra[j] : zero4, o);
 #pragma unroll
       for (int q = 0; q < NS; q++) *(uint2*)(A + q * PA + j * 64 * 32) = o[q];
@@ -446,7 +443,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvP p) {
 #pragma unroll
     for (int j = 0; j < NB; j++) {
       uint2 o[NS];
-      if (DBG & 4) { const f32x4 v = pb[j] ? rb[j] : zero4; for (int q = 0; q < NS; q++) o[q] = uint2{__builtin_bit_cast(unsigned, v[0]) + q, __builtin_bit_cast(unsigned, v[2])}; } else
       split4<NS>(pb[j] ? rb[j] : zero4, o);
 #pragma unroll
       for (int q = 0; q < NS; q++) *(uint2*)(B + q * PB + j * 64 * 32) = o[q];
@@ -480,7 +476,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvP p) {
           for (int a = 0; a < TM; a++)
 #pragma unroll
             for (int b = 0; b < TN; b++)
-              if (DBG & 1) acc[a][b][(qa + qb) & 15] += (float)fa[qa][a][0] * (float)fb[qb][b][0]; else
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
         }
       }
@@ -1283,9 +1278,7 @@ template <int BM, int BN, int WM, int WN, int NS, int S>
 int launch_glds(const ConvP& p, hipStream_t s) {
   const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN);
   const size_t ring = (size_t)S * (BM * 64 + NS * BN * 32), epi = (size_t)BM * BN * sizeof(float);
-  size_t lds = ring > epi ? ring : epi;
-  static const int pad = getenv("MMT_LDS_PAD") ? atoi(getenv("MMT_LDS_PAD")) : 0;  // tuning aid: forces 1 block per CU
-  if ((size_t)pad > lds) lds = pad;
+  const size_t lds = ring > epi ? ring : epi;
   auto kern = conv_fwd_glds_kernel<BM, BN, WM, WN, NS, S>;
   if (lds > 65536) {
     static bool done = false;  // per instantiation
@@ -1303,11 +1296,7 @@ int launch_glds(const ConvP& p, hipStream_t s) {
 template <int NS>
 int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
   switch (variant) {
-    case 1: {
-      static const int st = getenv("MMT_STAGES") ? atoi(getenv("MMT_STAGES")) : 3;
-      if (st == 4) return launch_glds<128, 128, 4, 1, NS, 4>(p, s);
-      return launch_glds<128, 128, 4, 1, NS, 3>(p, s);
-    }
+    case 1: return launch_glds<128, 128, 4, 1, NS, 3>(p, s);
     case 3: return launch_glds<128, 64, 4, 1, NS, 3>(p, s);
     default: return launch_glds<64, 64, 2, 2, NS, 3>(p, s);
   }
@@ -1315,12 +1304,6 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
 
 template <int NS>
 int launch_split_variant(int variant, const ConvP& p, hipStream_t s) {
-  static const int dbg = getenv("MMT_DBG") ? atoi(getenv("MMT_DBG")) : 0;
-  if (NS == 3 && variant == 1 && dbg) {
-    const int tiles = mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
-#define DBGCASE(D) case D: hipLaunchKernelGGL((conv_fwd_split_kernel<128, 128, 2, 2, 3, D>), dim3(tiles), dim3(256), 65536, s, p); return 0;
-    switch (dbg) { DBGCASE(1) DBGCASE(2) DBGCASE(4) DBGCASE(8) DBGCASE(3) DBGCASE(6) DBGCASE(7) DBGCASE(5) }
-  }
   switch (variant) {
     case 1: return launch_split<128, 128, 2, 2, NS>(p, s);
     case 3: return launch_split<128, 64, 2, 2, NS>(p, s);
@@ -1406,8 +1389,7 @@ extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int variant = pick_variant(p);
   const int prec = precision();
-  static const int noglds = getenv("MMT_NO_GLDS") ? atoi(getenv("MMT_NO_GLDS")) : 0;
-  if (prec > 0 && variant != 0 && (p.Cin & 15) == 0 && p.wpl && !noglds) {
+  if (prec > 0 && variant != 0 && (p.Cin & 15) == 0 && p.wpl) {
     if (((size_t)p.wpl & 15) || (p.wpl_stride & 7)) return MMT_EINVAL;
     if (prec == 1) return launch_glds_variant<1>(variant, p, s);
     if (prec == 2) return launch_glds_variant<2>(variant, p, s);
@@ -1462,8 +1444,7 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   float* ws = split > 1 ? workspace : nullptr;
   const bool fast = (p.Cout & 3) == 0 && p.Wo >= 8 && p.Ho >= 8;
   const int prec = precision();
-  static const int nosplit = getenv("MMT_WGRAD_FP32") ? atoi(getenv("MMT_WGRAD_FP32")) : 0;
-  if (prec > 0 && !nosplit && (p.Cout & 3) == 0 && (mps & 15) == 0) {
+  if (prec > 0 && (p.Cout & 3) == 0 && (mps & 15) == 0) {
     const dim3 grid(tx, ty, split);
 #define WGS(NS, INC) hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)
     if (fast) { if (prec == 1) WGS(1, true); else if (prec == 2) WGS(2, true); else WGS(3, true); }
