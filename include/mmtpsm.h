@@ -123,6 +123,12 @@ int mmt_get_conv_precision(void);
 typedef struct { long src_off, dst_off; int Cout, K, unit0, pad; } mmt_pack_desc;
 long mmt_packed_weight_elems(int Cout, int K);
 int mmt_pack_weight(const float* w, void* planes, long plane_stride, int Cout, int K, void* stream);
+/* packed planes of the data-gradient weights of a convolution, straight from its forward weight w[Cout][KH][KW][Cin]:
+ * the matrix [Cin][(KH-1-kh, KW-1-kw, co)] = w * scale[co] (what mmt_weight_flip_transpose produces in fp32) in the tiled
+ * plane form; Cout % 16 == 0.  mmt_conv_forward accepts w == NULL when w_planes is given and the shape is one the
+ * DMA-fed kernels take (Cin % 16 == 0, Cout > 32 of THAT call, mode != 0). */
+int mmt_pack_weight_flipped(const float* w, const float* scale, void* planes, long plane_stride, int Cout, int KH, int KW,
+                            int Cin, void* stream);
 int mmt_pack_weights(const float* base, void* planes, long plane_stride, const mmt_pack_desc* descs /*[dev]*/,
                      const int* unit_desc /*[dev]*/, int n_units, void* stream);
 

@@ -777,6 +777,35 @@ __global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__
   if (unit < n_units) pack_unit(w, dst, plane_stride, Cout, K, unit, threadIdx.x & 63);
 }
 
+// packed planes of the DATA-GRADIENT weights straight from w: the matrix wd[ci][(KH-1-kh, KW-1-kw, co)] = w[co][kh][kw][ci]
+// * scale[co] (what weight_flip_kernel materialises in fp32) is never written; needs Cout % 16 == 0
+__global__ __launch_bounds__(256) void pack_flip_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                        unsigned short* __restrict__ dst, long plane_stride, int Cout,
+                                                        int KH, int KW, int Cin, int n_units) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (unit >= n_units) return;
+  const int nb32 = (Cin + 31) >> 5;
+  const int step = unit / nb32, blk = unit - step * nb32;
+  const int r = lane >> 1, h = lane & 1;
+  const int ci = blk * 32 + r;
+  const int lh = h ^ ((r >> 3) & 1);
+  const int k0 = step * 16 + lh * 8;          // first of this lane's 8 k' = (flipped tap, co)
+  const int ft = k0 / Cout, co0 = k0 - ft * Cout;
+  const int tap = KH * KW - 1 - ft;           // un-flipped tap index kh*KW + kw
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int co = co0 + j;
+    v[j] = ci < Cin ? w[((long)co * KH * KW + tap) * Cin + ci] * (scale ? scale[co] : 1.f) : 0.f;
+  }
+  uint2 o0[3], o1[3];
+  split4<3>(f32x4{v[0], v[1], v[2], v[3]}, o0);
+  split4<3>(f32x4{v[4], v[5], v[6], v[7]}, o1);
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    *(uint4*)(dst + q * plane_stride + (long)unit * 512 + lane * 8) = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+}
+
 __global__ __launch_bounds__(256) void pack_many_kernel(const float* __restrict__ base, unsigned short* __restrict__ dst,
                                                         long plane_stride, const PackDesc* __restrict__ descs,
                                                         const int* __restrict__ unit_desc, int n_units) {
@@ -1346,6 +1375,17 @@ extern "C" int mmt_pack_weight(const float* w, void* planes, long plane_stride, 
   return 0;
 }
 
+extern "C" int mmt_pack_weight_flipped(const float* w, const float* scale, void* planes, long plane_stride, int Cout,
+                                       int KH, int KW, int Cin, void* stream) {
+  const long n = mmt_packed_weight_elems(Cin, KH * KW * Cout);  // rows = Cin, K' = KH*KW*Cout
+  if (!w || !planes || n < 0 || (Cout & 15) || plane_stride < n || (plane_stride & 7) || ((size_t)planes & 15)) return MMT_EINVAL;
+  const int units = (int)(n / 512);
+  hipLaunchKernelGGL(pack_flip_kernel, dim3((units + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, scale,
+                     (unsigned short*)planes, plane_stride, Cout, KH, KW, Cin, units);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmt_pack_weights(const float* base, void* planes, long plane_stride, const mmt_pack_desc* descs,
                                 const int* unit_desc, int n_units, void* stream) {
   if (!base || !planes || !descs || !unit_desc || (plane_stride & 7) || ((size_t)planes & 15)) return MMT_EINVAL;
@@ -1384,11 +1424,12 @@ extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
-  if (!p.w || !p.y) return MMT_EINVAL;
+  if (!p.y) return MMT_EINVAL;
   if (p.M == 0 || p.Cout == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int variant = pick_variant(p);
   const int prec = precision();
+  if (!p.w && !(prec > 0 && variant != 0 && (p.Cin & 15) == 0 && p.wpl)) return MMT_EINVAL;  // planes-only call
   if (prec > 0 && variant != 0 && (p.Cin & 15) == 0 && p.wpl) {
     if (((size_t)p.wpl & 15) || (p.wpl_stride & 7)) return MMT_EINVAL;
     if (prec == 1) return launch_glds_variant<1>(variant, p, s);

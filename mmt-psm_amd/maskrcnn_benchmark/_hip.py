@@ -44,6 +44,7 @@ _SIGS = {
     "mmt_get_conv_precision": [],
     "mmt_pack_weight": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
     "mmt_pack_weights": [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p],
+    "mmt_pack_weight_flipped": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_conv_wgrad_splits": [ctypes.POINTER(ConvArgs)],
     "mmt_conv_wgrad": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_colsum": [c_void_p, c_int, c_int, c_void_p, c_void_p],
@@ -201,17 +202,32 @@ def _conv_args(x, w, stride, pad, Ho, Wo):
 
 
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
-                 mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0):
+                 mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0,
+                 w_shape=None, planes=None):
     """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory).
-    y_out/y_offset (elements): write into an existing NHWC tensor at a shifted base (transposed-conv taps)."""
+    y_out/y_offset (elements): write into an existing NHWC tensor at a shifted base (transposed-conv taps).
+    w=None with w_shape + planes: the weight exists only as packed bf16 planes (pack_weight_flipped)."""
     x = nhwc(x)
-    w = nhwc(w)
     N, Cin, H, W = x.shape
-    Cout, _, KH, KW = w.shape
-    Ho = (H + 2 * pad - KH) // stride + 1
-    Wo = (W + 2 * pad - KW) // stride + 1
-    a = _conv_args(x, w, stride, pad, Ho, Wo)
-    _keep = _weight_planes(w, a)  # noqa: F841  (keeps a per-call plane buffer alive until the launch is queued)
+    if w is None:
+        Cout, Cin_w, KH, KW = w_shape
+        if Cin_w != Cin:
+            raise RuntimeError("conv channel mismatch: x has %d, w has %d" % (Cin, Cin_w))
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        a = ConvArgs()
+        a.x = x.data_ptr()
+        a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
+        a.stride, a.pad, a.Ho, a.Wo = stride, pad, Ho, Wo
+        a.out_stride, a.mask_scale = 1, 1.0
+        a.w_planes, a.w_plane_stride = planes.data_ptr(), planes.stride(0)
+    else:
+        w = nhwc(w)
+        Cout, _, KH, KW = w.shape
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        a = _conv_args(x, w, stride, pad, Ho, Wo)
+        _keep = _weight_planes(w, a)  # noqa: F841  (keeps a per-call plane buffer alive until the launch is queued)
     if out_stride > 1:
         oh, ow = out_hw
         y = y_out if y_out is not None else empty_nhwc(N, Cout, oh, ow, x.device, zero=True)
@@ -264,6 +280,19 @@ def pack_weight(w):
     k = w.numel() // cout
     planes = torch.empty((3, packed_elems(cout, k)), dtype=torch.bfloat16, device=w.device)
     _check(lib().mmt_pack_weight(w.data_ptr(), planes.data_ptr(), planes.stride(0), cout, k, _stream()), "mmt_pack_weight")
+    return planes
+
+
+def pack_weight_flipped(w, scale=None):
+    """packed planes of the data-gradient weights of conv(x, w) (* scale[co]) -- or None when the data gradient does not
+    run on the DMA-fed kernels (then the caller materialises them with weight_flip_transpose)"""
+    Cout, Cin, KH, KW = w.shape
+    if get_conv_precision() == 0 or (Cout & 15) or Cin <= 32:
+        return None
+    w = nhwc(w)
+    planes = torch.empty((3, packed_elems(Cin, KH * KW * Cout)), dtype=torch.bfloat16, device=w.device)
+    _check(lib().mmt_pack_weight_flipped(w.data_ptr(), _p(scale), planes.data_ptr(), planes.stride(0), Cout, KH, KW, Cin,
+                                         _stream()), "mmt_pack_weight_flipped")
     return planes
 
 

@@ -39,15 +39,19 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
 
 def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, res=None, res_mode=0):
     """data gradient of y = conv(x, w) (* scale[co]) w.r.t. x, with optional fused (x>0) mask / residual add"""
-    wd = H.weight_flip_transpose(w, scale)
     kh = w.shape[2]
+    if stride != 1 and kh != 1:
+        raise RuntimeError("strided data-gradient is implemented for 1x1 convolutions (STRIDE_IN_1X1) only")
+    # the transposed / tap-flipped / BN-scaled weights: straight into packed bf16 planes when the DMA-fed kernels take the
+    # data gradient (one launch, nothing materialised in fp32), else as an fp32 tensor
+    planes = H.pack_weight_flipped(w, scale)
+    kw = dict(w_shape=(w.shape[1], w.shape[0], kh, w.shape[3]), planes=planes) if planes is not None else {}
+    wd = None if planes is not None else H.weight_flip_transpose(w, scale)
     if stride == 1:
         return H.conv_forward(g, wd, stride=1, pad=kh - 1 - pad, mask=mask, mask_scale=mask_scale, res=res,
-                              res_mode=res_mode)
-    if kh != 1:
-        raise RuntimeError("strided data-gradient is implemented for 1x1 convolutions (STRIDE_IN_1X1) only")
+                              res_mode=res_mode, **kw)
     return H.conv_forward(g, wd, out_stride=stride, out_hw=tuple(x_shape[2:]), mask=mask, mask_scale=mask_scale,
-                          res=res, res_mode=res_mode)
+                          res=res, res_mode=res_mode, **kw)
 
 
 class ConvFn(torch.autograd.Function):
