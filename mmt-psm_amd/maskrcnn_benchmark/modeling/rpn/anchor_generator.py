@@ -76,14 +76,21 @@ class AnchorGenerator(nn.Module):
                 & (anchors[:, 3] < image_height + t))
 
     def forward(self, image_list, feature_maps):
-        """-> list (per image) of list (per level) of BoxList with field 'visibility' (anchor_generator.py:110-123)"""
-        per_level = self.grid_anchors([f.shape[-2:] for f in feature_maps])
+        """-> list (per image) of list (per level) of BoxList with field 'visibility' (anchor_generator.py:110-123).
+        Anchors AND their visibility masks are constants of (grid sizes, image size): built once, then served from the
+        cache (the fixed 1000x1000 crops of the path hit it every time; ~200 small launches per call otherwise)."""
+        grids = tuple((int(f.shape[-2]), int(f.shape[-1])) for f in feature_maps)
+        per_level = self.grid_anchors(grids)
         out = []
         for (ih, iw) in image_list.image_sizes:
+            key = ("vis", grids, int(iw), int(ih), str(per_level[0].device), tuple(a.data_ptr() for a in per_level))
+            vis = self._cache.get(key)
+            if vis is None:
+                vis = self._cache[key] = [self.visibility(a, iw, ih) for a in per_level]
             lv = []
-            for a in per_level:
+            for a, v in zip(per_level, vis):
                 b = BoxList(a, (iw, ih), mode="xyxy")
-                b.add_field("visibility", self.visibility(a, iw, ih))
+                b.add_field("visibility", v)
                 lv.append(b)
             out.append(lv)
         return out

@@ -88,28 +88,29 @@ class RPNPostProcessor(nn.Module):
         dev = objectness[0].device
         sizes = [a[0].size for a in anchors]  # (W,H) per image
         lim = dev_const([[s[0] - 1, s[1] - 1, s[0] - 1, s[1] - 1] for s in sizes], torch.float32, dev)
-        cand_box, cand_score, cand_extra, ks = [], [], [], []
+        cand_extra, ks, scs, regs, ancs = [], [], [], [], []
         for lvl in range(L):
             o, r = _flat(objectness[lvl].detach(), box_regression[lvl].detach())
-            o = o.sigmoid()
             k = min(pre_n, o.shape[1])
-            sc, idx = o.topk(k, dim=1, sorted=True)
+            lg, idx = o.sigmoid().topk(k, dim=1, sorted=True)  # on the probabilities, as rpn/inference.py:93 (ties!)
             r = torch.gather(r, 1, idx[:, :, None].expand(-1, -1, 4))
-            anc = anchors[0][lvl].bbox[idx.reshape(-1)].view(N, k, 4)  # same grid for every image
-            props = self.box_coder.decode(r.reshape(-1, 4), anc.reshape(-1, 4)).view(N, k, 4)
-            props = torch.minimum(props.clamp(min=0), lim[:, None, :])  # clip_to_image(remove_empty=False)
-            if self.min_size > 0:
-                ws = props[..., 2] - props[..., 0] + 1
-                hs = props[..., 3] - props[..., 1] + 1
-                sc = torch.where((ws >= self.min_size) & (hs >= self.min_size), sc, torch.full_like(sc, -1.0))
-            cand_box.append(props)
-            cand_score.append(sc)
+            scs.append(lg)
+            regs.append(r)
+            ancs.append(anchors[0][lvl].bbox[idx.reshape(-1)].view(N, k, 4))  # same grid for every image
             cand_extra.append((r, idx))
             ks.append(k)
         kmax = max(ks)
-        # one batched NMS over all (image, level) segments, image-major so that per-image lists are contiguous
-        boxes = torch.cat([torch.cat([cand_box[l][n] for l in range(L)], 0) for n in range(N)], 0)
-        scores = torch.cat([torch.cat([cand_score[l][n] for l in range(L)], 0) for n in range(N)], 0)
+        # decode / clip / min-size filter ONCE over all levels; (N, sum_k, .) is already the image-major, level-minor order
+        # the batched NMS wants, so no per-(image, level) slicing and re-concatenation
+        sc = torch.cat(scs, 1)
+        props = self.box_coder.decode(torch.cat(regs, 1).reshape(-1, 4), torch.cat(ancs, 1).reshape(-1, 4)).view(N, -1, 4)
+        props = torch.minimum(props.clamp(min=0), lim[:, None, :])  # clip_to_image(remove_empty=False)
+        if self.min_size > 0:
+            ws = props[..., 2] - props[..., 0] + 1
+            hs = props[..., 3] - props[..., 1] + 1
+            sc = torch.where((ws >= self.min_size) & (hs >= self.min_size), sc, torch.full_like(sc, -1.0))
+        boxes = props.reshape(-1, 4)
+        scores = sc.reshape(-1)
         offs = [0]
         for n in range(N):
             for l in range(L):
@@ -219,13 +220,21 @@ class RPNLossComputation(object):
             regs.append(self.box_coder.encode(tb[m.clamp(min=0)], ab))
         return labels, regs
 
-    @staticmethod
-    def _cat_anchors(anchors):
+    def _cat_anchors(self, anchors):
+        """per image (all-level anchors, visibility, area): constants of the anchor grid, cached on its device addresses"""
+        cache = self.__dict__.setdefault("_anchor_cache", {})
         out = []
         for per_img in anchors:
-            b = torch.cat([a.bbox for a in per_img], 0)
-            v = torch.cat([a.get_field("visibility") for a in per_img], 0)
-            out.append((b, v, (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)))
+            key = tuple((a.bbox.data_ptr(), a.get_field("visibility").data_ptr()) for a in per_img)
+            ent = cache.get(key)
+            if ent is None:
+                if len(cache) > 64:
+                    cache.clear()
+                b = torch.cat([a.bbox for a in per_img], 0)
+                v = torch.cat([a.get_field("visibility") for a in per_img], 0)
+                ent = cache[key] = (b, v, (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1),
+                                    [a.bbox for a in per_img], [a.get_field("visibility") for a in per_img])  # keep-alive
+            out.append(ent[:3])
         return out
 
     def teacher_sample_selection(self, anchors, objectness, box_regression, targets):
