@@ -64,6 +64,22 @@ int mmt_roi_align_backward(const mmt_pyramid* pyr /*[host]*/, const float* rois,
 int mmt_nms_batched(const float* boxes, const int32_t* seg_off, int B, int max_n, float thr,
                     uint64_t* mask_ws, int32_t* keep, int32_t* keep_cnt, void* stream);
 
+/* ---------------------------------------------------------------- ground-truth assignment (anchors / proposals)
+ * replaces, for N images at once, boxlist_iou (structures/boxlist_ops.py:53-87) + Matcher (modeling/matcher.py:37-139) +
+ * the label rules of rpn/loss.py:56-83 / box_head/loss.py:38-80 + BoxCoder.encode (modeling/box_coder.py:23-53).
+ *   cand      [A_total,4] xyxy candidates, image n owns rows cand_off[n]..cand_off[n+1]-1 (cand_off, gt_off: device int32
+ *             [N+1]); shared_cand=1: ONE [A,4] array (and visible[A]) shared by all images (the anchor grid)
+ *   gt        [G_total,4], gt_labels [G_total] int64 (needed for labels_i); every image must own >= 1 gt
+ *   matches   int32 [A_total]: index of the matched gt inside its image, -1 below `low`, -2 between `low` and `high`;
+ *             allow_low_quality: candidates that are the (tied) best of some gt keep their argmax (top_ws: G_total uint32)
+ *   labels_f  (RPN, optional) 1 / 0 / -1 (ignored or not visible);  labels_i (box head, optional) class / 0 / -1
+ *   reg       (optional) [A_total,4] regression targets against the matched (or first) gt with weights (wx,wy,ww,wh)
+ * Bit-identical to the tensor formulation (same expression order, no FMA contraction). */
+int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
+                      const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total, int shared_cand,
+                      float high, float low, int allow_low_quality, float wx, float wy, float ww, float wh, uint32_t* top_ws,
+                      int32_t* matches, float* labels_f, int64_t* labels_i, float* reg, void* stream);
+
 /* ---------------------------------------------------------------- implicit-GEMM convolution (fp32 MFMA)
  * replaces ATen/cuDNN conv2d + FrozenBatchNorm2d (layers/batch_norm.py:19-24) + ReLU + residual
  * add (backbone/resnet.py:254-274) + FPN lateral/top-down add (backbone/fpn.py:57-62), nn.Linear

@@ -1,0 +1,123 @@
+// Ground-truth assignment for anchors / proposals in one launch (two with low-quality matches).
+//
+// Replaces, per image, the chain boxlist_iou (structures/boxlist_ops.py:53-87) -> Matcher (modeling/matcher.py:37-139)
+// -> label rules (rpn/loss.py:56-83, box_head/loss.py:38-80) -> BoxCoder.encode (modeling/box_coder.py:23-53) that the
+// reference (and, until now, this port) runs as ~45 separate elementwise / reduction launches per image over a
+// [G x A] IoU matrix.  Here one thread owns one candidate box and walks the (few) ground-truth boxes of its image.
+// Arithmetic is the same expression order as the tensor code (built with -ffp-contract=off), so IoUs, the argmax and the
+// regression targets are bit-identical to it.
+#include "common.h"
+
+namespace {
+__device__ __forceinline__ float iou_pm1(const float* g, float garea, const float* c, float carea) {
+  const float ltx = fmaxf(g[0], c[0]), lty = fmaxf(g[1], c[1]);
+  const float rbx = fminf(g[2], c[2]), rby = fminf(g[3], c[3]);
+  const float w = fmaxf(rbx - ltx + 1.f, 0.f), h = fmaxf(rby - lty + 1.f, 0.f);
+  const float inter = w * h;
+  return inter / (garea + carea - inter);
+}
+
+__device__ __forceinline__ int image_of(const int* __restrict__ off, int N, int a) {
+  int n = 0;
+  while (n + 1 < N && a >= off[n + 1]) n++;
+  return n;
+}
+
+// top[g] = max over the candidates of g's image of IoU(g, candidate)   (IoU >= 0: uint order == float order)
+__global__ __launch_bounds__(256) void match_top_kernel(const float* __restrict__ cand, const int* __restrict__ cand_off,
+                                                        const float* __restrict__ gt, const int* __restrict__ gt_off,
+                                                        int N, int A_total, int shared_cand, unsigned* __restrict__ top) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= A_total) return;
+  const int n = image_of(cand_off, N, a);
+  const float* c = cand + (long)(shared_cand ? a - cand_off[n] : a) * 4;
+  const float carea = (c[2] - c[0] + 1.f) * (c[3] - c[1] + 1.f);
+  for (int g = gt_off[n]; g < gt_off[n + 1]; g++) {
+    const float* gb = gt + (long)g * 4;
+    const float v = iou_pm1(gb, (gb[2] - gb[0] + 1.f) * (gb[3] - gb[1] + 1.f), c, carea);
+    if (v > 0.f) atomicMax(top + g, __float_as_uint(v));
+  }
+}
+
+__global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ cand, const int* __restrict__ cand_off,
+                                                    const float* __restrict__ gt, const int* __restrict__ gt_off,
+                                                    const int64_t* __restrict__ gt_labels,
+                                                    const uint8_t* __restrict__ visible, int N, int A_total,
+                                                    int shared_cand, float high, float low, const unsigned* __restrict__ top,
+                                                    float wx, float wy, float ww, float wh, int32_t* __restrict__ matches,
+                                                    float* __restrict__ labels_f, int64_t* __restrict__ labels_i,
+                                                    float* __restrict__ reg) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= A_total) return;
+  const int n = image_of(cand_off, N, a);
+  const int al = a - cand_off[n];
+  const float* c = cand + (long)(shared_cand ? al : a) * 4;
+  const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+  const float cc[4] = {c0, c1, c2, c3};
+  const float carea = (c2 - c0 + 1.f) * (c3 - c1 + 1.f);
+  const int g0 = gt_off[n], g1 = gt_off[n + 1];
+  float best = -1.f;
+  int arg = 0;
+  bool is_best = false;
+  for (int g = g0; g < g1; g++) {
+    const float* gb = gt + (long)g * 4;
+    const float v = iou_pm1(gb, (gb[2] - gb[0] + 1.f) * (gb[3] - gb[1] + 1.f), cc, carea);
+    if (v > best) { best = v; arg = g - g0; }            // first maximum, as torch.max over dim 0
+    if (top != nullptr && v == __uint_as_float(top[g])) is_best = true;
+  }
+  int m = arg;
+  if (best < low) m = -1;                                  // Matcher.BELOW_LOW_THRESHOLD
+  else if (best < high) m = -2;                            // Matcher.BETWEEN_THRESHOLDS
+  if (top != nullptr && is_best) m = arg;                  // allow_low_quality_matches (matcher.py:118-139)
+  matches[a] = m;
+  const int mi = m < 0 ? 0 : m;
+  if (labels_f != nullptr) {                               // RPN: 1 matched, 0 background, -1 ignored / not visible
+    float l = m >= 0 ? 1.f : 0.f;
+    if (visible != nullptr && !visible[shared_cand ? al : a]) l = -1.f;
+    if (m == -2) l = -1.f;
+    labels_f[a] = l;
+  }
+  if (labels_i != nullptr) {                               // box head: class of the matched gt, 0 background, -1 ignored
+    int64_t l = gt_labels[g0 + mi];
+    if (m == -1) l = 0;
+    if (m == -2) l = -1;
+    labels_i[a] = l;
+  }
+  if (reg != nullptr) {                                    // BoxCoder.encode(gt[mi], candidate)
+    const float* gb = gt + (long)(g0 + mi) * 4;
+    const float pw = c2 - c0 + 1.f, ph = c3 - c1 + 1.f;
+    const float px = c0 + 0.5f * pw, py = c1 + 0.5f * ph;
+    const float gw = gb[2] - gb[0] + 1.f, gh = gb[3] - gb[1] + 1.f;
+    const float gx = gb[0] + 0.5f * gw, gy = gb[1] + 0.5f * gh;
+    float* o = reg + (long)a * 4;
+    o[0] = wx * (gx - px) / pw;
+    o[1] = wy * (gy - py) / ph;
+    o[2] = ww * logf(gw / pw);
+    o[3] = wh * logf(gh / ph);
+  }
+}
+}  // namespace
+
+extern "C" int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
+                                 const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total,
+                                 int shared_cand, float high, float low, int allow_low_quality, float wx, float wy, float ww,
+                                 float wh, uint32_t* top_ws, int32_t* matches, float* labels_f, int64_t* labels_i, float* reg,
+                                 void* stream) {
+  if (!cand || !cand_off || !gt || !gt_off || !matches || N < 1 || (labels_i && !gt_labels)) return MMT_EINVAL;
+  if (allow_low_quality && !top_ws) return MMT_EINVAL;
+  if (A_total <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = mmt_cdiv(A_total, 256);
+  if (allow_low_quality) {
+    hipError_t e = hipMemsetAsync(top_ws, 0, (size_t)(G_total > 0 ? G_total : 1) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(match_top_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_off, gt, gt_off, N, A_total, shared_cand,
+                       top_ws);
+    MMT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(match_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_off, gt, gt_off, gt_labels, visible, N, A_total,
+                     shared_cand, high, low, allow_low_quality ? top_ws : (const unsigned*)nullptr, wx, wy, ww, wh, matches,
+                     labels_f, labels_i, reg);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}

@@ -38,6 +38,9 @@ _SIGS = {
     "mmt_roi_align_forward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_roi_align_backward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_nms_batched": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_match_targets": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                          c_float, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p],
     "mmt_conv_forward": [ctypes.POINTER(ConvArgs), c_void_p],
     "mmt_conv_variant": [ctypes.POINTER(ConvArgs)],
     "mmt_set_conv_precision": [ctypes.c_int],
@@ -185,6 +188,32 @@ def nms_batched(boxes, seg_off, max_n, thr):
         _check(lib().mmt_nms_batched(_p(boxes), _p(seg_off), B, max_n, float(thr), _p(ws), _p(keep), _p(cnt), _stream()),
                "mmt_nms_batched")
     return keep, cnt
+
+
+def match_targets(cand, cand_off, gt, gt_off, n_images, high, low, allow_low_quality=False, gt_labels=None,
+                  visible=None, shared_cand=False, rpn_labels=False, box_labels=False, weights=None):
+    """ground-truth assignment for all images of a batch in one launch (include/mmtpsm.h: mmt_match_targets).
+    cand (A,4) [shared_cand: one anchor grid for all images] / (A_total,4); cand_off, gt_off: device int32 [N+1].
+    -> matches int32 (A_total,), labels (float for the RPN / int64 for the box head / None), regression targets or None"""
+    cand = _dev(cand, "cand").float().contiguous()
+    gt = _dev(gt, "gt").float().contiguous()
+    A_total = cand.shape[0] * (n_images if shared_cand else 1)
+    dev = cand.device
+    matches = torch.empty((A_total,), dtype=torch.int32, device=dev)
+    lf = torch.empty((A_total,), dtype=torch.float32, device=dev) if rpn_labels else None
+    li = torch.empty((A_total,), dtype=torch.int64, device=dev) if box_labels else None
+    reg = torch.empty((A_total, 4), dtype=torch.float32, device=dev) if weights is not None else None
+    top = torch.empty((max(gt.shape[0], 1),), dtype=torch.int32, device=dev) if allow_low_quality else None
+    wx, wy, ww, wh = weights if weights is not None else (1.0, 1.0, 1.0, 1.0)
+    vis = None
+    if visible is not None:
+        vis = visible.to(torch.uint8) if visible.dtype != torch.uint8 else visible
+    gl = gt_labels.to(torch.int64).contiguous() if gt_labels is not None else None
+    _check(lib().mmt_match_targets(_p(cand), _p(cand_off), _p(gt), _p(gt_off), _p(gl), _p(vis), n_images, A_total, gt.shape[0],
+                                   1 if shared_cand else 0, float(high), float(low), 1 if allow_low_quality else 0, float(wx),
+                                   float(wy), float(ww), float(wh), _p(top), _p(matches), _p(lf), _p(li), _p(reg), _stream()),
+           "mmt_match_targets")
+    return matches, (lf if rpn_labels else li), reg
 
 
 # ------------------------------------------------------------------------------------------ conv

@@ -112,16 +112,29 @@ class FastRCNNLossComputation(object):
         self.proposal_matcher, self.fg_bg_sampler, self.box_coder, self.cfg = proposal_matcher, fg_bg_sampler, box_coder, cfg
 
     def prepare_targets(self, proposals, targets):
-        labels, regs = [], []
+        """box_head/loss.py:38-80 for all images at once (`mmt_match_targets`: IoU + Matcher + labels + encode)"""
+        N = len(proposals)
+        dev = proposals[0].bbox.device
         for p, t in zip(proposals, targets):
-            m = self.proposal_matcher(boxlist_iou(t, p))
-            mi = m.clamp(min=0)
-            lab = t.get_field("labels")[mi].to(torch.int64)
-            lab = torch.where(m == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(lab), lab)
-            lab = torch.where(m == Matcher.BETWEEN_THRESHOLDS, torch.full_like(lab, -1), lab)
-            labels.append(lab)
-            regs.append(self.box_coder.encode(t.bbox[mi], p.bbox))
-        return labels, regs
+            if len(t) == 0:
+                raise ValueError("No ground-truth boxes available for one of the images during training")
+            if len(p) == 0:
+                raise ValueError("No proposal boxes available for one of the images during training")
+        A = [len(p) for p in proposals]
+        coff, goff = [0], [0]
+        for a, t in zip(A, targets):
+            coff.append(coff[-1] + a)
+            goff.append(goff[-1] + len(t))
+        cand = torch.cat([p.bbox for p in proposals], 0) if N > 1 else proposals[0].bbox
+        gt = torch.cat([t.bbox.to(dev) for t in targets], 0) if N > 1 else targets[0].bbox.to(dev)
+        gl = torch.cat([t.get_field("labels").to(dev) for t in targets], 0) if N > 1 else targets[0].get_field("labels").to(dev)
+        m = self.proposal_matcher
+        # data-dependent offsets (proposal counts): plain H2D tensors, the counts came from a host sync anyway
+        _, lab, reg = H.match_targets(cand, torch.tensor(coff, dtype=torch.int32, device=dev), gt,
+                                      torch.tensor(goff, dtype=torch.int32, device=dev), N, m.high_threshold,
+                                      m.low_threshold, m.allow_low_quality_matches, gt_labels=gl, box_labels=True,
+                                      weights=self.box_coder.weights)
+        return list(lab.split(A, 0)), list(reg.split(A, 0))
 
     def subsample(self, proposals, targets):
         """box_head/loss.py:82-116"""

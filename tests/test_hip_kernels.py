@@ -421,3 +421,58 @@ def test_packed_weight_planes_bookkeeping(hip, restore_mode):
     assert close(fwd())
     flat.refresh_planes()
     assert close(fwd())
+
+
+# ------------------------------------------------------------------------------------------ target assignment
+@pytest.mark.parametrize("lowq", [False, True])
+def test_match_targets_against_tensor_formulation(hip, lowq):
+    """mmt_match_targets == boxlist_iou + Matcher + label rules + BoxCoder.encode (bit-exact), several images, ties"""
+    from maskrcnn_benchmark.modeling.matcher import Matcher
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    from maskrcnn_benchmark.structures.boxlist_ops import box_iou_tensor
+    g = torch.Generator().manual_seed(7 + lowq)
+    hi, lo = (0.7, 0.3) if lowq else (0.5, 0.5)
+    matcher, coder = Matcher(hi, lo, allow_low_quality_matches=lowq), BoxCoder(weights=(10., 10., 5., 5.))
+
+    def boxes(n, scale):
+        xy = torch.rand(n, 2, generator=g) * scale
+        wh = torch.rand(n, 2, generator=g) * scale * 0.4 + 2
+        return torch.cat([xy, xy + wh], 1).round()  # integer coordinates -> exact IoU ties are likely
+
+    def area(b):
+        return (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+
+    gts = [boxes(5, 60), boxes(9, 60), boxes(1, 60)]
+    gls = [torch.randint(1, 3, (len(b),), generator=g) for b in gts]
+    # per-image candidates (box head form); image 1 contains exact copies of its gts and duplicates (ties)
+    cands = [boxes(300, 60), torch.cat([boxes(200, 60), gts[1], gts[1][:3]], 0), boxes(64, 60)]
+    coff = torch.tensor([0, 300, 512, 576], dtype=torch.int32).cuda()
+    goff = torch.tensor([0, 5, 14, 15], dtype=torch.int32).cuda()
+    m, lab, reg = hip.match_targets(torch.cat(cands).cuda(), coff, torch.cat(gts).cuda(), goff, 3, hi, lo, lowq,
+                                    gt_labels=torch.cat(gls).cuda(), box_labels=True, weights=coder.weights)
+    ms, ls, rs = m.split([300, 212, 64]), lab.split([300, 212, 64]), reg.split([300, 212, 64])
+    for i in range(3):
+        gt, c = gts[i].cuda(), cands[i].cuda()
+        ref = matcher(box_iou_tensor(gt, area(gt), c, area(c)))
+        np.testing.assert_array_equal(ms[i].cpu().numpy(), ref.cpu().numpy())
+        rl = gls[i].cuda()[ref.clamp(min=0)]
+        rl = torch.where(ref == -1, torch.zeros_like(rl), rl)
+        rl = torch.where(ref == -2, torch.full_like(rl, -1), rl)
+        np.testing.assert_array_equal(ls[i].cpu().numpy(), rl.cpu().numpy())
+        np.testing.assert_array_equal(rs[i].cpu().numpy(), coder.encode(gt[ref.clamp(min=0)], c).cpu().numpy())
+    # shared anchor grid (RPN form) with visibility
+    anc = boxes(5000, 60).cuda()
+    vis = (torch.rand(5000, generator=g) > 0.2).cuda()
+    coder1 = BoxCoder(weights=(1., 1., 1., 1.))
+    m, lab, reg = hip.match_targets(anc, torch.tensor([0, 5000, 10000], dtype=torch.int32).cuda(), torch.cat(gts[:2]).cuda(),
+                                    goff[:3].contiguous(), 2, hi, lo, lowq, visible=vis, shared_cand=True, rpn_labels=True,
+                                    weights=coder1.weights)
+    for i in range(2):
+        gt = gts[i].cuda()
+        ref = matcher(box_iou_tensor(gt, area(gt), anc, area(anc)))
+        rl = (ref >= 0).float()
+        rl = torch.where(vis, rl, torch.full_like(rl, -1.0))
+        rl = torch.where(ref == -2, torch.full_like(rl, -1.0), rl)
+        np.testing.assert_array_equal(lab[i * 5000:(i + 1) * 5000].cpu().numpy(), rl.cpu().numpy())
+        np.testing.assert_array_equal(reg[i * 5000:(i + 1) * 5000].cpu().numpy(),
+                                      coder1.encode(gt[ref.clamp(min=0)], anc).cpu().numpy())
