@@ -23,19 +23,38 @@ __device__ __forceinline__ int image_of(const int* __restrict__ off, int N, int 
   return n;
 }
 
-// top[g] = max over the candidates of g's image of IoU(g, candidate)   (IoU >= 0: uint order == float order)
+// top[g] = max over the candidates of g's image of IoU(g, candidate)   (IoU >= 0: uint order == float order).
+// Block-level reduction first: one atomic per (block, gt) -- per-thread atomics on the dozen gt addresses serialised
+// (0.84 ms for the 2 x 262k anchors of a batch; now ~20 us).
 __global__ __launch_bounds__(256) void match_top_kernel(const float* __restrict__ cand, const int* __restrict__ cand_off,
                                                         const float* __restrict__ gt, const int* __restrict__ gt_off,
                                                         int N, int A_total, int shared_cand, unsigned* __restrict__ top) {
+  __shared__ float red[4];
   const int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= A_total) return;
-  const int n = image_of(cand_off, N, a);
-  const float* c = cand + (long)(shared_cand ? a - cand_off[n] : a) * 4;
+  const bool valid = a < A_total;
+  const int n = image_of(cand_off, N, valid ? a : A_total - 1);
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const float* cp = cand + (long)(shared_cand ? a - cand_off[n] : a) * 4;
+    c[0] = cp[0]; c[1] = cp[1]; c[2] = cp[2]; c[3] = cp[3];
+  }
   const float carea = (c[2] - c[0] + 1.f) * (c[3] - c[1] + 1.f);
-  for (int g = gt_off[n]; g < gt_off[n + 1]; g++) {
+  const int n_lo = image_of(cand_off, N, blockIdx.x * 256);
+  const int n_hi = image_of(cand_off, N, min(blockIdx.x * 256 + 255, A_total - 1));
+  for (int g = gt_off[n_lo]; g < gt_off[n_hi + 1]; g++) {   // block-uniform loop over the gts of the images it touches
     const float* gb = gt + (long)g * 4;
-    const float v = iou_pm1(gb, (gb[2] - gb[0] + 1.f) * (gb[3] - gb[1] + 1.f), c, carea);
-    if (v > 0.f) atomicMax(top + g, __float_as_uint(v));
+    float v = 0.f;
+    if (valid && g >= gt_off[n] && g < gt_off[n + 1])
+      v = iou_pm1(gb, (gb[2] - gb[0] + 1.f) * (gb[3] - gb[1] + 1.f), c, carea);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      if (m > 0.f) atomicMax(top + g, __float_as_uint(m));
+    }
+    __syncthreads();
   }
 }
 
