@@ -6,6 +6,7 @@ and of the EMA (alpha = min(1 - 1/(it+1), MT.ALPHA)) is reproduced; EMA and SGD 
 storage; with WORLD_SIZE > 1 the student gradients are averaged by ONE RCCL all-reduce over the flat gradient
 buffer (new functionality: the reference has no gradient synchronisation at all)."""
 import logging
+import os
 import time
 from functools import partial
 
@@ -93,6 +94,12 @@ class MTtrainer(object):
         self.flat_s = flatten_model(self.student)
         self.flat_t = flatten_model(self.teacher)
         self._unl_iter = None
+        # The teacher's no-grad forward and the student's supervised forward are independent until the consistency
+        # losses: run the teacher on its own HIP stream (issued from a helper thread -- both forwards contain host syncs),
+        # so that its large convolutions fill the GPU while the other stream is in launch-latency-bound target / proposal
+        # glue, and vice versa.  MMT_OVERLAP_TEACHER=0 restores the serial order.
+        self.overlap_teacher = os.environ.get("MMT_OVERLAP_TEACHER", "1") != "0" and self.device.type == "cuda"
+        self.t_stream = torch.cuda.Stream(device=self.device) if self.overlap_teacher else None
 
     # ---- one iteration (the unit bench.py times)
     def train_step(self, iteration, data_s, target_s, data_u_list=None):
@@ -110,9 +117,10 @@ class MTtrainer(object):
                 parts = [fused.split_batch(l, n) for l in pyr]
                 feats_s = tuple(p[0] for p in parts)
                 feats_u = [tuple(p[1] for p in parts)]
+        job = self._start_teacher(data_u_list) if (use_mt and self.overlap_teacher) else None
         loss_dict = self.forward_source(data_s, target_s, feats_s)
         if use_mt:
-            loss_dict.update(self.forward_unlabel(data_u_list, feats_u))
+            loss_dict.update(self.forward_unlabel(data_u_list, feats_u, job))
         self.scheduler.step()
         losses_dict = self.weight_sum_loss(loss_dict, iteration)
         losses = sum(v for v in losses_dict.values())
@@ -160,16 +168,44 @@ class MTtrainer(object):
     def forward_source(self, image, target, features=None):
         return self.student(image.to(self.device), [t.to(self.device) for t in target], features=features)
 
-    def forward_unlabel(self, data_u_list, features=None):
-        """MTtrainer.py:247-275 (N_STEP_UNLABEL = 1)"""
+    def _start_teacher(self, data_u_list):
+        """launch teacher.forward_teacher on the side stream from a helper thread; -> job dict (joined in forward_unlabel)"""
+        import threading
         teacher_list = [f.to(self.device) for f in data_u_list[:self.teacher_bs]]
-        student = [s.to(self.device) for s in data_u_list[-self.student_bs:]]
-        with torch.no_grad():
+        self.t_stream.wait_stream(torch.cuda.current_stream())  # EMA / weight packing of the previous step, inputs
+        job = {}
+
+        def run():
             try:
-                teacher_results = self.teacher.forward_teacher(teacher_list)
-            except ValueError as e:  # no pseudo boxes for an image: the reference skips the pair (bare except)
-                self.logger.info("teacher produced no boxes (%s), skip this pair", e)
-                return {}
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self.t_stream), torch.no_grad():
+                    job["result"] = self.teacher.forward_teacher(teacher_list)
+            except BaseException as e:  # re-raised (or handled) by the step thread
+                job["error"] = e
+
+        job["thread"] = threading.Thread(target=run, name="mmt-teacher")
+        job["thread"].start()
+        return job
+
+    def forward_unlabel(self, data_u_list, features=None, job=None):
+        """MTtrainer.py:247-275 (N_STEP_UNLABEL = 1)"""
+        student = [s.to(self.device) for s in data_u_list[-self.student_bs:]]
+        try:
+            if job is not None:
+                job["thread"].join()
+                # everything the teacher produced is read on this stream from here on; the side stream is not touched again
+                # before the next step re-synchronises it (see _start_teacher), which also orders the re-use of its memory
+                torch.cuda.current_stream().wait_stream(self.t_stream)
+                if "error" in job:
+                    raise job["error"]
+                teacher_results = job["result"]
+            else:
+                teacher_list = [f.to(self.device) for f in data_u_list[:self.teacher_bs]]
+                with torch.no_grad():
+                    teacher_results = self.teacher.forward_teacher(teacher_list)
+        except ValueError as e:  # no pseudo boxes for an image: the reference skips the pair (bare except)
+            self.logger.info("teacher produced no boxes (%s), skip this pair", e)
+            return {}
         return self.student.forward_student(student, teacher_results, features=features)
 
     def update_teacher(self, it):
