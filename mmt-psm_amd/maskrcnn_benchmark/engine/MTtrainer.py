@@ -183,7 +183,7 @@ class MTtrainer(object):
             except BaseException as e:  # re-raised (or handled) by the step thread
                 job["error"] = e
 
-        job["thread"] = threading.Thread(target=run, name="mmt-teacher")
+        job["thread"] = threading.Thread(target=run, name="mmt-teacher", daemon=True)
         job["thread"].start()
         return job
 
