@@ -342,6 +342,73 @@ def gen_model(size=160, n_inst=4, tag="model160", relation=False):
     print({k: float(v) for k, v in out.items() if v.numel() == 1})
 
 
+def gen_transforms():
+    """input augmentation: the reference's OWN transform classes (data/transforms/{transforms,build}.py),
+    loaded from the reference tree, with seeded `random` / `numpy.random`.  torchvision is absent from this image: the five
+    PIL code paths of torchvision.transforms.functional the classes call are provided by a stand-in module that forwards to
+    Pillow (what torchvision itself does for PIL images)."""
+    import copy
+    import random
+    import types
+    from PIL import Image, ImageEnhance
+
+    Fm = types.ModuleType("torchvision.transforms.functional")
+    Fm.resize = lambda img, size, interpolation=Image.BILINEAR: img.resize(size[::-1], interpolation)
+    Fm.hflip = lambda img: img.transpose(Image.FLIP_LEFT_RIGHT)
+    Fm.adjust_brightness = lambda img, f: ImageEnhance.Brightness(img).enhance(f)
+    Fm.adjust_contrast = lambda img, f: ImageEnhance.Contrast(img).enhance(f)
+
+    def adjust_hue(img, hue_factor):
+        h, s, v = img.convert("HSV").split()
+        nh = np.array(h, dtype=np.uint8)
+        nh += np.uint8(int(hue_factor * 255) & 255)  # `np_h += np.uint8(hue_factor * 255)` with the C wrap-around cast
+        return Image.merge("HSV", (Image.fromarray(nh, "L"), s, v)).convert("RGB")
+
+    Fm.adjust_hue = adjust_hue
+    Fm.to_tensor = lambda img: torch.from_numpy(np.array(img)).permute(2, 0, 1).float().div(255)
+    Fm.normalize = lambda t, mean, std: (t - torch.tensor(mean, dtype=t.dtype)[:, None, None]) / torch.tensor(std, dtype=t.dtype)[:, None, None]
+    tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+    tv.transforms, tvt.functional = tvt, Fm
+    saved = {k: sys.modules.get(k) for k in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional")}
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": Fm})
+    try:
+        d = os.path.join(os.path.dirname(mb.__file__), "data", "transforms")
+        spec = importlib.util.spec_from_file_location("ref_transforms", os.path.join(d, "__init__.py"),
+                                                      submodule_search_locations=[d])
+        rt = importlib.util.module_from_spec(spec)
+        sys.modules["ref_transforms"] = rt
+        spec.loader.exec_module(rt)
+        cfg = make_cfg(["INPUT.MIN_SIZE_TRAIN", 80, "INPUT.MAX_SIZE_TRAIN", 133])
+        out = {}
+        rng = np.random.default_rng(5)
+        for case, (h, w) in enumerate([(100, 100), (90, 120)]):
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            img[:10, :10] = 0
+            img[10:20, :10] = 255
+            img[20:30, :10] = (200, 30, 30)
+            out["img%d" % case] = img
+            for domain in ("no_label", "source"):
+                random.seed(100 + case)
+                np.random.seed(200 + case)
+                tr = rt.build_transforms(cfg, True, domain)
+                pil = Image.fromarray(img, "RGB")
+                if domain == "no_label":  # data/datasets/Pap.py:818-830
+                    base, _ = tr[0](pil, None)
+                    for k in range(3):
+                        t, _ = tr[1](copy.deepcopy(base), None)
+                        out["%s%d_view%d" % (domain, case, k)] = t.numpy()
+                else:
+                    t, _ = tr(pil, None)
+                    out["%s%d" % (domain, case)] = t.numpy()
+        save("transforms", **out)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["nms", "roi", "small", "mt", "masks", "model"]
     if "nms" in which:
@@ -358,3 +425,5 @@ if __name__ == "__main__":
         gen_model()
     if "irnet" in which:
         gen_model(tag="model160_irnet", relation=True)
+    if "transforms" in which:
+        gen_transforms()

@@ -186,3 +186,45 @@ def test_irnet_end_to_end_golden(synth):
     sl = om.forward_student(sd, cfg, unl[-1:], tr)
     for k, v in sl.items():
         assert v.item() == pytest.approx(float(g["stu_" + k]), rel=1e-5), k
+
+
+# ------------------------------------------------------------------------------------------ input augmentation (8f-3)
+def test_transforms_pipeline_golden():
+    """oracle/transforms.py (draw order + pixel arithmetic, both the Pillow-backed and the restated layer) against the
+    outputs of the reference's own transform classes"""
+    import random
+    from oracle import transforms as OT
+    g = gold("transforms")
+    for case in range(2):
+        img = g["img%d" % case]
+        for restated in (False, True):
+            random.seed(100 + case)
+            np.random.seed(200 + case)
+            views = OT.pipeline(img, "no_label", 3, 80, 133, random, np.random, restated)
+            for k, (_, t) in enumerate(views):
+                np.testing.assert_array_equal(t, g["no_label%d_view%d" % (case, k)])
+            random.seed(100 + case)
+            np.random.seed(200 + case)
+            (_, t), = OT.pipeline(img, "source", 1, 80, 133, random, np.random, restated)
+            np.testing.assert_array_equal(t, g["source%d" % case])
+
+
+def test_transforms_restatement_matches_pillow_exhaustively():
+    """the colour-space maps of the restated layer == Pillow's for all 2^24 triples, both directions; blends, luma mean and
+    the 8-bit bilinear resample on random images / factors / sizes"""
+    from PIL import Image
+    from oracle import transforms as OT
+    allc = np.arange(1 << 24, dtype=np.uint32)
+    tri = np.stack([(allc >> 16) & 255, (allc >> 8) & 255, allc & 255], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    np.testing.assert_array_equal(OT.np_rgb2hsv(tri), np.array(Image.fromarray(tri, "RGB").convert("HSV")))
+    np.testing.assert_array_equal(OT.np_hsv2rgb(tri), np.array(Image.fromarray(tri, "HSV").convert("RGB")))
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        h, w = int(rng.integers(8, 60)), int(rng.integers(8, 60))
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        b, c, hu = [float(rng.uniform(*r)) for r in ((0.85, 1.15), (0.85, 1.15), (-0.05, 0.05))]
+        if trial % 5 == 0:
+            b, c, hu = 1.0, 0.0, 0.0
+        np.testing.assert_array_equal(OT.np_color(img, b, c, hu), OT.pil_color(img, b, c, hu))
+        oh, ow = int(rng.integers(5, 90)), int(rng.integers(5, 90))
+        np.testing.assert_array_equal(OT.np_resize(img, oh, ow), OT.pil_resize(img, oh, ow))
