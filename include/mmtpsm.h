@@ -64,6 +64,25 @@ int mmt_roi_align_backward(const mmt_pyramid* pyr /*[host]*/, const float* rois,
 int mmt_nms_batched(const float* boxes, const int32_t* seg_off, int B, int max_n, float thr,
                     uint64_t* mask_ws, int32_t* keep, int32_t* keep_cnt, void* stream);
 
+/* ---------------------------------------------------------------- input augmentation
+ * replaces the PIL / torchvision calls behind data/transforms/transforms.py:28-205 (Resize, RandomHorizontalFlip,
+ * AdjustBrightness, AdjustContrast, AdjustHue, RandomErasing, ToTensor, Normalize); images are uint8 [H][W][3] RGB on the
+ * device.  Random numbers are drawn by the host mirror exactly as the reference draws them; the kernels are deterministic.
+ *   mmt_resample_u8   one pass of Pillow's 8-bit bilinear (antialiased) resample along x (horizontal=1) or y: bounds
+ *                     [out][2] (first tap, tap count), coeffs [out][ksize] 22-bit fixed point (host: precompute_coeffs)
+ *   mmt_aug_views     V views of one base image: flip, brightness[v], contrast[v], hue_shift[v] (0..255; < 0: no colour
+ *                     chain at all, the test-time pipeline), ToTensor,
+ *                     BGR*255 - mean3; writes fp32 [H][W] pixels of out_C (>= 3) channels with row pitch out_W pixels into
+ *                     out + v*view_stride (a zero-initialised, size-divisible-padded NHWC batch); sums_ws: V uint64
+ *   mmt_aug_erase     R rectangles {view, top, left, h, w} filled from fills + fill_off[r] (h*w RGB bytes each) */
+int mmt_resample_u8(const uint8_t* src, uint8_t* dst, int H, int W, int out_size, int horizontal, const int32_t* bounds,
+                    const int32_t* coeffs, int ksize, void* stream);
+int mmt_aug_views(const uint8_t* img, int H, int W, int flip, const float* brightness, const float* contrast,
+                  const int32_t* hue_shift, unsigned long long* sums_ws, int V, const float* mean3 /*[host]*/, float* out,
+                  long view_stride, int out_W, int out_C, void* stream);
+int mmt_aug_erase(float* out, long view_stride, int out_W, int out_C, const int32_t* rects, const long* fill_off,
+                  const uint8_t* fills, int R, const float* mean3 /*[host]*/, void* stream);
+
 /* ---------------------------------------------------------------- ground-truth assignment (anchors / proposals)
  * replaces, for N images at once, boxlist_iou (structures/boxlist_ops.py:53-87) + Matcher (modeling/matcher.py:37-139) +
  * the label rules of rpn/loss.py:56-83 / box_head/loss.py:38-80 + BoxCoder.encode (modeling/box_coder.py:23-53).

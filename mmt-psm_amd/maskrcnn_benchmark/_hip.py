@@ -38,6 +38,11 @@ _SIGS = {
     "mmt_roi_align_forward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_roi_align_backward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_nms_batched": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_resample_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "mmt_aug_views": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float),
+                      c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
+    "mmt_aug_erase": [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float),
+                      c_void_p],
     "mmt_match_targets": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                           c_float, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p],
@@ -188,6 +193,39 @@ def nms_batched(boxes, seg_off, max_n, thr):
         _check(lib().mmt_nms_batched(_p(boxes), _p(seg_off), B, max_n, float(thr), _p(ws), _p(keep), _p(cnt), _stream()),
                "mmt_nms_batched")
     return keep, cnt
+
+
+# ------------------------------------------------------------------------------------------ input augmentation
+def resample_u8(img, out_size, horizontal, bounds, coeffs):
+    """img uint8 (H,W,3) on the device -> resampled along one axis (Pillow 8-bit bilinear); bounds/coeffs: device int32"""
+    _dev(img, "img")
+    Hh, Ww = img.shape[0], img.shape[1]
+    out = torch.empty((Hh, out_size, 3) if horizontal else (out_size, Ww, 3), dtype=torch.uint8, device=img.device)
+    _check(lib().mmt_resample_u8(_p(img), _p(out), Hh, Ww, out_size, 1 if horizontal else 0, _p(bounds), _p(coeffs),
+                                 coeffs.shape[1], _stream()), "mmt_resample_u8")
+    return out
+
+
+def aug_views(img, flip, brightness, contrast, hue_shift, mean3, out):
+    """img uint8 (H,W,3); per-view device tensors brightness/contrast (float32 [V]), hue_shift (int32 [V], < 0: no colour
+    chain); out: zero-initialised fp32 (V, Hp, Wp, C>=3) NHWC batch -> the H x W corner of every view filled in place"""
+    _dev(img, "img")
+    V, Hp, Wp, C = out.shape
+    m = (c_float * 3)(*[float(x) for x in mean3])
+    ws = torch.empty((V,), dtype=torch.int64, device=img.device)
+    _check(lib().mmt_aug_views(_p(img), img.shape[0], img.shape[1], 1 if flip else 0, _p(brightness), _p(contrast),
+                               _p(hue_shift), _p(ws), V, m, _p(out), Hp * Wp * C, Wp, C, _stream()), "mmt_aug_views")
+    return out
+
+
+def aug_erase(out, rects, fill_off, fills, mean3):
+    """RandomErasing rectangles {view, top, left, h, w} (int32 [R,5]) filled with the RGB bytes fills[fill_off[r]:...];
+    rectangles of ONE call must not overlap inside a view (the caller serialises overlapping ones)"""
+    V, Hp, Wp, C = out.shape
+    m = (c_float * 3)(*[float(x) for x in mean3])
+    _check(lib().mmt_aug_erase(_p(out), Hp * Wp * C, Wp, C, _p(rects), _p(fill_off), _p(fills), rects.shape[0], m, _stream()),
+           "mmt_aug_erase")
+    return out
 
 
 def match_targets(cand, cand_off, gt, gt_off, n_images, high, low, allow_low_quality=False, gt_labels=None,

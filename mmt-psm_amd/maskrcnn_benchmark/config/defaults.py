@@ -133,6 +133,9 @@ _DEFAULTS = {
                           "FEATURE_EXTRACTOR": "RoiAlignMaskFeatureExtractor", "RANK": True, "CLSWIZE": True,
                           "XY_COOR": True, "IOU_COOR": False},
     },
+    "INPUT": {"MIN_SIZE_TRAIN": 800, "MAX_SIZE_TRAIN": 1333, "MIN_SIZE_TEST": 800, "MAX_SIZE_TEST": 1333,
+              "PIXEL_MEAN": [102.9801, 115.9465, 122.7717], "PIXEL_STD": [1.0, 1.0, 1.0], "TO_BGR255": True},
+    "TEST": {"TTA": False},
     "DATALOADER": {"SIZE_DIVISIBILITY": 32},
     "DATASETS": {"NO_LABEL": True, "SYN": False},
     "SOLVER": {"BASE_LR": 0.005, "BIAS_LR_FACTOR": 2, "MOMENTUM": 0.9, "WEIGHT_DECAY": 0.0001,
