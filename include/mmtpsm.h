@@ -217,7 +217,8 @@ int mmt_mask_pool(const int32_t* seg, int N, int IH, int IW, int H, int W, float
  *              = roww[r] * sum_c( t_c * (log t_c - log_softmax(student[r])_c) ) (kind 1, 'kl')
  *   rowgrad[r,c] = roww[r] * (softmax(student[r])_c - t_c)
  * roww[r] in {0, 1, CLS_BALANCE_WEIGHT}: 0 = not selected, 1 = positive, w = kept hard negative.  The caller
- * normalises by 1/(S*3) ('ce': .mean(0).sum()/3) or 1/(S*NC) ('kl': element mean), S = #selected. */
+ * normalises by 1/(S*3) ('ce': .mean(0).sum()/3) or 1/(S*NC) ('kl', 'mse': element mean), S = #selected.
+ * kind: 0 soft-target CE ('bce'/'ce'), 1 KL, 2 MSE on the logits (rowloss = roww * sum_c (s_c - mean_k t_kc)^2). */
 int mmt_psm_rows(const float* teacher, int Kaug, const float* student, int R, int NC, const float* roww,
                  float temp, int sharpen, int kind, float* rowloss, float* rowgrad, void* stream);
 /* per-ROI perturbation sensitivity v[r] = sum_c std_k(q[k,r,c]) (unbiased, :164-173,191-194); q = softmax of the

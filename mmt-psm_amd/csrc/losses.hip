@@ -196,6 +196,16 @@ __global__ __launch_bounds__(256) void psm_rows_kernel(const float* __restrict__
     sl[c] = student[(long)r * NC + c];
     smax = fmaxf(smax, sl[c]);
   }
+  if (kind == 2) {  // 'mse' (box_head/loss.py:273-274): squared error against the mean teacher LOGITS
+    float l2 = 0.f;
+    for (int c = 0; c < NC; c++) {
+      const float d = sl[c] - t[c];
+      l2 += d * d;
+      rowgrad[(long)r * NC + c] = w * 2.f * d;
+    }
+    rowloss[r] = w * l2;
+    return;
+  }
   float tsum = 0.f, ssum = 0.f;
   for (int c = 0; c < NC; c++) { t[c] = expf(t[c] - tmax); tsum += t[c]; ssum += expf(sl[c] - smax); }
   const float lse = smax + logf(ssum);

@@ -168,9 +168,9 @@ class FastRCNNLossComputation(object):
         labels = torch.cat([p.get_field("labels") for p in proposals], 0)
         teacher = torch.stack([t.detach() for t in class_logits_t]).contiguous()  # (K, R, NC)
         typ = cfg.MT.CLS_LOSS_TYPE
-        kind = {"bce": 0, "ce": 0, "kl": 1}.get(typ)
+        kind = {"bce": 0, "ce": 0, "kl": 1, "mse": 2}.get(typ)
         if kind is None:
-            raise NotImplementedError("MT.CLS_LOSS_TYPE=%s: the MI355X path implements 'bce'/'ce' and 'kl'" % typ)
+            raise NotImplementedError("MT.CLS_LOSS_TYPE=%s: the MI355X path implements 'bce'/'ce', 'kl' and 'mse'" % typ)
         pos, neg = labels > 0, labels == 0
         n_pos, n_neg = pos.sum(), neg.sum()
         if cfg.MT.RANK_FILTER > 0:

@@ -239,7 +239,7 @@ def test_mgd_golden_and_grad(hip):
 def test_psm_golden_and_grad(hip):
     from oracle import model as om
     g = gold("mt_losses")
-    for case, typ in enumerate(("bce", "bce", "kl")):
+    for case, typ in enumerate(("bce", "bce", "kl", "mse")):
         cfg = om.default_cfg(mt_cls_loss_type=typ)
         t = T(g["psm%d_t" % case])
         s = T(g["psm%d_s" % case]).clone().requires_grad_()
@@ -257,9 +257,9 @@ def test_psm_golden_and_grad(hip):
         w_neg = 1.5 if typ == "bce" else 1.0
         roww[order[:nkeep]] = w_neg
         S = int(pos.sum()) + nkeep
-        kind = 0 if typ == "bce" else 1
+        kind = {"bce": 0, "kl": 1, "mse": 2}[typ]
         rl, rg = hip.psm_rows(t.cuda(), s.detach().cuda(), roww.cuda(), 0.5, 1, kind)
-        norm = 1.0 / (S * 3)
+        norm = 1.0 / (S * 3)  # NC = 3: 'ce' .mean(0).sum()/3 and the element mean of 'kl' / 'mse' coincide
         assert (rl.sum() * norm).item() == pytest.approx(float(g["psm%d" % case]), rel=2e-5)
         np.testing.assert_allclose((rg * norm).cpu().numpy(), s.grad.numpy(), rtol=1e-4, atol=1e-8)
 
