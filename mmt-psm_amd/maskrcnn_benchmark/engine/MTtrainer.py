@@ -70,6 +70,71 @@ def allreduce_gradients(flat):
             flat.grad.mul_(1.0 / ws)
 
 
+class BucketedAllReduce(object):
+    """The same exchange, started while the backward pass is still running.  The flat gradient is cut at the stage
+    boundaries of the backbone ([layer2 | layer3 | layer4 | FPN + heads]: the weights region of engine/flat.py is in
+    parameter order); backward runs through these pieces from the right, and a tensor hook on each stage output
+    (modeling/backbone/backbone.py) says when the pieces to its right are final.  Each finished piece goes out as an
+    asynchronous all-reduce that overlaps the backward of the earlier stages; whatever is left (layer2, the bias region)
+    is reduced at the end.  One scaling pass by 1/world afterwards, as in `allreduce_gradients`."""
+
+    # a hook on the output of stage K fires when everything AFTER stage K is done
+    AFTER = {"layer4": "backbone.fpn.", "layer3": "backbone.body.layer4.", "layer2": "backbone.body.layer3.",
+             "layer1": "backbone.body.layer2."}
+
+    def __init__(self, flat, body):
+        self.flat, self.body = flat, body
+        names = [n for n, _ in flat._named if n in flat.index and flat.index[n][0] < flat.n_weights]
+        cuts = {}
+        for stage, prefix in self.AFTER.items():
+            first = next((n for n in names if n.startswith(prefix)), None)
+            if first is not None:
+                cuts[stage] = flat.index[first][0]
+        # piece that becomes final when `stage` fires: [cut(stage), cut(previous firing stage) or n_weights)
+        order = [s for s in ("layer4", "layer3", "layer2", "layer1") if s in cuts]
+        self.pieces, hi = {}, flat.n_weights
+        for s_ in order:
+            lo = cuts[s_]
+            if lo < hi:
+                self.pieces[s_] = (lo, hi)
+            hi = min(hi, lo)
+        self.reset()
+
+    def reset(self):
+        self.registered, self.fired, self.done, self.works = {}, {}, [], []
+
+    def install(self):
+        self.reset()
+        self.body.grad_ready = self._event
+
+    def _event(self, stage, what):
+        if what == "registered":
+            self.registered[stage] = self.registered.get(stage, 0) + 1
+            return
+        self.fired[stage] = self.fired.get(stage, 0) + 1
+        # several backbone passes in one step (unbatched fallback): wait for the last one
+        if stage in self.pieces and self.fired[stage] == self.registered.get(stage, 0):
+            lo, hi = self.pieces[stage]
+            self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self.done.append((lo, hi))
+
+    def finish(self):
+        """after backward: reduce what no hook covered, wait for everything, scale"""
+        self.body.grad_ready = None
+        n, pos = self.flat.grad.numel(), 0
+        for lo, hi in sorted(self.done) + [(n, n)]:
+            if pos < lo:
+                self.works.append(dist.all_reduce(self.flat.grad[pos:lo], op=dist.ReduceOp.SUM, async_op=True))
+            pos = max(pos, hi)
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        ws = get_world_size()
+        if ws > 1:
+            self.flat.grad.mul_(1.0 / ws)
+        self.reset()
+
+
 class MTtrainer(object):
     def __init__(self, model_s, model_t, data_loader, optimizer, scheduler, ckpt_s, ckpt_t, checkpoint_period, cfg):
         self.cfg = cfg
@@ -100,10 +165,14 @@ class MTtrainer(object):
         # glue, and vice versa.  MMT_OVERLAP_TEACHER=0 restores the serial order.
         self.overlap_teacher = os.environ.get("MMT_OVERLAP_TEACHER", "1") != "0" and self.device.type == "cuda"
         self.t_stream = torch.cuda.Stream(device=self.device) if self.overlap_teacher else None
+        self._bucketed = None  # BucketedAllReduce, built lazily when enabled (see _bucketed_allreduce)
 
     # ---- one iteration (the unit bench.py times)
     def train_step(self, iteration, data_s, target_s, data_u_list=None):
         use_mt = iteration > self.start_mt and self.lambda_value > 0 and data_u_list is not None
+        bucketed = self._bucketed_allreduce()
+        if bucketed is not None:
+            bucketed.install()  # the stage hooks are registered by the forward passes below
         feats_s = feats_u = None
         if use_mt and self.student_bs == 1:
             # one student backbone pass over [labeled crops ; unlabeled student view] (same per-image arithmetic,
@@ -125,12 +194,29 @@ class MTtrainer(object):
         losses_dict = self.weight_sum_loss(loss_dict, iteration)
         losses = sum(v for v in losses_dict.values())
         self.optimizer.zero_grad()
-        losses.backward()
-        allreduce_gradients(self.flat_s)
+        if bucketed is None:
+            losses.backward()
+            allreduce_gradients(self.flat_s)
+        else:
+            try:
+                losses.backward()
+            finally:
+                bucketed.finish()
         self.optimizer.step()
         if self.lambda_value > 0 and iteration > (self.start_mt - 10):
             self.update_teacher(iteration - (self.start_mt - 10))
         return losses_dict
+
+    def _bucketed_allreduce(self):
+        """the overlapped exchange, when there is somebody to exchange with"""
+        # opt-in (MMT_BUCKETED_ALLREDUCE=1): on the 1-GPU box (RCCL, world size 1) the four asynchronous collectives cost
+        # 3 ms/step more than the single all-reduce after backward; whether the overlap pays at 2..8 GPUs has to be
+        # measured on a multi-GPU node first
+        if not (dist.is_available() and dist.is_initialized()) or os.environ.get("MMT_BUCKETED_ALLREDUCE", "0") != "1":
+            return None
+        if self._bucketed is None:
+            self._bucketed = BucketedAllReduce(self.flat_s, self.student.backbone.body)
+        return self._bucketed
 
     def train(self):
         self.student.train()

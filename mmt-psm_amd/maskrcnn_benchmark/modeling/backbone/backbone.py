@@ -81,6 +81,10 @@ class ResNet(nn.Module):
                 stride, in_ch = 1, out2 * f
             self.add_module("layer%d" % i, nn.Sequential(*blocks))
             self.stages.append("layer%d" % i)
+        # set by the training engine: callable(stage_name, "registered" | "fired").  A tensor hook on every trainable
+        # stage output reports when the gradient of that output is final, i.e. when the backward of everything that
+        # consumes it (the next stage, the FPN, the heads) has finished -- the cue for the bucketed gradient all-reduce
+        self.grad_ready = None
         self.freeze_at = cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT
         for si in range(self.freeze_at):
             m = self.stem if si == 0 else getattr(self, "layer%d" % si)
@@ -97,6 +101,10 @@ class ResNet(nn.Module):
                     x = getattr(self, name)(x)
             else:
                 x = getattr(self, name)(x)
+                cb = self.grad_ready
+                if cb is not None and x.requires_grad:
+                    cb(name, "registered")
+                    x.register_hook(lambda g, name=name, cb=cb: cb(name, "fired"))
             outs.append(x)
         return outs
 
