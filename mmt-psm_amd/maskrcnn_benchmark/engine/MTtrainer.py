@@ -164,7 +164,11 @@ class MTtrainer(object):
         # so that its large convolutions fill the GPU while the other stream is in launch-latency-bound target / proposal
         # glue, and vice versa.  MMT_OVERLAP_TEACHER=0 restores the serial order.
         self.overlap_teacher = os.environ.get("MMT_OVERLAP_TEACHER", "1") != "0" and self.device.type == "cuda"
-        self.t_stream = torch.cuda.Stream(device=self.device) if self.overlap_teacher else None
+        # priority -1: HIP maps streams of one priority onto a few hardware queues round-robin; once RCCL has created its own
+        # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
+        # main stream and the overlap silently disappears (measured: 63.7 vs 59.9 ms/step).  A different priority class
+        # has its own queues.
+        self.t_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.overlap_teacher else None
         self._bucketed = None  # BucketedAllReduce, built lazily when enabled (see _bucketed_allreduce)
 
     # ---- one iteration (the unit bench.py times)
@@ -209,10 +213,9 @@ class MTtrainer(object):
 
     def _bucketed_allreduce(self):
         """the overlapped exchange, when there is somebody to exchange with"""
-        # opt-in (MMT_BUCKETED_ALLREDUCE=1): on the 1-GPU box (RCCL, world size 1) the four asynchronous collectives cost
-        # 3 ms/step more than the single all-reduce after backward; whether the overlap pays at 2..8 GPUs has to be
-        # measured on a multi-GPU node first
-        if not (dist.is_available() and dist.is_initialized()) or os.environ.get("MMT_BUCKETED_ALLREDUCE", "0") != "1":
+        # MMT_BUCKETED_ALLREDUCE=0 falls back to the single all-reduce after backward.  (With RCCL at world size 1 the two
+        # cost the same, 59.6 vs 60.2 ms/step; what the overlap buys at 2..8 GPUs is the xGMI time of ~3/4 of the 176 MB.)
+        if not (dist.is_available() and dist.is_initialized()) or os.environ.get("MMT_BUCKETED_ALLREDUCE", "1") == "0":
             return None
         if self._bucketed is None:
             self._bucketed = BucketedAllReduce(self.flat_s, self.student.backbone.body)

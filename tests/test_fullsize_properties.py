@@ -205,7 +205,6 @@ def test_bucketed_allreduce_covers_every_gradient_exactly_once(monkeypatch):
         t.mul_(2.0)
         return Work() if async_op else None
 
-    monkeypatch.setenv("MMT_BUCKETED_ALLREDUCE", "1")
     monkeypatch.setattr(dist, "is_initialized", lambda: True)
     monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
     monkeypatch.setattr(MT, "get_world_size", lambda: 2)
