@@ -24,6 +24,7 @@
 // 32 KiB of operand traffic (mostly L2 hits: neighbouring pixels/taps) => ~32 FLOP/B >> the 26 FLOP/B
 // ridge of HBM, so the algorithmic HBM traffic is input + weights + output once.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -78,53 +79,68 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
         if (vec) { const f32x4 t = ldg4(q); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
         else { for (int e = 0; e < 4; e++) o[e] = e < nv ? q[e] : 0.f; }
       };
-      for (int row = r0; row < BM; row += RPP) {
-        const int m = m0 + row;
-        if (m >= p.M) break;
-        const f32x4 t = *(const f32x4*)(ct + row * BN + cc * 4);
-        float v[4] = {t[0] * sc[0] + sh[0], t[1] * sc[1] + sh[1], t[2] * sc[2] + sh[2], t[3] * sc[3] + sh[3]};
-        long oidx = (long)m * p.Cout + c;
-        float u[4];
-        if (p.res_mode >= 2 || p.out_stride > 1) {
-          const int img = m / HoWo, rem = m - img * HoWo;
-          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-          if (p.res_mode == 2) {
-            const int h2 = p.Ho >> 1, w2 = p.Wo >> 1;
-            ld(p.res + (((long)img * h2 + (ho >> 1)) * w2 + (wo >> 1)) * p.Cout + c, u);
+      // rows in groups of G: every residual / mask / mul load of a group is issued before the first use, so a thread
+      // pays one global-load latency per group instead of one per row (the row loop is not unrollable past its stores)
+      constexpr int ROWS = BM / RPP, G = ROWS < 4 ? ROWS : 4;
+      static_assert(ROWS % G == 0, "row groups");
+      for (int g0 = 0; g0 < ROWS; g0 += G) {
+        if (m0 + r0 + g0 * RPP >= p.M) break;
+        float ur[G][4], um[G][4], ul[G][4], u1[G][4], u2[G][4], u3[G][4];
+        long oidx[G];
+        bool ok[G];
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += u[e];
-          } else if (p.res_mode == 3) {
-            const int h2 = p.Ho * 2, w2 = p.Wo * 2;
-            const float* rp = p.res + (((long)img * h2 + 2 * ho) * w2 + 2 * wo) * p.Cout + c;
-            float u1[4], u2[4], u3[4];
-            ld(rp, u); ld(rp + p.Cout, u1); ld(rp + (long)w2 * p.Cout, u2); ld(rp + (long)w2 * p.Cout + p.Cout, u3);
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += (u[e] + u1[e]) + (u2[e] + u3[e]);
+        for (int g = 0; g < G; g++) {
+          const int m = m0 + r0 + (g0 + g) * RPP;
+          ok[g] = m < p.M;
+          oidx[g] = (long)m * p.Cout + c;
+          if (!ok[g]) continue;
+          if (p.res_mode >= 2 || p.out_stride > 1) {
+            const int img = m / HoWo, rem = m - img * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            if (p.res_mode == 2) {
+              const int h2 = p.Ho >> 1, w2 = p.Wo >> 1;
+              ld(p.res + (((long)img * h2 + (ho >> 1)) * w2 + (wo >> 1)) * p.Cout + c, ur[g]);
+            } else if (p.res_mode == 3) {
+              const int h2 = p.Ho * 2, w2 = p.Wo * 2;
+              const float* rp = p.res + (((long)img * h2 + 2 * ho) * w2 + 2 * wo) * p.Cout + c;
+              ld(rp, ur[g]); ld(rp + p.Cout, u1[g]); ld(rp + (long)w2 * p.Cout, u2[g]);
+              ld(rp + (long)w2 * p.Cout + p.Cout, u3[g]);
+            }
+            if (p.out_stride > 1)
+              oidx[g] = (((long)img * p.out_H + ho * p.out_stride) * p.out_W + wo * p.out_stride) * p.Cout + c;
           }
-          if (p.out_stride > 1)
-            oidx = (((long)img * p.out_H + ho * p.out_stride) * p.out_W + wo * p.out_stride) * p.Cout + c;
+          if (p.res_mode == 1) ld(p.res + (long)m * p.Cout + c, ur[g]);
+          if (p.mask) ld(p.mask + oidx[g], um[g]);
+          if (p.mul) ld(p.mul + (long)m * p.Cout + c, ul[g]);
         }
-        if (p.res_mode == 1) {
-          ld(p.res + (long)m * p.Cout + c, u);
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += u[e];
-        }
-        if (p.relu) {
+        for (int g = 0; g < G; g++) {
+          if (!ok[g]) continue;
+          const int row = r0 + (g0 + g) * RPP;
+          const f32x4 t = *(const f32x4*)(ct + row * BN + cc * 4);
+          float v[4] = {t[0] * sc[0] + sh[0], t[1] * sc[1] + sh[1], t[2] * sc[2] + sh[2], t[3] * sc[3] + sh[3]};
+          if (p.res_mode == 1 || p.res_mode == 2) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (p.mask) {
-          ld(p.mask + oidx, u);
+            for (int e = 0; e < 4; e++) v[e] += ur[g][e];
+          } else if (p.res_mode == 3) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = u[e] > 0.f ? v[e] * p.mask_scale : 0.f;
-        }
-        if (p.mul) {
-          ld(p.mul + (long)m * p.Cout + c, u);
+            for (int e = 0; e < 4; e++) v[e] += (ur[g][e] + u1[g][e]) + (u2[g][e] + u3[g][e]);
+          }
+          if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] *= u[e];
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (p.mask) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = um[g][e] > 0.f ? v[e] * p.mask_scale : 0.f;
+          }
+          if (p.mul) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] *= ul[g][e];
+          }
+          if (vec) *(f32x4*)(p.y + oidx[g]) = f32x4{v[0], v[1], v[2], v[3]};
+          else for (int e = 0; e < nv; e++) p.y[oidx[g] + e] = v[e];
         }
-        if (vec) *(f32x4*)(p.y + oidx) = f32x4{v[0], v[1], v[2], v[3]};
-        else for (int e = 0; e < nv; e++) p.y[oidx + e] = v[e];
       }
     }
   }
@@ -1184,6 +1200,273 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p,
   }
 }
 
+// Same tile, same LDS image and same arithmetic as conv_wgrad_split_kernel, software-pipelined one step deeper: the
+// global loads of pixel step t+2 are issued behind the first MFMAs of step t, and the split + LDS stores of step t+1
+// (whose loads went out a whole step earlier) are cut into micro-ops that sit behind the individual MFMAs of step t.
+// In the kernel above the three parts of a step -- MFMAs, split arithmetic, load latency -- simply add up (0.47 + 0.31
+// + 0.33 ms on the 3x3 256-channel FPN shape); here the matrix pipe covers the other two.  Branch-free: steps past
+// the end load nothing (predicated to offset 0) and store zeros into a buffer nobody reads.
+template <int NS, int MODE>  // pixel decode: 0 divisions, 1 carry-select per pixel (Ho, Wo >= 8), 2 per thread (+ Wo % 4 == 0)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, const float* __restrict__ dy,
+                                                                 const float* __restrict__ rowscale,
+                                                                 float* __restrict__ dw, int m_per_split,
+                                                                 float* __restrict__ ws, float* __restrict__ dbias) {
+  constexpr int PL = 2 * 128 * 16;
+  constexpr int STAGE = 2 * NS * PL;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ring = (char*)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int co0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int NP = p.KH * p.KW * p.Cin;
+  const int ms = blockIdx.z * m_per_split;
+  const int me = min(p.M, ms + m_per_split);
+  if (ms >= me) return;
+  const int HoWo = p.Ho * p.Wo;
+
+  const bool roleB = wave >= 2;
+  const int cq = (wave & 1) * 16 + (lane & 15);
+  const int pg = lane >> 4;
+  const int ch = (roleB ? n0 : co0) + cq * 4;
+  bool col_ok;
+  int bkh = 0, bkw = 0, bci = 0;
+  if (roleB) {
+    col_ok = ch < NP;
+    if (col_ok) { const int tap = ch / p.Cin; bci = ch - tap * p.Cin; bkh = tap / p.KW; bkw = tap - bkh * p.KW; }
+  } else {
+    col_ok = ch < p.Cout;
+  }
+  const int woff = (pg >> 1) * 2048 + cq * 16 + (pg & 1) * 8 + (roleB ? NS * PL : 0);
+  int r_img[4], r_ho[4], r_wo[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int m = ms + pg * 4 + j;
+    r_img[j] = m / HoWo;
+    const int rem = m - r_img[j] * HoWo;
+    r_ho[j] = rem / p.Wo;
+    r_wo[j] = rem - r_ho[j] * p.Wo;
+  }
+  const int step_q = 16 / p.Wo, step_r = 16 - step_q * p.Wo;
+  const bool do_bias = dbias != nullptr && blockIdx.x == 0 && !roleB;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+  const int lr = lane & 31, kh2 = lane >> 5;
+  const int froff = kh2 * 2048 + lr * 16;
+  const int ntile = (me - ms + 15) / 16;
+
+  // the whole pipeline once per staging role (wave-uniform), so that each copy is straight-line code
+  auto run = [&](auto role_tag) {
+    constexpr bool RB = decltype(role_tag)::value;
+    int m_load = ms + pg * 4;  // first pixel of this thread's next load (advances 16 per step)
+    // Loads are raw buffer loads: 32-bit byte offset against a scalar descriptor (no 64-bit address arithmetic), and
+    // lanes outside the tensor / in the halo get offset 2^31 >= num_records, for which the hardware returns zeros.
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(RB ? p.x : dy), 0, (int)((RB ? (long)p.N * p.H * p.W * p.Cin : (long)p.M * p.Cout) * 4), 0x00020000);
+    auto bload = [&](unsigned voff) {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+    };
+    // MODE 2 (Wo % 4 == 0): the thread's four pixels share an output row, so one (ih, iw, offset) triple is carried
+    // per thread, with the tap folded into the wrap limits; stepping 16 pixels wraps at most once in each direction
+    int t_iw = 0, t_ih = 0, t_off = 0;
+    const int lim_w = p.Wo * p.stride - p.pad + bkw, lim_h = p.Ho * p.stride - p.pad + bkh;
+    const int a_w = step_r * p.stride, a_h = step_q * p.stride, WoS = p.Wo * p.stride, HoS = p.Ho * p.stride;
+    const int d_step = (a_h * p.W + a_w) * p.Cin * 4, d_cw = (p.stride * p.W - WoS) * p.Cin * 4;
+    const int d_ch = (p.H - HoS) * p.W * p.Cin * 4, d_px = p.stride * p.Cin * 4;
+    if (RB && MODE == 2) {
+      t_iw = r_wo[0] * p.stride - p.pad + bkw;
+      t_ih = r_ho[0] * p.stride - p.pad + bkh;
+      t_off = (((r_img[0] * p.H + t_ih) * p.W + t_iw) * p.Cin + bci) * 4;
+    }
+    unsigned a_off = ((unsigned)m_load * (unsigned)p.Cout + (unsigned)ch) * 4u;  // dy role: byte offset of pixel 0
+    auto load_px = [&](int j, f32x4 (&rg)[4]) {
+      if (!RB) {
+        const bool mok = m_load + j < me && col_ok;
+        rg[j] = bload(mok ? a_off + (unsigned)(j * p.Cout * 4) : OOB);
+        if (j == 3) { a_off += 16u * (unsigned)p.Cout * 4u; m_load += 16; }
+        return;
+      }
+      if (MODE == 2) {
+        const int iw = t_iw + j * p.stride;
+        const bool ok = m_load < me && col_ok && (unsigned)t_ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        rg[j] = bload(ok ? (unsigned)(t_off + j * d_px) : OOB);
+        if (j == 3) {
+          t_iw += a_w;
+          const bool cw = t_iw >= lim_w;
+          t_iw = cw ? t_iw - WoS : t_iw;
+          t_ih += a_h;
+          t_ih = cw ? t_ih + p.stride : t_ih;
+          const bool chh = t_ih >= lim_h;
+          t_ih = chh ? t_ih - HoS : t_ih;
+          t_off += d_step;
+          t_off = cw ? t_off + d_cw : t_off;
+          t_off = chh ? t_off + d_ch : t_off;
+          m_load += 16;
+        }
+        return;
+      }
+      const int m = m_load + j;
+      const bool mok = m < me && col_ok;
+      int img, ho, wo;
+      if (MODE == 1) { img = r_img[j]; ho = r_ho[j]; wo = r_wo[j]; }
+      else { const int mm = m < me ? m : 0; img = mm / HoWo; const int rem = mm - img * HoWo; ho = rem / p.Wo; wo = rem - ho * p.Wo; }
+      const int ih = ho * p.stride - p.pad + bkh, iw = wo * p.stride - p.pad + bkw;
+      const bool ok = mok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      rg[j] = bload(ok ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + bci) * 4u : OOB);
+      if (MODE == 1) {
+        int wo2 = r_wo[j] + step_r, ho2 = r_ho[j] + step_q;
+        const bool cw = wo2 >= p.Wo;
+        wo2 = cw ? wo2 - p.Wo : wo2;
+        ho2 = cw ? ho2 + 1 : ho2;
+        const bool chh = ho2 >= p.Ho;
+        r_wo[j] = wo2;
+        r_ho[j] = chh ? ho2 - p.Ho : ho2;
+        r_img[j] = chh ? r_img[j] + 1 : r_img[j];
+      }
+      if (j == 3) m_load += 16;
+    };
+    // split state of the tile being stored: residuals per channel e (4 pixels each), packed pairs of the level
+    float sv[4][4];
+    unsigned su[4][2];
+    auto split_begin = [&](const f32x4 (&rg)[4]) {
+      if (!RB && do_bias) bsum += (rg[0] + rg[1]) + (rg[2] + rg[3]);
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) sv[e][j] = rg[j][e];
+    };
+    auto split_cvt = [&](int e, int q, char* base) {
+      su[e][0] = pk_bf16(sv[e][0], sv[e][1]);
+      su[e][1] = pk_bf16(sv[e][2], sv[e][3]);
+      *(uint2*)(base + q * PL + e * 512) = uint2{su[e][0], su[e][1]};
+    };
+    // plain v_sub_f32: the compiler would pair these into v_pk_add_f32, which is the slower choice beside MFMAs
+    auto fsub = [](float a, unsigned b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto split_sub = [&](int e) {
+      sv[e][0] = fsub(sv[e][0], su[e][0] << 16);
+      sv[e][1] = fsub(sv[e][1], su[e][0] & 0xffff0000u);
+      sv[e][2] = fsub(sv[e][2], su[e][1] << 16);
+      sv[e][3] = fsub(sv[e][3], su[e][1] & 0xffff0000u);
+    };
+    constexpr int SPL = 2 * NS - 1;          // cvt, (sub, cvt) x (NS-1) per channel
+    constexpr int NMICRO = 4 + 1 + 4 * SPL;  // split_begin, 4 pixel loads, 4 channels x SPL pieces
+    auto micro = [&](int idx, char* base, f32x4 (&rg_g)[4], const f32x4 (&rg_w)[4]) {
+      if (idx == 0) { split_begin(rg_w); return; }
+      idx -= 1;
+      if (idx < 4) { load_px(idx, rg_g); return; }
+      idx -= 4;
+      // level-major over the four channels: consecutive pieces are independent
+      const int lvl = idx >> 2, e = idx & 3;
+      if (lvl & 1) split_sub(e); else split_cvt(e, lvl >> 1, base);
+    };
+    // one step: fragments of `buf`, MFMAs with the staging of step t+1 (from rg_w, into buf^1) and the loads of
+    // step t+2 (into rg_g) behind them
+    auto step = [&](int buf, f32x4 (&rg_g)[4], const f32x4 (&rg_w)[4]) {
+      const char* A = ring + buf * STAGE + froff + (wm * 2) * 512;
+      const char* B = ring + buf * STAGE + NS * PL + froff + (wn * 2) * 512;
+      char* base = ring + (buf ^ 1) * STAGE + woff;
+      bf16x8 fa[NS][2], fb[NS][2];
+      // in the order the MFMAs want them (smallest terms first: fa[0], fb[NS-1] lead)
+#pragma unroll
+      for (int q = 0; q < NS; q++)
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+          fa[q][a] = *(const bf16x8*)(A + q * PL + a * 512);
+          fb[NS - 1 - q][a] = *(const bf16x8*)(B + (NS - 1 - q) * PL + a * 512);
+        }
+      constexpr int NM = 4 * (NS * (NS + 1) / 2);
+      int j = 0, mi = 0;
+#pragma unroll
+      for (int sum = NS - 1; sum >= 0; sum--)
+#pragma unroll
+        for (int qa = 0; qa <= sum; qa++) {
+          const int qb = sum - qa;
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
+              j++;
+#pragma unroll
+              for (int r = 0; r < (NMICRO + NM - 1) / NM; r++)
+                if (mi < (j * NMICRO + NM - 1) / NM) { micro(mi, base, rg_g, rg_w); mi++; }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+      __syncthreads();
+    };
+
+    f32x4 rgP[4], rgQ[4];
+    {  // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers
+#pragma unroll
+      for (int j = 0; j < 4; j++) load_px(j, rgP);
+      char* base = ring + woff;
+      split_begin(rgP);
+#pragma unroll
+      for (int lvl = 0; lvl < SPL; lvl++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) { if (lvl & 1) split_sub(e); else split_cvt(e, lvl >> 1, base); }
+#pragma unroll
+      for (int j = 0; j < 4; j++) load_px(j, rgP);
+      __syncthreads();
+    }
+    for (int t = 0; t < ntile; t += 2) {
+      step(0, rgQ, rgP);
+      if (t + 1 < ntile) step(1, rgP, rgQ);
+    }
+  };
+  if (roleB) run(std::true_type{}); else run(std::false_type{});
+  if (do_bias) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float t = bsum[e];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (pg == 0 && ch + e < p.Cout) atomicAdd(dbias + ch + e, t);
+    }
+  }
+  {
+    float* ct = lds;  // [128][128]
+    const int rq = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * rq;
+          ct[(4 * i + wm * 2 + a) * 128 + 4 * lr + wn * 2 + b] = acc[a][b][r];
+        }
+    __syncthreads();
+    const int cc = tid & 31, r0 = tid >> 5;
+    const int n = n0 + cc * 4;
+    if (n < NP) {
+      const bool direct = ws == nullptr;
+      float* dst = direct ? dw : ws + (long)blockIdx.z * p.Cout * NP;
+      for (int row = r0; row < 128; row += 8) {
+        const int co = co0 + row;
+        if (co >= p.Cout) break;
+        f32x4 v = *(const f32x4*)(ct + row * 128 + cc * 4);
+        float* q = dst + (long)co * NP + n;
+        if (direct) {
+          const float sc = rowscale ? rowscale[co] : 1.f;
+          const f32x4 o = *(const f32x4*)q;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = o[e] + v[e] * sc;
+        }
+        *(f32x4*)q = v;
+      }
+    }
+  }
+}
+
 // dw[co][n] += rowscale[co] * sum_s ws[s][co][n]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Cout, int NP,
                                                            const float* __restrict__ rowscale,
@@ -1402,7 +1685,8 @@ static int pick_variant(const ConvP& p) {
   // K <= 256 (the 1x1 layers of layer1/layer2/FPN laterals): 2-8 k-tiles per output tile, so prologue and epilogue
   // dominate; the 64x64 configuration keeps ~4x more blocks resident to overlap them (measured +10..25 %)
   static const int lowk = getenv("MMT_LOWK") ? atoi(getenv("MMT_LOWK")) : 256;
-  if (p.K <= lowk) return 2;
+  static const int lowv = getenv("MMT_LOWK_VARIANT") ? atoi(getenv("MMT_LOWK_VARIANT")) : 3;
+  if (p.K <= lowk) return (p.Cout >= 64 && (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 64) >= 768) ? lowv : 2;
   // enough 128x128 tiles to fill 256 CUs (2 resident blocks each) -> 128x128; else 128x64 (twice the blocks, A tile
   // still reused across 64 output channels); else 64x64 (4x the blocks)
   const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
@@ -1487,9 +1771,17 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   const int prec = precision();
   if (prec > 0 && (p.Cout & 3) == 0 && (mps & 15) == 0) {
     const dim3 grid(tx, ty, split);
-#define WGS(NS, INC) hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)
+    static const int pipe = getenv("MMT_WGRAD_PIPE") ? atoi(getenv("MMT_WGRAD_PIPE")) : 1;
+    // the pipelined kernel addresses both operands with 32-bit byte offsets (buffer loads)
+    const bool small = (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31);
+    const int mode = !fast ? 0 : ((p.Wo & 3) == 0 ? 2 : 1);
+#define WGP(NS, MODE) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<NS, MODE>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)
+#define WGP3(NS) do { if (mode == 2) WGP(NS, 2); else if (mode == 1) WGP(NS, 1); else WGP(NS, 0); } while (0)
+#define WGS(NS, INC) do { if (pipe && small) WGP3(NS); else hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias); } while (0)
     if (fast) { if (prec == 1) WGS(1, true); else if (prec == 2) WGS(2, true); else WGS(3, true); }
     else { if (prec == 1) WGS(1, false); else if (prec == 2) WGS(2, false); else WGS(3, false); }
+#undef WGP3
+#undef WGP
 #undef WGS
     dbias = nullptr;  // summed inside the kernel
   } else if (fast)

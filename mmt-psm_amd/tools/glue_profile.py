@@ -61,6 +61,20 @@ for e in ev:
         agg[owner][1] += k.duration
         tot[0] += 1
         tot[1] += k.duration
+other = collections.defaultdict(lambda: [0, 0.0])
+for e in ev:
+    ks = e.kernels if hasattr(e, "kernels") else []
+    if not ks:
+        continue
+    t0 = e.time_range.start
+    if any(s0 <= t0 <= s1 for s0, s1, _ in scopes):
+        continue
+    for k in ks:
+        other[e.name][0] += 1
+        other[e.name][1] += k.duration
+print("-- launches outside the scopes, by op")
+for n, (c, t) in sorted(other.items(), key=lambda kv: -kv[1][0])[:28]:
+    print("   %-40s kernels %5d   GPU %7.2f ms" % (n[:40], c, t / 1e3))
 print("total kernels %d, %.2f ms" % (tot[0], tot[1] / 1e3))
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-22s kernels %5d   GPU %7.2f ms" % (n, c, t / 1e3))

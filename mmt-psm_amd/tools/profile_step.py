@@ -41,6 +41,17 @@ for k, v in agg.items():
     bykind[k[0]][1] += v[2]
 for k, v in bykind.items():
     print("  %-6s %7.2f ms  %6.1f TFLOP/s" % (k, v[0], v[1] / v[0] / 1e9))
-print("%-6s %3s %5s %5s %5s %5s %2s %1s %1s | %4s %8s %8s" % ("kind", "N", "H", "W", "Cin", "Cout", "k", "s", "o", "n", "ms", "TF/s"))
-for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
-    print("%-6s %3d %5d %5d %5d %5d %2d %1d %1d | %4d %8.3f %8.1f" % (key + (v[0], v[1], v[2] / v[1] / 1e9)))
+def min_bytes(key):
+    # input + output once (fp32); residual / mask operands not counted
+    kind, N, H, W, Cin, Cout, k, s, _ = key
+    Ho, Wo = (H + s - 1) // s, (W + s - 1) // s
+    return 4.0 * N * (H * W * Cin + Ho * Wo * Cout)
+
+
+print("%-6s %3s %5s %5s %5s %5s %2s %1s %1s | %4s %8s %8s %8s %7s" % (
+    "kind", "N", "H", "W", "Cin", "Cout", "k", "s", "o", "n", "ms", "TF/s", "GB/s", "floor%"))
+for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    by = min_bytes(key) * v[0]
+    floor = max(v[2] / 416.7e9, by / 6.0e9)  # ms at the split-bf16 peak / at 6 TB/s
+    print("%-6s %3d %5d %5d %5d %5d %2d %1d %1d | %4d %8.3f %8.1f %8.0f %7.0f" % (
+        key + (v[0], v[1], v[2] / v[1] / 1e9, by / v[1] / 1e6, 100 * floor / v[1])))
