@@ -765,6 +765,170 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
 // where (row r, physical half h) holds the q-th bf16 term of w[32 blk + r][16 step + 8 (h ^ ((r>>3)&1)) + 0..7]
 // (zeros for rows >= Cout).  One wave produces one 1 KiB unit of each plane: lane = (row, half).
 struct PackDesc { long src_off, dst_off; int Cout, K, unit0, pad; };
+// ------------------------------------------------------------------------- 1x1 convolutions with K = 64 / 128
+// The expanding 1x1 layers of layer1 / layer2 (64 -> 256, 128 -> 512: output + residual dominate, 2-6 FLOP/B) are not
+// matrix-bound and not HBM-bound in the tiled kernel above but INSTRUCTION-bound: a block owns one 128 x 64 tile with
+// only 4-8 k-steps, so its ~600-instruction prologue (row decode, ring fill, first split), the per-step bookkeeping
+// and the epilogue are paid per 48 MFMAs (measured: 1230 vector + 630 scalar instructions per wave per tile).
+// Here a block owns 128 ROWS and walks across all Cout panels:
+//   * each wave loads its 32 rows of A straight into registers (no LDS) and splits them into bf16 fragments ONCE for
+//     the whole K and for every panel (instead of once per panel);
+//   * the pre-split weight planes of panel nt+1 are DMA-copied into the other LDS buffer while panel nt is multiplied;
+//   * per panel: KT x 6 x TN MFMAs from registers / LDS fragments, then the shared epilogue.
+// Arithmetic and summation order are those of conv_fwd_glds_kernel (bit-identical results).
+template <int KT, int BN, int NS>
+__global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, const unsigned short* __restrict__ wpl,
+                                                              const long wpl_stride) {
+  constexpr int TN = BN / 32;
+  constexpr int PIECES = KT * NS * TN;       // 1 KiB DMA pieces per panel: [kt][plane][32-column block]
+  constexpr int BBUF = PIECES * 1024;
+  constexpr int CT_BYTES = 128 * BN * 4;     // epilogue staging
+  static_assert(PIECES % 4 == 0, "pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const bring = (char*)lds + CT_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, kh2 = lane >> 5;
+  const int tiles_m = (p.M + 127) >> 7;
+  int bid = blockIdx.x;
+  {  // each XCD walks its own contiguous range of rows
+    const int q = tiles_m >> 3, r = tiles_m & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = bid * 128;
+  const int K = 16 * KT;
+  const int nb32 = (p.Cout + 31) >> 5;
+  const int npanel = (p.Cout + BN - 1) / BN;
+  auto issue_b = [&](int nt, int buf) {
+#pragma unroll
+    for (int i = 0; i < PIECES / 4; i++) {
+      const int piece = wave + 4 * i;  // wave-uniform
+      const int kt = piece / (NS * TN), q = (piece / TN) % NS, rb = piece % TN;
+      int nb = nt * TN + rb;
+      if (nb >= nb32) nb = nb32 - 1;  // panel hanging over Cout: any valid block (those columns are never stored)
+      dma16(wpl + q * wpl_stride + ((long)kt * nb32 + nb) * 512 + lane * 8, bring + buf * BBUF + piece * 1024);
+    }
+  };
+  issue_b(0, 0);
+  // ---- A: rows m0 + 32 wave + lr, k = 16 kt + 8 kh2 .. + 7 per step; rows past M read zeros (buffer bounds)
+  bf16x8 fa[KT][NS];
+  {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long)p.M * K * 4), 0x00020000);
+    const int m = m0 + wave * 32 + lr;
+    const unsigned base = m < p.M ? ((unsigned)m * (unsigned)K + 8u * kh2) * 4u : 0x80000000u;
+    f32x4 ra[KT][2];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        ra[kt][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + kt * 64 + h * 16), 0, 0));
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+      uint2 o0[NS], o1[NS];
+      split4<NS>(ra[kt][0], o0);
+      split4<NS>(ra[kt][1], o1);
+#pragma unroll
+      for (int q = 0; q < NS; q++) {
+        const uint4 u = {o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+        fa[kt][q] = __builtin_bit_cast(bf16x8, u);
+      }
+    }
+  }
+  const int boff = lr * 32 + (((kh2 ^ (lr >> 3)) & 1) << 4);
+  // Epilogue (plain / residual-add output, Cout % 4 == 0 -- the launcher checks) inlined: the residual rows of a panel are
+  // requested BEFORE its MFMAs, so their latency hides behind the matrix phase instead of sitting in the epilogue
+  // (with two to four blocks per CU nothing else would cover it).  Same expressions as conv_epilogue.
+  constexpr int C4 = BN / 4, RPP = 256 / C4, ROWS = 128 / RPP;
+  constexpr bool fast_epi = true;  // the launcher sends everything else to the tiled kernel
+  const int cc = tid % C4, r0 = tid / C4;
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res_mode == 1 ? p.res : p.x), 0, p.res_mode == 1 ? (int)((long)p.M * p.Cout * 4) : 0, 0x00020000);
+  for (int nt = 0; nt < npanel; nt++) {
+    const int buf = nt & 1;
+    // own DMA pieces of this panel landed (for nt > 0 they were waited for before the previous epilogue already)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // panel nt readable by everybody; everybody is done with the other buffer and with the staging area
+    if (nt + 1 < npanel) issue_b(nt + 1, buf ^ 1);
+    const int c = nt * BN + cc * 4;
+    f32x4 ur[ROWS], sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    if (fast_epi) {
+      const bool cok = c < p.Cout;
+#pragma unroll
+      for (int g = 0; g < ROWS; g++) {
+        const int m = m0 + r0 + g * RPP;
+        const unsigned off = (cok && m < p.M) ? ((unsigned)m * (unsigned)p.Cout + (unsigned)c) * 4u : 0x80000000u;
+        ur[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));
+      }
+      if (cok) {
+        if (p.scale) sc4 = ldg4(p.scale + c);
+        if (p.shift) sh4 = ldg4(p.shift + c);
+      }
+    }
+    f32x16 acc[1][TN];
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[0][b][r] = 0.f;
+    const char* bb = bring + buf * BBUF + boff;
+    // B fragments one k-step ahead, fenced: left alone the compiler hoists the fragment reads of ALL k-steps (and spills)
+    bf16x8 fb[2][NS][TN];
+    auto read_b = [&](int kt, bf16x8 (&f)[NS][TN]) {
+#pragma unroll
+      for (int q = 0; q < NS; q++)
+#pragma unroll
+        for (int b = 0; b < TN; b++) f[q][b] = *(const bf16x8*)(bb + ((kt * NS + q) * TN + b) * 1024);
+    };
+    read_b(0, fb[0]);
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+      if (kt + 1 < KT) read_b(kt + 1, fb[(kt + 1) & 1]);
+#pragma unroll
+      for (int sum = NS - 1; sum >= 0; sum--)
+#pragma unroll
+        for (int qa = 0; qa <= sum; qa++) {
+          const int qb = sum - qa;
+#pragma unroll
+          for (int b = 0; b < TN; b++)
+            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kt][qa], fb[kt & 1][qb][b], acc[0][b], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the next panel's planes must have landed before this wave's epilogue puts loads and stores behind them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* ct = lds;  // [128][BN]
+    {
+      const int col_l = lane & 31, rq = lane >> 5;
+#pragma unroll
+      for (int b = 0; b < TN; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+          ct[row * BN + b * 32 + col_l] = acc[0][b][r];
+        }
+    }
+    __syncthreads();
+    if (c < p.Cout) {
+#pragma unroll
+      for (int g = 0; g < ROWS; g++) {
+        const int row = r0 + g * RPP, m = m0 + row;
+        if (m >= p.M) break;
+        const f32x4 t = *(const f32x4*)(ct + row * BN + cc * 4);
+        float v[4] = {t[0] * sc4[0] + sh4[0], t[1] * sc4[1] + sh4[1], t[2] * sc4[2] + sh4[2], t[3] * sc4[3] + sh4[3]};
+        if (p.res_mode == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += ur[g][e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        *(f32x4*)(p.y + (long)m * p.Cout + c) = f32x4{v[0], v[1], v[2], v[3]};
+      }
+    }
+  }
+}
+
 
 __device__ __forceinline__ void pack_unit(const float* __restrict__ w, unsigned short* __restrict__ dst, long plane_stride,
                                           int Cout, int K, int unit, int lane) {
@@ -1605,8 +1769,35 @@ int launch_glds(const ConvP& p, hipStream_t s) {
   return 0;
 }
 
+template <int KT, int BN, int NS>
+int launch_rows(const ConvP& p, hipStream_t s) {
+  const size_t lds = (size_t)128 * BN * 4 + 2 * (size_t)KT * NS * (BN / 32) * 1024;
+  auto kern = conv1x1_rows_kernel<KT, BN, NS>;
+  if (lds > 65536) {
+    static bool done = false;  // per instantiation
+    if (!done) {
+      const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(mmt_cdiv(p.M, 128)), dim3(256), lds, s, p, p.wpl, p.wpl_stride);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int NS>
 int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
+  // 1x1 / stride 1 layers with K = 64 or 128 and many rows: one block per 128 rows, all Cout panels (see the kernel)
+  const char* rows_env = getenv("MMT_ROWS");  // read per call: the parity tests switch it
+  const int rows = rows_env ? atoi(rows_env) : 1;
+  if (rows && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * 512 &&
+      (p.Cout & 3) == 0 && p.res_mode <= 1 && !p.mask && !p.mul && p.out_stride == 1 &&
+      (long)p.M * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31)) {
+    static const int bn64 = getenv("MMT_ROWS_BN") ? atoi(getenv("MMT_ROWS_BN")) : 32;
+    if (p.Cin == 64) return bn64 == 64 ? launch_rows<4, 64, NS>(p, s) : launch_rows<4, 32, NS>(p, s);
+    if (p.Cin == 128) return launch_rows<8, 32, NS>(p, s);
+  }
   switch (variant) {
     case 1: return launch_glds<128, 128, 4, 1, NS, 3>(p, s);
     case 3: return launch_glds<128, 64, 4, 1, NS, 3>(p, s);
@@ -1690,7 +1881,8 @@ static int pick_variant(const ConvP& p) {
   // enough 128x128 tiles to fill 256 CUs (2 resident blocks each) -> 128x128; else 128x64 (twice the blocks, A tile
   // still reused across 64 output channels); else 64x64 (4x the blocks)
   const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
-  if (t128 >= 384 && p.Cout > 64) return 1;
+  static const int t128min = getenv("MMT_T128") ? atoi(getenv("MMT_T128")) : 256;
+  if (t128 >= t128min && p.Cout > 64) return 1;
   static const int mid = getenv("MMT_MID") ? atoi(getenv("MMT_MID")) : 1;
   const long t12864 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 64);
   if (mid && t12864 >= 256 && p.Cout >= 64) return 3;

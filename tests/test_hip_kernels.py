@@ -356,8 +356,11 @@ def test_conv_arithmetic_modes_forward(hip, restore_mode, case):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 24, 24, 96, 3, 1, 1), (3, 128, 30, 30, 160, 1, 2, 0), (1, 48, 17, 23, 64, 3, 1, 1),
-                                  (1000, 256, 1, 1, 512, 1, 1, 0), (2, 20, 12, 12, 36, 3, 1, 1), (20, 256, 14, 14, 256, 3, 1, 1)])
+                                  (1000, 256, 1, 1, 512, 1, 1, 0), (2, 20, 12, 12, 36, 3, 1, 1), (20, 256, 14, 14, 256, 3, 1, 1),
+                                  (2, 32, 40, 40, 64, 3, 2, 1), (2, 32, 40, 36, 64, 3, 2, 1), (3, 64, 16, 12, 128, 3, 1, 1)])
 def test_conv_arithmetic_modes_wgrad(hip, restore_mode, case):
+    """the three pixel-decode variants of the pipelined kernel are all here: Wo % 4 == 0 (one carried position per
+    thread, strides 1 and 2), other Wo >= 8 (one per pixel), and 1 x 1 / tiny maps (divisions)"""
     N, Cin, H, W, Cout, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
     x = cl(torch.randn(N, Cin, H, W, generator=g))
@@ -375,6 +378,36 @@ def test_conv_arithmetic_modes_wgrad(hip, restore_mode, case):
         err[mode] = (dw.double() - 2 * ref).abs().max().item() / (2 * scl)
         assert err[mode] < MODE_TOL[mode], (mode, err[mode])
     assert err[3] <= 2.0 * err[0] + 2e-7, err
+
+
+@pytest.mark.parametrize("case", [(4, 64, 128, 128, 256), (1, 64, 257, 259, 96), (1, 128, 300, 300, 200), (2, 128, 192, 192, 512)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_conv1x1_rows_kernel(hip, restore_mode, case, residual):
+    """1x1 layers with K = 64 / 128 and >= 64k rows run on conv1x1_rows_kernel (one block per 128 rows, all Cout
+    panels): bit-identical to the tiled kernel (MMT_ROWS=0), fp32-grade against fp64; ragged M and Cout included"""
+    import os
+    N, Cin, H, W, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x, w = cl(torch.randn(N, Cin, H, W, generator=g)), cl(torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
+    res = cl(torch.randn(N, Cout, H, W, generator=g)) if residual else None
+    ref = F.conv2d(x.double(), w.double()) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    ref = F.relu(ref + res.double()) if residual else F.relu(ref)
+    old = os.environ.get("MMT_ROWS")
+    try:
+        for mode in (3, 1):
+            hip.set_conv_precision(mode)
+            os.environ["MMT_ROWS"] = "1"
+            y1 = hip.conv_forward(x, w, sc, sh, 1, 0, relu=True, res=res, res_mode=1 if residual else 0)
+            os.environ["MMT_ROWS"] = "0"
+            y0 = hip.conv_forward(x, w, sc, sh, 1, 0, relu=True, res=res, res_mode=1 if residual else 0)
+            assert torch.equal(y0, y1), mode
+            assert (y1.double() - ref).abs().max().item() < MODE_TOL[mode] * ref.abs().max().item()
+    finally:
+        if old is None:
+            os.environ.pop("MMT_ROWS", None)
+        else:
+            os.environ["MMT_ROWS"] = old
 
 
 def test_packed_weight_planes_bookkeeping(hip, restore_mode):
