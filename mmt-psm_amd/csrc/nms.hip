@@ -9,8 +9,8 @@
 //
 // Stage 1 (nms_mask_kernel): block (cb, rb, seg) of 64 threads; thread i owns row box rb*64+i and
 // produces the 64-bit word of suppressions against column boxes cb*64..cb*64+63 (only j > i).
-// Stage 2 (nms_sweep_kernel): one wave per segment.  Lane w owns word w of the "removed" bitmap
-// (n <= 64*64 boxes).  Rows are staged through LDS 64 at a time; inside a 64-row chunk the serial
+// Stage 2 (nms_sweep_kernel): one sweeping wave per segment (+ three staging waves).  Lane w owns word w of the
+// "removed" bitmap (n <= 64*64 boxes).  Rows are staged through LDS 64 at a time; inside a 64-row chunk the serial
 // keep/suppress recurrence runs on the diagonal word with v_readlane broadcasts, then the kept rows of
 // the chunk are OR-ed into every lane's word with independent (pipelined) LDS reads.
 #include "common.h"
@@ -62,50 +62,98 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const int* __restrict__ seg_off, int max_n, int words,
-                                                       const unsigned long long* __restrict__ mask,
-                                                       int* __restrict__ keep, int* __restrict__ keep_cnt) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long rows[];  // [64][words]
-  const int seg = blockIdx.x, lane = threadIdx.x;
+// OR of a 32-bit value over the 64 lanes (uniform result): inclusive OR-scan inside each row of 16 lanes with DPP
+// row shifts, then the four row totals
+__device__ __forceinline__ unsigned wave_or32(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  return __builtin_amdgcn_readlane(v, 15) | __builtin_amdgcn_readlane(v, 31) | __builtin_amdgcn_readlane(v, 47) |
+         __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+  return ((unsigned long long)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
+}
+
+__global__ __launch_bounds__(256) void nms_sweep_kernel(const int* __restrict__ seg_off, int max_n, int words,
+                                                        const unsigned long long* __restrict__ mask,
+                                                        int* __restrict__ keep, int* __restrict__ keep_cnt) {
+  // wave 0 sweeps chunk c out of LDS buffer c & 1 while waves 1..3 stage the rows of chunk c + 1 into the other one:
+  // the sweep is a latency chain on a single wave, so the global-load latency of the staging must not sit in it
+  extern __shared__ __attribute__((aligned(16))) unsigned long long rows[];  // [2][64][words]
+  const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = seg_off[seg + 1] - seg_off[seg];
   const unsigned long long* M = mask + (long)seg * max_n * words;
   int* kp = keep + (long)seg * max_n;
-  unsigned long long removed = 0;  // lane w: word w
+  unsigned long long removed = 0;  // wave 0, lane w: word w
   int cnt = 0;
   const int nchunks = (n + 63) / 64;
+  // rows r0..r0+rn-1 of chunk c, words c..nchunks-1 (lower words are irrelevant from there on)
+  auto stage = [&](int c, int t, int nt) {
+    const int r0 = c * 64, rn = min(64, n - r0), wn = nchunks - c;
+    unsigned long long* dst = rows + (c & 1) * 64 * words;
+    const int tot = rn * wn;
+    for (int base = t; base < tot; base += 8 * nt) {  // eight loads in flight per thread, then the LDS stores
+      unsigned long long v[8];
+      int at[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int idx = base + u * nt;
+        const int rr = idx / wn, ww = c + idx - rr * wn;
+        at[u] = idx < tot ? rr * words + ww : -1;
+        v[u] = idx < tot ? M[(long)r0 * words + at[u]] : 0ULL;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (at[u] >= 0) dst[at[u]] = v[u];
+    }
+  };
+  if (nchunks > 0) stage(0, tid, 256);
+  __syncthreads();
   for (int c = 0; c < nchunks; c++) {
-    const int r0 = c * 64, rn = min(64, n - r0);
-    // stage rows r0..r0+rn-1, words c..nchunks-1 (lower words are irrelevant from here on)
-    const int wn = nchunks - c;
-    for (int idx = lane; idx < rn * wn; idx += 64) {
-      const int rr = idx / wn, ww = c + idx % wn;
-      rows[rr * words + ww] = M[(long)(r0 + rr) * words + ww];
-    }
-    __syncthreads();
-    // serial recurrence on the diagonal word; lane rr holds diag of row rr
-    const unsigned long long diag = lane < rn ? rows[lane * words + c] : 0ULL;
-    unsigned long long rem = readlane64(removed, c);
-    unsigned long long keptbits = 0;
-    for (int bpos = 0; bpos < rn; bpos++) {
-      const unsigned long long d = readlane64(diag, bpos);
-      if (!((rem >> bpos) & 1ULL)) { keptbits |= 1ULL << bpos; rem |= d; }
-    }
-    // emit kept indices (ascending) and fold kept rows into the bitmap
-    {
-      const bool mine = (keptbits >> lane) & 1ULL;
-      const int before = __popcll(keptbits & ((1ULL << lane) - 1ULL));
-      if (mine) kp[cnt + before] = r0 + lane;
-      cnt += __popcll(keptbits);
-    }
-    if (lane >= c && lane < nchunks) {
-      unsigned long long acc = removed;
-      for (int rr = 0; rr < rn; rr++)
-        if ((keptbits >> rr) & 1ULL) acc |= rows[rr * words + lane];
-      removed = acc;
+    if (wave > 0) {
+      if (c + 1 < nchunks) stage(c + 1, tid - 64, 192);
+    } else {
+      const unsigned long long* buf = rows + (c & 1) * 64 * words;
+      const int r0 = c * 64, rn = min(64, n - r0);
+      // serial recurrence on the diagonal word; lane rr holds diag of row rr
+      const unsigned long long diag = lane < rn ? buf[lane * words + c] : 0ULL;
+      // keep_i = alive_i && no kept j < i suppresses i.  Instead of walking the 64 boxes one by one (a ~100-cycle
+      // scalar step each), iterate K <- alive & ~OR_{j in K} diag_j from K = alive: position i is final after i + 1
+      // rounds at the latest (diag_j only has bits > j), the fixpoint is unique, and in practice a handful of rounds
+      // reach it; one round is a 64-bit OR-reduction over the wave (DPP row scans + four readlanes).
+      const unsigned long long rem = readlane64(removed, c);
+      const unsigned long long alive = ~rem & (rn == 64 ? ~0ULL : ((1ULL << rn) - 1ULL));
+      unsigned long long keptbits = alive;
+      for (int round = 0; round < 64; round++) {
+        const bool in = (keptbits >> lane) & 1ULL;
+        const unsigned long long sup = wave_or64(in ? diag : 0ULL);
+        const unsigned long long next = alive & ~sup;
+        if (next == keptbits) break;
+        keptbits = next;
+      }
+      // emit kept indices (ascending) and fold kept rows into the bitmap
+      {
+        const bool mine = (keptbits >> lane) & 1ULL;
+        const int before = __popcll(keptbits & ((1ULL << lane) - 1ULL));
+        if (mine) kp[cnt + before] = r0 + lane;
+        cnt += __popcll(keptbits);
+      }
+      if (lane >= c && lane < nchunks) {
+        unsigned long long acc = removed;
+#pragma unroll 8
+        for (int rr = 0; rr < rn; rr++) {  // branch-free: independent, pipelined LDS reads
+          const unsigned long long v = buf[rr * words + lane];
+          acc |= ((keptbits >> rr) & 1ULL) ? v : 0ULL;
+        }
+        removed = acc;
+      }
     }
     __syncthreads();
   }
-  if (lane == 0) keep_cnt[seg] = cnt;
+  if (tid == 0) keep_cnt[seg] = cnt;
 }
 
 extern "C" int mmt_nms_batched(const float* boxes, const int32_t* seg_off, int B, int max_n, float thr,
@@ -116,8 +164,8 @@ extern "C" int mmt_nms_batched(const float* boxes, const int32_t* seg_off, int B
   hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, (hipStream_t)stream, boxes, seg_off, max_n,
                      words, thr, (unsigned long long*)mask_ws);
   MMT_LAUNCH_CHECK();
-  const size_t lds = (size_t)64 * words * sizeof(unsigned long long);
-  hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, seg_off, max_n, words,
+  const size_t lds = (size_t)2 * 64 * words * sizeof(unsigned long long);
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, seg_off, max_n, words,
                      (const unsigned long long*)mask_ws, keep, keep_cnt);
   MMT_LAUNCH_CHECK();
   return 0;
