@@ -1370,7 +1370,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p,
 // In the kernel above the three parts of a step -- MFMAs, split arithmetic, load latency -- simply add up (0.47 + 0.31
 // + 0.33 ms on the 3x3 256-channel FPN shape); here the matrix pipe covers the other two.  Branch-free: steps past
 // the end load nothing (predicated to offset 0) and store zeros into a buffer nobody reads.
-template <int NS, int MODE>  // pixel decode: 0 divisions, 1 carry-select per pixel (Ho, Wo >= 8), 2 per thread (+ Wo % 4 == 0)
+// MODE = pixel decode: 0 divisions, 1 carry-select per pixel (Ho, Wo >= 8), 2 per thread (+ Wo % 4 == 0);
+// VEC4 = Cout % 4 == 0 (16-byte dy loads)
+template <int NS, int MODE, bool VEC4>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, const float* __restrict__ dy,
                                                                  const float* __restrict__ rowscale,
                                                                  float* __restrict__ dw, int m_per_split,
@@ -1453,7 +1455,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
     auto load_px = [&](int j, f32x4 (&rg)[4]) {
       if (!RB) {
         const bool mok = m_load + j < me && col_ok;
-        rg[j] = bload(mok ? a_off + (unsigned)(j * p.Cout * 4) : OOB);
+        const unsigned off = a_off + (unsigned)(j * p.Cout * 4);
+        if (VEC4) {
+          rg[j] = bload(mok ? off : OOB);
+        } else {  // Cout % 4 != 0 (the 15-channel predictors): rows are not 16-byte aligned and may end inside the quad
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            rg[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rsrc, (int)(mok && ch + e < p.Cout ? off + 4u * e : OOB), 0, 0));
+        }
         if (j == 3) { a_off += 16u * (unsigned)p.Cout * 4u; m_load += 16; }
         return;
       }
@@ -1961,13 +1971,16 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   float* ws = split > 1 ? workspace : nullptr;
   const bool fast = (p.Cout & 3) == 0 && p.Wo >= 8 && p.Ho >= 8;
   const int prec = precision();
-  if (prec > 0 && (p.Cout & 3) == 0 && (mps & 15) == 0) {
+  static const int pipe_any = getenv("MMT_WGRAD_PIPE") ? atoi(getenv("MMT_WGRAD_PIPE")) : 1;
+  const bool small_t = (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31);
+  if (prec > 0 && ((p.Cout & 3) == 0 || (pipe_any && small_t)) && (mps & 15) == 0) {
     const dim3 grid(tx, ty, split);
     static const int pipe = getenv("MMT_WGRAD_PIPE") ? atoi(getenv("MMT_WGRAD_PIPE")) : 1;
     // the pipelined kernel addresses both operands with 32-bit byte offsets (buffer loads)
     const bool small = (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31);
-    const int mode = !fast ? 0 : ((p.Wo & 3) == 0 ? 2 : 1);
-#define WGP(NS, MODE) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<NS, MODE>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)
+    const int mode = !(p.Wo >= 8 && p.Ho >= 8) ? 0 : ((p.Wo & 3) == 0 ? 2 : 1);
+    const bool vec4 = (p.Cout & 3) == 0;
+#define WGP(NS, MODE) do { if (vec4) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<NS, MODE, true>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias); else hipLaunchKernelGGL((conv_wgrad_pipe_kernel<NS, MODE, false>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias); } while (0)
 #define WGP3(NS) do { if (mode == 2) WGP(NS, 2); else if (mode == 1) WGP(NS, 1); else WGP(NS, 0); } while (0)
 #define WGS(NS, INC) do { if (pipe && small) WGP3(NS); else hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias); } while (0)
     if (fast) { if (prec == 1) WGS(1, true); else if (prec == 2) WGS(2, true); else WGS(3, true); }

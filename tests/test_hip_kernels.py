@@ -357,10 +357,12 @@ def test_conv_arithmetic_modes_forward(hip, restore_mode, case):
 
 @pytest.mark.parametrize("case", [(2, 64, 24, 24, 96, 3, 1, 1), (3, 128, 30, 30, 160, 1, 2, 0), (1, 48, 17, 23, 64, 3, 1, 1),
                                   (1000, 256, 1, 1, 512, 1, 1, 0), (2, 20, 12, 12, 36, 3, 1, 1), (20, 256, 14, 14, 256, 3, 1, 1),
-                                  (2, 32, 40, 40, 64, 3, 2, 1), (2, 32, 40, 36, 64, 3, 2, 1), (3, 64, 16, 12, 128, 3, 1, 1)])
+                                  (2, 32, 40, 40, 64, 3, 2, 1), (2, 32, 40, 36, 64, 3, 2, 1), (3, 64, 16, 12, 128, 3, 1, 1),
+                                  (2, 64, 32, 32, 15, 1, 1, 0), (600, 1024, 1, 1, 15, 1, 1, 0), (2, 32, 20, 20, 30, 3, 1, 1)])
 def test_conv_arithmetic_modes_wgrad(hip, restore_mode, case):
     """the three pixel-decode variants of the pipelined kernel are all here: Wo % 4 == 0 (one carried position per
-    thread, strides 1 and 2), other Wo >= 8 (one per pixel), and 1 x 1 / tiny maps (divisions)"""
+    thread, strides 1 and 2), other Wo >= 8 (one per pixel), and 1 x 1 / tiny maps (divisions); Cout % 4 != 0 (the
+    15-channel predictors) takes the element-wise dy loads"""
     N, Cin, H, W, Cout, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
     x = cl(torch.randn(N, Cin, H, W, generator=g))
