@@ -270,10 +270,12 @@ def _conv_args(x, w, stride, pad, Ho, Wo):
 
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
                  mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0,
-                 w_shape=None, planes=None):
+                 w_shape=None, planes=None, out_size=None):
     """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory).
     y_out/y_offset (elements): write into an existing NHWC tensor at a shifted base (transposed-conv taps).
-    w=None with w_shape + planes: the weight exists only as packed bf16 planes (pack_weight_flipped)."""
+    w=None with w_shape + planes: the weight exists only as packed bf16 planes (pack_weight_flipped).
+    out_size=(Ho, Wo): fewer output rows / columns than `pad` on both sides would give, i.e. a smaller pad at the
+    bottom / right (taps that fall outside the input read zeros either way)."""
     x = nhwc(x)
     N, Cin, H, W = x.shape
     if w is None:
@@ -293,6 +295,10 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         Cout, _, KH, KW = w.shape
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
+        if out_size is not None:
+            if out_size[0] > Ho or out_size[1] > Wo or out_stride > 1:
+                raise RuntimeError("conv_forward: out_size can only trim the output")
+            Ho, Wo = out_size
         a = _conv_args(x, w, stride, pad, Ho, Wo)
         _keep = _weight_planes(w, a)  # noqa: F841  (keeps a per-call plane buffer alive until the launch is queued)
     if out_stride > 1:

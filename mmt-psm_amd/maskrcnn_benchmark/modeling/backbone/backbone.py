@@ -21,14 +21,38 @@ class StemWithFixedBatchNorm(nn.Module):
         self.conv1 = Conv2d(3, out, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = FrozenBatchNorm2d(out)
 
+    def _s2d_weight(self):
+        """the 7x7 / stride-2 filter as a 4x4 / stride-1 filter over the 2x2 space-to-depth image: pad the filter
+        to 8x8 with a zero row / column in FRONT (tap kh sits at 2a + b - 1), fold the parity (b_h, b_w) and the
+        4-padded RGB channel into 16 input channels.  Cached: the stem is frozen (reference resnet.py:StemWithFixedBatchNorm
+        + FREEZE_CONV_BODY_AT >= 1), re-made only if the parameter is written."""
+        w = self.conv1.weight
+        key = (w.data_ptr(), w._version)
+        if getattr(self, "_s2d_key", None) != key:
+            co = w.shape[0]
+            w8 = w.new_zeros((co, 8, 8, 4))
+            w8[:, 1:, 1:, :3] = w.detach().permute(0, 2, 3, 1)
+            ws = w8.view(co, 4, 2, 4, 2, 4).permute(0, 1, 3, 2, 4, 5).reshape(co, 4, 4, 16)
+            self._s2d_w = ws.contiguous().permute(0, 3, 1, 2)  # (co, 16, 4, 4) in channels_last memory
+            self._s2d_key = key
+        return self._s2d_w
+
     def forward(self, x):
-        # the MFMA loader wants 16-byte channel groups: pad RGB -> 4 channels (zero weight on the 4th)
         n, c, h, w = x.shape
+        s, b = self.bn1.folded()
+        if h % 2 == 0 and w % 2 == 0:
+            # 16-channel space-to-depth image -> the DMA-fed split-bf16 kernel instead of the 4-channel fp32 one:
+            # out(ho) = sum_kh x(2 ho - 3 + kh) w(kh) = sum_{a,b} z(ho - 2 + a, b) w8(2 a + b),  z(i, b) = x(2 i + b)
+            z = x.new_zeros((n, h // 2, w // 2, 2, 2, 4))
+            z[..., :3] = x.view(n, c, h // 2, 2, w // 2, 2).permute(0, 2, 4, 3, 5, 1)
+            y = H.conv_forward(z.view(n, h // 2, w // 2, 16).permute(0, 3, 1, 2), self._s2d_weight(), s, b, 1, 2,
+                               relu=True, out_size=(h // 2, w // 2))
+            return H.maxpool3x3s2(y)
+        # odd sizes: pad RGB -> 4 channels (zero weight on the 4th), fp32-input kernel
         x4 = x.new_zeros((n, h, w, 4))
         x4[..., :3] = x.permute(0, 2, 3, 1)
         w4 = self.conv1.weight.new_zeros((self.conv1.out_channels, 7, 7, 4))
         w4[..., :3] = self.conv1.weight.detach().permute(0, 2, 3, 1)
-        s, b = self.bn1.folded()
         y = H.conv_forward(x4.permute(0, 3, 1, 2), w4.permute(0, 3, 1, 2), s, b, 2, 3, relu=True)
         return H.maxpool3x3s2(y)
 
