@@ -10,6 +10,8 @@ wants is the memory order.  Post-processing is batched over images: per level on
 clip over the whole batch, then a SINGLE `mmt_nms_batched` launch pair over all (image, level) segments with
 the greedy sweep on the device (the reference does 5*N separate NMS calls each with a D2H mask copy).
 """
+import os
+
 import torch
 
 from maskrcnn_benchmark.utils.miscellaneous import dev_const
@@ -58,6 +60,9 @@ def _flat(obj, reg):
     return obj.permute(0, 2, 3, 1).reshape(N, -1), reg.permute(0, 2, 3, 1).reshape(N, -1, 4)
 
 
+_EARLY_WAIT = os.environ.get("MMT_RPN_EARLY_WAIT", "0") == "1"
+
+
 class RPNPostProcessor(nn.Module):
     def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder=None, fpn_post_nms_top_n=None,
                  is_teacher=False):
@@ -68,7 +73,7 @@ class RPNPostProcessor(nn.Module):
         self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
         self.is_teacher = is_teacher
 
-    def forward(self, anchors, objectness, box_regression, targets=None, shared=None):
+    def forward(self, anchors, objectness, box_regression, targets=None, shared=None, between=None):
         """anchors: list[image] of list[level] BoxList -> list[BoxList] (rpn/inference.py:139-172).
         `shared` (dict or None): the teacher runs its TEST-config and TRAIN-config selectors on the same head outputs
         (generalized_rcnn.py:126,146); decode + NMS are then done once on the larger pre-NMS top-k and each selector
@@ -81,7 +86,7 @@ class RPNPostProcessor(nn.Module):
             c = self.compute_candidates(anchors, objectness, box_regression, pre)
             if shared is not None:
                 shared[key] = c
-        return self.select(c, targets)
+        return self.select(c, targets, between)
 
     def compute_candidates(self, anchors, objectness, box_regression, pre_n):
         N, L = len(anchors), len(objectness)
@@ -120,7 +125,7 @@ class RPNPostProcessor(nn.Module):
         return dict(N=N, L=L, ks=ks, kmax=kmax, sizes=sizes, boxes=boxes, scores=scores, seg_off=seg_off, keep=keep,
                     cnt=cnt, extra_src=cand_extra, dev=dev)
 
-    def select(self, c, targets=None):
+    def select(self, c, targets=None, between=None):
         N, L, ks, kmax, dev = c["N"], c["L"], c["ks"], c["kmax"], c["dev"]
         boxes, scores, seg_off, keep, cnt, sizes = c["boxes"], c["scores"], c["seg_off"], c["keep"], c["cnt"], c["sizes"]
         per_img = sum(ks)
@@ -161,8 +166,12 @@ class RPNPostProcessor(nn.Module):
             }
         out = []
         if order is None:
-            counts = kept.view(N, per_img).sum(1).tolist()  # the one host sync of the proposal pipeline
-            idx_all = kept.nonzero().squeeze(1)
+            # the one host sync of the proposal pipeline: only the per-image counts cross to the host, through a pinned
+            # buffer and an event, so that whatever `between` enqueues (the RPN losses) keeps the GPU busy while the host
+            # is released and builds the proposal lists / box-head launches.  nonzero_static: no sync of its own.
+            cap = min(self.fpn_post_nms_top_n, total) if (L > 1 and training) else total
+            idx_all = torch.nonzero_static(kept, size=cap).squeeze(1)
+            counts = self._counts_to_host(kept.view(N, per_img).sum(1), between)
             st = 0
             for n in range(N):
                 ii = idx_all[st:st + counts[n]]
@@ -170,7 +179,7 @@ class RPNPostProcessor(nn.Module):
                 out.append(self._boxlist(boxes, scores, extra, ii, sizes[n]))
         else:
             top, ok = order
-            counts = ok.sum(1).tolist()
+            counts = self._counts_to_host(ok.sum(1), between)
             for n in range(N):
                 ii = top[n, :counts[n]] + n * per_img
                 out.append(self._boxlist(boxes, scores, extra, ii, sizes[n]))
@@ -182,6 +191,25 @@ class RPNPostProcessor(nn.Module):
                 res.append(g)
             out = res
         return out
+
+    def _counts_to_host(self, cnt, between):
+        """device int64 vector -> python list; `between()` runs after the copy is queued and before the host waits"""
+        if not cnt.is_cuda:
+            if between is not None:
+                self.between_result = between()
+            return cnt.tolist()
+        pin = getattr(self, "_pin", None)
+        if pin is None or pin.numel() < cnt.numel():
+            pin = self._pin = torch.empty(max(16, cnt.numel()), dtype=torch.int64).pin_memory()
+        pin[:cnt.numel()].copy_(cnt, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if _EARLY_WAIT:  # A/B switch: wait first, enqueue afterwards (the old order)
+            ev.synchronize()
+        if between is not None:
+            self.between_result = between()
+        ev.synchronize()
+        return pin[:cnt.numel()].tolist()
 
     @staticmethod
     def _boxlist(boxes, scores, extra, ii, size):
@@ -319,9 +347,16 @@ class RPNModule(nn.Module):
         objectness, rpn_box_regression = self._head(features)
         anchors = self.anchor_generator(images, features)
         if self.training or self.mode == "train":
-            with torch.no_grad():
-                boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
-            lo, lb = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
+            grad_on = torch.is_grad_enabled()
+
+            def losses():
+                with torch.set_grad_enabled(grad_on):
+                    return self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
+
+            with torch.no_grad():  # the losses are enqueued inside the selector, between its count copy and its host wait
+                boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets, between=losses)
+            lo, lb = self.box_selector_train.between_result
+            self.box_selector_train.between_result = None
             return boxes, {"loss_objectness": lo, "loss_rpn_box_reg": lb}
         with torch.no_grad():
             boxes = self.box_selector_test(anchors, objectness, rpn_box_regression, shared=getattr(self, "shared", None))
