@@ -141,10 +141,17 @@ class FastRCNNLossComputation(object):
         labels, regs = self.prepare_targets(proposals, targets)
         pos, neg = self.fg_bg_sampler(labels, tag="roi_sampler")
         out = []
-        for p, lab, rg, pm, nm in zip(proposals, labels, regs, pos, neg):
+        # ONE host transfer for the whole batch (sampled and positive counts per image) instead of one blocking nonzero per
+        # image; the positive counts travel with the proposals so the mask head needs no sync of its own
+        both = [pm | nm for pm, nm in zip(pos, neg)]
+        cnts = torch.stack([m.sum() for m in both] + [m.sum() for m in pos]).tolist()
+        N = len(proposals)
+        for i, (p, lab, rg, m) in enumerate(zip(proposals, labels, regs, both)):
             p.add_field("labels", lab)
             p.add_field("regression_targets", rg)
-            out.append(p[torch.nonzero(pm | nm).squeeze(1)])
+            q = p[torch.nonzero_static(m, size=cnts[i]).squeeze(1)]
+            q.n_pos = cnts[N + i]
+            out.append(q)
         self._proposals = out
         return out
 

@@ -22,7 +22,8 @@ def keep_only_positive_boxes(boxes):
     pos_boxes, pos_inds = [], []
     for b in boxes:
         m = b.get_field("labels") > 0
-        pos_boxes.append(b[m.nonzero().squeeze(1)])
+        n_pos = getattr(b, "n_pos", None)  # set by the box head's sampler: no blocking nonzero here
+        pos_boxes.append(b[torch.nonzero_static(m, size=n_pos).squeeze(1) if n_pos is not None else m.nonzero().squeeze(1)])
         pos_inds.append(m)
     return pos_boxes, pos_inds
 
