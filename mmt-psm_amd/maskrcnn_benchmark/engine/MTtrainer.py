@@ -164,6 +164,7 @@ class MTtrainer(object):
         # so that its large convolutions fill the GPU while the other stream is in launch-latency-bound target / proposal
         # glue, and vice versa.  MMT_OVERLAP_TEACHER=0 restores the serial order.
         self.overlap_teacher = os.environ.get("MMT_OVERLAP_TEACHER", "1") != "0" and self.device.type == "cuda"
+        self.early_sup_backward = os.environ.get("MMT_EARLY_SUP_BACKWARD", "1") != "0"
         # priority -1: HIP maps streams of one priority onto a few hardware queues round-robin; once RCCL has created its own
         # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
         # main stream and the overlap silently disappears (measured: 63.7 vs 59.9 ms/step).  A different priority class
@@ -178,6 +179,7 @@ class MTtrainer(object):
         if bucketed is not None:
             bucketed.install()  # the stage hooks are registered by the forward passes below
         feats_s = feats_u = None
+        cut = None
         if use_mt and self.student_bs == 1:
             # one student backbone pass over [labeled crops ; unlabeled student view] (same per-image arithmetic,
             # larger GEMMs forward and backward); the two forwards below consume their slice of the pyramid
@@ -190,22 +192,50 @@ class MTtrainer(object):
                 parts = [fused.split_batch(l, n) for l in pyr]
                 feats_s = tuple(p[0] for p in parts)
                 feats_u = [tuple(p[1] for p in parts)]
+                if self.early_sup_backward:
+                    # Cut the graph at the pyramid: the supervised heads run their backward as soon as their losses exist
+                    # -- while this thread would otherwise only wait for the teacher -- and the consistency heads after
+                    # theirs; the backbone + FPN then run backward ONCE on the two slices' gradients together.
+                    cut = (feats_s + feats_u[0],)
+                    feats_s = tuple(t.detach().requires_grad_(True) for t in feats_s)
+                    feats_u = [tuple(t.detach().requires_grad_(True) for t in feats_u[0])]
+                    cut = cut + (feats_s + feats_u[0],)
         job = self._start_teacher(data_u_list) if (use_mt and self.overlap_teacher) else None
-        loss_dict = self.forward_source(data_s, target_s, feats_s)
-        if use_mt:
-            loss_dict.update(self.forward_unlabel(data_u_list, feats_u, job))
         self.scheduler.step()
-        losses_dict = self.weight_sum_loss(loss_dict, iteration)
-        losses = sum(v for v in losses_dict.values())
-        self.optimizer.zero_grad()
-        if bucketed is None:
-            losses.backward()
-            allreduce_gradients(self.flat_s)
+        if cut is not None:
+            self.optimizer.zero_grad()
+        loss_dict = self.forward_source(data_s, target_s, feats_s)
+        if cut is not None:
+            losses_dict = self.weight_sum_loss(loss_dict, iteration)
+            sum(v for v in losses_dict.values()).backward()
+            unl = self.weight_sum_loss(self.forward_unlabel(data_u_list, feats_u, job), iteration)
+            losses_dict.update(unl)
+            if unl:
+                sum(v for v in unl.values()).backward()
+            roots, leaves = cut
+            pairs = [(r, l.grad) for r, l in zip(roots, leaves) if l.grad is not None]
+            if bucketed is None:
+                torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
+                allreduce_gradients(self.flat_s)
+            else:
+                try:
+                    torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
+                finally:
+                    bucketed.finish()
         else:
-            try:
+            if use_mt:
+                loss_dict.update(self.forward_unlabel(data_u_list, feats_u, job))
+            losses_dict = self.weight_sum_loss(loss_dict, iteration)
+            losses = sum(v for v in losses_dict.values())
+            self.optimizer.zero_grad()
+            if bucketed is None:
                 losses.backward()
-            finally:
-                bucketed.finish()
+                allreduce_gradients(self.flat_s)
+            else:
+                try:
+                    losses.backward()
+                finally:
+                    bucketed.finish()
         self.optimizer.step()
         if self.lambda_value > 0 and iteration > (self.start_mt - 10):
             self.update_teacher(iteration - (self.start_mt - 10))
