@@ -309,6 +309,9 @@ class MTtrainer(object):
     def forward_unlabel(self, data_u_list, features=None, job=None):
         """MTtrainer.py:247-275 (N_STEP_UNLABEL = 1)"""
         student = [s.to(self.device) for s in data_u_list[-self.student_bs:]]
+        emb = None
+        if job is not None and features is not None and self.cfg.MT.FG_HINT:
+            emb = self.student.get_emb_feature(features)  # independent of the teacher: queued before the wait
         try:
             if job is not None:
                 job["thread"].join()
@@ -325,7 +328,7 @@ class MTtrainer(object):
         except ValueError as e:  # no pseudo boxes for an image: the reference skips the pair (bare except)
             self.logger.info("teacher produced no boxes (%s), skip this pair", e)
             return {}
-        return self.student.forward_student(student, teacher_results, features=features)
+        return self.student.forward_student(student, teacher_results, features=features, embeddings=emb)
 
     def update_teacher(self, it):
         """MTtrainer.py:277-281 as one launch over the flat parameter buffers"""

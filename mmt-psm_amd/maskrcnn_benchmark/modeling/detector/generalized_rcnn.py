@@ -151,12 +151,15 @@ class GeneralizedRCNN(nn.Module):
         return {"result_t": result, "class_logit_t": class_logits, "embedding": embeddings, "seg_mask": integral,
                 "ffi_boxes": ffi_boxes}
 
-    def forward_student(self, images, result_t, features=None):
+    def forward_student(self, images, result_t, features=None, embeddings=None):
+        """`embeddings`: the student's hint-adaptor outputs when the caller already computed them (they do not depend on
+        the teacher, so the trainer launches them before it waits for the teacher)"""
         images = [to_image_list(im) for im in images] if isinstance(images, list) else [to_image_list(images)]
         feat_list = features if features is not None else self.extract_aug_feat(images, teacher=False)
         loss_dict = {}
         if self.cfg.MT.FG_HINT:
-            loss_dict.update(mt_fg_loss=self.get_fg_feature_loss(feat_list, result_t["seg_mask"], result_t["embedding"]))
+            emb = embeddings if embeddings is not None else self.get_emb_feature(feat_list)
+            loss_dict.update(mt_fg_loss=fg_hint_loss(result_t["embedding"], emb, result_t["seg_mask"]))
         if self.cfg.MT.CLS_LOSS:
             loss_dict.update(self.box_heads.forward_student(feat_list, result_t["result_t"], result_t["class_logit_t"]))
         return loss_dict
