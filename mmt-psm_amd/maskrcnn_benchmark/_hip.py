@@ -104,7 +104,13 @@ def _check(code, what):
         raise RuntimeError("%s failed with code %d" % (what, code))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """raw hipStream_t of torch's current stream on the current device (per thread: the teacher thread has its own)"""
+    if _raw_stream is not None:  # one C call instead of building a torch.cuda.Stream object (~9 us, ~230 calls per step)
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
