@@ -165,6 +165,7 @@ class MTtrainer(object):
         # glue, and vice versa.  MMT_OVERLAP_TEACHER=0 restores the serial order.
         self.overlap_teacher = os.environ.get("MMT_OVERLAP_TEACHER", "1") != "0" and self.device.type == "cuda"
         self.early_sup_backward = os.environ.get("MMT_EARLY_SUP_BACKWARD", "1") != "0"
+        self.student_passes = os.environ.get("MMT_STUDENT_PASSES", "split")  # "split" | "batched"
         # priority -1: HIP maps streams of one priority onto a few hardware queues round-robin; once RCCL has created its own
         # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
         # main stream and the overlap silently disappears (measured: 63.7 vs 59.9 ms/step).  A different priority class
@@ -179,13 +180,21 @@ class MTtrainer(object):
         if bucketed is not None:
             bucketed.install()  # the stage hooks are registered by the forward passes below
         feats_s = feats_u = None
-        cut = None
+        early, cut = False, None
         if use_mt and self.student_bs == 1:
-            # one student backbone pass over [labeled crops ; unlabeled student view] (same per-image arithmetic,
-            # larger GEMMs forward and backward); the two forwards below consume their slice of the pyramid
             xs = data_s.tensors.to(self.device)
             xu = data_u_list[-1].tensors.to(self.device)
-            if xs.shape[1:] == xu.shape[1:]:
+            if self.student_passes == "split":
+                # Two student backbone passes, labeled crops and unlabeled view.  The supervised branch then runs its WHOLE
+                # backward (heads, FPN, backbone) while this thread would otherwise only wait for the teacher -- the teacher is
+                # the critical path of the forward and its launch-bound stretches leave the GPU room -- and only the
+                # consistency branch is left for after the teacher.  (Batching the two passes makes larger GEMMs but keeps
+                # the backbone backward behind the teacher: 50.0 vs 51.8 ms/step.)
+                feats_s = tuple(self.student.backbone(xs))
+                feats_u = [tuple(self.student.backbone(xu))]
+                early = True
+            elif xs.shape[1:] == xu.shape[1:]:
+                # one pass over [labeled crops ; unlabeled student view]; the two forwards consume their slice of the pyramid
                 from maskrcnn_benchmark.layers import fused
                 pyr = self.student.backbone(torch.cat([xs, xu], 0))
                 n = xs.shape[0]
@@ -193,49 +202,40 @@ class MTtrainer(object):
                 feats_s = tuple(p[0] for p in parts)
                 feats_u = [tuple(p[1] for p in parts)]
                 if self.early_sup_backward:
-                    # Cut the graph at the pyramid: the supervised heads run their backward as soon as their losses exist
-                    # -- while this thread would otherwise only wait for the teacher -- and the consistency heads after
-                    # theirs; the backbone + FPN then run backward ONCE on the two slices' gradients together.
-                    cut = (feats_s + feats_u[0],)
+                    # graph cut at the pyramid: the heads run backward per branch (the supervised ones before the teacher
+                    # is back), backbone + FPN once on the two slices' gradients together
+                    roots = feats_s + feats_u[0]
                     feats_s = tuple(t.detach().requires_grad_(True) for t in feats_s)
                     feats_u = [tuple(t.detach().requires_grad_(True) for t in feats_u[0])]
-                    cut = cut + (feats_s + feats_u[0],)
+                    cut = (roots, feats_s + feats_u[0])
+                    early = True
         job = self._start_teacher(data_u_list) if (use_mt and self.overlap_teacher) else None
         self.scheduler.step()
-        if cut is not None:
+        if early:
             self.optimizer.zero_grad()
         loss_dict = self.forward_source(data_s, target_s, feats_s)
-        if cut is not None:
-            losses_dict = self.weight_sum_loss(loss_dict, iteration)
-            sum(v for v in losses_dict.values()).backward()
-            unl = self.weight_sum_loss(self.forward_unlabel(data_u_list, feats_u, job), iteration)
-            losses_dict.update(unl)
-            if unl:
-                sum(v for v in unl.values()).backward()
-            roots, leaves = cut
-            pairs = [(r, l.grad) for r, l in zip(roots, leaves) if l.grad is not None]
-            if bucketed is None:
-                torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
-                allreduce_gradients(self.flat_s)
-            else:
-                try:
+        try:
+            if early:
+                losses_dict = self.weight_sum_loss(loss_dict, iteration)
+                sum(v for v in losses_dict.values()).backward()
+                unl = self.weight_sum_loss(self.forward_unlabel(data_u_list, feats_u, job), iteration)
+                losses_dict.update(unl)
+                if unl:
+                    sum(v for v in unl.values()).backward()
+                if cut is not None:
+                    pairs = [(r, l.grad) for r, l in zip(*cut) if l.grad is not None]
                     torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
-                finally:
-                    bucketed.finish()
-        else:
-            if use_mt:
-                loss_dict.update(self.forward_unlabel(data_u_list, feats_u, job))
-            losses_dict = self.weight_sum_loss(loss_dict, iteration)
-            losses = sum(v for v in losses_dict.values())
-            self.optimizer.zero_grad()
-            if bucketed is None:
-                losses.backward()
-                allreduce_gradients(self.flat_s)
             else:
-                try:
-                    losses.backward()
-                finally:
-                    bucketed.finish()
+                if use_mt:
+                    loss_dict.update(self.forward_unlabel(data_u_list, feats_u, job))
+                losses_dict = self.weight_sum_loss(loss_dict, iteration)
+                self.optimizer.zero_grad()
+                sum(v for v in losses_dict.values()).backward()
+        finally:
+            if bucketed is not None:
+                bucketed.finish()
+        if bucketed is None:
+            allreduce_gradients(self.flat_s)
         self.optimizer.step()
         if self.lambda_value > 0 and iteration > (self.start_mt - 10):
             self.update_teacher(iteration - (self.start_mt - 10))
