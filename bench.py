@@ -214,6 +214,17 @@ def main():
     for i in range(args.warmup):
         step(i)
     dt, prof, losses = timed(args.warmup, args.steps)
+    single = None
+    if world == 1 and trainer.overlap_teacher and not os.environ.get("MMT_BENCH_NO_FP32_LEG"):
+        # the same launches with the teacher on the main stream: kernel durations without a second stream sharing the GPU
+        trainer.overlap_teacher = False
+        step(args.warmup + args.steps)
+        n1 = max(2, args.steps // 2)
+        dt1, prof1, _ = timed(args.warmup + args.steps + 1, n1)
+        fl1, ms1 = sum(p[0] for p in prof1), sum(p[1].elapsed_time(p[2]) for p in prof1)
+        trainer.overlap_teacher = True
+        if ms1 > 0:
+            single = {"ms_per_step": round(dt1 / n1 * 1e3, 3), "steps": n1, "achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2)}
     ref_fp32 = None
     if mode != 0 and world == 1 and not os.environ.get("MMT_BENCH_NO_FP32_LEG"):
         # the same workload on the fp32-input MFMA kernels (mode 0), reported next to the headline number
@@ -257,6 +268,11 @@ def main():
             "roofline": roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, args),
         }
         out["config"]["conv_arithmetic"] = ARITH[mode]
+        if single is not None:
+            # `achieved` above is bracketed on the launch stream while the teacher's stream shares the GPU; this is the same
+            # kernel, same shapes, in a single-stream run of the same step (MMT_OVERLAP_TEACHER=0)
+            single["frac"] = round(single["achieved"] / out["roofline"]["peak"], 4)
+            out["roofline"]["single_stream"] = single
         if ref_fp32 is not None:
             out["fp32_mfma_mode"] = ref_fp32
         if world == 1 and not args.no_cpu_baseline:
