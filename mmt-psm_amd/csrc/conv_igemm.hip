@@ -24,6 +24,8 @@
 // 32 KiB of operand traffic (mostly L2 hits: neighbouring pixels/taps) => ~32 FLOP/B >> the 26 FLOP/B
 // ridge of HBM, so the algorithmic HBM traffic is input + weights + output once.
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include "common.h"
 
@@ -46,23 +48,28 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p;
 // tile row = 512 B), and the (img,ho,wo) decode is per row instead of per element.  Matters for the low-K 1x1
 // layers, which are store-bound: their whole runtime is this epilogue.
 template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)], float* lds,
-                                              const int m0, const int n0, const int tid, const int lane,
-                                              const int wm, const int wn, const int HoWo) {
+__device__ __forceinline__ void conv_epilogue_stage(f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)], float* lds,
+                                                    const int lane, const int wm, const int wn) {
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  float* ct = lds;  // [BM][BN]
+  const int col_l = lane & 31, rq = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+        ct[row * BN + (wn * TN + b) * 32 + col_l] = acc[a][b][r];
+      }
+}
+
+// second half of the epilogue: the [BM][BN] tile in LDS (complete, synchronised) -> scale/shift, residual, ReLU, ... -> y
+template <int BM, int BN>
+__device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds, const int m0, const int n0, const int tid,
+                                                     const int HoWo) {
   {
     float* ct = lds;  // [BM][BN]
-    const int col_l = lane & 31, rq = lane >> 5;
-#pragma unroll
-    for (int a = 0; a < TM; a++)
-#pragma unroll
-      for (int b = 0; b < TN; b++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-          ct[row * BN + (wn * TN + b) * 32 + col_l] = acc[a][b][r];
-        }
-    __syncthreads();
     constexpr int C4 = BN / 4, RPP = 256 / C4;
     const int cc = tid % C4, r0 = tid / C4;
     const int c = n0 + cc * 4;
@@ -144,6 +151,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
       }
     }
   }
+}
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)], float* lds,
+                                              const int m0, const int n0, const int tid, const int lane,
+                                              const int wm, const int wn, const int HoWo) {
+  conv_epilogue_stage<BM, BN, WM, WN>(acc, lds, lane, wm, wn);
+  __syncthreads();
+  conv_epilogue_finish<BM, BN>(p, lds, m0, n0, tid, HoWo);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -522,7 +538,8 @@ __device__ __forceinline__ void dma16(const void* g, void* l) {
 
 template <int BM, int BN, int WM, int WN, int NS, int S>
 __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, const unsigned short* __restrict__ wpl,
-                                                               const long wpl_stride) {
+                                                               const long wpl_stride, const int ksplit,
+                                                               float* __restrict__ ws) {
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int A_BYTES = BM * 64;           // [BM][16] fp32
   constexpr int PB = BN * 32;                // one bf16 plane [BN][16]
@@ -543,9 +560,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
   const int tiles_n = (p.Cout + BN - 1) / BN;
   int bid = blockIdx.x;
   {
-    const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int nwg = tiles_m * tiles_n * ksplit, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // split-K (few tiles, long K: the deep 3x3 layers at small batch, fc6): the ksplit blocks of a tile are neighbours
+  const int ks = bid % ksplit;
+  bid /= ksplit;
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int HoWo = p.Ho * p.Wo;
@@ -589,14 +609,24 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
   // itself the compiler issues the staging code in one burst and chains MFMAs on the same accumulator).  Measured on
   // this part: vector-ALU work hardly ever co-executes with an MFMA of the OTHER wave of the SIMD (SQ_VALU_MFMA_COEXEC
   // 7 % of MFMA-busy), so hiding it in the MFMA shadow of the same wave is what counts.
-  int s_kh = 0, s_kw = 0, s_ci = 0;   // tap / channel position of the next A chunk to fetch
+  const int nkt_all = p.K >> 4;
+  const int kt0 = (int)((long)ks * nkt_all / ksplit), nkt = (int)((long)(ks + 1) * nkt_all / ksplit) - kt0;
+  int s_kh, s_kw, s_ci;   // tap / channel position of the next A chunk to fetch (this block's K range starts at step kt0)
+  {
+    const int k0 = kt0 * 16, tap0 = k0 / p.Cin;
+    s_ci = k0 - tap0 * p.Cin;
+    s_kh = tap0 / p.KW;
+    s_kw = tap0 - s_kh * p.KW;
+  }
+  bool fresh = true;  // a K range may start in the middle of a tap
   int c_kh = 0, c_kw = 0, c_ci = 0;   // ... latched for the DMAs of this step
   unsigned roff[NIA];  // element offset of (row, current tap, channel 0 + this lane's chunk); valid flag
   bool rok[NIA];
   const float* const zsrc = g_zero16;
   auto tap_next = [&]() {
     c_kh = s_kh; c_kw = s_kw; c_ci = s_ci;
-    if (c_ci == 0) {  // first chunk of a tap (once per Cin/16 steps): bounds and row offsets for the whole tap
+    if (c_ci == 0 || fresh) {  // first chunk of a tap (once per Cin/16 steps): bounds and row offsets for the whole tap
+      fresh = false;
 #pragma unroll
       for (int i = 0; i < NIA; i++) {
         const int ih = aih0[i] + c_kh, iw = aiw0[i] + c_kw;
@@ -613,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
     dma16(src, ring + stage * STAGE + (wave + 4 * i) * 1024);
   };
   auto dma_b = [&](int i, int kt, int stage) {
-    const void* src = filling ? (const void*)(bsrc[i] + (long)kt * kt_stride) : (const void*)zsrc;
+    const void* src = filling ? (const void*)(bsrc[i] + (long)(kt0 + kt) * kt_stride) : (const void*)zsrc;
     dma16(src, ring + stage * STAGE + bdst[i]);
   };
   auto issue_all = [&](int kt, int stage) {  // prologue form
@@ -643,7 +673,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-  const int nkt = p.K >> 4;
   f32x4 va[TM][2];        // raw fp32 A fragment halves of the next step; turned into residuals by the split levels
   unsigned ua[TM][2][2];  // packed bf16 pairs of the level being produced
   uint2 oa[TM][2][NS];    // bf16 terms of the A fragment halves
@@ -757,7 +786,47 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the tail steps must land before LDS is reused
   __syncthreads();
-  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tid, lane, wm, wn, HoWo);
+  if (ksplit == 1) {
+    conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tid, lane, wm, wn, HoWo);
+    return;
+  }
+  // split-K: every block parks its partial tile in the workspace; conv_splitk_finish_kernel (next launch on the stream) adds
+  // the partials in the fixed order 0..ksplit-1 and runs the epilogue.  (A single-launch form -- last block to arrive at a
+  // per-tile counter finishes -- needs device-scope fences, which on this part write back the XCD's L2: 0.14 vs 0.08 ms.)
+  conv_epilogue_stage<BM, BN, WM, WN>(acc, lds, lane, wm, wn);
+  __syncthreads();
+  constexpr int TILE4 = BM * BN / 4;
+  f32x4* slab = (f32x4*)ws + ((long)bid * ksplit + ks) * TILE4;
+  const f32x4* ct4 = (const f32x4*)lds;
+  for (int i = tid; i < TILE4; i += 256) slab[i] = ct4[i];
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p, const int ksplit, const float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  const int bid = blockIdx.x;
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  constexpr int TILE4 = BM * BN / 4, U = 4;
+  static_assert(TILE4 % (256 * U) == 0, "tile size");
+  const f32x4* base = (const f32x4*)ws + (long)bid * ksplit * TILE4;
+  for (int i0 = tid; i0 < TILE4; i0 += 256 * U) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = base[i0 + u * 256];
+    for (int j = 1; j < ksplit; j++) {
+      f32x4 t[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) t[u] = base[(long)j * TILE4 + i0 + u * 256];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] += t[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) ((f32x4*)lds)[i0 + u * 256] = v[u];
+  }
+  __syncthreads();
+  conv_epilogue_finish<BM, BN>(p, lds, tile_m * BM, tile_n * BN, tid, p.Ho * p.Wo);
 }
 
 // Weight packing for the DMA-fed kernels.  For a weight matrix [Cout][K] (K % 16 == 0) plane q of the packed form is
@@ -765,6 +834,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
 // where (row r, physical half h) holds the q-th bf16 term of w[32 blk + r][16 step + 8 (h ^ ((r>>3)&1)) + 0..7]
 // (zeros for rows >= Cout).  One wave produces one 1 KiB unit of each plane: lane = (row, half).
 struct PackDesc { long src_off, dst_off; int Cout, K, unit0, pad; };
+
 // ------------------------------------------------------------------------- 1x1 convolutions with K = 64 / 128
 // The expanding 1x1 layers of layer1 / layer2 (64 -> 256, 128 -> 512: output + residual dominate, 2-6 FLOP/B) are not
 // matrix-bound and not HBM-bound in the tiled kernel above but INSTRUCTION-bound: a block owns one 128 x 64 tile with
@@ -1760,9 +1830,46 @@ int launch_split(const ConvP& p, hipStream_t s) {
   return 0;
 }
 
+// split-K workspace (partial tiles), one per stream: kernels of a stream run in order and
+// may share it; the teacher's and the student's streams launch concurrently (from two host threads) and may not
+struct SplitWs { float* ws; };
+constexpr size_t SPLITK_WS_BYTES = (size_t)1024 * 128 * 128 * 4;  // 1024 partial tiles of 128 x 128 (64 MiB)
+static SplitWs split_workspace(hipStream_t s) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SplitWs> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return SplitWs{nullptr};
+  std::lock_guard<std::mutex> g(mu);
+  auto it = table.find({dev, s});
+  if (it != table.end()) return it->second;
+  SplitWs w{nullptr};
+  if (hipMalloc((void**)&w.ws, SPLITK_WS_BYTES) != hipSuccess) return SplitWs{nullptr};
+  table[{dev, s}] = w;
+  return w;
+}
+
+// number of K ranges for the 128 x 128 kernel: fill the 512 resident block slots when the tiles alone do not, keeping
+// at least 32 steps per range
+static int pick_ksplit(const ConvP& p) {
+  static const int on = getenv("MMT_SPLITK") ? atoi(getenv("MMT_SPLITK")) : 1;
+  if (!on || p.Cout < 128) return 1;
+  const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
+  const int nkt = p.K >> 4;
+  if (t128 >= 256 || nkt < 128) return 1;  // K >= 2048: shorter sums lose more in the second launch than they gain
+  int ks = (int)(512 / t128);
+  if (ks > nkt / 32) ks = nkt / 32;
+  if (ks > 16) ks = 16;
+  return ks < 2 ? 1 : ks;
+}
+
 template <int BM, int BN, int WM, int WN, int NS, int S>
-int launch_glds(const ConvP& p, hipStream_t s) {
-  const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN);
+int launch_glds(const ConvP& p, hipStream_t s, int ksplit = 1) {
+  const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN) * ksplit;
+  SplitWs w{nullptr};
+  if (ksplit > 1) {
+    w = split_workspace(s);
+    if (!w.ws || tiles > 1024) return MMT_EINVAL;
+  }
   const size_t ring = (size_t)S * (BM * 64 + NS * BN * 32), epi = (size_t)BM * BN * sizeof(float);
   const size_t lds = ring > epi ? ring : epi;
   auto kern = conv_fwd_glds_kernel<BM, BN, WM, WN, NS, S>;
@@ -1774,8 +1881,19 @@ int launch_glds(const ConvP& p, hipStream_t s) {
       done = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, p, p.wpl, p.wpl_stride);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, p, p.wpl, p.wpl_stride, ksplit, w.ws);
   MMT_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    auto fin = conv_splitk_finish_kernel<BM, BN>;
+    static bool fdone = false;
+    if (epi > 65536 && !fdone) {
+      const hipError_t e = hipFuncSetAttribute((const void*)fin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)epi);
+      if (e != hipSuccess) return (int)e;
+      fdone = true;
+    }
+    hipLaunchKernelGGL(fin, dim3(tiles / ksplit), dim3(256), epi, s, p, ksplit, w.ws);
+    MMT_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -1808,6 +1926,8 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
     if (p.Cin == 64) return bn64 == 64 ? launch_rows<4, 64, NS>(p, s) : launch_rows<4, 32, NS>(p, s);
     if (p.Cin == 128) return launch_rows<8, 32, NS>(p, s);
   }
+  const int ksplit = pick_ksplit(p);
+  if (ksplit > 1) return launch_glds<128, 128, 4, 1, NS, 3>(p, s, ksplit);
   switch (variant) {
     case 1: return launch_glds<128, 128, 4, 1, NS, 3>(p, s);
     case 3: return launch_glds<128, 64, 4, 1, NS, 3>(p, s);

@@ -335,7 +335,7 @@ MODE_TOL = {0: 1e-5, 3: 1e-5, 2: 6e-5, 1: 2e-2}  # max |err| / max |ref| against
 
 @pytest.mark.parametrize("case", [(2, 64, 24, 24, 96, 3, 1, 1), (3, 128, 30, 30, 160, 1, 2, 0), (1, 48, 17, 23, 64, 3, 1, 1),
                                   (2, 256, 64, 64, 256, 3, 1, 1), (2, 16, 40, 40, 64, 1, 1, 0), (8, 32, 64, 64, 64, 1, 1, 0),
-                                  (300, 1024, 1, 1, 1024, 1, 1, 0)])
+                                  (300, 1024, 1, 1, 1024, 1, 1, 0), (2, 256, 32, 32, 256, 3, 1, 1), (200, 4096, 1, 1, 256, 1, 1, 0)])
 def test_conv_arithmetic_modes_forward(hip, restore_mode, case):
     """every arithmetic mode of mmt_conv_forward against fp64, with and without pre-packed weight planes; the 3-term
     split (default) must be as accurate as the fp32-input MFMA"""
@@ -352,7 +352,10 @@ def test_conv_arithmetic_modes_forward(hip, restore_mode, case):
         err[mode] = (y.double() - ref).abs().max().item() / scl
         assert err[mode] < MODE_TOL[mode], (mode, err[mode])
     assert err[3] <= 2.0 * err[0] + 2e-7, err
-    # tiles hanging over M and Cout, zero-filled halo, K = 16 (a single step) are all in the cases above
+    # tiles hanging over M and Cout, zero-filled halo, K = 16 (a single step) are all in the cases above; the last two
+    # (few tiles, K >= 2048) take the split-K form of the DMA kernel (partials summed in a fixed order: repeatable)
+    hip.set_conv_precision(3)
+    assert torch.equal(hip.conv_forward(x, w, sc, sh, s, p, relu=True), hip.conv_forward(x, w, sc, sh, s, p, relu=True))
 
 
 @pytest.mark.parametrize("case", [(2, 64, 24, 24, 96, 3, 1, 1), (3, 128, 30, 30, 160, 1, 2, 0), (1, 48, 17, 23, 64, 3, 1, 1),
