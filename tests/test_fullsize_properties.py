@@ -161,7 +161,9 @@ def test_teacher_batched_views_equal_unbatched(synth, weights):
             ref += [t.backbone(x), t.backbone(torch.flip(x, (3,)))]
     for a, b in zip(feats, ref):
         for la, lb in zip(a, b):
-            assert torch.equal(la, lb)
+            # same per-image arithmetic; the deep, few-tile layers pick their number of K ranges (split-K) from the tile count,
+            # so the summation ORDER may differ between the batched and the single-view pass: equal to fp32 rounding
+            assert (la - lb).abs().max().item() <= 2e-5 * lb.abs().max().item()
 
 
 def test_bucketed_allreduce_covers_every_gradient_exactly_once(monkeypatch):
