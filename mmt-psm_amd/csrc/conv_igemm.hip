@@ -1919,7 +1919,8 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
   // 1x1 / stride 1 layers with K = 64 or 128 and many rows: one block per 128 rows, all Cout panels (see the kernel)
   const char* rows_env = getenv("MMT_ROWS");  // read per call: the parity tests switch it
   const int rows = rows_env ? atoi(rows_env) : 1;
-  if (rows && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * 512 &&
+  static const int rows_min = getenv("MMT_ROWS_MIN") ? atoi(getenv("MMT_ROWS_MIN")) : 256;  // blocks of 128 rows
+  if (rows && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * rows_min &&
       (p.Cout & 3) == 0 && p.res_mode <= 1 && !p.mask && !p.mul && p.out_stride == 1 &&
       (long)p.M * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31)) {
     static const int bn64 = getenv("MMT_ROWS_BN") ? atoi(getenv("MMT_ROWS_BN")) : 32;

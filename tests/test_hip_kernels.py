@@ -385,7 +385,7 @@ def test_conv_arithmetic_modes_wgrad(hip, restore_mode, case):
     assert err[3] <= 2.0 * err[0] + 2e-7, err
 
 
-@pytest.mark.parametrize("case", [(4, 64, 128, 128, 256), (1, 64, 257, 259, 96), (1, 128, 300, 300, 200), (2, 128, 192, 192, 512)])
+@pytest.mark.parametrize("case", [(4, 64, 128, 128, 256), (1, 64, 257, 259, 96), (1, 128, 300, 300, 200), (2, 128, 192, 192, 512), (2, 128, 128, 128, 512)])
 @pytest.mark.parametrize("residual", [False, True])
 def test_conv1x1_rows_kernel(hip, restore_mode, case, residual):
     """1x1 layers with K = 64 / 128 and >= 64k rows run on conv1x1_rows_kernel (one block per 128 rows, all Cout
