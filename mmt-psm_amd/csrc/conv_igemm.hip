@@ -1855,7 +1855,9 @@ static int pick_ksplit(const ConvP& p) {
   if (!on || p.Cout < 128) return 1;
   const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
   const int nkt = p.K >> 4;
-  if (t128 >= 256 || nkt < 128) return 1;  // K >= 2048: shorter sums lose more in the second launch than they gain
+  static const int tmax = getenv("MMT_SPLITK_T") ? atoi(getenv("MMT_SPLITK_T")) : 256;
+  static const int kmin = getenv("MMT_SPLITK_NKT") ? atoi(getenv("MMT_SPLITK_NKT")) : 128;
+  if (t128 >= tmax || nkt < kmin) return 1;  // K >= 2048: shorter sums lose more in the second launch than they gain
   int ks = (int)(512 / t128);
   if (ks > nkt / 32) ks = nkt / 32;
   if (ks > 16) ks = 16;
