@@ -801,17 +801,20 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
   for (int i = tid; i < TILE4; i += 256) slab[i] = ct4[i];
 }
 
+// one block per QUARTER tile (BM / 4 rows): four times the blocks of the main launch's tile count, or this small kernel is a
+// latency chain on a few dozen blocks
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p, const int ksplit, const float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int QM = BM / 4;
   const int tid = threadIdx.x;
   const int tiles_n = (p.Cout + BN - 1) / BN;
-  const int bid = blockIdx.x;
+  const int bid = blockIdx.x >> 2, part = blockIdx.x & 3;
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-  constexpr int TILE4 = BM * BN / 4, U = 4;
-  static_assert(TILE4 % (256 * U) == 0, "tile size");
-  const f32x4* base = (const f32x4*)ws + (long)bid * ksplit * TILE4;
-  for (int i0 = tid; i0 < TILE4; i0 += 256 * U) {
+  constexpr int TILE4 = BM * BN / 4, PART4 = QM * BN / 4, U = 4;
+  static_assert(PART4 % (256 * U) == 0, "tile size");
+  const f32x4* base = (const f32x4*)ws + (long)bid * ksplit * TILE4 + part * PART4;
+  for (int i0 = tid; i0 < PART4; i0 += 256 * U) {
     f32x4 v[U];
 #pragma unroll
     for (int u = 0; u < U; u++) v[u] = base[i0 + u * 256];
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p, 
     for (int u = 0; u < U; u++) ((f32x4*)lds)[i0 + u * 256] = v[u];
   }
   __syncthreads();
-  conv_epilogue_finish<BM, BN>(p, lds, tile_m * BM, tile_n * BN, tid, p.Ho * p.Wo);
+  conv_epilogue_finish<QM, BN>(p, lds, tile_m * BM + part * QM, tile_n * BN, tid, p.Ho * p.Wo);
 }
 
 // Weight packing for the DMA-fed kernels.  For a weight matrix [Cout][K] (K % 16 == 0) plane q of the packed form is
@@ -1855,7 +1858,7 @@ static int pick_ksplit(const ConvP& p) {
   if (!on || p.Cout < 128) return 1;
   const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
   const int nkt = p.K >> 4;
-  static const int tmax = getenv("MMT_SPLITK_T") ? atoi(getenv("MMT_SPLITK_T")) : 256;
+  static const int tmax = getenv("MMT_SPLITK_T") ? atoi(getenv("MMT_SPLITK_T")) : 512;
   static const int kmin = getenv("MMT_SPLITK_NKT") ? atoi(getenv("MMT_SPLITK_NKT")) : 128;
   if (t128 >= tmax || nkt < kmin) return 1;  // K >= 2048: shorter sums lose more in the second launch than they gain
   int ks = (int)(512 / t128);
@@ -1886,14 +1889,10 @@ int launch_glds(const ConvP& p, hipStream_t s, int ksplit = 1) {
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, p, p.wpl, p.wpl_stride, ksplit, w.ws);
   MMT_LAUNCH_CHECK();
   if (ksplit > 1) {
-    auto fin = conv_splitk_finish_kernel<BM, BN>;
-    static bool fdone = false;
-    if (epi > 65536 && !fdone) {
-      const hipError_t e = hipFuncSetAttribute((const void*)fin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)epi);
-      if (e != hipSuccess) return (int)e;
-      fdone = true;
-    }
-    hipLaunchKernelGGL(fin, dim3(tiles / ksplit), dim3(256), epi, s, p, ksplit, w.ws);
+    if constexpr (BM == 128 && BN == 128)
+      hipLaunchKernelGGL((conv_splitk_finish_kernel<BM, BN>), dim3(tiles / ksplit * 4), dim3(256), epi / 4, s, p, ksplit, w.ws);
+    else
+      return MMT_EINVAL;
     MMT_LAUNCH_CHECK();
   }
   return 0;
