@@ -369,10 +369,27 @@ def pack_weight_flipped(w, scale=None):
     if get_conv_precision() == 0 or (Cout & 15) or Cin <= 32:
         return None
     w = nhwc(w)
+    # A weight is used by several backward passes between two optimiser steps (labeled and unlabeled student pass, the RPN
+    # head on five levels): packed once per parameter generation of its flat buffer (engine/flat.py: refresh_planes).
+    ptr, key = w.data_ptr(), None
+    ent = PLANES.get(ptr)
+    if ent is not None:
+        flat = ent[0]()
+        if (flat is not None and ent[2] == w.numel() and flat.plane_versions.get(ptr) == w._version
+                and flat.plane_epoch >= PLANES_EPOCH):
+            key = (id(flat), flat.plane_gen, _p(scale), None if scale is None else scale._version)
+            hit = FLIPPED.get(ptr)
+            if hit is not None and hit[0] == key:
+                return hit[1]
     planes = torch.empty((3, packed_elems(Cin, KH * KW * Cout)), dtype=torch.bfloat16, device=w.device)
     _check(lib().mmt_pack_weight_flipped(w.data_ptr(), _p(scale), planes.data_ptr(), planes.stride(0), Cout, KH, KW, Cin,
                                          _stream()), "mmt_pack_weight_flipped")
+    if key is not None:
+        FLIPPED[ptr] = (key, planes)
     return planes
+
+
+FLIPPED = {}  # weight address -> ((flat id, generation, scale address, scale version), packed data-gradient planes)
 
 
 def pack_weights(base, planes, descs, unit_desc, n_units):

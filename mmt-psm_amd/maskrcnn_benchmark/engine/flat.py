@@ -49,6 +49,7 @@ class FlatParams(object):
         self.planes = None
         self.plane_versions = {}
         self.plane_epoch = -1
+        self.plane_gen = 0
         self._named = named
         self.refresh_planes()
 
@@ -58,6 +59,7 @@ class FlatParams(object):
         after everything that rewrites parameters through raw pointers (SGD, EMA, teacher initialisation).
         Convolutions look their weight up by address in _hip.PLANES."""
         from .. import _hip as H
+        self.plane_gen += 1  # the parameters changed: anything derived from them (H.FLIPPED) is stale
         if not self.data.is_cuda or H.get_conv_precision() == 0:
             return
         if self.planes is None:

@@ -459,6 +459,29 @@ def test_packed_weight_planes_bookkeeping(hip, restore_mode):
     assert close(fwd())
     flat.refresh_planes()
     assert close(fwd())
+    # (d) the data-gradient planes are cached per parameter generation (H.FLIPPED): reused inside a generation, rebuilt
+    # after the parameters moved
+    h = cl(torch.randn(2, 64, 20, 20))
+
+    def dgrad():
+        xx = h.clone().requires_grad_(True)
+        m[1](xx).sum().backward()
+        return xx.grad
+
+    def dgrad_ref():
+        xx = h.double().clone().requires_grad_(True)
+        F.conv2d(xx, m[1].weight.double(), m[1].bias.double()).sum().backward()
+        return xx.grad
+
+    g1 = dgrad()
+    key1 = hip.FLIPPED[m[1].weight.data_ptr()][0]
+    g2 = dgrad()
+    assert hip.FLIPPED[m[1].weight.data_ptr()][0] == key1 and torch.equal(g1, g2)
+    flat.data.mul_(0.5)
+    flat.refresh_planes()
+    g3, r3 = dgrad(), dgrad_ref()
+    assert hip.FLIPPED[m[1].weight.data_ptr()][0] != key1
+    assert (g3.double() - r3).abs().max().item() < 1e-5 * r3.abs().max().item()
 
 
 # ------------------------------------------------------------------------------------------ target assignment
