@@ -267,6 +267,14 @@ def main():
                        "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}},
             "roofline": roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, args),
         }
+        # the launches of that kernel with an un-split K (the large FPN / layer1-2 shapes); the others are the few-tile,
+        # long-K layers, whose bracketed duration also contains their small finish launch
+        uns = [q for q in prof if len(q) < 5 or q[4] <= 1]
+        if uns and len(uns) < len(prof):
+            fu, mu = sum(q[0] for q in uns), sum(q[1].elapsed_time(q[2]) for q in uns)
+            out["roofline"]["unsplit_k_launches"] = {
+                "launches_per_step": len(uns) // max(args.steps, 1), "achieved": round(fu / (mu * 1e-3) / 1e12, 2),
+                "frac": round(fu / (mu * 1e-3) / 1e12 / out["roofline"]["peak"], 4), "avg_launch_ms": round(mu / len(uns), 4)}
         out["config"]["conv_arithmetic"] = ARITH[mode]
         if single is not None:
             # `achieved` above is bracketed on the launch stream while the teacher's stream shares the GPU; this is the same

@@ -132,6 +132,9 @@ int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
 /* which tile configuration mmt_conv_forward picks for these shapes: 0 = 128x32, 1 = 128x128 (the dominant
  * kernel of the step, conv_fwd_kernel<128,128,2,2>), 2 = 64x64.  Used by bench.py for the roofline line. */
 int mmt_conv_variant(const mmt_conv_args* a /*[host]*/);
+/* number of K ranges mmt_conv_forward would use for this call on the DMA-fed kernel (1 = un-split; > 1: partial tiles go
+ * through the library's per-stream workspace and a finish launch).  Tuning / measurement aid like mmt_conv_variant. */
+int mmt_conv_ksplit(const mmt_conv_args* a /*[host]*/);
 /* arithmetic of the convolution GEMMs -- forward, data gradient and weight gradient (process-wide; initial value from
  * the environment variable MMT_CONV_PRECISION, default 3):
  *   3  fp32 operands split on the fly into three bf16 terms x = x0 + x1 + x2 (round-to-nearest at each level, exact to

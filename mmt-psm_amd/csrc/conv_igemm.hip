@@ -2030,7 +2030,18 @@ extern "C" int mmt_conv_variant(const mmt_conv_args* a) {
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
-  return pick_variant(p);
+  const int v = pick_variant(p);
+  // the split-K form runs on the 128 x 128 kernel whatever the tile variant would have been
+  if (v != 0 && precision() > 0 && (p.Cin & 15) == 0 && p.wpl && pick_ksplit(p) > 1) return 1;
+  return v;
+}
+
+extern "C" int mmt_conv_ksplit(const mmt_conv_args* a) {
+  ConvP p;
+  int e = fill(p, a);
+  if (e) return e;
+  if (pick_variant(p) != 0 && precision() > 0 && (p.Cin & 15) == 0 && p.wpl) return pick_ksplit(p);
+  return 1;
 }
 
 extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {

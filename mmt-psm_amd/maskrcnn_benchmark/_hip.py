@@ -48,6 +48,7 @@ _SIGS = {
                           c_void_p],
     "mmt_conv_forward": [ctypes.POINTER(ConvArgs), c_void_p],
     "mmt_conv_variant": [ctypes.POINTER(ConvArgs)],
+    "mmt_conv_ksplit": [ctypes.POINTER(ConvArgs)],
     "mmt_set_conv_precision": [ctypes.c_int],
     "mmt_get_conv_precision": [],
     "mmt_pack_weight": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
@@ -333,7 +334,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
             e1.record()
             PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1,
-                            ("fwd%d" % var, N, H, W, Cin, Cout, KH, stride, out_stride)))
+                            ("fwd%d" % var, N, H, W, Cin, Cout, KH, stride, out_stride),
+                            lib().mmt_conv_ksplit(ctypes.byref(a))))
             return y
     _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
     return y

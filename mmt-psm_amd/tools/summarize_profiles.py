@@ -55,11 +55,19 @@ for mode in (3, 0):
     tb = (2.0 * fkb + wkb) * 1024
     traffic["by_mode"][str(mode)] = {"kernel": DOM[mode], "dispatches": int(fe["dispatches"]), "fetch_size_kb_per_launch": fkb,
                                      "write_size_kb_per_launch": wkb, "traffic_bytes_per_launch": tb}
+    fin = [r for r in rows if "conv_splitk_finish_kernel" in r["Name"]]
+    fin_note = ""
+    if fin:
+        fin_note = (" (the event brackets of its %s split-K launches also contain their `conv_splitk_finish_kernel`, %.1f us each: "
+                    "+%.1f us on the average)" % (fin[0]["Calls"], float(fin[0]["AverageNs"]) / 1e3,
+                                                  float(fin[0]["TotalDurationNs"]) / 1e3 / int(dom["Calls"])))
     out += ["", "Dominant kernel `%s`: rocprof average %.1f us per launch vs %.1f us measured live by bench.py with events on the "
-            "launch stream (same command). PMC per launch (%s dispatches): FETCH_SIZE %.0f KB (x2 gfx950 correction = %.1f MB), "
-            "WRITE_SIZE %.0f KB -> traffic %.1f MB vs %.1f MB algorithmic (input + weights + output once)." % (
+            "launch stream (same command)" + fin_note + ". PMC per launch (%s dispatches): FETCH_SIZE %.0f KB (x2 gfx950 correction = %.1f MB), "
+            "WRITE_SIZE %.0f KB -> traffic %.1f MB vs %.1f MB algorithmic (input + weights + output once)."]
+    out[-1] = out[-1] % (
                 DOM[mode], float(dom["AverageNs"]) / 1e3, b["roofline"]["avg_launch_ms"] * 1e3, fe["dispatches"], fkb,
-                2 * fkb * 1024 / 1e6, wkb, tb / 1e6, b["roofline"]["algorithmic_bytes_per_launch"] / 1e6), ""]
+                2 * fkb * 1024 / 1e6, wkb, tb / 1e6, b["roofline"]["algorithmic_bytes_per_launch"] / 1e6)
+    out.append("")
 traffic["traffic_bytes_per_launch"] = traffic["by_mode"]["0"]["traffic_bytes_per_launch"]
 json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 hist = open(os.path.join(DST, "r01_history.md")).read() if os.path.exists(os.path.join(DST, "r01_history.md")) else ""
