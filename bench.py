@@ -34,7 +34,7 @@ CROP = 1000
 N_LAB, N_UNLAB, N_INST = 2, 2, 12
 
 
-def build(device, rank, irnet=False):
+def build(device, rank, irnet=False, crop=None, n_inst=None):
     import synthetic
     from maskrcnn_benchmark.config import make_default_cfg
     from maskrcnn_benchmark.modeling.detector import build_detection_model
@@ -75,8 +75,10 @@ def build(device, rank, irnet=False):
     trainer = MTtrainer(student, teacher, loaders, opt, sched, None, None, 10 ** 9, cfg)
     init_teacher_weight(student, teacher)
 
-    imgs, tgs = synthetic.make_labeled(N_LAB, CROP, N_INST, seed=1234 + rank)
-    unl = synthetic.make_unlabeled(N_UNLAB, CROP, cfg.MT.AUG_K + cfg.MT.AUG_S, seed=4321 + rank)
+    crop = CROP if crop is None else crop      # tests build the same trainer on small crops
+    n_inst = N_INST if n_inst is None else n_inst
+    imgs, tgs = synthetic.make_labeled(N_LAB, crop, n_inst, seed=1234 + rank)
+    unl = synthetic.make_unlabeled(N_UNLAB, crop, cfg.MT.AUG_K + cfg.MT.AUG_S, seed=4321 + rank)
     targets = []
     for t in tgs:
         b = BoxList(t["boxes"].to(device), t["size"], "xyxy")

@@ -1859,8 +1859,8 @@ static SplitWs split_workspace(hipStream_t s) {
 // number of K ranges for the 128 x 128 kernel: fill the 512 resident block slots when the tiles alone do not, keeping
 // at least 32 steps per range
 static int pick_ksplit(const ConvP& p) {
-  static const int on = getenv("MMT_SPLITK") ? atoi(getenv("MMT_SPLITK")) : 1;
-  if (!on || p.Cout < 128) return 1;
+  const char* on_env = getenv("MMT_SPLITK");  // read per call: the schedule-equivalence test switches it
+  if ((on_env && atoi(on_env) == 0) || p.Cout < 128) return 1;
   const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
   const int nkt = p.K >> 4;
   static const int tmax = getenv("MMT_SPLITK_T") ? atoi(getenv("MMT_SPLITK_T")) : 512;

@@ -346,6 +346,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
 #   flattened model here (one [3, total] buffer refreshed after each SGD / EMA step); anything else -- and any parameter
 #   modified in place since the last refresh (its version counter moved) -- is split per call.
 PLANES = {}
+GRAD_SLOTS = {}  # address of a parameter's slot in a flat gradient buffer -> (weakref FlatParams, parameter name); engine/flat.py
 PLANES_EPOCH = 0  # bumped by set_conv_precision: planes packed before a mode switch are not trusted afterwards (steps taken
                   # in mode 0 do not refresh them)
 

@@ -28,7 +28,7 @@ def reduce_loss_dict(loss_dict):
     if ws < 2:
         return dict(loss_dict)
     with torch.no_grad():
-        names = list(loss_dict.keys())
+        names = sorted(loss_dict.keys())  # same order on every rank
         allv = torch.stack([loss_dict[k].reshape(()) for k in names], 0)
         dist.reduce(allv, dst=0)
         if dist.get_rank() == 0:
@@ -76,11 +76,18 @@ class BucketedAllReduce(object):
     parameter order); backward runs through these pieces from the right, and a tensor hook on each stage output
     (modeling/backbone/backbone.py) says when the pieces to its right are final.  Each finished piece goes out as an
     asynchronous all-reduce that overlaps the backward of the earlier stages; whatever is left (layer2, the bias region)
-    is reduced at the end.  One scaling pass by 1/world afterwards, as in `allreduce_gradients`."""
+    is reduced at the end.  One scaling pass by 1/world afterwards, as in `allreduce_gradients`.
+
+    The sequence of collectives is the SAME on every rank whatever happened on it: always the stage pieces in the fixed
+    order layer4, layer3, layer2, layer1 (each exactly one all-reduce over the same [lo, hi)), then the fixed remainder
+    ranges in ascending order.  A piece whose hook did not fire often enough on this rank -- its teacher found no boxes
+    and the consistency branch was skipped, so the second backbone pass was never back-propagated -- is sent from
+    finish() as its own collective instead of being merged into a neighbour (ranks that did fire it sent exactly that)."""
 
     # a hook on the output of stage K fires when everything AFTER stage K is done
     AFTER = {"layer4": "backbone.fpn.", "layer3": "backbone.body.layer4.", "layer2": "backbone.body.layer3.",
              "layer1": "backbone.body.layer2."}
+    ORDER = ("layer4", "layer3", "layer2", "layer1")  # firing order of the hooks in a backward pass
 
     def __init__(self, flat, body):
         self.flat, self.body = flat, body
@@ -91,41 +98,56 @@ class BucketedAllReduce(object):
             if first is not None:
                 cuts[stage] = flat.index[first][0]
         # piece that becomes final when `stage` fires: [cut(stage), cut(previous firing stage) or n_weights)
-        order = [s for s in ("layer4", "layer3", "layer2", "layer1") if s in cuts]
         self.pieces, hi = {}, flat.n_weights
-        for s_ in order:
+        for s_ in (s for s in self.ORDER if s in cuts):
             lo = cuts[s_]
             if lo < hi:
                 self.pieces[s_] = (lo, hi)
             hi = min(hi, lo)
+        # what no stage piece covers (the weights before the first cut, the bias region): fixed ranges, sent last
+        self.rest, pos, n = [], 0, flat.grad.numel()
+        for lo, hi in sorted(self.pieces.values()) + [(n, n)]:
+            if pos < lo:
+                self.rest.append((pos, lo))
+            pos = max(pos, hi)
         self.reset()
 
     def reset(self):
-        self.registered, self.fired, self.done, self.works = {}, {}, [], []
+        self.registered, self.fired, self.sent, self.works = {}, {}, set(), []
 
     def install(self):
         self.reset()
         self.body.grad_ready = self._event
+
+    def _send(self, lo, hi):
+        self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def _event(self, stage, what):
         if what == "registered":
             self.registered[stage] = self.registered.get(stage, 0) + 1
             return
         self.fired[stage] = self.fired.get(stage, 0) + 1
-        # several backbone passes in one step (unbatched fallback): wait for the last one
-        if stage in self.pieces and self.fired[stage] == self.registered.get(stage, 0):
-            lo, hi = self.pieces[stage]
-            self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
-            self.done.append((lo, hi))
+        # several backbone passes in one step: the piece is final when the LAST registered pass has fired
+        if stage in self.pieces and stage not in self.sent and self.fired[stage] == self.registered.get(stage, 0):
+            # earlier pieces of the fixed order that this rank never completed go first, so the order stays the same
+            for s_ in self.ORDER:
+                if s_ == stage:
+                    break
+                if s_ in self.pieces and s_ not in self.sent:
+                    self._send(*self.pieces[s_])
+                    self.sent.add(s_)
+            self._send(*self.pieces[stage])
+            self.sent.add(stage)
 
     def finish(self):
-        """after backward: reduce what no hook covered, wait for everything, scale"""
+        """after backward: reduce what no hook covered (fixed order), wait for everything, scale"""
         self.body.grad_ready = None
-        n, pos = self.flat.grad.numel(), 0
-        for lo, hi in sorted(self.done) + [(n, n)]:
-            if pos < lo:
-                self.works.append(dist.all_reduce(self.flat.grad[pos:lo], op=dist.ReduceOp.SUM, async_op=True))
-            pos = max(pos, hi)
+        for s_ in self.ORDER:
+            if s_ in self.pieces and s_ not in self.sent:
+                self._send(*self.pieces[s_])
+                self.sent.add(s_)
+        for lo, hi in self.rest:
+            self._send(lo, hi)
         for w in self.works:
             if w is not None:
                 w.wait()
@@ -133,6 +155,26 @@ class BucketedAllReduce(object):
         if ws > 1:
             self.flat.grad.mul_(1.0 / ws)
         self.reset()
+
+
+def teacher_checksum(flat):
+    """exact (integer) checksum of a flat parameter buffer: the sum of its words read as int32, in int64"""
+    return flat.data.view(torch.int32).to(torch.int64).sum()
+
+
+def check_teacher_identity(flat_t):
+    """the teachers are never exchanged -- they stay identical on all ranks because every rank applies the
+    same EMA to the same (all-reduced) student from the same initial weights.  Asserted here with ONE small collective:
+    max over ranks of (checksum, -checksum); equal teachers <=> max(c) == -max(-c)."""
+    if get_world_size() < 2:
+        return True
+    c = teacher_checksum(flat_t)
+    v = torch.stack([c, -c])
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    hi, neg_lo = v.tolist()
+    if hi != -neg_lo:
+        raise RuntimeError("teacher weights diverged between ranks (checksum max %d != min %d)" % (hi, -neg_lo))
+    return True
 
 
 class MTtrainer(object):
@@ -172,6 +214,23 @@ class MTtrainer(object):
         # has its own queues.
         self.t_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.overlap_teacher else None
         self._bucketed = None  # BucketedAllReduce, built lazily when enabled (see _bucketed_allreduce)
+        # One random stream per model: the teacher's forward runs in a helper thread beside the student's, and with the
+        # global generator the interleaving of their draws (fg/bg sampler keys, dropout) would depend on thread timing.
+        # With its own generator each model draws the same sequence in the overlapped and in the serial schedule.
+        self.gen_s = self.gen_t = None
+        if self.device.type == "cuda":
+            self.gen_s = torch.Generator(device=self.device)
+            self.gen_t = torch.Generator(device=self.device)
+            self.seed_rng(torch.initial_seed())
+            self.student.set_rng(self.gen_s)
+            self.teacher.set_rng(self.gen_t)
+        self.teacher_check_period = int(os.environ.get("MMT_TEACHER_CHECK_PERIOD", "100"))
+
+    def seed_rng(self, seed):
+        """re-seed the student's and the teacher's random streams (samplers, dropout)"""
+        if self.gen_s is not None:
+            self.gen_s.manual_seed(int(seed) * 2 + 1)
+            self.gen_t.manual_seed(int(seed) * 2 + 2)
 
     # ---- one iteration (the unit bench.py times)
     def train_step(self, iteration, data_s, target_s, data_u_list=None):
@@ -210,28 +269,37 @@ class MTtrainer(object):
                     cut = (roots, feats_s + feats_u[0])
                     early = True
         job = self._start_teacher(data_u_list) if (use_mt and self.overlap_teacher) else None
-        self.scheduler.step()
-        if early:
-            self.optimizer.zero_grad()
-        loss_dict = self.forward_source(data_s, target_s, feats_s)
         try:
+            self.scheduler.step()
+            if early:
+                self.optimizer.zero_grad()
+            loss_dict = self.forward_source(data_s, target_s, feats_s)
             if early:
                 losses_dict = self.weight_sum_loss(loss_dict, iteration)
                 sum(v for v in losses_dict.values()).backward()
                 unl = self.weight_sum_loss(self.forward_unlabel(data_u_list, feats_u, job), iteration)
-                losses_dict.update(unl)
+                job = None
                 if unl:
                     sum(v for v in unl.values()).backward()
+                losses_dict.update(unl)
+                self._pad_mt_keys(losses_dict)
                 if cut is not None:
                     pairs = [(r, l.grad) for r, l in zip(*cut) if l.grad is not None]
                     torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
             else:
                 if use_mt:
-                    loss_dict.update(self.forward_unlabel(data_u_list, feats_u, job))
+                    unl = self.forward_unlabel(data_u_list, feats_u, job)
+                    job = None
+                    loss_dict.update(unl)
                 losses_dict = self.weight_sum_loss(loss_dict, iteration)
                 self.optimizer.zero_grad()
                 sum(v for v in losses_dict.values()).backward()
+                if use_mt:
+                    self._pad_mt_keys(losses_dict)
         finally:
+            if job is not None:  # an exception before the join: never leave the helper thread running on t_stream
+                job["thread"].join()
+                torch.cuda.current_stream().wait_stream(self.t_stream)
             if bucketed is not None:
                 bucketed.finish()
         if bucketed is None:
@@ -239,7 +307,18 @@ class MTtrainer(object):
         self.optimizer.step()
         if self.lambda_value > 0 and iteration > (self.start_mt - 10):
             self.update_teacher(iteration - (self.start_mt - 10))
+            if self.teacher_check_period > 0 and iteration % self.teacher_check_period == 0:
+                check_teacher_identity(self.flat_t)
         return losses_dict
+
+    def _pad_mt_keys(self, losses):
+        """A rank whose teacher found no boxes skips the consistency branch (reference: bare except, MTtrainer.py:258-265)
+        and has no mt_* losses this step; the logging reduce (reduce_loss_dict) stacks the values of every key, so all
+        ranks must carry the same keys: the skipped ones are reported as zeros (in place)."""
+        for k, on in (("mt_fg_loss", self.cfg.MT.FG_HINT), ("mt_classifier", self.cfg.MT.CLS_LOSS)):
+            if on and k not in losses:
+                losses[k] = next(iter(losses.values())).detach().new_zeros(())
+        return losses
 
     def _bucketed_allreduce(self):
         """the overlapped exchange, when there is somebody to exchange with"""

@@ -37,6 +37,13 @@ class FlatParams(object):
         self.data = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n_trainable, dtype=torch.float32, device=dev)
         self.momentum = torch.zeros(self.n_trainable, dtype=torch.float32, device=dev)
+        # names of the parameters that received a gradient since the last zero_grad: fused backward nodes report their direct
+        # writes (layers/fused.py::_touch, looked up by slot address), autograd deliveries are seen by a hook.  FlatSGD
+        # updates only these, which is torch.optim.SGD's `if p.grad is None: continue` (solver/build.py)
+        self.touched = set()
+        import weakref
+        from .. import _hip as H
+        me = weakref.ref(self)
         for n, p in named:
             o, k = self.index[n]
             view = self._view_like(self.data[o:o + k], p)
@@ -46,6 +53,8 @@ class FlatParams(object):
                 p.grad = self._view_like(self.grad[o:o + k], p)
                 # fused backward nodes accumulate weight gradients straight into this slot (layers/fused.py)
                 p._flat_grad = p.grad
+                H.GRAD_SLOTS[p.grad.data_ptr()] = (me, n)
+                p.register_post_accumulate_grad_hook(lambda q, n=n, me=me: me() is not None and me().touched.add(n))
         self.planes = None
         self.plane_versions = {}
         self.plane_epoch = -1
@@ -85,6 +94,21 @@ class FlatParams(object):
         H.pack_weights(self.data, self.planes, self._pack_descs, self._pack_units, self._n_units)
         self.plane_versions = {p.data_ptr(): p._version for _, p in self._named if p.dim() >= 2}
         self.plane_epoch = H.PLANES_EPOCH
+
+    def active_ranges(self, names, lo, hi):
+        """merged [a, b) element ranges inside [lo, hi) of the flat buffer covered by the parameters in `names`
+        (padding between neighbours included, so adjacent parameters merge into one range)"""
+        spans = sorted(self.index[n] for n in names if lo <= self.index[n][0] < hi)
+        order = sorted(o for o, _ in self.index.values() if lo <= o < hi) + [hi]
+        nxt = {o: order[i + 1] for i, o in enumerate(order[:-1])}
+        out = []
+        for o, _ in spans:
+            b = nxt[o]
+            if out and out[-1][1] == o:
+                out[-1][1] = b
+            else:
+                out.append([o, b])
+        return [(a, b) for a, b in out]
 
     @staticmethod
     def _view_like(flat, p):

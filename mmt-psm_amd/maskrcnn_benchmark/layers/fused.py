@@ -25,6 +25,16 @@ def _dst(t):
     return getattr(t, "_flat_grad", None) if t is not None else None
 
 
+def _touch(*slots):
+    """a backward node wrote into these flat-gradient slots: the parameter 'has a gradient' this step in torch.optim.SGD's
+    sense (solver/build.py: FlatSGD leaves parameters without one untouched, like torch's `if p.grad is None: continue`)"""
+    for d in slots:
+        if d is not None:
+            ent = H.GRAD_SLOTS.get(d.data_ptr())
+            if ent is not None and ent[0]() is not None:
+                ent[0]().touched.add(ent[1])
+
+
 def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst_b=None):
     """weight (and bias) gradient.  With flat storage the split-K atomics of `mmt_conv_wgrad` accumulate straight
     into the gradient buffer and None is returned to autograd (no zero-fill, no `grad += dw` pass); otherwise a
@@ -34,6 +44,7 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
     if with_bias:
         db = dst_b if dst_b is not None else torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
     H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
+    _touch(dst_w, dst_b if with_bias else None)
     return (None if dst_w is not None else dw), (None if (dst_b is not None or not with_bias) else db)
 
 
@@ -238,6 +249,7 @@ class DeconvFn(torch.autograd.Function):
             dst_w, dst_b = ctx.dst
             dw = dst_w if dst_w is not None else torch.zeros_like(w)
             H.conv_wgrad(g, x, tuple(w.shape), 2, 0, dw)  # 'input' = g (28x28), 'dy' = x (14x14)
+            _touch(dst_w, dst_b if has_b else None)
             if has_b:
                 db = dst_b if dst_b is not None else torch.zeros((w.shape[1],), dtype=torch.float32, device=w.device)
                 H.colsum(g, db)

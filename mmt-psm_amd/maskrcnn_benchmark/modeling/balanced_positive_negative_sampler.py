@@ -12,6 +12,8 @@ class BalancedPositiveNegativeSampler(object):
         self.batch_size_per_image = batch_size_per_image
         self.positive_fraction = positive_fraction
         self.replay = None  # callable(tag) -> list of (pos_idx, neg_idx) or None
+        self.generator = None  # torch.Generator of the owning model (engine: one per model, so that the teacher's helper
+        #                        thread and the student do not interleave draws from the global generator); None = global
 
     def __call__(self, matched_idxs, tag=None):
         pos_out, neg_out = [], []
@@ -29,7 +31,7 @@ class BalancedPositiveNegativeSampler(object):
                 n_pos_avail = pos.sum()
                 num_pos_t = torch.clamp(n_pos_avail, max=num_pos)
                 num_neg_t = torch.minimum(neg.sum(), self.batch_size_per_image - num_pos_t)
-                key = torch.rand(m.shape, device=m.device)
+                key = torch.rand(m.shape, device=m.device, generator=self.generator)
                 pm = self._take(key, pos, num_pos_t, num_pos)
                 nm = self._take(key, neg, num_neg_t, self.batch_size_per_image)
             pos_out.append(pm)

@@ -40,7 +40,7 @@ class GeneralizedRCNN(nn.Module):
         self.hint_adaptor = MaskRCNNFPNAdaptor(cfg)
         self.taps = None  # dict: records stage outputs (tests / debugging)
 
-    # ---- test instrumentation: replay of recorded discrete decisions (sampler index sets, dropout masks, proposals)
+    # ---- test instrumentation: replay of recorded random decisions (sampler index sets, dropout masks); see utils/replay.py
     def set_replay(self, replay):
         self._replay = replay
         fa = (lambda tag: replay.take_all(tag)) if replay is not None else None
@@ -49,9 +49,15 @@ class GeneralizedRCNN(nn.Module):
         self.box_heads.box.loss_evaluator.fg_bg_sampler.replay = fa
         self.box_heads.box.feature_extractor.replay = fn
 
+    def set_rng(self, generator):
+        """one torch.Generator for every random draw of this model (fg/bg samplers, box-head dropout); None = global"""
+        self.rpn.loss_evaluator.fg_bg_sampler.generator = generator
+        self.box_heads.box.loss_evaluator.fg_bg_sampler.generator = generator
+        self.box_heads.box.feature_extractor.generator = generator
+
     def _tap(self, name, value):
         rp = getattr(self, "_replay", None)
-        if rp is not None and rp.has(name):
+        if rp is not None and rp.substitute_lists and rp.has(name):
             from maskrcnn_benchmark.structures.bounding_box import BoxList
             rec, new = rp.take_all(name), []
             for r, old in zip(rec, value):
@@ -64,6 +70,10 @@ class GeneralizedRCNN(nn.Module):
                     b.add_field("objectness", r[1].to(old.bbox.device))
                 new.append(b)
             value = new
+        elif rp is not None and rp.has(name):
+            value, moved = rp.align(name, value)  # order of near-tied candidates only; never values (utils/replay.py)
+            if self.taps is not None:
+                self.taps[name + "_moved"] = moved
         if self.taps is not None:
             self.taps[name] = value
         return value
@@ -90,8 +100,6 @@ class GeneralizedRCNN(nn.Module):
         if self.relation_nms is not None:
             result, nms_loss = self._relation_nms(x, result, class_logits, box_regression, targets)
         if not self.training:
-            if self.taps is not None:
-                self.taps["detections_own"] = result  # before any replay: what this model itself detected
             result = self._tap("detections", result)
         result, detector_losses = self.mask_heads(losses, features, result, targets, images)
         if self.training:

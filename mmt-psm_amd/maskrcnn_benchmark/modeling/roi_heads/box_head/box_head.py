@@ -52,6 +52,7 @@ class FPN2MLPFeatureExtractor(nn.Module):
         self.fc7 = Linear(rep, rep)
         self.p_drop = cfg.MODEL.ROI_BOX_HEAD.DO
         self.replay = None
+        self.generator = None  # see BalancedPositiveNegativeSampler.generator
         self._register_state_dict_hook(self._to_reference_layout)
         self._register_load_state_dict_pre_hook(self._from_reference_layout)
 
@@ -80,7 +81,7 @@ class FPN2MLPFeatureExtractor(nn.Module):
         if self.p_drop > 0 and istrain:
             rec = self.replay("dropout") if self.replay is not None else None
             keep = rec.to(x.device) if rec is not None else torch.empty(
-                (x.shape[0], self.fc7.out_features), device=x.device).bernoulli_(1 - self.p_drop)
+                (x.shape[0], self.fc7.out_features), device=x.device).bernoulli_(1 - self.p_drop, generator=self.generator)
             mul = keep / (1 - self.p_drop)
         return self.fc7(x, relu=True, input_relu=True, mul=mul)
 
@@ -184,7 +185,7 @@ class FastRCNNLossComputation(object):
             if cfg.MT.HARD_NEG:
                 v = H.psm_variance(teacher, use_softmax=(typ == "bce"))
             else:
-                v = torch.rand(labels.shape, device=labels.device)
+                v = torch.rand(labels.shape, device=labels.device, generator=self.fg_bg_sampler.generator)
             vn = torch.where(neg, v, torch.full_like(v, -1.0))
             order = torch.argsort(vn, descending=True, stable=True)
             rank = torch.empty_like(order)
@@ -195,6 +196,11 @@ class FastRCNNLossComputation(object):
             roww = pos.to(torch.float32) + keep_neg.to(torch.float32) * wneg
             S = (n_pos + n_keep).to(torch.float32)
         else:
+            # no filtering: every row, weight 1.  For 'bce' the reference hands cls_loss the mean of the per-view softmax
+            # PROBABILITIES (m_logit_t of _mean_var_logits, box_head/loss.py:164-173,229) and cls_loss softmaxes that again
+            # (:281); reproduced as written: the kernel's "mean over views, then softmax" over ONE pre-averaged view
+            if typ == "bce":
+                teacher = torch.softmax(teacher, dim=2).mean(0, keepdim=True).contiguous()
             roww = torch.ones(labels.shape, device=labels.device)
             S = dev_const(float(labels.numel()), torch.float32, labels.device)
         nc = teacher.shape[2]

@@ -111,9 +111,14 @@ class RPNPostProcessor(nn.Module):
         props = self.box_coder.decode(torch.cat(regs, 1).reshape(-1, 4), torch.cat(ancs, 1).reshape(-1, 4)).view(N, -1, 4)
         props = torch.minimum(props.clamp(min=0), lim[:, None, :])  # clip_to_image(remove_empty=False)
         if self.min_size > 0:
+            # remove_small_boxes BEFORE the NMS (rpn/inference.py:124-129): a removed box must neither suppress anything nor
+            # take a post-NMS slot.  Fixed shapes: it keeps its position in the segment but is moved far outside the image
+            # (IoU 0 with every real box) and gets score -1, which `select` excludes before it counts the slots.
             ws = props[..., 2] - props[..., 0] + 1
             hs = props[..., 3] - props[..., 1] + 1
-            sc = torch.where((ws >= self.min_size) & (hs >= self.min_size), sc, torch.full_like(sc, -1.0))
+            ok = (ws >= self.min_size) & (hs >= self.min_size)
+            sc = torch.where(ok, sc, torch.full_like(sc, -1.0))
+            props = torch.where(ok[..., None], props, torch.full_like(props, -1.0e6))
         boxes = props.reshape(-1, 4)
         scores = sc.reshape(-1)
         offs = [0]
@@ -134,6 +139,8 @@ class RPNPostProcessor(nn.Module):
         own_pre = dev_const([min(self.pre_nms_top_n, k) for _ in range(N) for k in ks], torch.int32, dev)
         pos = seg_off[:-1, None].long() + keep.long()
         valid = (torch.arange(kmax, device=dev)[None, :] < cnt[:, None]) & (keep < own_pre[:, None])
+        if self.min_size > 0:  # boxes removed by the min-size filter hold no post-NMS slot
+            valid = valid & (scores[torch.where(valid, pos, torch.zeros_like(pos))] >= 0)
         if self.post_nms_top_n > 0:
             valid = valid & (torch.cumsum(valid.to(torch.int32), 1) <= self.post_nms_top_n)
         kept = torch.zeros(total + 1, dtype=torch.bool, device=dev)

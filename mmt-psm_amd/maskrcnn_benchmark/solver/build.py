@@ -20,17 +20,24 @@ class FlatSGD(object):
 
     def zero_grad(self):
         self.flat.grad.zero_()
+        self.flat.touched.clear()
 
     def step(self):
+        """torch.optim.SGD.step over the reference's per-tensor groups (solver/build.py:5-23): a parameter that received no
+        gradient since zero_grad (`p.grad is None` there: the hint adaptors before START_MT or when the teacher found nothing,
+        heads of a branch that did not run) is left alone -- no weight decay, no momentum decay -- and names containing
+        'box_heads.box.D' are never optimised (:11).  The parameters that did receive one form a few contiguous runs of the
+        flat buffer: one launch per run.  Momentum buffers start at zero, so torch's lazy `buf = d_p` first step is the
+        same arithmetic as `buf = momentum * 0 + d_p`."""
         f = self.flat
-        first = self.steps == 0
         lr = self.base_lr * self.lr_factor
         nw, nb = f.n_weights, f.n_biases
-        if nw:
-            H.sgd_momentum(f.data[:nw], f.grad[:nw], f.momentum[:nw], lr, self.weight_decay, self.momentum, first)
-        if nb:
-            H.sgd_momentum(f.data[nw:nw + nb], f.grad[nw:nw + nb], f.momentum[nw:nw + nb], lr * self.bias_lr_factor,
-                           self.weight_decay_bias, self.momentum, first)
+        names = [n for n in f.touched if "box_heads.box.D" not in n]
+        for a, b in f.active_ranges(names, 0, nw):
+            H.sgd_momentum(f.data[a:b], f.grad[a:b], f.momentum[a:b], lr, self.weight_decay, self.momentum, False)
+        for a, b in f.active_ranges(names, nw, nw + nb):
+            H.sgd_momentum(f.data[a:b], f.grad[a:b], f.momentum[a:b], lr * self.bias_lr_factor,
+                           self.weight_decay_bias, self.momentum, False)
         f.refresh_planes()
         self.steps += 1
         self.param_groups[0]["lr"] = lr

@@ -790,6 +790,7 @@ def psm_loss(cfg, class_logits, class_logits_t, labels):
     lg = class_logits_t
     if cfg.mt_cls_loss_type == "bce":
         lg = [F.softmax(l, dim=1) for l in lg]
+    m_logit = torch.mean(torch.stack(lg), dim=0)  # _mean_var_logits :164-173: of the PROBABILITIES for 'bce'
     v = torch.std(torch.stack(lg), dim=0)
     pos = torch.nonzero(labels > 0).squeeze(1)
     neg = torch.nonzero(labels == 0).squeeze(1)
@@ -808,7 +809,7 @@ def psm_loss(cfg, class_logits, class_logits_t, labels):
             sl = torch.cat([cl[pos], cl[neg][keep]])
             pn = (tp.shape[0], keep.shape[0])
         else:
-            tl, sl, pn = t_logits, cl, None
+            tl, sl, pn = m_logit, cl, None  # as written (:229): not the mean logits
         w = cfg.mt_cls_balance if cfg.mt_hard_neg else 1
         losses.append(psm_cls_loss(cfg, sl, tl.clone(), pn, w))
     return torch.mean(torch.stack(losses), dim=0)
@@ -897,3 +898,76 @@ def ema_alpha(cfg, it):  # engine/MTtrainer.py:277-278
 def ema_update(teacher_params, student_params, alpha):  # engine/MTtrainer.py:279-281
     for t, s in zip(teacher_params, student_params):
         t.mul_(alpha).add_(s, alpha=1 - alpha)
+
+
+# ------------------------------------------------------------------------------ one whole iteration [A]-[E]
+def lr_factor(last_epoch, steps=(5000,), gamma=0.1, warmup_factor=1.0 / 3, warmup_iters=500, method="linear"):
+    """WarmupMultiStepLR.get_lr / base_lr (solver/lr_scheduler.py:40-53)"""
+    from bisect import bisect_right
+    w = 1
+    if last_epoch < warmup_iters:
+        if method == "constant":
+            w = warmup_factor
+        else:
+            a = last_epoch / warmup_iters
+            w = warmup_factor * (1 - a) + a
+    return w * gamma ** bisect_right(list(steps), last_epoch)
+
+
+class Trainer(object):
+    """The body of MTtrainer.train (engine/MTtrainer.py:165-229) on plain state dicts, with the reference's own optimiser
+    construction (solver/build.py:5-23: one torch.optim.SGD group per trainable tensor, bias lr x BIAS_LR_FACTOR and
+    WEIGHT_DECAY_BIAS) and schedule (scheduler.step() BEFORE optimizer.step(), MTtrainer.py:182).  Gradients come from
+    torch autograd through the restated forwards; ROIAlign backward is the gradcheck'd restatement in oracle/native.
+
+    `trainable` / `param_order`: the reference's named_parameters() order and requires_grad set (tests/golden/
+    state_shapes.json, captured from the reference model)."""
+
+    def __init__(self, sd, cfg, trainable, param_order, base_lr=0.005, momentum=0.9, weight_decay=1e-4,
+                 bias_lr_factor=2, weight_decay_bias=0, max_iter=7000):
+        self.cfg, self.max_iter = cfg, max_iter
+        self.s = {k: v.clone() for k, v in sd.items()}
+        self.t = {k: v.clone() for k, v in sd.items()}
+        self.trainable = [k for k in trainable if k in self.s]
+        self.param_order = [k for k in param_order if k in self.s]
+        groups = []
+        for k in self.trainable:
+            self.s[k].requires_grad_(True)
+            if "box_heads.box.D" in k:  # solver/build.py:11
+                continue
+            lr, wd = base_lr, weight_decay
+            if "bias" in k:
+                lr, wd = base_lr * bias_lr_factor, weight_decay_bias
+            groups.append({"params": [self.s[k]], "lr": lr, "weight_decay": wd, "initial_lr": lr})
+        self.opt = torch.optim.SGD(groups, base_lr, momentum=momentum)
+        self.last_epoch = 0  # _LRScheduler.__init__ has stepped once
+
+    def step(self, iteration, images, targets, unlabeled=None, seeds=(None, None, None)):
+        """-> (weighted loss dict, taps of the supervised / teacher / student forwards).  `seeds`: torch.manual_seed
+        before each of the three forwards (None = leave the global generator alone)."""
+        cfg = self.cfg
+        taps_a, taps_b, taps_c = {}, {}, {}
+        if seeds[0] is not None:
+            torch.manual_seed(seeds[0])
+        loss = forward_supervised(self.s, cfg, images, targets, taps_a)          # [A] MTtrainer.py:176
+        if iteration > cfg.mt_start and cfg.mt_lambda > 0 and unlabeled is not None:  # :177
+            if seeds[1] is not None:
+                torch.manual_seed(seeds[1])
+            k = len(unlabeled) - 1  # AUG_K teacher views, AUG_S = 1 student view
+            tr = forward_teacher(self.t, cfg, unlabeled[:k], taps_b)             # [B] :258-261
+            if seeds[2] is not None:
+                torch.manual_seed(seeds[2])
+            loss.update(forward_student(self.s, cfg, unlabeled[-1:], tr, taps_c))  # [C] :266-267
+        self.last_epoch += 1                                                     # scheduler.step() :182
+        f = lr_factor(self.last_epoch)
+        for g in self.opt.param_groups:
+            g["lr"] = g["initial_lr"] * f
+        wl = weight_sum_losses(cfg, loss, iteration, self.max_iter)             # :183
+        self.opt.zero_grad()                                                     # [D] :191-193
+        sum(wl.values()).backward()
+        self.opt.step()
+        if cfg.mt_lambda > 0 and iteration > (cfg.mt_start - 10):                # [E] :195-196
+            alpha = ema_alpha(cfg, iteration - (cfg.mt_start - 10))
+            with torch.no_grad():
+                ema_update([self.t[k] for k in self.param_order], [self.s[k].detach() for k in self.param_order], alpha)
+        return {k: v.detach() for k, v in wl.items()}, (taps_a, taps_b, taps_c)

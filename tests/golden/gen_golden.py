@@ -185,8 +185,10 @@ def gen_mt_losses():
     from maskrcnn_benchmark.engine.MTtrainer import weight_sum_losses
     out = {}
     g = torch.Generator().manual_seed(1234)
-    for case, (R, typ) in enumerate(((12, "bce"), (257, "bce"), (257, "kl"), (64, "mse"))):
-        cfg = make_cfg(["MT.CLS_LOSS_TYPE", typ])
+    # case 4: RANK_FILTER 0 (the yacs default) with 'bce': cls_loss receives the mean of the per-view softmax probabilities
+    for case, (R, typ, rf) in enumerate(((12, "bce", 0.2), (257, "bce", 0.2), (257, "kl", 0.2), (64, "mse", 0.2),
+                                          (64, "bce", 0.0))):
+        cfg = make_cfg(["MT.CLS_LOSS_TYPE", typ, "MT.RANK_FILTER", rf])
         ev = make_roi_box_loss_evaluator(cfg)
         if R == 12:
             labels = torch.tensor([1, 2, 0, 0, 0, 1, 0, 2, 0, 0, 1, 0])

@@ -264,6 +264,28 @@ def test_psm_golden_and_grad(hip):
         np.testing.assert_allclose((rg * norm).cpu().numpy(), s.grad.numpy(), rtol=1e-4, atol=1e-8)
 
 
+def test_evaluate_psm_host_function_golden(hip):
+    """FastRCNNLossComputation.evaluatePSM as the model calls it (device ranking of the hard negatives included) against
+    the reference's values for every CLS_LOSS_TYPE and for RANK_FILTER 0 -- the yacs default, where 'bce' feeds the
+    mean of the per-view softmax probabilities through softmax once more (box_head/loss.py:164-173,229,281)"""
+    from maskrcnn_benchmark.config import make_default_cfg
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.box_head import make_roi_box_loss_evaluator
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    g = gold("mt_losses")
+    for case, (typ, rf) in enumerate((("bce", 0.2), ("bce", 0.2), ("kl", 0.2), ("mse", 0.2), ("bce", 0.0))):
+        cfg = make_default_cfg()
+        cfg.merge_from_list(["MT.CLS_LOSS_TYPE", typ, "MT.RANK_FILTER", rf])
+        ev = make_roi_box_loss_evaluator(cfg)
+        labels = T(g["psm%d_labels" % case]).cuda()
+        bl = BoxList(torch.zeros(len(labels), 4).cuda(), (10, 10), "xyxy")
+        bl.add_field("labels", labels)
+        s = T(g["psm%d_s" % case]).cuda().requires_grad_()
+        v = ev.evaluatePSM([s], [x for x in T(g["psm%d_t" % case]).cuda()], [bl])
+        assert v.item() == pytest.approx(float(g["psm%d" % case]), rel=2e-5), (case, typ, rf)
+        v.backward()
+        assert torch.isfinite(s.grad).all() and s.grad.abs().sum().item() > 0
+
+
 def test_ema_and_sgd(hip):
     g = gold("mt_losses")
     from oracle import model as om

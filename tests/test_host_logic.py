@@ -216,3 +216,135 @@ def test_data_parallel_exchange_gloo_world2(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "rank0ok" in out.stdout and "rank1ok" in out.stdout
+
+
+_BUCKET_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(sys.argv[1], "mmt-psm_amd"))
+from torch import nn
+from maskrcnn_benchmark.engine.flat import FlatParams
+from maskrcnn_benchmark.engine import MTtrainer as MT
+dist.init_process_group("gloo")
+rank, ws = dist.get_rank(), dist.get_world_size()
+
+
+class Body(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.layer1 = nn.Linear(8, 8)
+        self.layer2 = nn.Linear(8, 16)
+        self.layer3 = nn.Linear(16, 24)
+        self.layer4 = nn.Linear(24, 8)
+        self.grad_ready = None
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone = nn.Module()
+        self.backbone.body = Body()
+        self.backbone.fpn = nn.Linear(8, 40)
+        self.rpn = nn.Linear(40, 3)
+
+
+torch.manual_seed(0)
+net = Net()
+for p in net.backbone.body.layer1.parameters():
+    p.requires_grad_(False)                      # FREEZE_CONV_BODY_AT = 2: no hook ever fires for layer1's piece
+flat = FlatParams(net)
+b = MT.BucketedAllReduce(flat, net.backbone.body)
+assert set(b.pieces) == {"layer4", "layer3", "layer2", "layer1"}
+sent = []
+orig = MT.BucketedAllReduce._send
+def spy(self, lo, hi):
+    sent.append((lo, hi))
+    return orig(self, lo, hi)
+MT.BucketedAllReduce._send = spy
+
+
+def run(fires_per_stage):
+    # two backbone passes were registered on every rank; `fires_per_stage` of them are back-propagated on this rank
+    g = torch.Generator().manual_seed(7 + rank)
+    flat.grad.copy_(torch.randn(flat.grad.shape, generator=g))
+    mine = flat.grad.clone()
+    del sent[:]
+    b.install()
+    for _ in range(2):
+        for st in ("layer4", "layer3", "layer2"):
+            net.backbone.body.grad_ready(st, "registered")
+    for _ in range(fires_per_stage):
+        for st in ("layer4", "layer3", "layer2"):        # backward order of one pass
+            net.backbone.body.grad_ready(st, "fired")
+    b.finish()
+    parts = [torch.zeros_like(mine) for _ in range(ws)]
+    dist.all_gather(parts, mine)
+    assert torch.allclose(flat.grad, sum(parts) / ws, atol=1e-6), "exchanged gradient != mean"
+    seqs = [None] * ws
+    dist.all_gather_object(seqs, list(sent))
+    assert all(s == seqs[0] for s in seqs), seqs      # the SAME collective sequence on every rank
+    spans, pos = sorted(sent), 0
+    for lo, hi in spans:                               # exact cover of the flat gradient, nothing twice
+        assert lo == pos, spans
+        pos = hi
+    assert pos == flat.grad.numel()
+    return list(sent)
+
+
+a = run(2)                         # every rank back-propagates both passes
+c = run(2 if rank == 0 else 1)     # rank 1 skipped its consistency branch (teacher found no boxes)
+d = run(0 if rank == 0 else 2)     # ... or a rank back-propagated nothing through the backbone at all
+assert a == c == d
+# the padded loss dict reduces with the same keys everywhere
+red = MT.reduce_loss_dict({"loss": torch.tensor(1.0), "mt_fg_loss": torch.tensor(float(rank))})
+assert sorted(red) == ["loss", "mt_fg_loss"]
+# teacher identity checksum: equal buffers pass, a divergent rank is caught on every rank
+t = FlatParams(Net())
+t.data.copy_(flat.data)
+assert MT.check_teacher_identity(t)
+if rank == 1:
+    t.data[3] += 1e-4
+try:
+    MT.check_teacher_identity(t)
+    raise SystemExit("divergence not detected")
+except RuntimeError:
+    pass
+dist.destroy_process_group()
+sys.stdout.write("rank%dok\n" % rank); sys.stdout.flush()
+"""
+
+
+def test_bucketed_allreduce_rank_invariant_gloo_world2(tmp_path):
+    """ranks must issue the same collective sequence even when one of them skipped the consistency
+    branch; plus the teacher-identity checksum all-reduce of SURVEY 8(e)"""
+    script = tmp_path / "bucket.py"
+    script.write_text(_BUCKET_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29534", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "rank0ok" in out.stdout and "rank1ok" in out.stdout
+
+
+def test_flat_sgd_touches_only_parameters_with_gradients():
+    """solver/build.py: torch.optim.SGD skips parameters whose grad is None; the flat optimiser updates only the runs of
+    the buffer whose parameters reported a gradient since zero_grad"""
+    from torch import nn
+    from maskrcnn_benchmark.engine.flat import FlatParams
+    torch.manual_seed(1)
+    m = nn.Sequential(nn.Linear(4, 6), nn.Linear(6, 10), nn.Linear(10, 3), nn.Linear(3, 2))
+    f = FlatParams(m)
+    assert f.touched == set()
+    x = torch.randn(5, 4)
+    m[1](m[0](x)).sum().backward()                   # autograd delivers into the pre-set .grad views: seen by the hook
+    assert f.touched == {"0.weight", "0.bias", "1.weight", "1.bias"}
+    w = f.active_ranges(f.touched, 0, f.n_weights)
+    bz = f.active_ranges(f.touched, f.n_weights, f.n_weights + f.n_biases)
+    assert w == [(f.index["0.weight"][0], f.index["2.weight"][0])]          # two neighbours merged into one run
+    assert bz == [(f.index["0.bias"][0], f.index["2.bias"][0])]
+    f.touched.clear()
+    m[3](torch.randn(2, 3)).sum().backward()
+    assert f.active_ranges(f.touched, 0, f.n_weights) == [(f.index["3.weight"][0], f.n_weights)]
+    f.touched.update({"0.weight", "2.weight"})
+    r = f.active_ranges(f.touched, 0, f.n_weights)
+    assert r == [(f.index["0.weight"][0], f.index["1.weight"][0]), (f.index["2.weight"][0], f.n_weights)]

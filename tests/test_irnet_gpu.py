@@ -1,7 +1,7 @@
 """IR-Net (relation NMS + mask relation, BASELINE config 5 in fp32) on the MI355X against the CPU
-oracle (oracle/irnet.py, itself pinned to the reference by tests/golden/model160_irnet.npz).  Sampler sets, dropout
-masks and proposal lists are replayed from the oracle run as in test_model_gpu.py; the relation modules -- ranking,
-label preparation, attention, CIAM, second mask logits -- are computed by the product."""
+oracle (oracle/irnet.py, itself pinned to the reference by tests/golden/model160_irnet.npz).  Sampler sets and dropout
+masks are replayed from the oracle run as in test_model_gpu.py; proposal lists, detections and the relation modules --
+ranking, label preparation, attention, CIAM, second mask logits -- are computed by the product."""
 import json
 import os
 
@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from conftest import gold, GOLD
-from test_model_gpu import _targets_oracle, _targets_product
+from test_model_gpu import _targets_oracle, _targets_product, assert_lists_match
 
 pytestmark = pytest.mark.gpu
 SIZE = 160
@@ -56,11 +56,14 @@ def test_irnet_supervised_forward_backward(setup, synth):
         assert v.item() == pytest.approx(float(g["sup_" + k]), rel=tol(k, 1e-5))
     sum(ref.values()).backward()
 
+    student.taps = {}
     student.set_replay(Replay(taps))
     for p in student.parameters():
         p.grad = None
     out = student(to_image_list(list(imgs.cuda()), 32), _targets_product(tgs, "cuda"))
     student.set_replay(None)
+    assert_lists_match(student.taps, taps["rpn_proposals"], "rpn_proposals")
+    student.taps = None
     assert set(out) == set(ref) and "nms_loss" in out
     for k in ref:
         assert out[k].item() == pytest.approx(ref[k].item(), rel=tol(k, 1e-4)), k
@@ -96,11 +99,13 @@ def test_irnet_teacher_inference(setup, synth):
     torch.manual_seed(100)
     tr = om.forward_teacher(weights, ocfg, unl[:2], taps)
     teacher.taps = {}
-    teacher.set_replay(Replay({k: v for k, v in taps.items() if k != "detections"}))  # detections: the product's own
+    teacher.set_replay(Replay(taps))
     with torch.no_grad():
         out = teacher.forward_teacher([to_image_list(list(u.cuda()), 32) for u in unl[:2]])
     teacher.set_replay(None)
-    own = teacher.taps["detections_own"]
+    assert_lists_match(teacher.taps, taps["infer_proposals"], "infer_proposals")
+    assert_lists_match(teacher.taps, taps["teacher_proposals"], "teacher_proposals")
+    own = teacher.taps["detections"]
     teacher.taps = None
     for (rb, rs, rl, ro), o in zip(taps["detections"], own):  # relation-NMS output, before the mask-relation sort
         assert len(o) == rb.shape[0] and len(o) > 0
@@ -133,7 +138,9 @@ def test_irnet_bf16_products_mode(setup, synth):
     prev = _hip.get_conv_precision()
     _hip.set_conv_precision(1)
     try:
-        student.set_replay(Replay(taps))
+        # bf16 arithmetic against the fp32 oracle: discrete selections legitimately differ, so this ONE tolerance test
+        # also takes the proposal lists from the oracle run (utils/replay.py: substitute_lists)
+        student.set_replay(Replay(taps, substitute_lists=True))
         with torch.no_grad():
             out = student(to_image_list(list(imgs.cuda()), 32), _targets_product(tgs, "cuda"))
         student.set_replay(None)

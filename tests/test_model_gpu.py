@@ -16,6 +16,31 @@ pytestmark = pytest.mark.gpu
 SIZE = 160
 
 
+def assert_lists_match(taps_own, rec, what):
+    """taps_own[what]: list[BoxList] computed by the product; rec: the oracle's tap, per image (bbox, objectness) or
+    (bbox, scores, labels, objectness).  Same counts, same order, same boxes.  The one freedom: rows whose oracle scores
+    are equal up to the fp32 noise of the convolutions (< 2e-5 relative) may have been swapped back into the recorded
+    order by utils/replay.py::Replay.align (the reference leaves the order of equal scores unspecified); every such move
+    is listed in taps_own[what + "_moved"] and checked here to be exactly that."""
+    own = taps_own[what]
+    for n, i, j in taps_own.get(what + "_moved", []):
+        sc = rec[n][1]
+        assert abs(float(sc[i]) - float(sc[j])) <= 2e-5 * max(abs(float(sc[i])), 1e-3), (what, n, i, j, sc[i], sc[j])
+    assert len(taps_own.get(what + "_moved", [])) <= 8, (what, taps_own[what + "_moved"])
+    assert len(own) == len(rec), what
+    for i, (o, r) in enumerate(zip(own, rec)):
+        assert len(o) == r[0].shape[0], (what, i, len(o), r[0].shape[0])
+        assert len(o) > 0, (what, i)
+        np.testing.assert_allclose(o.bbox.cpu().numpy(), r[0].numpy(), rtol=0, atol=1e-3, err_msg=what)
+        if len(r) == 2:
+            np.testing.assert_allclose(o.get_field("objectness").cpu().numpy(), r[1].numpy(), rtol=1e-4, atol=1e-6,
+                                       err_msg=what)
+        else:
+            np.testing.assert_allclose(o.get_field("scores").cpu().numpy(), r[1].numpy(), rtol=1e-4, atol=1e-6,
+                                       err_msg=what)
+            np.testing.assert_array_equal(o.get_field("labels").cpu().numpy(), r[2].numpy(), err_msg=what)
+
+
 def _targets_oracle(om, tgs):
     return [om.Boxes(t["boxes"], t["size"], {"labels": t["labels"], "masks": t["polys"]}) for t in tgs]
 
@@ -87,6 +112,9 @@ def test_supervised_forward_backward(setup, synth, weights):
         p.grad = None
     out = student(il, _targets_product(tgs, "cuda"))
     student.set_replay(None)
+    # a7: the product's own RPNPostProcessor output (top-k, decode, clip, NMS, batch-wide top-k, + GT boxes)
+    assert_lists_match(student.taps, taps["rpn_proposals"], "rpn_proposals")
+    student.taps = None
     # features
     feats = student.backbone(il.tensors)
     for f, r in zip(feats, taps["features"]):
@@ -126,10 +154,16 @@ def test_teacher_student(setup, synth, weights):
     taps = {}
     torch.manual_seed(100)
     tr = om.forward_teacher(weights, ocfg, unl[:2], taps)
+    teacher.taps = {}
     teacher.set_replay(Replay(taps))
     with torch.no_grad():
         out = teacher.forward_teacher([to_image_list(list(u.cuda()), 32) for u in unl[:2]])
     teacher.set_replay(None)
+    # a7 / a22: nothing below was fed to the product -- these are its own lists
+    assert_lists_match(teacher.taps, taps["infer_proposals"], "infer_proposals")
+    assert_lists_match(teacher.taps, taps["detections"], "detections")
+    assert_lists_match(teacher.taps, taps["teacher_proposals"], "teacher_proposals")
+    teacher.taps = None
     for r, o in zip(tr["result_t"], out["result_t"]):
         np.testing.assert_allclose(o.bbox.cpu().numpy(), r.bbox.numpy(), atol=1e-3)
         np.testing.assert_array_equal(o.get_field("labels").cpu().numpy(), r.fields["labels"].numpy())

@@ -74,8 +74,8 @@ def test_box_coder_anchors_matcher_golden():
 
 def test_psm_mgd_golden():
     g = gold("mt_losses")
-    for case, typ in enumerate(("bce", "bce", "kl", "mse")):
-        cfg = om.default_cfg(mt_cls_loss_type=typ)
+    for case, (typ, rf) in enumerate((("bce", 0.2), ("bce", 0.2), ("kl", 0.2), ("mse", 0.2), ("bce", 0.0))):
+        cfg = om.default_cfg(mt_cls_loss_type=typ, mt_rank_filter=rf)
         t = [x for x in T(g["psm%d_t" % case])]
         v = om.psm_loss(cfg, [T(g["psm%d_s" % case])], t, T(g["psm%d_labels" % case]))
         assert v.item() == pytest.approx(float(g["psm%d" % case]), rel=1e-6), case

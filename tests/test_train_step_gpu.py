@@ -1,0 +1,310 @@
+"""What bench.py times, tested: engine/MTtrainer.py::train_step [A]-[E] (reference engine/MTtrainer.py:165-229).
+
+  * one whole iteration against the oracle's (oracle/model.py::Trainer: the reference's forwards, loss weighting,
+    torch.optim.SGD with the reference's parameter groups, EMA) at 160 x 160: weights after SGD, momentum buffers and the
+    teacher after the EMA, with only the random draws (sampler sets, dropout) replayed;
+  * an iteration before START_MT: parameters that received no gradient (the hint adaptors) are not touched -- torch SGD's
+    `if p.grad is None: continue` (solver/build.py:5-23) -- and the teacher is not updated;
+  * the default schedule of the bench (teacher on a side stream from a helper thread, two student backbone passes, early
+    supervised backward) against the serial / batched one: same gradient, same student, same teacher, at 160 and at
+    the full 1000 x 1000 crops;
+  * the product's own device sampler and dropout (not replayed in the bench): counts, membership, fractions."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, ROOT
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, ROOT)
+
+
+def _bench():
+    import bench
+    return bench
+
+
+def _named_flat(flat):
+    return {n: (o, k) for n, (o, k) in flat.index.items()}
+
+
+def _oracle_targets(om, tgs):
+    return [om.Boxes(t["boxes"], t["size"], {"labels": t["labels"], "masks": t["polys"]}) for t in tgs]
+
+
+@pytest.fixture(scope="module")
+def small():
+    """the bench's trainer on 160 x 160 crops with 4 instances (same builder, same synthetic data generator)"""
+    bench = _bench()
+    cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, crop=160, n_inst=4)
+    return cfg, trainer, batch
+
+
+def _load(trainer, weights):
+    """a fresh run: the fixture weights of the oracle run in both models (through the state-dict boundary, fc6 layout hook
+    included), zero momentum, schedule at its first step"""
+    from maskrcnn_benchmark.engine.MTtrainer import init_teacher_weight
+    missing, unexpected = trainer.student.load_state_dict(weights, strict=False)
+    assert all("cell_anchors" in k for k in missing), missing
+    trainer.flat_s.refresh_planes()
+    init_teacher_weight(trainer.student, trainer.teacher)
+    trainer.flat_s.momentum.zero_()
+    trainer.flat_s.grad.zero_()
+    trainer.flat_s.touched.clear()
+    trainer.scheduler.last_epoch = -1
+    trainer.scheduler.step()
+    trainer.optimizer.steps = 0
+
+
+def _snapshot(trainer):
+    return dict(s=trainer.flat_s.data.clone(), t=trainer.flat_t.data.clone(), m=trainer.flat_s.momentum.clone(),
+                le=trainer.scheduler.last_epoch, lf=trainer.optimizer.lr_factor, st=trainer.optimizer.steps)
+
+
+def _restore(trainer, snap):
+    trainer.flat_s.data.copy_(snap["s"])
+    trainer.flat_t.data.copy_(snap["t"])
+    trainer.flat_s.momentum.copy_(snap["m"])
+    trainer.flat_s.grad.zero_()
+    trainer.flat_s.touched.clear()
+    trainer.scheduler.last_epoch, trainer.optimizer.lr_factor, trainer.optimizer.steps = snap["le"], snap["lf"], snap["st"]
+    trainer.flat_s.refresh_planes()
+    trainer.flat_t.refresh_planes()
+
+
+def _oracle_trainer(synth, state_shapes, weights):
+    from oracle import model as om
+    return om, om.Trainer(weights, om.default_cfg(), state_shapes["trainable"], state_shapes["param_order"])
+
+
+def _fc6_to_ref(t):
+    return t.view(1024, 7, 7, 256).permute(0, 3, 1, 2).reshape(1024, -1)
+
+
+def _param(flat, model, name):
+    """a parameter of the flat buffer in the reference's layout"""
+    p = dict(model.named_parameters())[name].detach()
+    if name.endswith("fc6.weight"):
+        return _fc6_to_ref(p).cpu()
+    return p.cpu().contiguous()
+
+
+@pytest.mark.parametrize("iteration", [1400, 5], ids=["mean-teacher-step", "before-START_MT"])
+def test_full_step_matches_oracle(small, synth, state_shapes, weights, iteration):
+    from maskrcnn_benchmark.utils.replay import Replay
+    cfg, trainer, batch = small
+    _load(trainer, weights)
+    snap = _snapshot(trainer)
+    om, ot = _oracle_trainer(synth, state_shapes, weights)
+    imgs, tgs = synth.make_labeled(2, 160, 4, seed=1234)
+    unl = synth.make_unlabeled(2, 160, 3, seed=4321)
+    # the oracle's schedule position must be the product's: its scheduler has stepped as often as the trainer's
+    ot.last_epoch = trainer.scheduler.last_epoch
+    ref_losses, (ta, tb, tc) = ot.step(iteration, imgs, _oracle_targets(om, tgs), unl, seeds=(99, 100, 101))
+    before_s = {n: _param(trainer.flat_s, trainer.student, n) for n in state_shapes["param_order"]}
+    before_t = {n: _param(trainer.flat_t, trainer.teacher, n) for n in state_shapes["param_order"]}
+    # random draws only; the proposal list rides along for Replay.align (order of near-tied scores), never as values
+    stu = {"rpn_sampler": ta["rpn_sampler"], "roi_sampler": ta["roi_sampler"], "rpn_proposals": ta["rpn_proposals"],
+           "dropout": list(ta["dropout"]) + list(tc.get("dropout", []))}
+    trainer.student.set_replay(Replay(stu))
+    trainer.teacher.set_replay(Replay(tb))
+    try:
+        il, tg, ul = batch()
+        losses = trainer.train_step(iteration, il, tg, ul)
+        torch.cuda.synchronize()
+    finally:
+        trainer.student.set_replay(None)
+        trainer.teacher.set_replay(None)
+    try:
+        _check_step(cfg, trainer, ot, state_shapes, weights, losses, ref_losses, before_s, before_t, iteration)
+    finally:
+        _restore(trainer, snap)
+
+
+def _check_step(cfg, trainer, ot, state_shapes, weights, losses, ref_losses, before_s, before_t, iteration):
+    assert set(losses) == set(ref_losses)
+    for k, v in ref_losses.items():
+        assert float(losses[k]) == pytest.approx(float(v), rel=2e-4), k
+    mt = iteration > cfg.MT.START_MT
+    for n in state_shapes["param_order"]:
+        after = _param(trainer.flat_s, trainer.student, n)
+        d_own = after - before_s[n]
+        d_ref = ot.s[n].detach() - weights[n]
+        if n not in state_shapes["trainable"]:
+            assert torch.equal(after, before_s[n]), n            # frozen stem / layer1
+            continue
+        if n.startswith("hint_adaptor.") and not mt:
+            # no gradient this step: torch SGD skips the tensor (no weight decay either)
+            assert torch.equal(after, before_s[n]), n
+            assert torch.equal(ot.s[n].detach(), weights[n]), n
+            continue
+        scale = d_ref.abs().max().item()
+        if scale == 0.0:
+            # requires_grad but never reached by a loss (the always-constructed mask relation module with the relation
+            # off, mask_head.py:48): no gradient -> torch SGD leaves it alone; here it is kept out of the optimiser
+            assert torch.equal(after, before_s[n]), n
+            continue
+        # the update is the difference of two nearly equal fp32 weights: 3e-3 of its size + a few ulps of the weights
+        err = (d_own - d_ref).abs().max().item()
+        assert err < 3e-3 * scale + 4e-7 * before_s[n].abs().max().item(), (n, err, scale)
+        # the momentum buffer after the first step is d_p = grad + wd * w: the gradient itself, decay included
+        o, k = trainer.flat_s.index[n]
+        buf = trainer.flat_s.momentum[o:o + k].cpu()
+        rbuf = ot.opt.state[ot.s[n]]["momentum_buffer"]
+        if n.endswith("fc6.weight"):
+            buf = _fc6_to_ref(buf)
+        elif rbuf.dim() == 4:
+            buf = buf.view(rbuf.shape[0], rbuf.shape[2], rbuf.shape[3], rbuf.shape[1]).permute(0, 3, 1, 2)
+        assert (buf.reshape(rbuf.shape) - rbuf).abs().max().item() < 3e-3 * rbuf.abs().max().item(), n
+    # teacher: EMA after START_MT - 10, untouched before
+    for n in state_shapes["param_order"]:
+        after = _param(trainer.flat_t, trainer.teacher, n)
+        d_ref = ot.t[n] - weights[n]
+        if not mt:
+            assert torch.equal(after, before_t[n]), n
+            assert d_ref.abs().max().item() == 0.0
+            continue
+        d_own = after - before_t[n]
+        scale = d_ref.abs().max().item()
+        if scale == 0.0:
+            assert d_own.abs().max().item() == 0.0, n
+        else:
+            # a 1 % step towards the student: the difference of two nearly equal fp32 numbers, so a few ulps of the weights
+            tol = 3e-3 * scale + 4e-7 * before_t[n].abs().max().item()
+            assert (d_own - d_ref).abs().max().item() < tol, n
+
+
+def _run_schedule(trainer, batch, iteration, overlap, passes, early, seed):
+    trainer.overlap_teacher = overlap
+    if overlap and trainer.t_stream is None:
+        trainer.t_stream = torch.cuda.Stream(device=trainer.device, priority=-1)
+    trainer.student_passes, trainer.early_sup_backward = passes, early
+    trainer.seed_rng(seed)
+    il, tg, ul = batch()
+    losses = trainer.train_step(iteration, il, tg, ul)
+    torch.cuda.synchronize()
+    return ({k: float(v) for k, v in losses.items()}, trainer.flat_s.grad.clone(), trainer.flat_s.data.clone(),
+            trainer.flat_t.data.clone())
+
+
+def _close(a, b, tol, what):
+    err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+    assert err < tol, (what, err)
+
+
+def _schedule_equivalence(trainer, batch):
+    snap = _snapshot(trainer)
+    keep = (trainer.overlap_teacher, trainer.student_passes, trainer.early_sup_backward)
+    old_env = os.environ.get("MMT_SPLITK")
+    try:
+        _run_schedule(trainer, batch, 1400, True, "split", True, 3)   # warm-up: allocator, caches, plane packing
+        _restore(trainer, snap)
+        bench_l, bench_g, bench_s, bench_t = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
+        _restore(trainer, snap)
+        same_l, same_g, same_s, same_t = _run_schedule(trainer, batch, 1400, False, "split", True, 11)
+        _restore(trainer, snap)
+        # Second comparison, against ONE batched student pass and ONE backward after everything.  A batch of 4 instead of
+        # 2 + 2 changes the tile count of the deep layers and with it their number of split-K ranges, i.e. the ORDER of
+        # their fp32 sums: last-bit differences in the features that can flip one of the ~10^5 discrete decisions of a
+        # 1000 x 1000 step (a top-k boundary, an IoU threshold), which is noise of the arithmetic and not of the schedule.
+        # Both arms of this comparison therefore run with split-K off (MMT_SPLITK=0, read per call): every convolution
+        # is then bit-identical whatever batch its image sits in
+        # (test_fullsize_properties.py::test_conv_fullsize_linearity_and_batch_invariance).
+        os.environ["MMT_SPLITK"] = "0"
+        b2_l, b2_g, b2_s, b2_t = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
+        _restore(trainer, snap)
+        ser_l, ser_g, ser_s, ser_t = _run_schedule(trainer, batch, 1400, False, "batched", False, 11)
+        _restore(trainer, snap)
+    finally:
+        trainer.overlap_teacher, trainer.student_passes, trainer.early_sup_backward = keep
+        if old_env is None:
+            os.environ.pop("MMT_SPLITK", None)
+        else:
+            os.environ["MMT_SPLITK"] = old_env
+    assert set(bench_l) == set(ser_l) == set(same_l) and "mt_classifier" in bench_l and "mt_fg_loss" in bench_l
+    # (1) only the stream / thread schedule differs: same launches on the same data.  What may differ is the order of the
+    # fp32 atomics in the ROIAlign backward and in the split-K weight gradients
+    for k in bench_l:
+        assert bench_l[k] == pytest.approx(same_l[k], rel=1e-6), k
+    _close(bench_g, same_g, 1e-4, "gradient, overlapped vs serial")
+    _close(bench_s - snap["s"], same_s - snap["s"], 1e-4, "student update")
+    _close(bench_t - snap["t"], same_t - snap["t"], 1e-4, "teacher update")
+    # (2) two passes + early supervised backward + graph of two backward calls vs one batched pass + one backward
+    for k in b2_l:
+        assert b2_l[k] == pytest.approx(ser_l[k], rel=2e-5), k
+    _close(b2_g, ser_g, 1e-3, "gradient, bench schedule vs batched")
+    _close(b2_s - snap["s"], ser_s - snap["s"], 1e-3, "student update")
+    _close(b2_t - snap["t"], ser_t - snap["t"], 1e-3, "teacher update")
+    assert (bench_s != snap["s"]).any() and (bench_t != snap["t"]).any()
+
+
+def test_bench_schedule_equals_serial_160(small):
+    _, trainer, batch = small
+    _schedule_equivalence(trainer, batch)
+
+
+def test_bench_schedule_equals_serial_fullsize():
+    """the same at BASELINE.json's size: exactly the trainer, data and step bench.py times"""
+    bench = _bench()
+    _, trainer, batch = bench.build(torch.device("cuda", 0), 0)
+    _schedule_equivalence(trainer, batch)
+
+
+def test_device_sampler_properties():
+    """BalancedPositiveNegativeSampler on the device (what runs when nothing is replayed): counts, membership and the
+    positive fraction of balanced_positive_negative_sampler.py:20-72, uniformity of the draw"""
+    from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    g = torch.Generator(device="cuda").manual_seed(5)
+    s = BalancedPositiveNegativeSampler(512, 0.25)
+    s.generator = g
+    n = 3000
+    lab = torch.zeros(n, dtype=torch.int64, device="cuda")
+    lab[:300] = 1 + (torch.arange(300, device="cuda") % 2)   # 300 positives (classes 1, 2)
+    lab[300:400] = -1                                         # 100 ignored
+    few = torch.zeros(n, dtype=torch.int64, device="cuda")
+    few[:7] = 2                                               # fewer positives than the quota
+    none = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+    none[:100] = 0                                            # no positives, fewer negatives than the batch
+    pos, neg = s([lab, few, none])
+    assert int(pos[0].sum()) == 128 and int(neg[0].sum()) == 384
+    assert bool((lab[pos[0]] >= 1).all()) and bool((lab[neg[0]] == 0).all())
+    assert int(pos[1].sum()) == 7 and int(neg[1].sum()) == 505 and bool((few[pos[1]] == 2).all())
+    assert int(pos[2].sum()) == 0 and int(neg[2].sum()) == 100
+    assert not bool((pos[0] & neg[0]).any())
+    # uniform without replacement: over many draws every positive is picked with frequency 128 / 300
+    cnt = torch.zeros(n, device="cuda")
+    for _ in range(400):
+        p, _n = s([lab])
+        cnt += p[0].float()
+    f = (cnt[:300] / 400).cpu().numpy()
+    assert abs(f.mean() - 128 / 300) < 1e-6 and f.min() > 0.30 and f.max() < 0.56
+    assert float(cnt[300:].sum()) == 0.0
+    # same generator state -> same draw (what makes the overlapped and the serial schedule comparable)
+    g.manual_seed(9)
+    a = s([lab])[0][0].clone()
+    g.manual_seed(9)
+    assert torch.equal(a, s([lab])[0][0])
+
+
+def test_dropout_mask_properties(small):
+    """FPN2MLPFeatureExtractor's own dropout draw: keep-probability 1 - DO, scaled by 1 / (1 - DO), off in eval"""
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    cfg, trainer, _ = small
+    fe = trainer.student.box_heads.box.feature_extractor
+    feats = [torch.randn(1, 256, s, s, device="cuda").contiguous(memory_format=torch.channels_last) for s in (40, 20, 10, 5)]
+    xy = torch.rand(256, 2, device="cuda") * 100
+    boxes = [BoxList(torch.cat([xy, xy + 30], 1), (160, 160), "xyxy")]
+    trainer.seed_rng(21)
+    with torch.no_grad():
+        ev = fe(feats, boxes, istrain=False)
+        tr = fe(feats, boxes, istrain=True)
+    live = ev > 0
+    kept = (tr != 0) & live
+    frac = kept.sum().item() / live.sum().item()
+    assert abs(frac - (1 - cfg.MODEL.ROI_BOX_HEAD.DO)) < 0.01, frac
+    ratio = tr[kept] / ev[kept]
+    assert (ratio - 1 / (1 - cfg.MODEL.ROI_BOX_HEAD.DO)).abs().max().item() < 1e-5
