@@ -98,40 +98,34 @@ def build(device, rank, irnet=False, crop=None, n_inst=None):
 
 
 def cpu_baseline():
-    """The oracle (CPU restatement pinned to the reference, oracle/model.py) on a bounded sample: ONE full step
-    (A-E) on 1 labeled + 1 unlabeled 1000x1000 crop = half a per-GPU batch.  Baseline only."""
+    """The oracle (CPU restatement pinned to the reference, oracle/model.py::Trainer: the three forwards, loss weighting,
+    backward, torch.optim.SGD with the reference's parameter groups, EMA) on a bounded sample -- full steps [A]-[E] on
+    1 labeled + 1 unlabeled 1000x1000 crop = HALF a per-GPU batch -- 1 warm-up + 3 timed steps,
+    median.  Baseline only."""
+    import statistics
     import synthetic
     from oracle import model as om
     # intra-op threads are capped: on a 256-core host torch/oneDNN with 256 threads is ~20x SLOWER on these shapes
     # (measured: 775 s vs ~40 s); `cores` in the JSON is the thread count actually used
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    ocfg = om.default_cfg()
-    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "state_shapes.json")))["shapes"]
-    trainable = set(json.load(open(os.path.join(ROOT, "tests", "golden", "state_shapes.json")))["trainable"])
-    sd = synthetic.make_weights(shapes, seed=0)
-    sd = {k: v.requires_grad_(k in trainable) for k, v in sd.items()}
-    tsd = {k: v.detach().clone() for k, v in sd.items()}
+    ss = json.load(open(os.path.join(ROOT, "tests", "golden", "state_shapes.json")))
+    sd = synthetic.make_weights(ss["shapes"], seed=0)
+    ot = om.Trainer(sd, om.default_cfg(), ss["trainable"], ss["param_order"])
     imgs, tgs = synthetic.make_labeled(1, CROP, N_INST, seed=1234)
     unl = synthetic.make_unlabeled(1, CROP, 3, seed=4321)
     targets = [om.Boxes(t["boxes"], t["size"], {"labels": t["labels"], "masks": t["polys"]}) for t in tgs]
     torch.manual_seed(0)
-    t0 = time.time()
-    ld = om.forward_supervised(sd, ocfg, imgs, targets)
-    tr = om.forward_teacher(tsd, ocfg, unl[:2])
-    ld.update(om.forward_student(sd, ocfg, unl[-1:], tr))
-    ld = om.weight_sum_losses(ocfg, ld, 1100, 7000)
-    sum(ld.values()).backward()
-    with torch.no_grad():
-        for k, v in sd.items():
-            if v.grad is not None:
-                v.add_(v.grad, alpha=-0.005)
-        om.ema_update([tsd[k] for k in sd if sd[k].dtype == torch.float32 and k in trainable],
-                      [sd[k].detach() for k in sd if sd[k].dtype == torch.float32 and k in trainable], 0.99)
-    dt = time.time() - t0
+    times = []
+    for i in range(4):
+        t0 = time.time()
+        ot.step(1400 + i, imgs, targets, unl)
+        times.append(time.time() - t0)
+    dt = statistics.median(times[1:])
     return {"value": round(2.0 / dt, 5), "unit": "imgs/sec", "cores": cores, "kind": "port",
-            "sample": "1 full MT step (sup fwd, teacher K=2xflip, student MGD+PSM, bwd, SGD, EMA) on 1 labeled + 1 "
-                      "unlabeled 1000x1000 crop (half a per-GPU batch), fp32, %.1f s" % dt}
+            "sample": "full MT steps (sup fwd, teacher K=2xflip, student MGD+PSM, bwd, SGD, EMA) on 1 labeled + 1 "
+                      "unlabeled 1000x1000 crop (half a per-GPU batch), fp32; 1 warm-up (%.1f s) + 3 timed steps, median "
+                      "%.1f s (%s)" % (times[0], dt, ", ".join("%.1f" % t for t in times[1:]))}
 
 
 ARITH = {0: "fp32-input MFMA (IEEE fp32 products)",
@@ -140,7 +134,7 @@ ARITH = {0: "fp32-input MFMA (IEEE fp32 products)",
          2: "fp32 tensors; 2-term bf16 split (3 MFMAs)", 1: "fp32 tensors; bf16 products, fp32 accumulate"}
 
 
-def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, args):
+def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, nsteps):
     """dominant kernel = the 128x128 forward tile (also runs every stride-1 data gradient).  `achieved` is algorithmic
     FLOP/s (2*M*N*K per launch / event-bracketed launch time); `peak` is the matrix-pipe peak available to that
     arithmetic: the fp32-input MFMA peak in mode 0, the bf16 dense peak divided by the products per multiply-add else."""
@@ -151,8 +145,10 @@ def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, args):
     r = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
          "frac": round(ach / peak, 4), "traffic": traffic,
          "algorithmic_bytes_per_launch": round(alg_bytes / n, 1), "algorithmic_flop_per_launch": round(flops / n, 1),
-         "launches_per_step": len(prof) // max(args.steps, 1), "avg_launch_ms": round(ms / n, 4),
-         "share_of_step_time": round(ms / (dt * 1e3), 4)}
+         "launches_per_step": len(prof) // max(nsteps, 1), "avg_launch_ms": round(ms / n, 4),
+         "share_of_step_time": round(ms / (dt * 1e3), 4),
+         "measured_in": "a separate leg of %d steps with an event pair around every launch of this kernel on its launch "
+                        "stream (%.2f ms/step with the brackets); the headline leg carries no brackets" % (nsteps, dt / nsteps * 1e3)}
     if mode != 0:
         r["executed_mfma_tflops"] = round(ach * PRODUCTS[mode], 1)
         r["peak_note"] = "%.0f TFLOP/s bf16 dense / %d products; the same work on the fp32-input MFMA is capped at %.1f" % (
@@ -164,8 +160,9 @@ def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)    # 10 warm-up + 50 timed steps
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--profile-steps", type=int, default=10, help="steps of the separate event-bracketed leg (roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--irnet", action="store_true", help="IR-Net on (BASELINE configs[4] in fp32); not the headline line")
     args = ap.parse_args()
@@ -197,32 +194,45 @@ def main():
         il, targets, ul = batch()
         return trainer.train_step(it0 + i, il, targets, ul)
 
-    def timed(first, n):
+    def timed(first, n, profile):
+        """n steps between two (barrier + synchronize) pairs.  profile=False: the headline leg -- nothing but one event per
+        step boundary on the step stream (per-step durations for the median, no host sync).  profile=True: the separate
+        leg in which every launch of the dominant kernel is bracketed by an event pair on its launch stream."""
         sync()
-        _hip.PROFILE = []
+        _hip.PROFILE = [] if profile else None
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         t0 = time.perf_counter()
         for i in range(n):
+            marks[i].record()
             losses = step(first + i)
+        marks[n].record()
         sync()
         dt = time.perf_counter() - t0
-        prof, _hip.PROFILE = [p for p in _hip.PROFILE if p[3][0] == 'fwd1'], None
+        prof = [p for p in (_hip.PROFILE or []) if p[3][0] == 'fwd1']
+        _hip.PROFILE = None
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(n)]
         if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, prof, losses
+        return dt, prof, losses, per_step
 
     mode = _hip.get_conv_precision()
     for i in range(args.warmup):
         step(i)
-    dt, prof, losses = timed(args.warmup, args.steps)
+    dt, _, losses, per_step = timed(args.warmup, args.steps, False)
+    nxt = args.warmup + args.steps
+    npf = max(1, min(args.profile_steps, args.steps))
+    dtp, prof, _, _ = timed(nxt, npf, True)
+    nxt += npf
     single = None
     if world == 1 and trainer.overlap_teacher and not os.environ.get("MMT_BENCH_NO_FP32_LEG"):
         # the same launches with the teacher on the main stream: kernel durations without a second stream sharing the GPU
         trainer.overlap_teacher = False
-        step(args.warmup + args.steps)
-        n1 = max(2, args.steps // 2)
-        dt1, prof1, _ = timed(args.warmup + args.steps + 1, n1)
+        step(nxt)
+        n1 = max(2, npf // 2)
+        dt1, prof1, _, _ = timed(nxt + 1, n1, True)
+        nxt += 1 + n1
         fl1, ms1 = sum(p[0] for p in prof1), sum(p[1].elapsed_time(p[2]) for p in prof1)
         trainer.overlap_teacher = True
         if ms1 > 0:
@@ -231,9 +241,10 @@ def main():
     if mode != 0 and world == 1 and not os.environ.get("MMT_BENCH_NO_FP32_LEG"):
         # the same workload on the fp32-input MFMA kernels (mode 0), reported next to the headline number
         _hip.set_conv_precision(0)
-        step(args.warmup + args.steps)
-        n0 = max(2, args.steps // 2)
-        dt0, prof0, _ = timed(args.warmup + args.steps + 1, n0)
+        step(nxt)
+        n0 = max(2, npf // 2)
+        dt0, _, _, _ = timed(nxt + 1, n0, False)
+        _, prof0, _, _ = timed(nxt + 1 + n0, n0, True)
         fl0, ms0 = sum(p[0] for p in prof0), sum(p[1].elapsed_time(p[2]) for p in prof0)
         ref_fp32 = {"ms_per_step": round(dt0 / n0 * 1e3, 3), "value": round((N_LAB + N_UNLAB) * n0 / dt0, 4),
                     "steps": n0, "dominant_kernel_tflops": round(fl0 / (ms0 * 1e-3) / 1e12, 2) if ms0 > 0 else None,
@@ -242,7 +253,9 @@ def main():
 
     if rank == 0:
         imgs_per_step = (N_LAB + N_UNLAB) * world
-        value = imgs_per_step * args.steps / dt
+        value = imgs_per_step * args.steps / dt          # whole-job throughput over the K bracketed steps
+        import statistics
+        med = statistics.median(per_step)                 # per-step durations from the step-boundary events (rank 0)
         flops = sum(p[0] for p in prof)
         ms = sum(p[1].elapsed_time(p[2]) for p in prof)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -259,7 +272,11 @@ def main():
         out = {
             "metric": "imgs/sec (student+teacher step, 1000x1000, AUG_K=2)",
             "value": round(value, 4), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "median_ms_per_step": round(med, 3),
+            "p10_p90_ms_per_step": [round(sorted(per_step)[len(per_step) // 10], 3),
+                                    round(sorted(per_step)[(len(per_step) * 9) // 10 - (1 if len(per_step) >= 10 else 0)], 3)],
+            "imgs_per_sec_at_median": round(imgs_per_step / (med * 1e-3), 4),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MMT-PSM mean-teacher step (BASELINE configs[2]; configs[3] when n_gpus>1): per GPU 2 "
                                    "labeled + 2 unlabeled 1000x1000x3 crops, AUG_K=2 + flip, AUG_S=1, MT.LAMBDA 5, "
@@ -267,7 +284,7 @@ def main():
                                        "ON (relation NMS + mask relation; RELATION_NMS.LOSS 0.01)" if args.irnet else "off"),
                        "image_forwards_per_step_per_gpu": 12, "parallelism": "dp%d" % world,
                        "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}},
-            "roofline": roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, args),
+            "roofline": roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dtp, npf),
         }
         # the launches of that kernel with an un-split K (the large FPN / layer1-2 shapes); the others are the few-tile,
         # long-K layers, whose bracketed duration also contains their small finish launch
@@ -275,7 +292,7 @@ def main():
         if uns and len(uns) < len(prof):
             fu, mu = sum(q[0] for q in uns), sum(q[1].elapsed_time(q[2]) for q in uns)
             out["roofline"]["unsplit_k_launches"] = {
-                "launches_per_step": len(uns) // max(args.steps, 1), "achieved": round(fu / (mu * 1e-3) / 1e12, 2),
+                "launches_per_step": len(uns) // max(npf, 1), "achieved": round(fu / (mu * 1e-3) / 1e12, 2),
                 "frac": round(fu / (mu * 1e-3) / 1e12 / out["roofline"]["peak"], 4), "avg_launch_ms": round(mu / len(uns), 4)}
         out["config"]["conv_arithmetic"] = ARITH[mode]
         if single is not None:

@@ -178,11 +178,11 @@ def test_bucketed_allreduce_covers_every_gradient_exactly_once(monkeypatch):
     import bench
     from maskrcnn_benchmark.engine import MTtrainer as MT
     cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0)
-    trainer.overlap_teacher = False   # one thread, one RNG stream: two runs of a step draw the same samples
+    # the overlapped default schedule: each model draws from its own generator, so two runs of a step draw the same samples
 
     def grads(step):
         il, tg, ul = batch()
-        torch.manual_seed(7)
+        trainer.seed_rng(7)                            # the student's and the teacher's own random streams
         opt_step = trainer.optimizer.step
         trainer.optimizer.step = lambda: None          # keep the weights: same forward both times
         upd = trainer.update_teacher
