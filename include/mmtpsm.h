@@ -126,6 +126,11 @@ typedef struct {
    * NULL: the kernel splits the fp32 weights itself (slower). */
   const void* w_planes;
   long w_plane_stride;
+  /* optional: x pre-split into three bf16 planes (mmt_split_planes), each indexed exactly like x ([N][H][W][Cin]);
+   * taken by the split-bf16 kernels on 128 x 128 tiles (mode 3), ignored otherwise.  Results are bit-identical to
+   * the call without it: the same split, done once per tensor instead of once per use inside the kernel. */
+  const void* x_planes;
+  long x_plane_stride;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
@@ -167,6 +172,9 @@ int mmt_pack_weight(const float* w, void* planes, long plane_stride, int Cout, i
  * DMA-fed kernels take (Cin % 16 == 0, Cout > 32 of THAT call, mode != 0). */
 int mmt_pack_weight_flipped(const float* w, const float* scale, void* planes, long plane_stride, int Cout, int KH, int KW,
                             int Cin, void* stream);
+/* x[n] fp32 (n % 8 == 0, 16-byte aligned) -> three bf16 planes planes[q * plane_stride + i], x = p0 + p1 + p2 with
+ * round-to-nearest at each level (|x - sum| <= 2^-27 |x|): the activation-side counterpart of mmt_pack_weight */
+int mmt_split_planes(const float* x, void* planes, long plane_stride, long n, void* stream);
 int mmt_pack_weights(const float* base, void* planes, long plane_stride, const mmt_pack_desc* descs /*[dev]*/,
                      const int* unit_desc /*[dev]*/, int n_units, void* stream);
 

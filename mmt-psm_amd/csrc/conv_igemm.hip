@@ -39,6 +39,7 @@ struct ConvP {
   float mask_scale;
   int M, K, cin32, cin4;  // derived
   const unsigned short* wpl; long wpl_stride;  // pre-split bf16 planes of w (or null)
+  const unsigned short* xpl; long xpl_stride;  // pre-split bf16 planes of x, same NHWC indexing as x (or null)
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
@@ -799,6 +800,265 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
   f32x4* slab = (f32x4*)ws + ((long)bid * ksplit + ks) * TILE4;
   const f32x4* ct4 = (const f32x4*)lds;
   for (int i = tid; i < TILE4; i += 256) slab[i] = ct4[i];
+}
+
+// ------------------------------------------------------------------------------------ split-bf16 forward, both operands as planes
+// Same GEMM, same products in the same order as conv_fwd_glds_kernel (bit-identical results), with the ACTIVATIONS
+// pre-split as well: x arrives as NS bf16 planes with x's own NHWC indexing (mmt_split_planes, or written by the
+// producing convolution's epilogue).  What that buys, from the counters of the kernel above:
+//   * a 3x3 convolution re-reads every input value 9 x Cout/128 times; there each read is split again in registers
+//     (~45 vector instructions per wave per 16-k step beside 24 MFMAs: with two waves per SIMD that is the issue budget
+//     of the MFMA gaps).  Here the main loop has NO vector arithmetic: per step and wave 6 DMA issues, 12 ds_read_b128,
+//     24 MFMAs;
+//   * without a per-wave split the wave grid is free: 2 x 2 waves of 64 x 64 (12 fragment reads per 24 MFMAs, 14 before).
+// A-plane LDS image = the B-plane image: per 32-row block [32 rows][2 halves][8 bf16] with half ^= (row >> 3) & 1; a DMA
+// instruction fills one block of one plane (lane = (row, half): 16 B from the row's pixel, channel c0 + 8 * logical half).
+template <int BM, int BN, int WM, int WN, int NS, int S, int DBG = 0>  // DBG (timing experiments only): 1 no DMA, 2 no fragment reads, 4 no barrier
+__global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, const int ksplit, float* __restrict__ ws) {
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int PA = BM * 32, PB = BN * 32;  // bytes of one plane of the A / B tile
+  constexpr int A_BYTES = NS * PA;
+  constexpr int STAGE = A_BYTES + NS * PB;
+  constexpr int NIA_TOT = NS * BM / 32, NIB_TOT = NS * BN / 32;
+  constexpr int NIA = (NIA_TOT + 3) / 4, NIB = (NIB_TOT + 3) / 4, NI = NIA + NIB;
+  static_assert(BM / 32 == 4 || BM / 32 == 2, "row blocks per wave");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ring = (char*)lds;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = tiles_m * tiles_n * ksplit, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ks = bid % ksplit;
+  bid /= ksplit;
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HoWo = p.Ho * p.Wo;
+
+  // ---- A DMA geometry: instruction t = wave + 4 i -> plane t / (BM/32), row block t % (BM/32); with BM/32 == 4 a wave
+  // always fills ITS OWN row block (one pixel per lane pair) in every plane
+  const unsigned short* asrc[NIA];
+  int adst[NIA];
+  int arow_blk[NIA];
+#pragma unroll
+  for (int i = 0; i < NIA; i++) {
+    const int t = (wave + 4 * i) % NIA_TOT;
+    const int q = t / (BM / 32), rb = t % (BM / 32);
+    asrc[i] = p.xpl + q * p.xpl_stride;
+    adst[i] = q * PA + rb * 1024;
+    arow_blk[i] = rb;
+  }
+  // rows: with BM/32 == 4 all of this wave's instructions share one row block; with BM/32 == 2 they alternate (0,1,0,..)
+  constexpr int NRB = (BM / 32 == 4) ? 1 : 2;
+  unsigned abase[NRB];
+  int aih0[NRB], aiw0[NRB];
+  bool aok[NRB];
+  const int lrow = lane >> 1;
+  const int achunk = (((lane & 1) ^ ((lrow >> 3) & 1)) << 3);  // bf16 elements: logical half held by this lane
+#pragma unroll
+  for (int j = 0; j < NRB; j++) {
+    const int rb = (BM / 32 == 4) ? (wave % 4) : ((wave + 4 * j) % NIA_TOT) % (BM / 32);
+    const int m = m0 + rb * 32 + lrow;
+    aok[j] = m < p.M;
+    const int mm = aok[j] ? m : 0;
+    const int img = mm / HoWo, rem = mm - img * HoWo;
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    aih0[j] = ho * p.stride - p.pad;
+    aiw0[j] = wo * p.stride - p.pad;
+    abase[j] = (unsigned)img * (unsigned)(p.H * p.W * p.Cin);
+  }
+  const int nb32 = (p.Cout + 31) >> 5;
+  const long kt_stride = (long)nb32 * 512;  // bf16 elements per 16-k step
+  const unsigned short* bsrc[NIB];
+  int bdst[NIB];
+#pragma unroll
+  for (int i = 0; i < NIB; i++) {
+    const int t = (wave + 4 * i) % NIB_TOT;
+    const int q = t / (BN / 32), rb = t % (BN / 32);
+    int nb = n0 / 32 + rb;
+    if (nb >= nb32) nb = nb32 - 1;
+    bsrc[i] = p.wpl + q * p.wpl_stride + (long)nb * 512 + lane * 8;
+    bdst[i] = A_BYTES + q * PB + rb * 1024;
+  }
+  const int nkt_all = p.K >> 4;
+  const int kt0 = (int)((long)ks * nkt_all / ksplit), nkt = (int)((long)(ks + 1) * nkt_all / ksplit) - kt0;
+  int s_kh, s_kw, s_ci;
+  {
+    const int k0 = kt0 * 16, tap0 = k0 / p.Cin;
+    s_ci = k0 - tap0 * p.Cin;
+    s_kh = tap0 / p.KW;
+    s_kw = tap0 - s_kh * p.KW;
+  }
+  bool fresh = true;
+  int c_ci = 0;
+  unsigned roff[NRB];
+  bool rok[NRB];
+  const unsigned short* const zsrc = (const unsigned short*)g_zero16;
+  auto tap_next = [&]() {
+    c_ci = s_ci;
+    if (s_ci == 0 || fresh) {
+      fresh = false;
+#pragma unroll
+      for (int j = 0; j < NRB; j++) {
+        const int ih = aih0[j] + s_kh, iw = aiw0[j] + s_kw;
+        rok[j] = aok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        roff[j] = abase[j] + (unsigned)((ih * p.W + iw) * p.Cin + achunk);
+      }
+    }
+    s_ci += 16;
+    if (s_ci >= p.Cin) { s_ci = 0; if (++s_kw == p.KW) { s_kw = 0; ++s_kh; } }
+  };
+  bool filling = true;
+  auto dma_a = [&](int i, int stage) {
+    const int j = NRB == 1 ? 0 : (i & 1);
+    const unsigned short* src = rok[j] && filling ? asrc[i] + (roff[j] + (unsigned)c_ci) : zsrc;
+    dma16(src, ring + stage * STAGE + adst[i]);
+  };
+  auto dma_b = [&](int i, int kt, int stage) {
+    const void* src = filling ? (const void*)(bsrc[i] + (long)(kt0 + kt) * kt_stride) : (const void*)zsrc;
+    dma16(src, ring + stage * STAGE + bdst[i]);
+  };
+  auto issue_all = [&](int kt, int stage) {
+    tap_next();
+#pragma unroll
+    for (int i = 0; i < NIA; i++) dma_a(i, stage);
+#pragma unroll
+    for (int i = 0; i < NIB; i++) dma_b(i, kt, stage);
+  };
+
+  const int lr = lane & 31, kh2 = lane >> 5;
+  const int foff = lr * 32 + (((kh2 ^ (lr >> 3)) & 1) << 4);
+  const int aoff = (wm * TM) * 1024 + foff;
+  const int boff = A_BYTES + (wn * TN) * 1024 + foff;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  constexpr int M_DMA = NIA + NIB, M_RA = NS * TM, M_RB = NS * TN;
+  constexpr int NMICRO = M_DMA + M_RA + M_RB;
+  auto micro = [&](int idx, int kt_fill, int stage_free, int stage_next, bf16x8 (&fan)[NS][TM], bf16x8 (&fbn)[NS][TN]) {
+    if (DBG & 16) {  // spread: every third micro-op is a DMA (0,3,6,.. -> DMA 0..5), the others are the fragment reads
+      if (idx % 3 == 0 && idx / 3 < NIA + NIB) idx = idx / 3;
+      else idx = NIA + NIB + (idx - min(idx / 3 + 1, NIA + NIB));
+    }
+    if (idx < NIA) { if (!(DBG & 1) && !((DBG & 8) && (kt_fill % 3))) dma_a(idx, stage_free); return; }
+    idx -= NIA;
+    if (idx < NIB) { if (!(DBG & 1) && !((DBG & 32) && (kt_fill % 3))) dma_b(idx, kt_fill, stage_free); return; }
+    idx -= NIB;
+    if (DBG & 2) return;
+    const char* st = ring + stage_next * STAGE;
+    if (idx < M_RA) { const int q = idx / TM, a = idx % TM; fan[q][a] = *(const bf16x8*)(st + aoff + q * PA + a * 1024); return; }
+    idx -= M_RA;
+    { const int q = idx / TN, b = idx % TN; fbn[q][b] = *(const bf16x8*)(st + boff + q * PB + b * 1024); }
+  };
+  auto wait_dma = [&](int steps_in_flight) {
+    static_assert(S >= 3 && S <= 5 && 3 * NI < 64, "vmcnt range");
+    if (steps_in_flight <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (steps_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NI) : "memory");
+    else if (steps_in_flight == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * NI) : "memory");
+  };
+  auto step = [&](int kt, int stage_next, int stage_free, const bf16x8 (&fa)[NS][TM], const bf16x8 (&fb)[NS][TN],
+                  bf16x8 (&fan)[NS][TM], bf16x8 (&fbn)[NS][TN]) {
+    if (!(DBG & (1 | 8 | 32))) wait_dma(S - 2); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+    tap_next();
+    filling = kt + S < nkt;
+    const int kt_fill = min(kt + S, nkt - 1);
+    constexpr int NM = TM * TN * (NS * (NS + 1) / 2);
+    int j = 0, mi = 0;
+#pragma unroll
+    for (int sum = NS - 1; sum >= 0; sum--)
+#pragma unroll
+      for (int qa = 0; qa <= sum; qa++) {
+        const int qb = sum - qa;
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+          for (int b = 0; b < TN; b++) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
+            j++;
+#pragma unroll
+            for (int r = 0; r < (NMICRO + NM - 1) / NM; r++)
+              if (mi < (j * NMICRO + NM - 1) / NM) { micro(mi, kt_fill, stage_free, stage_next, fan, fbn); mi++; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+  };
+#pragma unroll
+  for (int t = 0; t < S - 1; t++) { filling = t < nkt; issue_all(min(t, nkt - 1), t); }
+  wait_dma(S - 2);
+  __builtin_amdgcn_s_barrier();
+  filling = S - 1 < nkt;
+  issue_all(min(S - 1, nkt - 1), S - 1);
+  bf16x8 fa0[NS][TM], fb0[NS][TN], fa1[NS][TM], fb1[NS][TN];
+  if (DBG & 2) {  // keep the register sets defined
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+#pragma unroll
+      for (int a = 0; a < TM; a++) fa1[q][a] = *(const bf16x8*)(ring + aoff + q * PA + a * 1024);
+#pragma unroll
+      for (int b = 0; b < TN; b++) fb1[q][b] = *(const bf16x8*)(ring + boff + q * PB + b * 1024);
+    }
+  }
+  {
+    const char* st = ring;
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+#pragma unroll
+      for (int a = 0; a < TM; a++) fa0[q][a] = *(const bf16x8*)(st + aoff + q * PA + a * 1024);
+#pragma unroll
+      for (int b = 0; b < TN; b++) fb0[q][b] = *(const bf16x8*)(st + boff + q * PB + b * 1024);
+    }
+  }
+  int stage = 0;
+  for (int kt = 0; kt < nkt; kt += 2) {
+    const int s1 = stage == S - 1 ? 0 : stage + 1, s2 = s1 == S - 1 ? 0 : s1 + 1;
+    step(kt, s1, stage, fa0, fb0, fa1, fb1);
+    if (kt + 1 < nkt) step(kt + 1, s2, s1, fa1, fb1, fa0, fb0);
+    stage = s2;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (ksplit == 1) {
+    conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tid, lane, wm, wn, HoWo);
+    return;
+  }
+  conv_epilogue_stage<BM, BN, WM, WN>(acc, lds, lane, wm, wn);
+  __syncthreads();
+  constexpr int TILE4 = BM * BN / 4;
+  f32x4* slab = (f32x4*)ws + ((long)bid * ksplit + ks) * TILE4;
+  const f32x4* ct4 = (const f32x4*)lds;
+  for (int i = tid; i < TILE4; i += 256) slab[i] = ct4[i];
+}
+
+// x (n fp32 values, n % 8 == 0) -> NS bf16 planes of the same indexing: x = p0 + p1 + p2, round-to-nearest at each level
+// (the split the kernels above do in registers, done ONCE per tensor instead of once per use)
+template <int NS>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ pl,
+                                                           const long plane_stride, const long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const f32x4 v0 = ((const f32x4*)x)[2 * i], v1 = ((const f32x4*)x)[2 * i + 1];
+    uint2 o0[NS], o1[NS];
+    split4<NS>(v0, o0);
+    split4<NS>(v1, o1);
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+      ((uint4*)(pl + q * plane_stride))[i] = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+  }
 }
 
 // one block per QUARTER tile (BM / 4 rows): four times the blocks of the main launch's tile count, or this small kernel is a
@@ -1810,6 +2070,7 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.relu = a->relu; p.res_mode = a->res_mode; p.out_stride = a->out_stride < 1 ? 1 : a->out_stride;
   p.out_H = a->out_H; p.out_W = a->out_W; p.mask_scale = a->mask_scale;
   p.wpl = (const unsigned short*)a->w_planes; p.wpl_stride = a->w_plane_stride;
+  p.xpl = (const unsigned short*)a->x_planes; p.xpl_stride = a->x_plane_stride;
   if ((long)p.N * p.Ho * p.Wo > 0x7fffffffL) return MMT_EINVAL;
   if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL || (long)p.N * p.Ho * p.Wo * p.Cout >= 0x7fffffffL ||
       (long)p.Cout * p.KH * p.KW * p.Cin >= 0x7fffffffL) return MMT_EINVAL;  // kernels use 32-bit element offsets
@@ -1903,6 +2164,48 @@ int launch_glds(const ConvP& p, hipStream_t s, int ksplit = 1) {
   return 0;
 }
 
+template <int BM, int BN, int WM, int WN, int NS, int S>
+int launch_pp(const ConvP& p, hipStream_t s, int ksplit = 1) {
+  const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN) * ksplit;
+  SplitWs w{nullptr};
+  if (ksplit > 1) {
+    w = split_workspace(s);
+    if (!w.ws || tiles > 1024) return MMT_EINVAL;
+  }
+  const size_t ring = (size_t)S * NS * (BM + BN) * 32, epi = (size_t)BM * BN * sizeof(float);
+  const size_t lds = ring > epi ? ring : epi;
+  void (*kern)(const ConvP, const int, float*) = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S>;
+#ifdef MMT_PP_EXPERIMENTS
+  {
+    const char* d = getenv("MMT_PP_DBG");
+    const int dbg = d ? atoi(d) : 0;
+    if (dbg == 1) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 1>;
+    if (dbg == 2) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 2>;
+    if (dbg == 3) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 3>;
+    if (dbg == 4) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 4>;
+    if (dbg == 7) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 7>;
+    if (dbg == 8) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 8>;
+    if (dbg == 16) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 16>;
+    if (dbg == 24) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 24>;
+    if (dbg == 40) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 40>;
+  }
+#endif
+  if (lds > 65536) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, p, ksplit, w.ws);
+  MMT_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    if constexpr (BM == 128 && BN == 128)
+      hipLaunchKernelGGL((conv_splitk_finish_kernel<BM, BN>), dim3(tiles / ksplit * 4), dim3(256), epi / 4, s, p, ksplit, w.ws);
+    else
+      return MMT_EINVAL;
+    MMT_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 template <int KT, int BN, int NS>
 int launch_rows(const ConvP& p, hipStream_t s) {
   const size_t lds = (size_t)128 * BN * 4 + 2 * (size_t)KT * NS * (BN / 32) * 1024;
@@ -1934,6 +2237,9 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
     if (p.Cin == 128) return launch_rows<8, 32, NS>(p, s);
   }
   const int ksplit = pick_ksplit(p);
+  // activations pre-split into planes by the caller: the all-planes kernel (128 x 128 tiles, 2 x 2 waves)
+  if (p.xpl && NS == 3 && (ksplit > 1 || variant == 1) && !((size_t)p.xpl & 15) && !(p.xpl_stride & 7))
+    return launch_pp<128, 128, 2, 2, NS, 3>(p, s, ksplit);
   if (ksplit > 1) return launch_glds<128, 128, 4, 1, NS, 3>(p, s, ksplit);
   switch (variant) {
     case 1: return launch_glds<128, 128, 4, 1, NS, 3>(p, s);
@@ -2004,6 +2310,18 @@ extern "C" int mmt_pack_weights(const float* base, void* planes, long plane_stri
   static_assert(sizeof(mmt_pack_desc) == sizeof(PackDesc), "descriptor layout");
   hipLaunchKernelGGL(pack_many_kernel, dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream, base,
                      (unsigned short*)planes, plane_stride, (const PackDesc*)descs, unit_desc, n_units);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_split_planes(const float* x, void* planes, long plane_stride, long n, void* stream) {
+  if (!x || !planes || n < 0 || (n & 7) || plane_stride < n || (plane_stride & 7) || ((size_t)planes & 15) || ((size_t)x & 15))
+    return MMT_EINVAL;
+  if (n == 0) return 0;
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_planes_kernel<3>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes,
+                     plane_stride, n / 8);
   MMT_LAUNCH_CHECK();
   return 0;
 }

@@ -26,7 +26,8 @@ class ConvArgs(ctypes.Structure):
                 ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int), ("KH", c_int),
                 ("KW", c_int), ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int),
                 ("relu", c_int), ("res_mode", c_int), ("out_stride", c_int), ("out_H", c_int), ("out_W", c_int),
-                ("mask_scale", c_float), ("w_planes", c_void_p), ("w_plane_stride", ctypes.c_long)]
+                ("mask_scale", c_float), ("w_planes", c_void_p), ("w_plane_stride", ctypes.c_long),
+                ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long)]
 
 
 class MgdTeachers(ctypes.Structure):
@@ -52,6 +53,7 @@ _SIGS = {
     "mmt_set_conv_precision": [ctypes.c_int],
     "mmt_get_conv_precision": [],
     "mmt_pack_weight": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
+    "mmt_split_planes": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p],
     "mmt_pack_weights": [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p],
     "mmt_pack_weight_flipped": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_conv_wgrad_splits": [ctypes.POINTER(ConvArgs)],
@@ -275,9 +277,18 @@ def _conv_args(x, w, stride, pad, Ho, Wo):
     return a
 
 
+def split_planes(x, out=None):
+    """x (dense fp32, numel % 8 == 0) -> (3, numel) bf16 planes with x = p0 + p1 + p2 (include/mmtpsm.h: mmt_split_planes)"""
+    n = x.numel()
+    if out is None:
+        out = torch.empty((3, n), dtype=torch.bfloat16, device=x.device)
+    _check(lib().mmt_split_planes(x.data_ptr(), out.data_ptr(), out.stride(0), n, _stream()), "mmt_split_planes")
+    return out
+
+
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
                  mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0,
-                 w_shape=None, planes=None, out_size=None):
+                 w_shape=None, planes=None, out_size=None, x_planes=None):
     """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory).
     y_out/y_offset (elements): write into an existing NHWC tensor at a shifted base (transposed-conv taps).
     w=None with w_shape + planes: the weight exists only as packed bf16 planes (pack_weight_flipped).
@@ -315,6 +326,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     else:
         y = y_out if y_out is not None else empty_nhwc(N, Cout, Ho, Wo, x.device)
     a.y = y.data_ptr() + 4 * int(y_offset)
+    if x_planes is not None:
+        a.x_planes, a.x_plane_stride = x_planes.data_ptr(), x_planes.stride(0)
     a.scale, a.shift = _p(scale), _p(shift)
     a.relu = 1 if relu else 0
     if res is not None:

@@ -55,9 +55,8 @@ def main():
         bl.add_field("masks", SegmentationMask([[p.tolist() for p in inst] for inst in t["polys"]], t["size"], mode="poly"))
         targets.append(bl)
 
-    def sup():
-        with torch.no_grad():  # timing the forward; backward does not exist on the reference's CPU path
-            return student(to_image_list(list(imgs), 32), targets)
+    def sup():  # training-mode forward with autograd recording, as MTtrainer runs it (backward does not exist on CPU)
+        return student(to_image_list(list(imgs), 32), targets)
 
     state = {}
 
