@@ -1045,6 +1045,250 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
   for (int i = tid; i < TILE4; i += 256) slab[i] = ct4[i];
 }
 
+// ------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1, all planes, tap strips
+// What the experiments on conv_fwd_pp_kernel showed (tools/bench_pp_dbg.py, FPN 3x3 N=8): without its DMAs the main loop
+// takes 2.3 ms, with them 3.3 ms, and the cost is linear in the BYTES moved L2 -> LDS (24 KB per 128x128x16 step), not in
+// their issue pattern; fragment reads and barriers are free.  So this kernel moves fewer bytes per multiply:
+//   * the three horizontal taps (kw = 0, 1, 2) of one (kh, 16-channel slab) read the SAME input pixels shifted by one: a
+//     strip of TW + 2 pixels per image row is copied once and the three taps read it at row offsets 0, 1, 2
+//     (the half-swizzle of the plane image, half ^= (row >> 3) & 1 on absolute strip rows, stays conflict-free for every
+//     shift) -- A traffic / 2.4;
+//   * tile = 256 output pixels (R = 256 / TW image rows x TW pixels) x 128 channels on EIGHT waves (2 per SIMD, 64 x 64
+//     each): the weight planes of a step feed twice the pixels -- B traffic per multiply / 2.
+//   -> 11 KB per 128x128x16 step-equivalent instead of 24.
+// K order: (kh, channel slab, kw) -- the packed weight planes are indexed, not re-packed.  One barrier per super-step
+// (three taps = 72 MFMAs per wave), placed before the last tap: the fragments of that tap are in registers by then, so the
+// stage is free for the copies of super-step s + 2 while tap 0 of s + 1 is pre-read from the other stage.
+template <int TW, int NS, int DBG = 0>  // DBG (timing experiments): 1 no copies in the loop, 2 no fragment reads, 4 no barrier / waits
+__global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p) {
+  constexpr int BM = 256, BN = 128, R = BM / TW, SW = TW + 32, TM = 2, TN = 2;
+  constexpr int PA = R * SW * 32;              // bytes of one A plane of a stage (strip rows x 32 B)
+  constexpr int PB = BN * 32;                  // one B plane of one tap
+  constexpr int A_BYTES = NS * PA, B_TAP = NS * PB, STAGE = A_BYTES + 3 * B_TAP;
+  constexpr int NA = R * (SW / 32) * NS, NB = 3 * (BN / 32) * NS, NSLOT = (NA + 7) / 8 + (NB + 7) / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ring = (char*)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;     // 4 x 2 waves of 64 x 64
+
+  const int tiles_w = p.Wo / TW, tiles_h = p.Ho / R, tiles_n = (p.Cout + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = bid % tiles_n;
+  int t = bid / tiles_n;
+  const int tw = t % tiles_w; t /= tiles_w;
+  const int th = t % tiles_h, img = t / tiles_h;
+  const int ho0 = th * R, wo0 = tw * TW, n0 = tile_n * BN;
+  const int slabs = p.Cin >> 4, nss = 3 * slabs;   // super-steps: (kh, slab)
+
+  // ---- copy slots of this wave.  Slots 0 .. SA-1 carry A items (wave + 8 i < NA: plane, strip row r, 32-pixel block),
+  // slots SA .. SA+SB-1 B items (tap, plane, 32-channel block).  Everything that does not change from super-step to
+  // super-step is computed here: a copy in the loop is one buffer_load ... lds with a per-lane VGPR offset fixed for the
+  // whole kernel and a scalar offset per super-step; lanes outside the image (and strip pixels past TW + 2) carry an
+  // offset beyond the descriptor's range and read zeros -- no address arithmetic, no predication in the loop.
+  constexpr int SA = (NA + 7) / 8, SB = (NB + 7) / 8;
+  constexpr unsigned OOB = 0x80000000u;
+  const int nb32 = (p.Cout + 31) >> 5;
+  const long kt_stride = (long)nb32 * 512;
+  const int lpx = lane >> 1;
+  const int achunk = (((lane & 1) ^ ((lpx >> 3) & 1)) << 3);
+  const long n_x = (long)p.N * p.H * p.W * p.Cin;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.xpl, 0, (int)(unsigned)(((NS - 1) * p.xpl_stride + n_x) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpl, 0, 0x7ffffff0, 0x00020000);
+  unsigned voff[SA + SB];   // per-lane byte offset of the slot (OOB = zeros)
+  int sdst[SA + SB];        // LDS byte offset inside a stage
+  int srow[SA];             // A: strip row r (decides with kh whether the input row exists); -1 = no item
+#pragma unroll
+  for (int i = 0; i < SA; i++) {
+    const int item = wave + 8 * i;
+    srow[i] = -1; voff[i] = OOB; sdst[i] = 0;
+    if (item < NA) {
+      const int q = item / (R * (SW / 32)), rem = item % (R * (SW / 32)), r = rem / (SW / 32), blk = rem % (SW / 32);
+      const int px = blk * 32 + lpx, iw = wo0 - 1 + px;
+      const bool ok = px < TW + 2 && (unsigned)iw < (unsigned)p.W;
+      // input row ho0 + r + kh - 1: the (kh - 1) rows and the channel slab go into the scalar offset
+      const long e = q * p.xpl_stride + ((long)(img * p.H + ho0 + r) * p.W + iw) * p.Cin + achunk;
+      voff[i] = ok ? (unsigned)(e * 2) : OOB;
+      sdst[i] = q * PA + (r * SW + blk * 32) * 32;
+      srow[i] = r;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < SB; i++) {
+    const int item = wave + 8 * i;
+    voff[SA + i] = OOB; sdst[SA + i] = -1;
+    if (item < NB) {
+      const int kw = item / ((BN / 32) * NS), rem = item % ((BN / 32) * NS), q = rem / (BN / 32), rb = rem % (BN / 32);
+      int nb = n0 / 32 + rb;
+      if (nb >= nb32) nb = nb32 - 1;
+      voff[SA + i] = (unsigned)((q * p.wpl_stride + (long)kw * slabs * kt_stride + (long)nb * 512 + lane * 8) * 2);
+      sdst[SA + i] = A_BYTES + kw * B_TAP + q * PB + rb * 1024;
+    }
+  }
+  // per input-row offset kh the A slots' VGPR offsets are fixed (a slot whose input row does not exist reads zeros);
+  // recomputed when the super-step being FILLED enters a new kh (three times per kernel), never inside the slab loop
+  const int row_bytes = p.W * p.Cin * 2;
+  unsigned vo_a[SA];
+  int f_kh = 0, f_cs = 0;          // (kh, slab) of the super-step whose copies are being issued
+  int soff_a = 0, soff_b = 0;      // its scalar byte offsets: A = max(kh - 1, 0) rows + slab, B = (kh * 3 * slabs + slab) steps
+  const int b_step = (int)(kt_stride * 2);
+  auto fill_enter_kh = [&]() {
+#pragma unroll
+    for (int i = 0; i < SA; i++) {
+      const bool rowok = srow[i] >= 0 && (unsigned)(ho0 + srow[i] + f_kh - 1) < (unsigned)p.H;
+      // voff addresses input row ho0 + r; kh = 0 wants the row above (offsets are unsigned: subtract here, add in soff else)
+      vo_a[i] = (rowok && voff[i] != OOB) ? (f_kh == 0 ? voff[i] - (unsigned)row_bytes : voff[i]) : OOB;
+    }
+    soff_a = (f_kh >= 1 ? (f_kh - 1) * row_bytes : 0);
+  };
+  fill_enter_kh();
+  auto fill_advance = [&]() {      // next super-step to fill
+    soff_a += 32;
+    soff_b += b_step;
+    if (++f_cs == slabs) {
+      f_cs = 0;
+      ++f_kh;
+      soff_b += 2 * slabs * b_step;  // the weight steps of kw = 1, 2 of the finished kh lie in between
+      fill_enter_kh();
+    }
+  };
+  auto issue_slot = [&](int i, int stage) {
+    char* const st = ring + stage * STAGE;
+    if (i < SA) {
+      if (srow[i] < 0) return;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(st + sdst[i]), 16, (int)vo_a[i], soff_a, 0, 0);
+    } else if (i < SA + SB) {
+      if (sdst[i] < 0) return;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(st + sdst[i]), 16, (int)voff[i], soff_b, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses, fixed for the kernel (per stage: the stage is a literal at every call site): A row =
+  // strip row of (image row, pixel) + kw, the half-swizzle follows the ABSOLUTE strip row; B = plane image of the tap
+  const int lr = lane & 31, kh2 = lane >> 5;
+  const char* aaddr[2][3][TM];
+  const char* baddr[2][3];
+#pragma unroll
+  for (int sg = 0; sg < 2; sg++)
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++) {
+#pragma unroll
+      for (int a = 0; a < TM; a++) {
+        const int mrow = wm * 64 + a * 32 + lr;
+        const int row = (mrow / TW) * SW + (mrow % TW) + kw;
+        aaddr[sg][kw][a] = ring + sg * STAGE + row * 32 + (((kh2 ^ (row >> 3)) & 1) << 4);
+      }
+      baddr[sg][kw] = ring + sg * STAGE + A_BYTES + kw * B_TAP + (wn * TN) * 1024 + lr * 32 + (((kh2 ^ (lr >> 3)) & 1) << 4);
+    }
+  auto read_tap = [&](int sg, int kw, bf16x8 (&fa)[NS][TM], bf16x8 (&fb)[NS][TN], int idx) {
+    // idx-th fragment read of the tap (0 .. NS*(TM+TN) - 1), dealt out behind individual MFMAs in the order the next tap
+    // consumes them: its first products are a0*b2, then a1*b1, a2*b0, so (a plane g, b plane NS-1-g) for g = 0, 1, ..
+    const int g = idx / (TM + TN), k = idx % (TM + TN);
+    if (k < TM) {
+      fa[g][k] = *(const bf16x8*)(aaddr[sg][kw][k] + g * PA);
+    } else {
+      const int q = NS - 1 - g, b = k - TM;
+      fb[q][b] = *(const bf16x8*)(baddr[sg][kw] + q * PB + b * 1024);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  constexpr int NM = TM * TN * (NS * (NS + 1) / 2), NF = NS * (TM + TN);
+  constexpr int NRD = NM * 2 / 3;  // the reads of the next tap ride behind the first two thirds of the MFMAs: the last one
+                                   // has a third of the tap (~250 cycles) to land before the next tap's first MFMA wants it
+  // one tap: NM MFMAs on (fa, fb); behind them the NF fragment reads of the NEXT tap (into fan / fbn, from stage sg_next) and
+  // the copy slots [dma0, dma0 + ndma) of the super-step being filled into stage `stage_fill`
+  auto tap = [&](const bf16x8 (&fa)[NS][TM], const bf16x8 (&fb)[NS][TN], bf16x8 (&fan)[NS][TM], bf16x8 (&fbn)[NS][TN],
+                 int sg_next, int kw_next, bool do_read, int dma0, int ndma, int stage_fill, bool do_dma) {
+    int j = 0, ri = 0, di = 0;
+#pragma unroll
+    for (int sum = NS - 1; sum >= 0; sum--)
+#pragma unroll
+      for (int qa = 0; qa <= sum; qa++) {
+        const int qb = sum - qa;
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+          for (int b = 0; b < TN; b++) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
+            j++;
+            if (ri < (j * NF + NRD - 1) / NRD && ri < NF) { if (do_read && !(DBG & 2)) read_tap(sg_next, kw_next, fan, fbn, ri); ri++; }
+            if (di < (j * ndma + NM - 1) / NM && di < ndma) { if (do_dma && !(DBG & 1)) issue_slot(dma0 + di, stage_fill); di++; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+  };
+
+  // ---- prologue: stage 0 <- super-step 0, stage 1 <- super-step 1, fragments of tap 0
+#pragma unroll
+  for (int i = 0; i < NSLOT; i++) issue_slot(i, 0);
+  fill_advance();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < NSLOT; i++) issue_slot(i, 1);
+  fill_advance();                  // the fill state now describes super-step 2
+  bf16x8 fa0[NS][TM], fb0[NS][TN], fa1[NS][TM], fb1[NS][TN];
+#pragma unroll
+  for (int i = 0; i < NF; i++) { read_tap(0, 0, fa0, fb0, i); if (DBG & 2) read_tap(0, 1, fa1, fb1, i); }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  constexpr int D0 = (NSLOT + 1) / 2, D1 = NSLOT - D0;   // copy slots issued behind tap 2 / behind tap 0 of the next super-step
+  // one super-step in stage SG (a literal at the call sites); P / Q = register sets, P holds its tap 0.  The copies of
+  // super-step ss + 2 go out behind tap 2 of ss (first half) and tap 0 of ss + 1 (second half), into this same stage
+  auto superstep = [&](int ss, int SG, bf16x8 (&fa_p)[NS][TM], bf16x8 (&fb_p)[NS][TN], bf16x8 (&fa_q)[NS][TM], bf16x8 (&fb_q)[NS][TN]) {
+    // tap 0 (regs p) | pre-read tap 1 -> q | second half of the copies of super-step ss + 1 (into the other stage)
+    const bool second = ss >= 1 && ss + 1 < nss;
+    tap(fa_p, fb_p, fa_q, fb_q, SG, 1, true, D0, D1, SG ^ 1, second);
+    if (second) fill_advance();
+    // tap 1 (regs q) | pre-read tap 2 -> p
+    tap(fa_q, fb_q, fa_p, fb_p, SG, 2, true, 0, 0, 0, false);
+    // every copy into the other stage has landed, everybody's reads of this stage are complete
+    if (!(DBG & 4)) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    // tap 2 (regs p) | pre-read tap 0 of ss + 1 -> q from the other stage | first half of the copies of ss + 2 into this stage
+    // (after the last super-step this pre-read fetches stale bytes nobody uses: unconditional, because a branch around
+    // register-producing reads makes the compiler re-pack every bf16 fragment register at the join -- 600 v_perm / v_lshr
+    // per loop body, measured)
+    tap(fa_p, fb_p, fa_q, fb_q, SG ^ 1, 0, true, 0, D0, SG, ss + 2 < nss);
+  };
+  for (int ss = 0; ss < nss; ss += 2) {
+    superstep(ss, 0, fa0, fb0, fa1, fb1);
+    superstep(ss + 1, 1, fa1, fb1, fa0, fb0);   // nss is even (Cin % 32 == 0)
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- epilogue: the 256 x 128 tile as two 128-row halves, each finished by 256 threads with the shared row epilogue.
+  // Tile row m (0..255) = output pixel (ho0 + m / TW, wo0 + m % TW); the row epilogue wants the linear pixel index, which
+  // is contiguous only inside one image row, so each 128-row half is handed over in runs of min(TW, 128) rows
+  conv_epilogue_stage<BM, BN, 4, 2>(acc, lds, lane, wm, wn);
+  __syncthreads();
+  {
+    const int half = tid >> 8, t2 = tid & 255;
+    constexpr int RUN = TW < 128 ? TW : 128;
+#pragma unroll
+    for (int run = 0; run < 128 / RUN; run++) {
+      const int mrow = half * 128 + run * RUN;
+      const int m_lin = (img * p.Ho + ho0 + mrow / TW) * p.Wo + wo0 + mrow % TW;
+      conv_epilogue_finish<RUN, BN>(p, lds + mrow * BN, m_lin, n0, t2, p.Ho * p.Wo);
+    }
+  }
+}
+
 // x (n fp32 values, n % 8 == 0) -> NS bf16 planes of the same indexing: x = p0 + p1 + p2, round-to-nearest at each level
 // (the split the kernels above do in registers, done ONCE per tensor instead of once per use)
 template <int NS>
@@ -2206,6 +2450,48 @@ int launch_pp(const ConvP& p, hipStream_t s, int ksplit = 1) {
   return 0;
 }
 
+// 3x3 / stride 1 / pad 1 with both operands as planes: which strip width (0 = not taken)
+static int strip_tw(const ConvP& p) {
+  if (!p.xpl || !p.wpl || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.out_stride != 1 || p.Ho != p.H ||
+      p.Wo != p.W || (p.Cin & 31) || p.Cout <= 32 || ((size_t)p.xpl & 15) || (p.xpl_stride & 7))
+    return 0;
+  const char* e = getenv("MMT_STRIP");  // read per call (A/B timing)
+  if (e && atoi(e) == 0) return 0;
+  int tw = 0;
+  if (p.Wo % 128 == 0 && p.Ho % 2 == 0) tw = 128;
+  else if (p.Wo % 64 == 0 && p.Ho % 4 == 0) tw = 64;
+  if (!tw || p.Cin < 128) return 0;  // K = 576 (the 64-channel layer1 convs): 12 super-steps do not amortise the fill
+  const long blocks = (long)p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
+  return blocks >= 256 ? tw : 0;  // one 512-thread block per CU: fewer blocks leave CUs idle (those layers go split-K)
+}
+
+template <int TW>
+int launch_strip(const ConvP& p, hipStream_t s) {
+  constexpr int NS = 3, R = 256 / TW, SW = TW + 32;
+  const size_t ring = (size_t)2 * (NS * R * SW * 32 + 3 * NS * 128 * 32), epi = (size_t)256 * 128 * sizeof(float);
+  const size_t lds = ring > epi ? ring : epi;
+  void (*kern)(const ConvP) = conv3x3_strip_kernel<TW, NS>;
+#ifdef MMT_PP_EXPERIMENTS
+  {
+    const char* d = getenv("MMT_PP_DBG");
+    const int dbg = d ? atoi(d) : 0;
+    if (dbg == 1) kern = conv3x3_strip_kernel<TW, NS, 1>;
+    if (dbg == 2) kern = conv3x3_strip_kernel<TW, NS, 2>;
+    if (dbg == 3) kern = conv3x3_strip_kernel<TW, NS, 3>;
+    if (dbg == 4) kern = conv3x3_strip_kernel<TW, NS, 4>;
+    if (dbg == 7) kern = conv3x3_strip_kernel<TW, NS, 7>;
+  }
+#endif
+  {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int blocks = p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, p);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int KT, int BN, int NS>
 int launch_rows(const ConvP& p, hipStream_t s) {
   const size_t lds = (size_t)128 * BN * 4 + 2 * (size_t)KT * NS * (BN / 32) * 1024;
@@ -2236,9 +2522,15 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
     if (p.Cin == 64) return bn64 == 64 ? launch_rows<4, 64, NS>(p, s) : launch_rows<4, 32, NS>(p, s);
     if (p.Cin == 128) return launch_rows<8, 32, NS>(p, s);
   }
+  if (NS == 3) {
+    const int tw = strip_tw(p);
+    if (tw == 128) return launch_strip<128>(p, s);
+    if (tw == 64) return launch_strip<64>(p, s);
+  }
   const int ksplit = pick_ksplit(p);
   // activations pre-split into planes by the caller: the all-planes kernel (128 x 128 tiles, 2 x 2 waves)
-  if (p.xpl && NS == 3 && (ksplit > 1 || variant == 1) && !((size_t)p.xpl & 15) && !(p.xpl_stride & 7))
+  static const int use_pp = getenv("MMT_PP") ? atoi(getenv("MMT_PP")) : 0;  // measured: no faster than the kernel below
+  if (use_pp && p.xpl && NS == 3 && (ksplit > 1 || variant == 1) && !((size_t)p.xpl & 15) && !(p.xpl_stride & 7))
     return launch_pp<128, 128, 2, 2, NS, 3>(p, s, ksplit);
   if (ksplit > 1) return launch_glds<128, 128, 4, 1, NS, 3>(p, s, ksplit);
   switch (variant) {
