@@ -131,6 +131,10 @@ typedef struct {
    * the call without it: the same split, done once per tensor instead of once per use inside the kernel. */
   const void* x_planes;
   long x_plane_stride;
+  /* optional: ALSO write the result as three bf16 planes (same split as mmt_split_planes, same indexing as y) from the
+   * epilogue, for a following 3x3 convolution that wants x_planes; Cout % 4 == 0, out_stride == 1 */
+  void* y_planes;
+  long y_plane_stride;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
@@ -140,6 +144,10 @@ int mmt_conv_variant(const mmt_conv_args* a /*[host]*/);
 /* number of K ranges mmt_conv_forward would use for this call on the DMA-fed kernel (1 = un-split; > 1: partial tiles go
  * through the library's per-stream workspace and a finish launch).  Tuning / measurement aid like mmt_conv_variant. */
 int mmt_conv_ksplit(const mmt_conv_args* a /*[host]*/);
+/* 1 when mmt_conv_forward would run this call on the all-planes 3x3 kernel if x_planes were given (mode 3; 3x3, stride 1,
+ * pad 1, Cin % 32 == 0, Cin >= 128, W % 64 == 0, enough 256-pixel tiles to fill the chip): the caller then splits x once
+ * with mmt_split_planes (or has the producing convolution write the planes) and passes them. */
+int mmt_conv_wants_planes(const mmt_conv_args* a /*[host]*/);
 /* arithmetic of the convolution GEMMs -- forward, data gradient and weight gradient (process-wide; initial value from
  * the environment variable MMT_CONV_PRECISION, default 3):
  *   3  fp32 operands split on the fly into three bf16 terms x = x0 + x1 + x2 (round-to-nearest at each level, exact to

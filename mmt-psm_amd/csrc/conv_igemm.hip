@@ -40,7 +40,11 @@ struct ConvP {
   int M, K, cin32, cin4;  // derived
   const unsigned short* wpl; long wpl_stride;  // pre-split bf16 planes of w (or null)
   const unsigned short* xpl; long xpl_stride;  // pre-split bf16 planes of x, same NHWC indexing as x (or null)
+  unsigned short* ypl; long ypl_stride;        // also write y as three bf16 planes (for a 3x3 consumer), or null
 };
+
+template <int NS>
+__device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]);
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
 
@@ -148,6 +152,12 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
           }
           if (vec) *(f32x4*)(p.y + oidx[g]) = f32x4{v[0], v[1], v[2], v[3]};
           else for (int e = 0; e < nv; e++) p.y[oidx[g] + e] = v[e];
+          if (p.ypl) {  // (host: only with Cout % 4 == 0) the consumer's plane split, done here while the values are in registers
+            uint2 o[3];
+            split4<3>(f32x4{v[0], v[1], v[2], v[3]}, o);
+#pragma unroll
+            for (int q = 0; q < 3; q++) *(uint2*)(p.ypl + q * p.ypl_stride + oidx[g]) = o[q];
+          }
         }
       }
     }
@@ -2315,6 +2325,8 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.out_H = a->out_H; p.out_W = a->out_W; p.mask_scale = a->mask_scale;
   p.wpl = (const unsigned short*)a->w_planes; p.wpl_stride = a->w_plane_stride;
   p.xpl = (const unsigned short*)a->x_planes; p.xpl_stride = a->x_plane_stride;
+  p.ypl = (unsigned short*)a->y_planes; p.ypl_stride = a->y_plane_stride;
+  if (p.ypl && ((a->Cout & 3) || ((size_t)p.ypl & 7) || (p.ypl_stride & 3) || a->out_stride > 1)) return MMT_EINVAL;
   if ((long)p.N * p.Ho * p.Wo > 0x7fffffffL) return MMT_EINVAL;
   if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL || (long)p.N * p.Ho * p.Wo * p.Cout >= 0x7fffffffL ||
       (long)p.Cout * p.KH * p.KW * p.Cin >= 0x7fffffffL) return MMT_EINVAL;  // kernels use 32-bit element offsets
@@ -2451,8 +2463,8 @@ int launch_pp(const ConvP& p, hipStream_t s, int ksplit = 1) {
 }
 
 // 3x3 / stride 1 / pad 1 with both operands as planes: which strip width (0 = not taken)
-static int strip_tw(const ConvP& p) {
-  if (!p.xpl || !p.wpl || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.out_stride != 1 || p.Ho != p.H ||
+static int strip_tw(const ConvP& p, bool need_planes = true) {
+  if ((need_planes && !p.xpl) || !p.wpl || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.out_stride != 1 || p.Ho != p.H ||
       p.Wo != p.W || (p.Cin & 31) || p.Cout <= 32 || ((size_t)p.xpl & 15) || (p.xpl_stride & 7))
     return 0;
   const char* e = getenv("MMT_STRIP");  // read per call (A/B timing)
@@ -2641,15 +2653,25 @@ extern "C" int mmt_conv_variant(const mmt_conv_args* a) {
   int e = fill(p, a);
   if (e) return e;
   const int v = pick_variant(p);
+  if (v != 0 && precision() == 3 && strip_tw(p)) return 4;  // conv3x3_strip_kernel (x_planes given)
   // the split-K form runs on the 128 x 128 kernel whatever the tile variant would have been
   if (v != 0 && precision() > 0 && (p.Cin & 15) == 0 && p.wpl && pick_ksplit(p) > 1) return 1;
   return v;
+}
+
+extern "C" int mmt_conv_wants_planes(const mmt_conv_args* a) {
+  ConvP p;
+  int e = fill(p, a);
+  if (e) return 0;
+  if (precision() != 3 || pick_variant(p) == 0) return 0;
+  return strip_tw(p, false) ? 1 : 0;
 }
 
 extern "C" int mmt_conv_ksplit(const mmt_conv_args* a) {
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
+  if (pick_variant(p) != 0 && precision() == 3 && strip_tw(p)) return 1;
   if (pick_variant(p) != 0 && precision() > 0 && (p.Cin & 15) == 0 && p.wpl) return pick_ksplit(p);
   return 1;
 }

@@ -27,7 +27,8 @@ class ConvArgs(ctypes.Structure):
                 ("KW", c_int), ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int),
                 ("relu", c_int), ("res_mode", c_int), ("out_stride", c_int), ("out_H", c_int), ("out_W", c_int),
                 ("mask_scale", c_float), ("w_planes", c_void_p), ("w_plane_stride", ctypes.c_long),
-                ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long)]
+                ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long),
+                ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long)]
 
 
 class MgdTeachers(ctypes.Structure):
@@ -54,6 +55,7 @@ _SIGS = {
     "mmt_get_conv_precision": [],
     "mmt_pack_weight": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
     "mmt_split_planes": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p],
+    "mmt_conv_wants_planes": [ctypes.POINTER(ConvArgs)],
     "mmt_pack_weights": [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p],
     "mmt_pack_weight_flipped": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_conv_wgrad_splits": [ctypes.POINTER(ConvArgs)],
@@ -79,6 +81,8 @@ _lib = None
 # tool only) extends that to every conv / wgrad launch.
 PROFILE = None
 PROFILE_ALL = False
+# eligible 3x3 convolutions split their input into bf16 planes first and run on conv3x3_strip_kernel (csrc/conv_igemm.hip)
+AUTO_PLANES = os.environ.get("MMT_AUTO_PLANES", "1") != "0"
 
 
 def lib():
@@ -286,14 +290,36 @@ def split_planes(x, out=None):
     return out
 
 
+def planes_wanted_3x3(N, C, H, W, Cout):
+    """would a 3x3 / stride 1 / pad 1 convolution (C -> Cout) over an (N, C, H, W) tensor run on the all-planes kernel?
+    (asked by the PRODUCER of that tensor, which then writes the planes from its epilogue: conv_forward(want_planes=True))"""
+    if not AUTO_PLANES or get_conv_precision() != 3:
+        return False
+    a = ConvArgs()
+    a.x, a.w_planes = 16, 16  # placeholders: only the shape is looked at
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, C, Cout, 3, 3
+    a.stride, a.pad, a.Ho, a.Wo, a.out_stride = 1, 1, H, W, 1
+    return lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1
+
+
+def planes_of(x):
+    """the bf16 planes a producing convolution attached to this very tensor object (still valid: not modified since)"""
+    t = getattr(x, "_mmt_planes", None)
+    if t is not None and t[1] == x._version and t[0].shape[1] == x.numel():
+        return t[0]
+    return None
+
+
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
                  mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0,
-                 w_shape=None, planes=None, out_size=None, x_planes=None):
+                 w_shape=None, planes=None, out_size=None, x_planes=None, want_planes=False):
     """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory).
     y_out/y_offset (elements): write into an existing NHWC tensor at a shifted base (transposed-conv taps).
     w=None with w_shape + planes: the weight exists only as packed bf16 planes (pack_weight_flipped).
     out_size=(Ho, Wo): fewer output rows / columns than `pad` on both sides would give, i.e. a smaller pad at the
     bottom / right (taps that fall outside the input read zeros either way)."""
+    if x_planes is None:
+        x_planes = planes_of(x)
     x = nhwc(x)
     N, Cin, H, W = x.shape
     if w is None:
@@ -326,6 +352,16 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     else:
         y = y_out if y_out is not None else empty_nhwc(N, Cout, Ho, Wo, x.device)
     a.y = y.data_ptr() + 4 * int(y_offset)
+    y_planes = None
+    if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0:
+        y_planes = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=x.device)
+        a.y_planes, a.y_plane_stride = y_planes.data_ptr(), y_planes.stride(0)
+    auto_split = (x_planes is None and AUTO_PLANES and a.KH == 3 and a.w_planes
+                  and lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1)
+    if auto_split:
+        # one pass over x; the 3x3 kernel then reads bf16 planes (9 taps x Cout/128 re-reads).  Allocated here, filled
+        # below INSIDE the profiling bracket: the pass is part of this convolution's cost
+        x_planes = torch.empty((3, x.numel()), dtype=torch.bfloat16, device=x.device)
     if x_planes is not None:
         a.x_planes, a.x_plane_stride = x_planes.data_ptr(), x_planes.stride(0)
     a.scale, a.shift = _p(scale), _p(shift)
@@ -341,16 +377,24 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         a.mul = mul.data_ptr()
     if PROFILE is not None:
         var = lib().mmt_conv_variant(ctypes.byref(a))
-        if var == 1 or PROFILE_ALL:
+        if var in (1, 4) or PROFILE_ALL:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+            if auto_split:
+                split_planes(x, x_planes)
             _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
             e1.record()
             PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1,
                             ("fwd%d" % var, N, H, W, Cin, Cout, KH, stride, out_stride),
                             lib().mmt_conv_ksplit(ctypes.byref(a))))
+            if y_planes is not None:
+                y._mmt_planes = (y_planes, y._version)
             return y
+    if auto_split:
+        split_planes(x, x_planes)
     _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
+    if y_planes is not None:
+        y._mmt_planes = (y_planes, y._version)
     return y
 
 

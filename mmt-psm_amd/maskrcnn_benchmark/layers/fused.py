@@ -48,7 +48,7 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
     return (None if dst_w is not None else dw), (None if (dst_b is not None or not with_bias) else db)
 
 
-def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, res=None, res_mode=0):
+def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, res=None, res_mode=0, want_planes=False):
     """data gradient of y = conv(x, w) (* scale[co]) w.r.t. x, with optional fused (x>0) mask / residual add"""
     kh = w.shape[2]
     if stride != 1 and kh != 1:
@@ -60,7 +60,7 @@ def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, re
     wd = None if planes is not None else H.weight_flip_transpose(w, scale)
     if stride == 1:
         return H.conv_forward(g, wd, stride=1, pad=kh - 1 - pad, mask=mask, mask_scale=mask_scale, res=res,
-                              res_mode=res_mode, **kw)
+                              res_mode=res_mode, want_planes=want_planes, **kw)
     return H.conv_forward(g, wd, out_stride=stride, out_hw=tuple(x_shape[2:]), mask=mask, mask_scale=mask_scale,
                           res=res, res_mode=res_mode, **kw)
 
@@ -138,7 +138,11 @@ class BottleneckFn(torch.autograd.Function):
     def forward(ctx, x, w1, w2, w3, wd, bn, stride):
         s1, b1, s2, b2, s3, b3, sd, bd = bn
         x = H.nhwc(x)
-        o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True)
+        # o1 feeds one 3x3 convolution: where that runs on bf16 planes, conv1's epilogue writes them (no split pass)
+        mid = w1.shape[0]
+        ho, wo = (x.shape[2] + stride - 1) // stride, (x.shape[3] + stride - 1) // stride
+        wp = H.planes_wanted_3x3(x.shape[0], mid, ho, wo, w2.shape[0])
+        o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True, want_planes=wp)
         o2 = H.conv_forward(o1, w2, s2, b2, 1, 1, relu=True)
         r = x if wd is None else H.conv_forward(x, wd, sd, bd, stride, 0)
         out = H.conv_forward(o2, w3, s3, b3, 1, 0, relu=True, res=r, res_mode=1)
@@ -157,7 +161,8 @@ class BottleneckFn(torch.autograd.Function):
         g = H.nhwc(g)  # masked by (out > 0) by the consumer
         d1, d2, d3, dd = ctx.dst
         dw3, _ = _wgrad(o2, g, w3, 1, 0, s3, dst_w=d3)
-        d_o2 = _dgrad(g, w3, o2.shape, 1, 0, s3, mask=o2)
+        d_o2 = _dgrad(g, w3, o2.shape, 1, 0, s3, mask=o2,
+                      want_planes=H.planes_wanted_3x3(o2.shape[0], o2.shape[1], o2.shape[2], o2.shape[3], w2.shape[1]))
         dw2, _ = _wgrad(o1, d_o2, w2, 1, 1, s2, dst_w=d2)
         d_o1 = _dgrad(d_o2, w2, o1.shape, 1, 1, s2, mask=o1)
         dw1, _ = _wgrad(x, d_o1, w1, stride, 0, s1, dst_w=d1)
@@ -179,15 +184,18 @@ class FPNFn(torch.autograd.Function):
     epilogue, 4 output 3x3 (+bias).  Returns P2..P5 (P6 = P5[::2, ::2] is taken by the caller)."""
 
     @staticmethod
-    def forward(ctx, c2, c3, c4, c5, wi1, bi1, wi2, bi2, wi3, bi3, wi4, bi4, wl1, bl1, wl2, bl2, wl3, bl3, wl4, bl4):
+    def forward(ctx, c2, c3, c4, c5, wi1, bi1, wi2, bi2, wi3, bi3, wi4, bi4, wl1, bl1, wl2, bl2, wl3, bl3, wl4, bl4,
+                out_planes=True):
         cs = [H.nhwc(c) for c in (c2, c3, c4, c5)]
         wi, bi = (wi1, wi2, wi3, wi4), (bi1, bi2, bi3, bi4)
         wl, bl = (wl1, wl2, wl3, wl4), (bl1, bl2, bl3, bl4)
         inner = [None] * 4
-        inner[3] = H.conv_forward(cs[3], wi[3], None, bi[3])
+        # inner_k feeds the 3x3 output convolution, P_k the 3x3 RPN head convolution: planes from the producing epilogues
+        wp = [H.planes_wanted_3x3(c.shape[0], wi[k].shape[0], c.shape[2], c.shape[3], wl[k].shape[0]) for k, c in enumerate(cs)]
+        inner[3] = H.conv_forward(cs[3], wi[3], None, bi[3], want_planes=wp[3])
         for k in (2, 1, 0):
-            inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2)
-        outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1) for k in range(4)]
+            inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2, want_planes=wp[k])
+        outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes) for k in range(4)]
         ctx.save_for_backward(*cs, *inner, *wi, *wl)
         ctx.dst = ([(_dst(wi[k]), _dst(bi[k])) for k in range(4)], [(_dst(wl[k]), _dst(bl[k])) for k in range(4)])
         return tuple(outs)
@@ -213,7 +221,7 @@ class FPNFn(torch.autograd.Function):
             out += [dwi[k], dbi[k]]
         for k in range(4):
             out += [dwl[k], dbl[k]]
-        return tuple(out)
+        return tuple(out) + (None,)
 
 
 class DeconvFn(torch.autograd.Function):

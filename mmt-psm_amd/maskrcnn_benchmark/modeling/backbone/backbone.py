@@ -156,7 +156,9 @@ class FPN(nn.Module):
         for n in self.layer_blocks:
             m = getattr(self, n)
             args += [m.weight, m.bias]
-        res = list(fused.FPNFn.apply(*args))
+        # out_planes: the pyramid levels go to the RPN head's 3x3 convolution as they are (False for the teacher, whose
+        # RPN head sees one view's slice of the batched pyramid)
+        res = list(fused.FPNFn.apply(*args, getattr(self, "out_planes", True)))
         if self.top_blocks is not None:
             res.extend(self.top_blocks(res[-1]))
         return tuple(res)

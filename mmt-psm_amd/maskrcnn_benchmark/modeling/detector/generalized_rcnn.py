@@ -30,6 +30,8 @@ class GeneralizedRCNN(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.backbone = build_backbone(cfg)
+        if is_teacher and hasattr(self.backbone, "fpn"):
+            self.backbone.fpn.out_planes = False  # layers/fused.py::FPNFn
         self.rpn = build_rpn(cfg, is_teacher)
         self.box_heads = box_roi_heads(cfg)
         self.mask_heads = mask_roi_heads(cfg, is_student)

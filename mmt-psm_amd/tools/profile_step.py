@@ -26,7 +26,7 @@ e1.record()
 torch.cuda.synchronize()
 prof, _hip.PROFILE = _hip.PROFILE, None
 agg = collections.OrderedDict()
-for fl, a, b, key in prof:
+for fl, a, b, key in (q[:4] for q in prof):
     t = a.elapsed_time(b)
     d = agg.setdefault(key, [0, 0.0, 0.0])
     d[0] += 1

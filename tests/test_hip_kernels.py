@@ -559,3 +559,49 @@ def test_match_targets_against_tensor_formulation(hip, lowq):
         np.testing.assert_array_equal(lab[i * 5000:(i + 1) * 5000].cpu().numpy(), rl.cpu().numpy())
         np.testing.assert_array_equal(reg[i * 5000:(i + 1) * 5000].cpu().numpy(),
                                       coder1.encode(gt[ref.clamp(min=0)], anc).cpu().numpy())
+
+
+def test_conv3x3_strip_kernel_planes(hip, restore_mode):
+    """conv3x3_strip_kernel (3x3 / stride 1 / pad 1 on pre-split bf16 planes, 256 x 128 tiles on eight waves, one input strip
+    per (kh, 16-channel slab) serving the three horizontal taps) against fp64 and against the in-register-split kernel it
+    replaces for these shapes: same split, same products, K summed in the order (kh, slab, kw) -- fp32-grade like it.
+    Both strip widths, image borders, a Cout that is not a multiple of 128, every epilogue operand."""
+    import os
+    hip.set_conv_precision(3)
+    g = torch.Generator().manual_seed(31)
+    for (N, C, H, W, Co, opts) in ((2, 128, 128, 128, 192, "res"), (8, 256, 64, 64, 256, "relu"), (32, 128, 32, 64, 128, "mask"),
+                                   (8, 160, 64, 128, 64, ""), (1, 256, 64, 64, 256, "relu")):
+        x = cl(torch.randn(N, C, H, W, generator=g))
+        w = cl(torch.randn(Co, C, 3, 3, generator=g) * 0.05)
+        sc, sh = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+        res = cl(torch.randn(N, Co, H, W, generator=g)) if opts == "res" else None
+        mask = cl(torch.randn(N, Co, H, W, generator=g)) if opts == "mask" else None
+        kw = dict(relu=opts in ("res", "relu"), res=res, res_mode=1 if res is not None else 0, mask=mask, mask_scale=2.0)
+        planes = hip.split_planes(x)
+        # p0 + p1 + p2 reproduces x to 2^-24 relative (three round-to-nearest bf16 terms)
+        rec = planes.float().sum(0).view(N, H, W, C).permute(0, 3, 1, 2)
+        assert (rec - x).abs().max().item() <= 2e-7 * x.abs().max().item()
+        os.environ["MMT_STRIP"] = "0"
+        try:
+            y_old = hip.conv_forward(x, w, sc, sh, 1, 1, **kw)
+        finally:
+            os.environ.pop("MMT_STRIP", None)
+        y_new = hip.conv_forward(x, w, sc, sh, 1, 1, x_planes=planes, **kw)
+        y_auto = hip.conv_forward(x, w, sc, sh, 1, 1, **kw)          # the wrapper splits by itself when the library wants planes
+        ref = F.conv2d(x.double(), w.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        if res is not None:
+            ref = ref + res.double()
+        if kw["relu"]:
+            ref = F.relu(ref)
+        if mask is not None:
+            ref = torch.where(mask > 0, ref * 2.0, torch.zeros_like(ref))
+        scale = ref.abs().max().item()
+        e_old, e_new = (y_old.double() - ref).abs().max().item() / scale, (y_new.double() - ref).abs().max().item() / scale
+        assert e_new < MODE_TOL[3], (N, C, H, W, Co, e_new)
+        assert e_new < 2.0 * e_old + 1e-7, (e_new, e_old)
+        assert torch.equal(y_new, y_auto)
+        blocks = N * (H * W // 256) * ((Co + 127) // 128)
+        if blocks >= 256:
+            assert not torch.equal(y_new, y_old)   # it really was the other kernel (another summation order)
+        else:
+            assert torch.equal(y_new, y_old)       # too few tiles to fill the chip: planes ignored, same kernel as before

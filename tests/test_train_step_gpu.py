@@ -211,16 +211,18 @@ def _schedule_equivalence(trainer, batch):
         # 2 + 2 changes the tile count of the deep layers and with it their number of split-K ranges, i.e. the ORDER of
         # their fp32 sums: last-bit differences in the features that can flip one of the ~10^5 discrete decisions of a
         # 1000 x 1000 step (a top-k boundary, an IoU threshold), which is noise of the arithmetic and not of the schedule.
-        # Both arms of this comparison therefore run with split-K off (MMT_SPLITK=0, read per call): every convolution
-        # is then bit-identical whatever batch its image sits in
+        # Both arms of this comparison therefore run with split-K and the tap-strip 3x3 kernel off (MMT_SPLITK=0,
+        # MMT_STRIP=0, read per call): every convolution is then bit-identical whatever batch its image sits in
         # (test_fullsize_properties.py::test_conv_fullsize_linearity_and_batch_invariance).
         os.environ["MMT_SPLITK"] = "0"
+        os.environ["MMT_STRIP"] = "0"   # the tap-strip 3x3 kernel sums K as (kh, slab, kw) and is chosen by block count
         b2_l, b2_g, b2_s, b2_t = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
         _restore(trainer, snap)
         ser_l, ser_g, ser_s, ser_t = _run_schedule(trainer, batch, 1400, False, "batched", False, 11)
         _restore(trainer, snap)
     finally:
         trainer.overlap_teacher, trainer.student_passes, trainer.early_sup_backward = keep
+        os.environ.pop("MMT_STRIP", None)
         if old_env is None:
             os.environ.pop("MMT_SPLITK", None)
         else:
