@@ -22,6 +22,28 @@ class FlatSGD(object):
         self.flat.grad.zero_()
         self.flat.touched.clear()
 
+    def state_dict(self):
+        """what Checkpointer.save stores under "optimizer": the momentum of every trainable parameter by name (the
+        flat layout is an implementation detail of this build and not part of the file)"""
+        f = self.flat
+        named = dict(f._named)
+        buf = {}
+        for n, (o, k) in f.index.items():
+            if o < f.n_trainable:
+                buf[n] = f._view_like(f.momentum[o:o + k], named[n]).detach().cpu().contiguous()  # the parameter's shape
+        return {"momentum_buffers": buf, "steps": self.steps, "lr_factor": self.lr_factor,
+                "hyper": {"base_lr": self.base_lr, "momentum": self.momentum, "weight_decay": self.weight_decay,
+                          "bias_lr_factor": self.bias_lr_factor, "weight_decay_bias": self.weight_decay_bias}}
+
+    def load_state_dict(self, sd):
+        f = self.flat
+        for n, v in sd["momentum_buffers"].items():
+            if n in f.index and f.index[n][0] < f.n_trainable:
+                o, k = f.index[n]
+                f._view_like(f.momentum[o:o + k], dict(f._named)[n]).copy_(v.to(f.momentum.device))
+        self.steps = int(sd.get("steps", 0))
+        self.lr_factor = float(sd.get("lr_factor", self.lr_factor))
+
     def step(self):
         """torch.optim.SGD.step over the reference's per-tensor groups (solver/build.py:5-23): a parameter that received no
         gradient since zero_grad (`p.grad is None` there: the hint adaptors before START_MT or when the teacher found nothing,
@@ -56,6 +78,14 @@ class WarmupMultiStepLR(object):
         self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
         self.last_epoch = last_epoch
         self.step()
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch, "milestones": list(self.milestones), "gamma": self.gamma,
+                "warmup_factor": self.warmup_factor, "warmup_iters": self.warmup_iters, "warmup_method": self.warmup_method}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = int(sd["last_epoch"])
+        self.optimizer.lr_factor = self.factor()
 
     def factor(self):
         w = 1

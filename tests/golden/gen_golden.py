@@ -411,6 +411,63 @@ def gen_transforms():
                 sys.modules[k] = v
 
 
+def gen_checkpoint():
+    """the reference's own suffix-matching aligner on three key sets, and a tiny checkpoint FILE written by the
+    reference's Checkpointer.save (model + torch SGD + the reference's WarmupMultiStepLR) -> tests/golden/checkpoint_*"""
+    import tempfile
+    import types
+    from collections import OrderedDict
+    if not hasattr(torch, "_six"):  # SURVEY D12: utils/imports.py:4 reads torch._six.PY3
+        torch._six = types.SimpleNamespace(PY3=True, PY37=True)
+    import importlib; hub = importlib.import_module("torch.hub")
+    for missing in ("_download_url_to_file", "urlparse", "HASH_REGEX"):  # utils/model_zoo.py:5-7 (URL cache, unused here)
+        if not hasattr(hub, missing):
+            setattr(hub, missing, None)
+    from maskrcnn_benchmark.utils.model_serialization import align_and_update_state_dicts, strip_prefix_if_present
+    from maskrcnn_benchmark.utils.checkpoint import Checkpointer
+    from maskrcnn_benchmark.solver.lr_scheduler import WarmupMultiStepLR
+    shapes = json.load(open(os.path.join(HERE, "state_shapes.json")))["shapes"]
+    model_keys = list(shapes.keys())
+    cases = {}
+    # (a) DataParallel prefix on every loaded key  (b) ImageNet-style: body keys without 'backbone.body.', plus decoys that
+    # are SHORTER suffixes of the same keys  (c) the complex model of the reference's tests/checkpoint.py:20-37
+    cases["module_prefix"] = (model_keys, ["module." + k for k in model_keys])
+    body = [k[len("backbone.body."):] for k in model_keys if k.startswith("backbone.body.")]
+    decoys = sorted({k.split(".", 2)[-1] for k in body if k.count(".") >= 2})
+    cases["suffix_longest"] = (model_keys, body + decoys + ["fc1000.weight", "unrelated.bias"])
+    cases["complex_model"] = (["block1.layer1.weight", "block1.layer1.bias", "layer2.weight", "layer2.bias",
+                               "res.layer2.weight", "res.layer2.bias"],
+                              ["layer1.weight", "layer1.bias", "layer2.weight", "layer2.bias", "res.layer2.weight",
+                               "res.layer2.bias"])
+    out = {}
+    for name, (cur, loaded) in cases.items():
+        msd = OrderedDict((k, torch.tensor([-1.0])) for k in cur)
+        lsd = OrderedDict((k, torch.tensor([float(i)])) for i, k in enumerate(loaded))
+        lsd = strip_prefix_if_present(lsd, prefix="module.")
+        lk = list(lsd.keys())
+        vals = {float(v): k for k, v in lsd.items()}
+        align_and_update_state_dicts(msd, lsd)
+        out[name] = {"model_keys": cur, "loaded_keys": loaded,
+                     "mapping": {k: (vals[float(v)] if float(v) >= 0 else None) for k, v in msd.items()}}
+    with open(os.path.join(HERE, "checkpoint_align.json"), "w") as f:
+        json.dump(out, f)
+    torch.manual_seed(3)
+    m = torch.nn.Sequential(torch.nn.Linear(2, 3), torch.nn.Linear(3, 1))
+    opt = torch.optim.SGD([{"params": [p], "lr": 0.01, "weight_decay": 1e-4} for p in m.parameters()], 0.01, momentum=0.9)
+    m(torch.ones(1, 2)).sum().backward()
+    opt.step()
+    sched = WarmupMultiStepLR(opt, (5000,), 0.1, warmup_factor=1.0 / 3, warmup_iters=500, warmup_method="linear")
+    with tempfile.TemporaryDirectory() as d:
+        Checkpointer(torch.nn.DataParallel(m), opt, sched, d, True).save("model_0000007", iteration=7)
+        tag = open(os.path.join(d, "last_checkpoint")).read()
+        assert tag == os.path.join(d, "model_0000007.pth")
+        data = open(os.path.join(d, "model_0000007.pth"), "rb").read()
+    with open(os.path.join(HERE, "checkpoint_ref_tiny.pth"), "wb") as f:
+        f.write(data)
+    print("wrote checkpoint_align.json, checkpoint_ref_tiny.pth (%d bytes)" % len(data),
+          {k: sum(v is not None for v in c["mapping"].values()) for k, c in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["nms", "roi", "small", "mt", "masks", "model"]
     if "nms" in which:
@@ -427,5 +484,7 @@ if __name__ == "__main__":
         gen_model()
     if "irnet" in which:
         gen_model(tag="model160_irnet", relation=True)
+    if "checkpoint" in which:
+        gen_checkpoint()
     if "transforms" in which:
         gen_transforms()
