@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
 // (three taps = 72 MFMAs per wave), placed before the last tap: the fragments of that tap are in registers by then, so the
 // stage is free for the copies of super-step s + 2 while tap 0 of s + 1 is pre-read from the other stage.
 template <int TW, int NS, int DBG = 0>  // DBG (timing experiments): 1 no copies in the loop, 2 no fragment reads, 4 no barrier / waits
-__global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p) {
+__global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, const int ksplit, float* __restrict__ ws) {
   constexpr int BM = 256, BN = 128, R = BM / TW, SW = TW + 32, TM = 2, TN = 2;
   constexpr int PA = R * SW * 32;              // bytes of one A plane of a stage (strip rows x 32 B)
   constexpr int PB = BN * 32;                  // one B plane of one tap
@@ -1088,12 +1088,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // split-K (few tiles: the N = 2 passes on the 64^2 / 128^2 maps): the ksplit blocks of a tile are neighbours and take
+  // consecutive, even-sized ranges of super-steps; partial tiles go to the workspace (host: only when Wo == TW, where a
+  // tile's 256 pixels are consecutive in memory and conv_splitk_finish_kernel<256, 128> finishes them)
+  const int ks = bid % ksplit;
+  bid /= ksplit;
+  const int tile_lin = bid;
   const int tile_n = bid % tiles_n;
   int t = bid / tiles_n;
   const int tw = t % tiles_w; t /= tiles_w;
   const int th = t % tiles_h, img = t / tiles_h;
   const int ho0 = th * R, wo0 = tw * TW, n0 = tile_n * BN;
-  const int slabs = p.Cin >> 4, nss = 3 * slabs;   // super-steps: (kh, slab)
+  const int slabs = p.Cin >> 4;                      // super-steps: (kh, slab), 3 * slabs of them
+  const int pairs = (3 * slabs) >> 1;                // ... handed out in pairs (the loop body is two super-steps)
+  const int ss0 = 2 * (int)((long)ks * pairs / ksplit), nss = 2 * (int)((long)(ks + 1) * pairs / ksplit) - ss0;
 
   // ---- copy slots of this wave.  Slots 0 .. SA-1 carry A items (wave + 8 i < NA: plane, strip row r, 32-pixel block),
   // slots SA .. SA+SB-1 B items (tap, plane, 32-channel block).  Everything that does not change from super-step to
@@ -1144,9 +1152,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p) {
   // recomputed when the super-step being FILLED enters a new kh (three times per kernel), never inside the slab loop
   const int row_bytes = p.W * p.Cin * 2;
   unsigned vo_a[SA];
-  int f_kh = 0, f_cs = 0;          // (kh, slab) of the super-step whose copies are being issued
-  int soff_a = 0, soff_b = 0;      // its scalar byte offsets: A = max(kh - 1, 0) rows + slab, B = (kh * 3 * slabs + slab) steps
+  int f_kh = ss0 / slabs, f_cs = ss0 % slabs;   // (kh, slab) of the super-step whose copies are being issued
   const int b_step = (int)(kt_stride * 2);
+  int soff_a = 0;                               // its scalar byte offsets: A = max(kh - 1, 0) rows + slab,
+  int soff_b = (f_kh * 3 * slabs + f_cs) * b_step;   // B = (kh * 3 * slabs + slab) steps
   auto fill_enter_kh = [&]() {
 #pragma unroll
     for (int i = 0; i < SA; i++) {
@@ -1154,7 +1163,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p) {
       // voff addresses input row ho0 + r; kh = 0 wants the row above (offsets are unsigned: subtract here, add in soff else)
       vo_a[i] = (rowok && voff[i] != OOB) ? (f_kh == 0 ? voff[i] - (unsigned)row_bytes : voff[i]) : OOB;
     }
-    soff_a = (f_kh >= 1 ? (f_kh - 1) * row_bytes : 0);
+    soff_a = (f_kh >= 1 ? (f_kh - 1) * row_bytes : 0) + f_cs * 32;
   };
   fill_enter_kh();
   auto fill_advance = [&]() {      // next super-step to fill
@@ -1287,6 +1296,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p) {
   // is contiguous only inside one image row, so each 128-row half is handed over in runs of min(TW, 128) rows
   conv_epilogue_stage<BM, BN, 4, 2>(acc, lds, lane, wm, wn);
   __syncthreads();
+  if (ksplit > 1) {
+    constexpr int TILE4 = BM * BN / 4;
+    f32x4* slab = (f32x4*)ws + ((long)tile_lin * ksplit + ks) * TILE4;
+    const f32x4* ct4 = (const f32x4*)lds;
+    for (int i = tid; i < TILE4; i += 512) slab[i] = ct4[i];
+    return;
+  }
   {
     const int half = tid >> 8, t2 = tid & 255;
     constexpr int RUN = TW < 128 ? TW : 128;
@@ -2462,6 +2478,22 @@ int launch_pp(const ConvP& p, hipStream_t s, int ksplit = 1) {
   return 0;
 }
 
+// K ranges for the tap-strip kernel: 1 when its 256 x 128 tiles fill the chip (one 512-thread block per CU), else enough
+// ranges to do so -- possible when a tile's pixels are consecutive in memory (Wo == TW: the finish kernel's row mapping),
+// Cout is a multiple of 128 and every range keeps >= 6 super-steps; 0 = not a shape for this kernel
+static int strip_ksplit(const ConvP& p, int tw) {
+  const long tiles = (long)p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
+  if (tiles >= 256) return 1;
+  const char* e = getenv("MMT_SPLITK");
+  if ((e && atoi(e) == 0) || p.Wo != tw || (p.Cout & 127) || tiles < 32) return 0;
+  int ks = (int)((256 + tiles - 1) / tiles);
+  const int pairs = 3 * (p.Cin >> 4) / 2;
+  if (ks > pairs / 3) ks = pairs / 3;
+  if (ks > 8) ks = 8;
+  if (tiles * ks > 512) ks = (int)(512 / tiles);
+  return ks >= 2 ? ks : 0;
+}
+
 // 3x3 / stride 1 / pad 1 with both operands as planes: which strip width (0 = not taken)
 static int strip_tw(const ConvP& p, bool need_planes = true) {
   if ((need_planes && !p.xpl) || !p.wpl || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.out_stride != 1 || p.Ho != p.H ||
@@ -2473,8 +2505,7 @@ static int strip_tw(const ConvP& p, bool need_planes = true) {
   if (p.Wo % 128 == 0 && p.Ho % 2 == 0) tw = 128;
   else if (p.Wo % 64 == 0 && p.Ho % 4 == 0) tw = 64;
   if (!tw || p.Cin < 128) return 0;  // K = 576 (the 64-channel layer1 convs): 12 super-steps do not amortise the fill
-  const long blocks = (long)p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
-  return blocks >= 256 ? tw : 0;  // one 512-thread block per CU: fewer blocks leave CUs idle (those layers go split-K)
+  return strip_ksplit(p, tw) ? tw : 0;
 }
 
 template <int TW>
@@ -2482,7 +2513,13 @@ int launch_strip(const ConvP& p, hipStream_t s) {
   constexpr int NS = 3, R = 256 / TW, SW = TW + 32;
   const size_t ring = (size_t)2 * (NS * R * SW * 32 + 3 * NS * 128 * 32), epi = (size_t)256 * 128 * sizeof(float);
   const size_t lds = ring > epi ? ring : epi;
-  void (*kern)(const ConvP) = conv3x3_strip_kernel<TW, NS>;
+  const int ksplit = strip_ksplit(p, TW);
+  SplitWs w{nullptr};
+  if (ksplit > 1) {
+    w = split_workspace(s);
+    if (!w.ws) return MMT_EINVAL;
+  }
+  void (*kern)(const ConvP, const int, float*) = conv3x3_strip_kernel<TW, NS>;
 #ifdef MMT_PP_EXPERIMENTS
   {
     const char* d = getenv("MMT_PP_DBG");
@@ -2498,9 +2535,13 @@ int launch_strip(const ConvP& p, hipStream_t s) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const int blocks = p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, p);
+  const int tiles = p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
+  hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit, w.ws);
   MMT_LAUNCH_CHECK();
+  if (ksplit > 1) {  // Wo == TW: tile t covers the 256 consecutive pixels [256 t', 256 t' + 256) of its channel block
+    hipLaunchKernelGGL((conv_splitk_finish_kernel<256, 128>), dim3(tiles * 4), dim3(256), (size_t)64 * 128 * 4, s, p, ksplit, w.ws);
+    MMT_LAUNCH_CHECK();
+  }
   return 0;
 }
 

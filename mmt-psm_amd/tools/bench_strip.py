@@ -16,7 +16,9 @@ def timeit(f, it=10):
 cases = [("fpn 3x3 256@256^2 N8", 8,256,256,256,256), ("fpn 3x3 256@256^2 N2", 2,256,256,256,256),
          ("rpn 3x3 256@128^2 N8", 8,256,128,128,256), ("rpn 3x3 256@128^2 N2", 2,256,128,128,256),
          ("l1 3x3 64@256^2 N8", 8,64,256,256,64), ("l2 3x3 128@128^2 N8", 8,128,128,128,128),
-         ("l3 3x3 256@64^2 N8", 8,256,64,64,256), ("p4 3x3 256@64^2 N8 (res)", 8,256,64,64,256)]
+         ("l3 3x3 256@64^2 N8", 8,256,64,64,256), ("p4 3x3 256@64^2 N8 (res)", 8,256,64,64,256),
+         ("p4 3x3 256@64^2 N2 splitK", 2,256,64,64,256), ("l2 3x3 128@128^2 N2 splitK", 2,128,128,128,128),
+         ("p4 3x3 256@64^2 N4 splitK", 4,256,64,64,256)]
 for name,N,Cin,H,W,Cout in cases:
     x = cl(torch.randn(N,Cin,H,W,device='cuda')); w = cl(torch.randn(Cout,Cin,3,3,device='cuda')*0.05)
     sc = torch.rand(Cout,device='cuda'); sh = torch.rand(Cout,device='cuda')

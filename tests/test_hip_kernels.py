@@ -569,8 +569,10 @@ def test_conv3x3_strip_kernel_planes(hip, restore_mode):
     import os
     hip.set_conv_precision(3)
     g = torch.Generator().manual_seed(31)
+    taken = 0  # shapes the library ran on the strip kernel: full grids, and the split-K form (few tiles, Wo == strip width)
     for (N, C, H, W, Co, opts) in ((2, 128, 128, 128, 192, "res"), (8, 256, 64, 64, 256, "relu"), (32, 128, 32, 64, 128, "mask"),
-                                   (8, 160, 64, 128, 64, ""), (1, 256, 64, 64, 256, "relu")):
+                                   (8, 160, 64, 128, 64, ""), (1, 256, 64, 64, 256, "relu"), (2, 256, 64, 64, 256, "res"),
+                                   (2, 128, 128, 128, 128, "relu"), (1, 256, 64, 64, 192, ""), (1, 64, 64, 64, 128, "")):
         x = cl(torch.randn(N, C, H, W, generator=g))
         w = cl(torch.randn(Co, C, 3, 3, generator=g) * 0.05)
         sc, sh = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda()
@@ -600,8 +602,9 @@ def test_conv3x3_strip_kernel_planes(hip, restore_mode):
         assert e_new < MODE_TOL[3], (N, C, H, W, Co, e_new)
         assert e_new < 2.0 * e_old + 1e-7, (e_new, e_old)
         assert torch.equal(y_new, y_auto)
-        blocks = N * (H * W // 256) * ((Co + 127) // 128)
-        if blocks >= 256:
+        if hip.planes_wanted_3x3(N, C, H, W, Co):
             assert not torch.equal(y_new, y_old)   # it really was the other kernel (another summation order)
+            taken += 1
         else:
-            assert torch.equal(y_new, y_old)       # too few tiles to fill the chip: planes ignored, same kernel as before
+            assert torch.equal(y_new, y_old)       # not a shape for it: planes ignored, same kernel as before
+    assert taken >= 6

@@ -212,3 +212,32 @@ def test_teacher_without_detections(setup, synth):
         pp.score_thresh = old
         teacher.set_module_mode("train")
         teacher.rpn.shared = None
+
+
+def test_inference_loop(setup, synth, tmp_path):
+    """engine/inference.py (reference :16-125): eval-mode detections per image id, on the host, saved as predictions.pth;
+    boxes / scores / labels / 28 x 28 mask probabilities as the reference's eval path returns them"""
+    from maskrcnn_benchmark.engine.inference import inference
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    cfg, _, teacher = setup
+    teacher.set_module_mode(None)
+    imgs, _ = synth.make_labeled(2, SIZE, 4, seed=1234)
+    more, _ = synth.make_labeled(2, SIZE, 4, seed=99)
+    loader = [(to_image_list(list(imgs), 32), None, (0, 1)), (to_image_list(list(more), 32), None, (2, 3))]
+    seen = {}
+    out = inference(teacher, loader, "synthetic", iou_types=("bbox", "segm"), output_folder=str(tmp_path),
+                    evaluator=lambda predictions, **kw: seen.update(kw) or {"n": len(predictions)})
+    assert out == {"n": 4} and seen["iou_types"] == ("bbox", "segm")
+    preds = torch.load(str(tmp_path / "predictions.pth"), weights_only=False)
+    assert sorted(preds) == [0, 1, 2, 3]
+    for p in preds.values():
+        assert p.bbox.device.type == "cpu" and p.size == (SIZE, SIZE) and len(p) > 0
+        assert set(p.fields()) >= {"scores", "labels", "mask"}
+        m = p.get_field("mask")
+        assert tuple(m.shape[1:]) == (1, 28, 28) and float(m.min()) >= 0.0 and float(m.max()) <= 1.0
+        assert int(p.get_field("labels").min()) >= 1
+    # same images, same detections as a direct eval-mode call
+    with torch.no_grad():
+        direct = teacher(to_image_list(list(imgs.cuda()), 32))
+    assert torch.equal(direct[0].bbox.cpu(), preds[0].bbox)
+    teacher.set_module_mode("train")
