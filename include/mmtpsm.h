@@ -94,6 +94,13 @@ int mmt_aug_erase(float* out, long view_stride, int out_W, int out_C, const int3
  *   labels_f  (RPN, optional) 1 / 0 / -1 (ignored or not visible);  labels_i (box head, optional) class / 0 / -1
  *   reg       (optional) [A_total,4] regression targets against the matched (or first) gt with weights (wx,wy,ww,wh)
  * Bit-identical to the tensor formulation (same expression order, no FMA contraction). */
+/* BoxCoder.decode (modeling/box_coder.py:52-95) of codes [R, ncls*4] against boxes [R,4] with weights (wx,wy,ww,wh) and the
+ * dw/dh clip, optionally followed by clip_to_image (structures/bounding_box.py:229-238): row r belongs to image i with
+ * row_off[i] <= r < row_off[i+1] and is clamped to [0, lim[2i]] x [0, lim[2i+1]] (= width-1, height-1).  Replaces ~25
+ * elementwise launches per call (rpn/inference.py:107-113, box_head/inference.py:60-75); bit-identical to them. */
+int mmt_box_decode(const float* codes, const float* boxes, int R, int ncls, float wx, float wy, float ww, float wh, float clip,
+                   const int32_t* row_off /*[n_img+1] or NULL*/, const float* lim /*[n_img,2] or NULL*/, int n_img, float* out,
+                   void* stream);
 int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
                       const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total, int shared_cand,
                       float high, float low, int allow_low_quality, float wx, float wy, float ww, float wh, uint32_t* top_ws,

@@ -2485,7 +2485,8 @@ static int strip_ksplit(const ConvP& p, int tw) {
   const long tiles = (long)p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
   if (tiles >= 256) return 1;
   const char* e = getenv("MMT_SPLITK");
-  if ((e && atoi(e) == 0) || p.Wo != tw || (p.Cout & 127) || tiles < 32) return 0;
+  const char* e2 = getenv("MMT_STRIP_SPLITK");
+  if ((e && atoi(e) == 0) || (e2 && atoi(e2) == 0) || p.Wo != tw || (p.Cout & 127) || tiles < 32) return 0;
   int ks = (int)((256 + tiles - 1) / tiles);
   const int pairs = 3 * (p.Cin >> 4) / 2;
   if (ks > pairs / 3) ks = pairs / 3;

@@ -115,7 +115,48 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ ca
     o[3] = wh * logf(gh / ph);
   }
 }
+// BoxCoder.decode (modeling/box_coder.py:52-95) for `ncls` boxes per row, + BoxList.clip_to_image(remove_empty=False)
+// (structures/bounding_box.py:229-238) when `lim` is given: one thread per (row, class).  Same operations in the same order
+// as the tensor formulation (every intermediate rounded to fp32, no FMA contraction): bit-identical to it.
+__global__ __launch_bounds__(256) void box_decode_kernel(const float* __restrict__ codes, const float* __restrict__ boxes,
+                                                         const int R, const int ncls, const float wx, const float wy,
+                                                         const float ww, const float wh, const float clipv,
+                                                         const int32_t* __restrict__ row_off, const float* __restrict__ lim,
+                                                         const int n_img, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)R * ncls) return;
+  const int r = (int)(i / ncls);
+  const f32x4 b = *(const f32x4*)(boxes + (long)r * 4);
+  const f32x4 c = *(const f32x4*)(codes + i * 4);
+  const float w = b[2] - b[0] + 1.f, h = b[3] - b[1] + 1.f;
+  const float cx = b[0] + 0.5f * w, cy = b[1] + 0.5f * h;
+  const float dx = c[0] / wx, dy = c[1] / wy;
+  const float dw = fminf(c[2] / ww, clipv), dh = fminf(c[3] / wh, clipv);
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  f32x4 o = {pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw - 1.f, pcy + 0.5f * ph - 1.f};
+  if (lim) {
+    int img = 0;
+    while (img + 1 < n_img && r >= row_off[img + 1]) img++;
+    const float lw = lim[2 * img], lh = lim[2 * img + 1];
+    o[0] = fminf(fmaxf(o[0], 0.f), lw);
+    o[1] = fminf(fmaxf(o[1], 0.f), lh);
+    o[2] = fminf(fmaxf(o[2], 0.f), lw);
+    o[3] = fminf(fmaxf(o[3], 0.f), lh);
+  }
+  *(f32x4*)(out + i * 4) = o;
+}
 }  // namespace
+
+extern "C" int mmt_box_decode(const float* codes, const float* boxes, int R, int ncls, float wx, float wy, float ww, float wh,
+                              float clip, const int32_t* row_off, const float* lim, int n_img, float* out, void* stream) {
+  if (!codes || !boxes || !out || R < 0 || ncls < 1 || (lim && (!row_off || n_img < 1))) return MMT_EINVAL;
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(box_decode_kernel, dim3(mmt_cdiv((long)R * ncls, 256)), dim3(256), 0, (hipStream_t)stream, codes, boxes,
+                     R, ncls, wx, wy, ww, wh, clip, row_off, lim, n_img, out);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
                                  const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total,

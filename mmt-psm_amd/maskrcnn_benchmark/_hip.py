@@ -54,6 +54,8 @@ _SIGS = {
     "mmt_set_conv_precision": [ctypes.c_int],
     "mmt_get_conv_precision": [],
     "mmt_pack_weight": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
+    "mmt_box_decode": [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_int,
+                       c_void_p, c_void_p],
     "mmt_split_planes": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p],
     "mmt_conv_wants_planes": [ctypes.POINTER(ConvArgs)],
     "mmt_pack_weights": [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p],
@@ -265,6 +267,18 @@ def match_targets(cand, cand_off, gt, gt_off, n_images, high, low, allow_low_qua
                                    float(wy), float(ww), float(wh), _p(top), _p(matches), _p(lf), _p(li), _p(reg), _stream()),
            "mmt_match_targets")
     return matches, (lf if rpn_labels else li), reg
+
+
+def box_decode(codes, boxes, weights, clip, row_off=None, lim=None):
+    """BoxCoder.decode (+ clip_to_image when row_off / lim are given) in one launch; codes (R, ncls*4), boxes (R, 4)"""
+    _dev(codes, "codes")
+    codes, boxes = codes.contiguous(), boxes.contiguous().to(torch.float32)
+    R, ncls = codes.shape[0], codes.shape[1] // 4
+    out = torch.empty_like(codes)
+    n_img = 0 if lim is None else lim.shape[0]
+    _check(lib().mmt_box_decode(_p(codes), _p(boxes), R, ncls, float(weights[0]), float(weights[1]), float(weights[2]),
+                                float(weights[3]), float(clip), _p(row_off), _p(lim), n_img, _p(out), _stream()), "mmt_box_decode")
+    return out
 
 
 # ------------------------------------------------------------------------------------------ conv

@@ -232,13 +232,16 @@ class PostProcessor(nn.Module):
         per = [len(b) for b in boxes]
         dev = prob.device
         cat = torch.cat([b.bbox for b in boxes], 0)
-        dec = self.box_coder.decode(box_regression.reshape(sum(per), -1), cat)
+        offs_rows = [0]
+        for n_ in per:
+            offs_rows.append(offs_rows[-1] + n_)
+        # decode (10,10,5,5) + clip_to_image of every (proposal, class): one launch
+        dec = H.box_decode(box_regression.reshape(sum(per), -1), cat, self.box_coder.weights, self.box_coder.bbox_xform_clip,
+                           dev_const(offs_rows, torch.int32, dev),
+                           dev_const([[b.size[0] - 1, b.size[1] - 1] for b in boxes], torch.float32, dev))
         nc = prob.shape[1]
         segs, metas = [], []
         for pr, bx, b in zip(prob.split(per, 0), dec.split(per, 0), boxes):
-            w, h = b.size
-            lim = dev_const([w - 1, h - 1, w - 1, h - 1], torch.float32, dev)
-            bx = torch.minimum(bx.reshape(-1, 4).clamp(min=0), lim).reshape(-1, nc * 4)
             for j in range(1, nc):
                 sc = pr[:, j]
                 masked = torch.where(sc > self.score_thresh, sc, torch.full_like(sc, -1.0))

@@ -92,7 +92,7 @@ class RPNPostProcessor(nn.Module):
         N, L = len(anchors), len(objectness)
         dev = objectness[0].device
         sizes = [a[0].size for a in anchors]  # (W,H) per image
-        lim = dev_const([[s[0] - 1, s[1] - 1, s[0] - 1, s[1] - 1] for s in sizes], torch.float32, dev)
+        lim = dev_const([[s[0] - 1, s[1] - 1] for s in sizes], torch.float32, dev)
         cand_extra, ks, scs, regs, ancs = [], [], [], [], []
         for lvl in range(L):
             o, r = _flat(objectness[lvl].detach(), box_regression[lvl].detach())
@@ -108,8 +108,11 @@ class RPNPostProcessor(nn.Module):
         # decode / clip / min-size filter ONCE over all levels; (N, sum_k, .) is already the image-major, level-minor order
         # the batched NMS wants, so no per-(image, level) slicing and re-concatenation
         sc = torch.cat(scs, 1)
-        props = self.box_coder.decode(torch.cat(regs, 1).reshape(-1, 4), torch.cat(ancs, 1).reshape(-1, 4)).view(N, -1, 4)
-        props = torch.minimum(props.clamp(min=0), lim[:, None, :])  # clip_to_image(remove_empty=False)
+        per_img = sum(ks)
+        # BoxCoder.decode + clip_to_image(remove_empty=False) of every candidate of the batch: one launch
+        props = H.box_decode(torch.cat(regs, 1).reshape(-1, 4), torch.cat(ancs, 1).reshape(-1, 4), self.box_coder.weights,
+                             self.box_coder.bbox_xform_clip, dev_const([i * per_img for i in range(N + 1)], torch.int32, dev),
+                             lim).view(N, -1, 4)
         if self.min_size > 0:
             # remove_small_boxes BEFORE the NMS (rpn/inference.py:124-129): a removed box must neither suppress anything nor
             # take a post-NMS slot.  Fixed shapes: it keeps its position in the segment but is moved far outside the image
