@@ -97,7 +97,7 @@ int mmt_aug_erase(float* out, long view_stride, int out_W, int out_C, const int3
 /* BoxCoder.decode (modeling/box_coder.py:52-95) of codes [R, ncls*4] against boxes [R,4] with weights (wx,wy,ww,wh) and the
  * dw/dh clip, optionally followed by clip_to_image (structures/bounding_box.py:229-238): row r belongs to image i with
  * row_off[i] <= r < row_off[i+1] and is clamped to [0, lim[2i]] x [0, lim[2i+1]] (= width-1, height-1).  Replaces ~25
- * elementwise launches per call (rpn/inference.py:107-113, box_head/inference.py:60-75); bit-identical to them. */
+ * elementwise launches per call (rpn/inference.py:107-113, box_head/inference.py:60-75); equal to the reference's host arithmetic (true divisions by the weights) up to exp() of the math library. */
 int mmt_box_decode(const float* codes, const float* boxes, int R, int ncls, float wx, float wy, float ww, float wh, float clip,
                    const int32_t* row_off /*[n_img+1] or NULL*/, const float* lim /*[n_img,2] or NULL*/, int n_img, float* out,
                    void* stream);

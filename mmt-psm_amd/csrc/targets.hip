@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ ca
 }
 // BoxCoder.decode (modeling/box_coder.py:52-95) for `ncls` boxes per row, + BoxList.clip_to_image(remove_empty=False)
 // (structures/bounding_box.py:229-238) when `lim` is given: one thread per (row, class).  Same operations in the same order
-// as the tensor formulation (every intermediate rounded to fp32, no FMA contraction): bit-identical to it.
+// as the reference's CPU code (true divisions by the weights, every intermediate rounded to fp32, no FMA contraction).
 __global__ __launch_bounds__(256) void box_decode_kernel(const float* __restrict__ codes, const float* __restrict__ boxes,
                                                          const int R, const int ncls, const float wx, const float wy,
                                                          const float ww, const float wh, const float clipv,
