@@ -94,6 +94,45 @@ int mmt_aug_erase(float* out, long view_stride, int out_W, int out_C, const int3
  *   labels_f  (RPN, optional) 1 / 0 / -1 (ignored or not visible);  labels_i (box head, optional) class / 0 / -1
  *   reg       (optional) [A_total,4] regression targets against the matched (or first) gt with weights (wx,wy,ww,wh)
  * Bit-identical to the tensor formulation (same expression order, no FMA contraction). */
+/* ---------------------------------------------------------------- proposal selection
+ * mmt_rpn_gather_decode: for every (image, level) and every index of that level's pre-NMS top-k (topk [N,k] int64, from
+ *   the top-k over the [N, H*W*A] objectness logits): sigmoid(logit), the 4 deltas, the anchor, BoxCoder.decode with
+ *   weights 1 and clip_to_image -> boxes / scores / idx / box_reg of shape [N, sumk(,4)], level l at columns
+ *   [out_off, out_off + k).  head = the fused RPN head output of the level, NHWC with C = A + 4A channels
+ *   (rpn/inference.py:86-113 without its top-k: ~12 launches per level -> 1 for all levels). */
+typedef struct { const float* head; const float* anchors; const int64_t* topk; int HW; int k; int out_off; int pad; } mmt_rpn_level;
+typedef struct {
+  mmt_rpn_level lv[8];
+  int L, N, A, C, sumk;
+  float clipv;
+  const float* lim;   /* [N][2] = (width - 1, height - 1) */
+  float* boxes; float* scores; int64_t* idx; float* box_reg;
+} mmt_rpn_select_args;
+int mmt_rpn_gather_decode(const mmt_rpn_select_args* a /*[host]*/, void* stream);
+/* mmt_rpn_post_select: after mmt_nms_batched over the N*L segments (keep [N*L,kmax], keep_cnt [N*L]): a kept candidate
+ *   survives when its rank in its segment is < post_n and its position < own_pre[level] (rpn/inference.py:130-135); of the
+ *   survivors the best fpn_post_n of the WHOLE BATCH (training: rpn/inference.py:223-234, written per image in (level,
+ *   rank) order, then the image's gt boxes gt[gt_off[n]..gt_off[n+1]) appended with score 1, :55-76) or of each image in
+ *   descending score order (inference, :235-242; fpn_post_n <= 2048).  Equal scores: the earlier candidate first.
+ *   Outputs have a fixed capacity `cap` per image (>= fpn_post_n + the largest gt count); out_cnt [N] stays on the device. */
+typedef struct {
+  const float* boxes; const float* scores; const int64_t* idx; const float* box_reg;
+  const int32_t* keep; const int32_t* keep_cnt;
+  int seg_off[9], own_pre[8];
+  int L, N, sumk, kmax, post_n, fpn_post_n, training, cap;
+  int min_size_filter;   /* candidates removed by RPN.MIN_SIZE carry score -1 (and a far-away box): they hold no slot */
+  int pad;
+  const float* gt; const int32_t* gt_off;
+  float* out_boxes; float* out_scores; int64_t* out_idx; float* out_reg; int32_t* out_level; int32_t* out_cnt;
+} mmt_rpn_post_args;
+int mmt_rpn_post_select(const mmt_rpn_post_args* a /*[host]*/, void* stream);
+/* mmt_sample_fg_bg: BalancedPositiveNegativeSampler (balanced_positive_negative_sampler.py:20-72) for n_images label
+ *   vectors labels[off[i]..off[i+1]) (float or int64: >= 1 positive, 0 negative, < 0 ignored) with caller-drawn uniform
+ *   keys: pos_mask / neg_mask (bytes) mark the min(#pos, max_pos) positives and min(#neg, batch - num_pos) negatives with
+ *   the smallest keys (equal keys: lower index first); counts [n_images][2].  One block per image. */
+int mmt_sample_fg_bg(const void* labels, int labels_are_float, const float* keys, const int32_t* off, int n_images,
+                     int batch_size_per_image, int max_pos, uint8_t* pos_mask, uint8_t* neg_mask, int32_t* counts, void* stream);
+
 /* BoxCoder.decode (modeling/box_coder.py:52-95) of codes [R, ncls*4] against boxes [R,4] with weights (wx,wy,ww,wh) and the
  * dw/dh clip, optionally followed by clip_to_image (structures/bounding_box.py:229-238): row r belongs to image i with
  * row_off[i] <= r < row_off[i+1] and is clamped to [0, lim[2i]] x [0, lim[2i+1]] (= width-1, height-1).  Replaces ~25

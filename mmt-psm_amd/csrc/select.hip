@@ -1,0 +1,351 @@
+// Selection kernels of the proposal pipeline: what the reference does with sigmoid / topk / index /
+// cat / nonzero / randperm tensor calls around its NMS (rpn/inference.py:78-243, balanced_positive_negative_sampler.py:20-72),
+// each of them a handful of launches per (image, level), as three launches per call here:
+//
+//   rpn_gather_kernel   after the per-level top-k of the objectness: gather of the logit, box deltas and anchors of every
+//                       selected index, sigmoid, BoxCoder.decode (weights 1), clip_to_image -> candidate boxes / scores
+//                       in the (image, level, rank) order the batched NMS wants
+//   rpn_post_kernel     after the NMS: the per-level POST_NMS_TOP_N cut, then FPN_POST_NMS_TOP_N over the whole batch
+//                       (training) or per image in score order (inference), ground-truth boxes appended (training):
+//                       fixed-capacity proposal tensors + counts on the device
+//   sample_kernel       BalancedPositiveNegativeSampler: the num_pos / num_neg candidates with the smallest random keys
+//
+// The last two are built on one primitive, an exact block-wide radix SELECT over 64-bit keys that are unique by construction
+// (value bits in the high word, element index in the low word): "the k largest keys" is then a well-defined set and order,
+// with the reference's unspecified order between equal values resolved as "lower index first".  Integer / comparison work
+// only besides the decode; built with -ffp-contract=off like targets.hip.
+#include <string.h>
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 1024;
+
+__device__ __forceinline__ unsigned f2ord(float f) {  // order-preserving float -> unsigned
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct SelShared {
+  unsigned hist[256];
+  unsigned long long prefix, mask;
+  int desired, count;
+};
+
+// Threshold T such that exactly min(k, #valid) of the keys key(i), i in [0, n), are >= T.  key(i) == 0 means "not a
+// candidate"; candidate keys are unique and non-zero.  Returns 1 (everything non-zero) when there are <= k candidates.
+// All NT threads call it; `sh` is block-shared.
+template <class KeyFn>
+__device__ unsigned long long block_select(KeyFn key, const int n, const int k, SelShared& sh) {
+  const int tid = threadIdx.x;
+  if (tid == 0) { sh.prefix = 0; sh.mask = 0; sh.desired = k; sh.count = 0; }
+  __syncthreads();
+  // count the candidates once: with <= k of them there is nothing to select
+  {
+    int c = 0;
+    for (int i = tid; i < n; i += NT) c += key(i) != 0ull;
+    if (c) atomicAdd(&sh.count, c);
+    __syncthreads();
+    if (sh.count <= k) return 1ull;
+  }
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    if (tid < 256) sh.hist[tid] = 0;
+    __syncthreads();
+    const unsigned long long prefix = sh.prefix, mask = sh.mask;
+    for (int i = tid; i < n; i += NT) {
+      const unsigned long long kk = key(i);
+      if (kk != 0ull && (kk & mask) == prefix) atomicAdd(&sh.hist[(unsigned)(kk >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int want = sh.desired, b = 255;
+      for (; b > 0; b--) {
+        const int c = (int)sh.hist[b];
+        if (c >= want) break;
+        want -= c;
+      }
+      sh.desired = want;
+      sh.prefix = prefix | ((unsigned long long)b << shift);
+      sh.mask = mask | (0xffull << shift);
+    }
+    __syncthreads();
+  }
+  return sh.prefix;  // all 64 bits fixed: the key of the k-th largest candidate
+}
+
+// descending bitonic sort of P (power of two, <= 2048) 64-bit keys in LDS
+__device__ void block_sort_desc(unsigned long long* a, const int P) {
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < P / 2; t += NT) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned long long x = a[lo], y = a[hi];
+        if ((x < y) == desc) { a[lo] = y; a[hi] = x; }
+      }
+    }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ RPN candidates
+// The top-k itself stays a library call per level (torch.topk over [N, H*W*A] logits: a multi-block radix select; one
+// block per segment would be bound by what ONE CU can pull from L2, ~10 passes x 12 MB for the 196k-anchor level).
+// Everything after it, for all levels and images at once: gather of the logit, the 4 deltas and the anchor of every
+// selected index, sigmoid, BoxCoder.decode (weights 1,1,1,1), clip_to_image -- one thread per candidate.
+struct RpnLevel { const float* head; const float* anchors; const long* topk; int HW; int k; int out_off; int pad; };
+struct RpnSelArgs {
+  RpnLevel lv[8];
+  int L, N, A, C, sumk;      // C = channels of the fused head output (A logits + 4A deltas), NHWC
+  float clipv;               // BoxCoder's dw / dh clip
+  const float* lim;          // [N][2] = (width - 1, height - 1)
+  float* boxes; float* scores; long* idx; float* box_reg;
+};
+
+__global__ __launch_bounds__(256) void rpn_gather_kernel(const RpnSelArgs a) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.N * a.sumk) return;
+  const int img = t / a.sumk, r = t - img * a.sumk;
+  int l = 0;
+  while (l + 1 < a.L && r >= a.lv[l + 1].out_off) l++;
+  const RpnLevel lv = a.lv[l];
+  const int j = r - lv.out_off;
+  const int i = (int)lv.topk[(long)img * lv.k + j];
+  const int px = i / a.A, an = i - px * a.A;
+  const float* hd = lv.head + ((long)img * lv.HW + px) * a.C;
+  const float logit = hd[an];
+  const float* d = hd + a.A + an * 4;
+  const f32x4 b = *(const f32x4*)(lv.anchors + (long)i * 4);
+  const float w = b[2] - b[0] + 1.f, h = b[3] - b[1] + 1.f;
+  const float cx = b[0] + 0.5f * w, cy = b[1] + 0.5f * h;
+  const float dw = fminf(d[2], a.clipv), dh = fminf(d[3], a.clipv);
+  const float pcx = d[0] * w + cx, pcy = d[1] * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  const float lw = a.lim[2 * img], lh = a.lim[2 * img + 1];
+  f32x4 bx = {pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw - 1.f, pcy + 0.5f * ph - 1.f};
+  bx[0] = fminf(fmaxf(bx[0], 0.f), lw); bx[1] = fminf(fmaxf(bx[1], 0.f), lh);
+  bx[2] = fminf(fmaxf(bx[2], 0.f), lw); bx[3] = fminf(fmaxf(bx[3], 0.f), lh);
+  *(f32x4*)(a.boxes + (long)t * 4) = bx;
+  a.scores[t] = 1.f / (1.f + expf(-logit));  // torch.sigmoid
+  a.idx[t] = i;
+  *(f32x4*)(a.box_reg + (long)t * 4) = f32x4{d[0], d[1], d[2], d[3]};
+}
+
+// ------------------------------------------------------------------------------------------------ after the NMS
+struct RpnPostArgs {
+  const float* boxes; const float* scores; const long* idx; const float* box_reg;   // candidates [N][sumk]
+  const int* keep; const int* keep_cnt;   // NMS result per segment (image-major, level-minor): [N*L][kmax], [N*L]
+  int seg_off[9], own_pre[8];             // level offsets inside an image's sumk candidates; this selector's pre-NMS prefix
+  int L, N, sumk, kmax, post_n, fpn_post_n, training, cap, min_size_filter, pad;
+  const float* gt; const int* gt_off;     // training: ground-truth boxes appended after the selection (or null)
+  float* out_boxes; float* out_scores; long* out_idx; float* out_reg; int* out_level; int* out_cnt;  // [N][cap] ..., [N]
+};
+
+// entry e of image n = (level l, rank j < min(post_n, kmax)): valid when j < keep_cnt and its position lies in the
+// selector's own pre-NMS prefix.  Training: ONE block ranks the valid entries of the whole batch, keeps the best
+// fpn_post_n and writes them per image in (level, rank) order.  Inference: one block per image, best fpn_post_n of the
+// image in descending score order.
+__global__ __launch_bounds__(NT) void rpn_post_kernel(const RpnPostArgs a) {
+  __shared__ SelShared sh;
+  __shared__ unsigned long long list[2048];
+  __shared__ int n_list, base;
+  __shared__ int wsum[NT / 64];
+  __shared__ int bad_rank[64];   // per segment: rank of the one min-size-removed box the NMS kept (they all sit on the same
+                                 // far-away spot, so the first survives and suppresses the rest), or INT_MAX
+  const int tid = threadIdx.x;
+  const int post = a.post_n > 0 && a.post_n < a.kmax ? a.post_n : a.kmax;   // valid ranks per segment that can survive
+  const int per = a.min_size_filter ? min(post + 1, a.kmax) : post;         // list ranks to look at
+  const int n_img = a.training ? a.N : 1, img0 = a.training ? 0 : blockIdx.x;
+  const int E = n_img * a.L * per;
+  if (tid < 64) bad_rank[tid] = 0x7fffffff;
+  __syncthreads();
+  if (a.min_size_filter) {
+    for (int sg = tid >> 6; sg < n_img * a.L; sg += NT / 64) {   // one wave per segment
+      const int img = img0 + sg / a.L, l = sg % a.L, seg = img * a.L + l;
+      const int c = min(a.keep_cnt[seg], per);
+      int best = 0x7fffffff;
+      for (int j = tid & 63; j < c; j += 64) {
+        const int p = a.keep[(long)seg * a.kmax + j];
+        if (a.scores[(long)img * a.sumk + a.seg_off[l] + p] < 0.f) best = min(best, j);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+      if ((tid & 63) == 0) bad_rank[sg] = best;
+    }
+    __syncthreads();
+  }
+  auto entry = [&](int e, int& img, int& pos) -> bool {   // -> valid; pos = candidate index inside the image
+    const int s = e / per, j = e - s * per;
+    img = img0 + s / a.L;
+    const int l = s % a.L, seg = img * a.L + l;
+    if (j >= a.keep_cnt[seg]) return false;
+    const int br = bad_rank[s];
+    if (j == br || j - (j > br) >= post) return false;   // the removed box holds no slot; ranks behind it move up by one
+    const int p = a.keep[(long)seg * a.kmax + j];
+    if (p >= a.own_pre[l]) return false;
+    pos = a.seg_off[l] + p;
+    return true;
+  };
+  auto key = [&](int e) -> unsigned long long {
+    int img, pos;
+    if (!entry(e, img, pos)) return 0ull;
+    return ((unsigned long long)f2ord(a.scores[(long)img * a.sumk + pos]) << 32) | (unsigned)(0xffffffffu - (unsigned)e);
+  };
+  const unsigned long long T = block_select(key, E, a.fpn_post_n, sh);
+  if (!a.training) {
+    // descending score order (rpn/inference.py:235-242: topk(sorted=True) then index)
+    if (tid == 0) n_list = 0;
+    int P = 2;
+    while (P < a.fpn_post_n && P < 2048) P <<= 1;
+    for (int i = tid; i < P; i += NT) list[i] = 0ull;
+    __syncthreads();
+    for (int e = tid; e < E; e += NT) {
+      const unsigned long long kk = key(e);
+      if (kk != 0ull && kk >= T) list[atomicAdd(&n_list, 1)] = kk;
+    }
+    block_sort_desc(list, P);
+    const int cnt = n_list;
+    for (int j = tid; j < cnt; j += NT) {
+      const int e = (int)(0xffffffffu - (unsigned)list[j]);
+      int img, pos;
+      entry(e, img, pos);
+      const long src = (long)img * a.sumk + pos, dst = (long)img * a.cap + j;
+      *(f32x4*)(a.out_boxes + dst * 4) = *(const f32x4*)(a.boxes + src * 4);
+      a.out_scores[dst] = a.scores[src];
+      a.out_idx[dst] = a.idx[src];
+      *(f32x4*)(a.out_reg + dst * 4) = *(const f32x4*)(a.box_reg + src * 4);
+      a.out_level[dst] = (e / per) % a.L;
+    }
+    if (tid == 0) a.out_cnt[img0] = cnt;
+    return;
+  }
+  // training: selected entries keep their (image, level, rank) order: an ordered compaction per image.  Each thread owns
+  // a contiguous run of entries, so a block scan of the run counts gives every selected entry its slot.
+  for (int img = 0; img < a.N; img++) {
+    const int e0 = img * a.L * per, e1 = e0 + a.L * per;
+    const int chunk = (a.L * per + NT - 1) / NT;
+    const int lo = e0 + tid * chunk, hi = min(lo + chunk, e1);
+    int c = 0;
+    for (int e = lo; e < hi; e++) { const unsigned long long kk = key(e); c += (kk != 0ull && kk >= T); }
+    // exclusive scan of c over the block
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += v; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < (tid >> 6); w++) wbase += wsum[w];
+    int slot = wbase + incl - c;
+    if (tid == NT - 1) base = wbase + incl;   // total of the image
+    for (int e = lo; e < hi; e++) {
+      const unsigned long long kk = key(e);
+      if (kk == 0ull || kk < T) continue;
+      int im, pos;
+      entry(e, im, pos);
+      const long src = (long)img * a.sumk + pos, dst = (long)img * a.cap + slot++;
+      *(f32x4*)(a.out_boxes + dst * 4) = *(const f32x4*)(a.boxes + src * 4);
+      a.out_scores[dst] = a.scores[src];
+      a.out_idx[dst] = a.idx[src];
+      *(f32x4*)(a.out_reg + dst * 4) = *(const f32x4*)(a.box_reg + src * 4);
+      a.out_level[dst] = (e / per) % a.L;
+    }
+    __syncthreads();
+    int total = base;
+    if (a.gt) {  // add_gt_proposals (rpn/inference.py:55-76): the image's gt boxes with objectness 1
+      const int g0 = a.gt_off[img], g1 = a.gt_off[img + 1];
+      for (int g = g0 + tid; g < g1; g += NT) {
+        const long dst = (long)img * a.cap + total + (g - g0);
+        *(f32x4*)(a.out_boxes + dst * 4) = *(const f32x4*)(a.gt + (long)g * 4);
+        a.out_scores[dst] = 1.f;
+        a.out_idx[dst] = -1;
+        *(f32x4*)(a.out_reg + dst * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        a.out_level[dst] = -1;
+      }
+      total += g1 - g0;
+    }
+    if (tid == 0) a.out_cnt[img] = total;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fg / bg sampler
+// labels: >= 1 positive, 0 negative, < 0 ignored; per image the num_pos = min(#pos, P) positives and
+// num_neg = min(#neg, B - num_pos) negatives with the SMALLEST keys (uniform random keys -> a uniform sample without
+// replacement, balanced_positive_negative_sampler.py:40-60); equal keys: lower index first.
+template <typename LT>
+__global__ __launch_bounds__(NT) void sample_kernel(const LT* __restrict__ labels, const float* __restrict__ keys,
+                                                    const int* __restrict__ off, const int batch, const int max_pos,
+                                                    unsigned char* __restrict__ pos_mask, unsigned char* __restrict__ neg_mask,
+                                                    int* __restrict__ counts) {
+  __shared__ SelShared sh;
+  __shared__ int npos_s, nneg_s;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int o0 = off[img], n = off[img + 1] - o0;
+  const LT* lab = labels + o0;
+  const float* ky = keys + o0;
+  if (tid == 0) { npos_s = 0; nneg_s = 0; }
+  __syncthreads();
+  int cp = 0, cn = 0;
+  for (int i = tid; i < n; i += NT) { const LT l = lab[i]; cp += l >= (LT)1; cn += l == (LT)0; }
+  if (cp) atomicAdd(&npos_s, cp);
+  if (cn) atomicAdd(&nneg_s, cn);
+  __syncthreads();
+  const int num_pos = min(npos_s, max_pos), num_neg = min(nneg_s, batch - num_pos);
+  // smallest key first = largest inverted key
+  auto kpos = [&](int i) -> unsigned long long {
+    if (!(lab[i] >= (LT)1)) return 0ull;
+    return ((unsigned long long)(~f2ord(ky[i])) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+  };
+  auto kneg = [&](int i) -> unsigned long long {
+    if (!(lab[i] == (LT)0)) return 0ull;
+    return ((unsigned long long)(~f2ord(ky[i])) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+  };
+  const unsigned long long Tp = num_pos > 0 ? block_select(kpos, n, num_pos, sh) : ~0ull;
+  __syncthreads();
+  const unsigned long long Tn = num_neg > 0 ? block_select(kneg, n, num_neg, sh) : ~0ull;
+  for (int i = tid; i < n; i += NT) {
+    const unsigned long long a = kpos(i), b = kneg(i);
+    pos_mask[o0 + i] = (a != 0ull && a >= Tp) ? 1 : 0;
+    neg_mask[o0 + i] = (b != 0ull && b >= Tn) ? 1 : 0;
+  }
+  if (tid == 0) { counts[2 * img] = num_pos; counts[2 * img + 1] = num_neg; }
+}
+
+}  // namespace
+
+extern "C" int mmt_rpn_gather_decode(const mmt_rpn_select_args* a, void* stream) {
+  if (!a || a->L < 1 || a->L > 8 || a->N < 1 || !a->boxes || !a->scores || !a->idx || !a->box_reg || !a->lim) return MMT_EINVAL;
+  static_assert(sizeof(mmt_rpn_select_args) == sizeof(RpnSelArgs), "argument layout");
+  RpnSelArgs k;
+  memcpy(&k, a, sizeof(k));
+  for (int l = 0; l < k.L; l++)
+    if (!k.lv[l].head || !k.lv[l].anchors || !k.lv[l].topk || k.lv[l].k < 1) return MMT_EINVAL;
+  hipLaunchKernelGGL(rpn_gather_kernel, dim3(mmt_cdiv((long)k.N * k.sumk, 256)), dim3(256), 0, (hipStream_t)stream, k);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_rpn_post_select(const mmt_rpn_post_args* a, void* stream) {
+  if (!a || a->L < 1 || a->L > 8 || a->N < 1 || !a->keep || !a->keep_cnt || !a->out_boxes || !a->out_cnt) return MMT_EINVAL;
+  static_assert(sizeof(mmt_rpn_post_args) == sizeof(RpnPostArgs), "argument layout");
+  RpnPostArgs k;
+  memcpy(&k, a, sizeof(k));
+  if (k.fpn_post_n < 1 || (!k.training && k.fpn_post_n > 2048) || k.cap < k.fpn_post_n || k.N * k.L > 64) return MMT_EINVAL;
+  hipLaunchKernelGGL(rpn_post_kernel, dim3(k.training ? 1 : k.N), dim3(NT), 0, (hipStream_t)stream, k);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_sample_fg_bg(const void* labels, int labels_are_float, const float* keys, const int32_t* off, int n_images,
+                                int batch_size_per_image, int max_pos, uint8_t* pos_mask, uint8_t* neg_mask, int32_t* counts,
+                                void* stream) {
+  if (!labels || !keys || !off || !pos_mask || !neg_mask || !counts || n_images < 1) return MMT_EINVAL;
+  if (labels_are_float)
+    hipLaunchKernelGGL(sample_kernel<float>, dim3(n_images), dim3(NT), 0, (hipStream_t)stream, (const float*)labels, keys, off,
+                       batch_size_per_image, max_pos, pos_mask, neg_mask, counts);
+  else
+    hipLaunchKernelGGL(sample_kernel<long>, dim3(n_images), dim3(NT), 0, (hipStream_t)stream, (const long*)labels, keys, off,
+                       batch_size_per_image, max_pos, pos_mask, neg_mask, counts);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}

@@ -31,6 +31,26 @@ class ConvArgs(ctypes.Structure):
                 ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long)]
 
 
+class RpnLevel(ctypes.Structure):
+    _fields_ = [("head", c_void_p), ("anchors", c_void_p), ("topk", c_void_p), ("HW", c_int), ("k", c_int),
+                ("out_off", c_int), ("pad", c_int)]
+
+
+class RpnSelectArgs(ctypes.Structure):
+    _fields_ = [("lv", RpnLevel * 8), ("L", c_int), ("N", c_int), ("A", c_int), ("C", c_int), ("sumk", c_int),
+                ("clipv", c_float), ("lim", c_void_p), ("boxes", c_void_p), ("scores", c_void_p), ("idx", c_void_p),
+                ("box_reg", c_void_p)]
+
+
+class RpnPostArgs(ctypes.Structure):
+    _fields_ = [("boxes", c_void_p), ("scores", c_void_p), ("idx", c_void_p), ("box_reg", c_void_p), ("keep", c_void_p),
+                ("keep_cnt", c_void_p), ("seg_off", c_int * 9), ("own_pre", c_int * 8), ("L", c_int), ("N", c_int),
+                ("sumk", c_int), ("kmax", c_int), ("post_n", c_int), ("fpn_post_n", c_int), ("training", c_int),
+                ("cap", c_int), ("min_size_filter", c_int), ("pad", c_int), ("gt", c_void_p), ("gt_off", c_void_p),
+                ("out_boxes", c_void_p), ("out_scores", c_void_p),
+                ("out_idx", c_void_p), ("out_reg", c_void_p), ("out_level", c_void_p), ("out_cnt", c_void_p)]
+
+
 class MgdTeachers(ctypes.Structure):
     _fields_ = [("t", c_void_p * 8), ("flip", c_int * 8), ("nt", c_int)]
 
@@ -54,6 +74,9 @@ _SIGS = {
     "mmt_set_conv_precision": [ctypes.c_int],
     "mmt_get_conv_precision": [],
     "mmt_pack_weight": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
+    "mmt_rpn_gather_decode": [ctypes.POINTER(RpnSelectArgs), c_void_p],
+    "mmt_rpn_post_select": [ctypes.POINTER(RpnPostArgs), c_void_p],
+    "mmt_sample_fg_bg": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_box_decode": [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_int,
                        c_void_p, c_void_p],
     "mmt_split_planes": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p],
@@ -267,6 +290,80 @@ def match_targets(cand, cand_off, gt, gt_off, n_images, high, low, allow_low_qua
                                    float(wy), float(ww), float(wh), _p(top), _p(matches), _p(lf), _p(li), _p(reg), _stream()),
            "mmt_match_targets")
     return matches, (lf if rpn_labels else li), reg
+
+
+def rpn_gather_decode(heads, anchors, topks, A, clip, lim):
+    """heads[l]: the fused RPN head output of level l, (N, 5A, H, W) NHWC-dense (A logits, then 4A deltas); anchors[l]
+    (H*W*A, 4); topks[l] (N, k_l) int64 indices into H*W*A -> boxes (N, sumk, 4), scores (N, sumk), idx (N, sumk),
+    box_reg (N, sumk, 4), level offsets (include/mmtpsm.h: mmt_rpn_gather_decode)"""
+    a = RpnSelectArgs()
+    L, N = len(heads), heads[0].shape[0]
+    offs, keep = [0], []
+    for l, (h, an, tk) in enumerate(zip(heads, anchors, topks)):
+        h = nhwc(h)
+        tk = tk.contiguous()
+        keep += [h, tk]
+        lv = a.lv[l]
+        lv.head, lv.anchors, lv.topk = h.data_ptr(), an.data_ptr(), tk.data_ptr()
+        lv.HW, lv.k, lv.out_off = h.shape[2] * h.shape[3], tk.shape[1], offs[-1]
+        if h.shape[1] != 5 * A or an.shape[0] != lv.HW * A:
+            raise RuntimeError("rpn_gather_decode: head / anchor shapes do not match A")
+        offs.append(offs[-1] + tk.shape[1])
+    sumk, dev = offs[-1], heads[0].device
+    boxes = torch.empty((N, sumk, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((N, sumk), dtype=torch.float32, device=dev)
+    idx = torch.empty((N, sumk), dtype=torch.int64, device=dev)
+    reg = torch.empty((N, sumk, 4), dtype=torch.float32, device=dev)
+    a.L, a.N, a.A, a.C, a.sumk, a.clipv, a.lim = L, N, A, 5 * A, sumk, float(clip), lim.data_ptr()
+    a.boxes, a.scores, a.idx, a.box_reg = boxes.data_ptr(), scores.data_ptr(), idx.data_ptr(), reg.data_ptr()
+    _check(lib().mmt_rpn_gather_decode(ctypes.byref(a), _stream()), "mmt_rpn_gather_decode")
+    return boxes, scores, idx, reg, offs
+
+
+def rpn_post_select(boxes, scores, idx, reg, keep, keep_cnt, level_off, own_pre, post_n, fpn_post_n, training, cap,
+                    gt=None, gt_off=None, min_size_filter=False):
+    """include/mmtpsm.h: mmt_rpn_post_select -> (out_boxes (N,cap,4), out_scores, out_idx, out_reg, out_level, out_cnt (N,))"""
+    N, sumk = scores.shape
+    L = len(level_off) - 1
+    dev = boxes.device
+    a = RpnPostArgs()
+    a.boxes, a.scores, a.idx, a.box_reg = boxes.data_ptr(), scores.data_ptr(), idx.data_ptr(), reg.data_ptr()
+    a.keep, a.keep_cnt = keep.data_ptr(), keep_cnt.data_ptr()
+    for l in range(L + 1):
+        a.seg_off[l] = level_off[l]
+    for l in range(L):
+        a.own_pre[l] = own_pre[l]
+    a.L, a.N, a.sumk, a.kmax = L, N, sumk, keep.shape[1]
+    a.post_n, a.fpn_post_n, a.training, a.cap = int(post_n), int(fpn_post_n), 1 if training else 0, int(cap)
+    a.min_size_filter = 1 if min_size_filter else 0
+    if gt is not None:
+        a.gt, a.gt_off = gt.data_ptr(), gt_off.data_ptr()
+    ob = torch.empty((N, cap, 4), dtype=torch.float32, device=dev)
+    osc = torch.empty((N, cap), dtype=torch.float32, device=dev)
+    oi = torch.empty((N, cap), dtype=torch.int64, device=dev)
+    orr = torch.empty((N, cap, 4), dtype=torch.float32, device=dev)
+    ol = torch.empty((N, cap), dtype=torch.int32, device=dev)
+    oc = torch.empty((N,), dtype=torch.int32, device=dev)
+    a.out_boxes, a.out_scores, a.out_idx, a.out_reg = ob.data_ptr(), osc.data_ptr(), oi.data_ptr(), orr.data_ptr()
+    a.out_level, a.out_cnt = ol.data_ptr(), oc.data_ptr()
+    _check(lib().mmt_rpn_post_select(ctypes.byref(a), _stream()), "mmt_rpn_post_select")
+    return ob, osc, oi, orr, ol, oc
+
+
+def sample_fg_bg(labels, keys, off, batch_size_per_image, max_pos):
+    """labels (float32 or int64, concatenated over images), keys (float32 uniform), off int32 (n_images + 1,) ->
+    pos_mask, neg_mask (bool), counts (n_images, 2) int32 (include/mmtpsm.h: mmt_sample_fg_bg)"""
+    _dev(labels, "labels")
+    n_img = off.numel() - 1
+    if labels.dtype not in (torch.float32, torch.int64):
+        raise RuntimeError("sample_fg_bg: labels must be float32 or int64")
+    labels, keys = labels.contiguous(), keys.contiguous()
+    pm = torch.empty(labels.shape, dtype=torch.uint8, device=labels.device)
+    nm = torch.empty(labels.shape, dtype=torch.uint8, device=labels.device)
+    cnt = torch.empty((n_img, 2), dtype=torch.int32, device=labels.device)
+    _check(lib().mmt_sample_fg_bg(_p(labels), 1 if labels.dtype == torch.float32 else 0, _p(keys), _p(off), n_img,
+                                  int(batch_size_per_image), int(max_pos), _p(pm), _p(nm), _p(cnt), _stream()), "mmt_sample_fg_bg")
+    return pm.view(torch.bool), nm.view(torch.bool), cnt
 
 
 def box_decode(codes, boxes, weights, clip, row_off=None, lim=None):

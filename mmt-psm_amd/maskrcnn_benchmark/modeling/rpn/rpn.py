@@ -88,118 +88,91 @@ class RPNPostProcessor(nn.Module):
                 shared[key] = c
         return self.select(c, targets, between)
 
+    @staticmethod
+    def _fused_head(o, r):
+        """(N,A,H,W) logits and (N,4A,H,W) deltas -> the (N,5A,H,W) NHWC tensor they are the two channel ranges of (RPNHead
+        produces exactly that: zero-copy), or a fused copy when they come from elsewhere"""
+        N, A, Hh, Ww = o.shape
+        C = 5 * A
+        st = (Hh * Ww * C, 1, Ww * C, C)
+        if o.stride() == st and r.stride() == st and r.data_ptr() == o.data_ptr() + 4 * A:
+            return torch.as_strided(o, (N, C, Hh, Ww), st)
+        return torch.cat([o, r], 1).contiguous(memory_format=torch.channels_last)
+
     def compute_candidates(self, anchors, objectness, box_regression, pre_n):
+        """rpn/inference.py:86-135 for every (image, level): top-k of the objectness (a library top-k per level, on the
+        logits -- ordered like their sigmoid), then ONE launch for gather + sigmoid + decode + clip of all levels
+        (`mmt_rpn_gather_decode`) and one `mmt_nms_batched` launch pair over all segments"""
         N, L = len(anchors), len(objectness)
         dev = objectness[0].device
         sizes = [a[0].size for a in anchors]  # (W,H) per image
         lim = dev_const([[s[0] - 1, s[1] - 1] for s in sizes], torch.float32, dev)
-        cand_extra, ks, scs, regs, ancs = [], [], [], [], []
+        A = objectness[0].shape[1]
+        heads, topks, ks = [], [], []
         for lvl in range(L):
-            o, r = _flat(objectness[lvl].detach(), box_regression[lvl].detach())
-            k = min(pre_n, o.shape[1])
-            lg, idx = o.sigmoid().topk(k, dim=1, sorted=True)  # on the probabilities, as rpn/inference.py:93 (ties!)
-            r = torch.gather(r, 1, idx[:, :, None].expand(-1, -1, 4))
-            scs.append(lg)
-            regs.append(r)
-            ancs.append(anchors[0][lvl].bbox[idx.reshape(-1)].view(N, k, 4))  # same grid for every image
-            cand_extra.append((r, idx))
+            head = self._fused_head(objectness[lvl].detach(), box_regression[lvl].detach())
+            flat = head[:, :A].permute(0, 2, 3, 1).reshape(N, -1)
+            k = min(pre_n, flat.shape[1])
+            topks.append(flat.topk(k, dim=1, sorted=True)[1])
+            heads.append(head)
             ks.append(k)
         kmax = max(ks)
-        # decode / clip / min-size filter ONCE over all levels; (N, sum_k, .) is already the image-major, level-minor order
-        # the batched NMS wants, so no per-(image, level) slicing and re-concatenation
-        sc = torch.cat(scs, 1)
-        per_img = sum(ks)
-        # BoxCoder.decode + clip_to_image(remove_empty=False) of every candidate of the batch: one launch
-        props = H.box_decode(torch.cat(regs, 1).reshape(-1, 4), torch.cat(ancs, 1).reshape(-1, 4), self.box_coder.weights,
-                             self.box_coder.bbox_xform_clip, dev_const([i * per_img for i in range(N + 1)], torch.int32, dev),
-                             lim).view(N, -1, 4)
+        boxes, scores, idx, reg, offs = H.rpn_gather_decode(heads, [anchors[0][lvl].bbox for lvl in range(L)], topks, A,
+                                                            self.box_coder.bbox_xform_clip, lim)
         if self.min_size > 0:
             # remove_small_boxes BEFORE the NMS (rpn/inference.py:124-129): a removed box must neither suppress anything nor
             # take a post-NMS slot.  Fixed shapes: it keeps its position in the segment but is moved far outside the image
-            # (IoU 0 with every real box) and gets score -1, which `select` excludes before it counts the slots.
-            ws = props[..., 2] - props[..., 0] + 1
-            hs = props[..., 3] - props[..., 1] + 1
+            # (IoU 0 with every real box) and gets score -1, which the selection excludes before it counts the slots.
+            ws = boxes[..., 2] - boxes[..., 0] + 1
+            hs = boxes[..., 3] - boxes[..., 1] + 1
             ok = (ws >= self.min_size) & (hs >= self.min_size)
-            sc = torch.where(ok, sc, torch.full_like(sc, -1.0))
-            props = torch.where(ok[..., None], props, torch.full_like(props, -1.0e6))
-        boxes = props.reshape(-1, 4)
-        scores = sc.reshape(-1)
-        offs = [0]
-        for n in range(N):
-            for l in range(L):
-                offs.append(offs[-1] + ks[l])
-        seg_off = dev_const(offs, torch.int32, dev)
-        keep, cnt = H.nms_batched(boxes, seg_off, kmax, self.nms_thresh)
-        return dict(N=N, L=L, ks=ks, kmax=kmax, sizes=sizes, boxes=boxes, scores=scores, seg_off=seg_off, keep=keep,
-                    cnt=cnt, extra_src=cand_extra, dev=dev)
+            scores = torch.where(ok, scores, torch.full_like(scores, -1.0))
+            boxes = torch.where(ok[..., None], boxes, torch.full_like(boxes, -1.0e6))
+        sumk = offs[-1]
+        seg = [n * sumk + offs[l] for n in range(N) for l in range(L)] + [N * sumk]
+        keep, cnt = H.nms_batched(boxes.view(-1, 4), dev_const(seg, torch.int32, dev), kmax, self.nms_thresh)
+        return dict(N=N, L=L, ks=ks, kmax=kmax, sizes=sizes, boxes=boxes, scores=scores, idx=idx, reg=reg, offs=offs,
+                    keep=keep, cnt=cnt, dev=dev)
 
     def select(self, c, targets=None, between=None):
+        """rpn/inference.py:130-135 (per-level POST_NMS_TOP_N), :216-243 (FPN_POST_NMS_TOP_N over the batch in training,
+        per image in score order otherwise), :55-76 (ground-truth boxes appended in training): one launch
+        (`mmt_rpn_post_select`) into fixed-capacity tensors; only the per-image counts cross to the host."""
         N, L, ks, kmax, dev = c["N"], c["L"], c["ks"], c["kmax"], c["dev"]
-        boxes, scores, seg_off, keep, cnt, sizes = c["boxes"], c["scores"], c["seg_off"], c["keep"], c["cnt"], c["sizes"]
-        per_img = sum(ks)
-        total = N * per_img
-        # this selector's own pre-NMS prefix per segment and post-NMS cap
-        own_pre = dev_const([min(self.pre_nms_top_n, k) for _ in range(N) for k in ks], torch.int32, dev)
-        pos = seg_off[:-1, None].long() + keep.long()
-        valid = (torch.arange(kmax, device=dev)[None, :] < cnt[:, None]) & (keep < own_pre[:, None])
-        if self.min_size > 0:  # boxes removed by the min-size filter hold no post-NMS slot
-            valid = valid & (scores[torch.where(valid, pos, torch.zeros_like(pos))] >= 0)
-        if self.post_nms_top_n > 0:
-            valid = valid & (torch.cumsum(valid.to(torch.int32), 1) <= self.post_nms_top_n)
-        kept = torch.zeros(total + 1, dtype=torch.bool, device=dev)
-        kept[torch.where(valid, pos, torch.full_like(pos, total)).reshape(-1)] = True
-        kept = kept[:total] & (scores >= 0)
+        sizes = c["sizes"]
         training = self.training
+        own_pre = [min(self.pre_nms_top_n, k) for k in ks]
+        per_seg = min(self.post_nms_top_n, kmax) if self.post_nms_top_n > 0 else kmax
         if L > 1:
-            masked = torch.where(kept, scores, torch.full_like(scores, -1.0))
-            if training:  # one top-k over the whole batch (rpn/inference.py:223-234)
-                k = min(self.fpn_post_nms_top_n, total)
-                _, top = masked.topk(k, sorted=True)
-                sel = torch.zeros(total, dtype=torch.bool, device=dev)
-                sel[top] = True
-                kept = kept & sel
-                order = None
-            else:  # per image top-k, score-sorted (rpn/inference.py:235-242)
-                k = min(self.fpn_post_nms_top_n, per_img)
-                tv, top = masked.view(N, per_img).topk(k, dim=1, sorted=True)
-                order = (top, tv >= 0)
-        else:
-            order = None
-        extra = None
-        if self.is_teacher:
-            src = c["extra_src"]
-            extra = {
-                "box_reg": torch.cat([torch.cat([src[l][0][n] for l in range(L)], 0) for n in range(N)], 0),
-                "rpn_topk": torch.cat([torch.cat([src[l][1][n] for l in range(L)], 0) for n in range(N)], 0),
-                "rpn_ancher_level": torch.cat([torch.cat([torch.full((ks[l],), l, dtype=torch.int64, device=dev)
-                                                          for l in range(L)], 0) for n in range(N)], 0),
-            }
+            fpn = min(self.fpn_post_nms_top_n, N * L * per_seg if training else L * per_seg)
+        else:  # single feature map: no cut over levels (rpn/inference.py:165-166)
+            fpn = N * per_seg if training else per_seg
+        gt = gt_off = None
+        max_gt = 0
+        if training and targets is not None:  # add_gt_proposals
+            goff = [0]
+            for t in targets:
+                goff.append(goff[-1] + len(t))
+            max_gt = max(len(t) for t in targets)
+            gt = torch.cat([t.bbox.to(dev) for t in targets], 0).contiguous() if N > 1 else targets[0].bbox.to(dev).contiguous()
+            gt_off = dev_const(goff, torch.int32, dev)
+        cap = min(fpn, L * per_seg) + max_gt
+        ob, osc, oi, orr, ol, oc = H.rpn_post_select(c["boxes"], c["scores"], c["idx"], c["reg"], c["keep"], c["cnt"],
+                                                     c["offs"], own_pre, self.post_nms_top_n, fpn, training, cap, gt, gt_off,
+                                                     min_size_filter=self.min_size > 0)
+        # the one host sync of the proposal pipeline: the per-image counts, through a pinned buffer and an event, so that
+        # whatever `between` enqueues (the RPN losses) keeps the GPU busy while the host is released
+        counts = self._counts_to_host(oc, between)
         out = []
-        if order is None:
-            # the one host sync of the proposal pipeline: only the per-image counts cross to the host, through a pinned
-            # buffer and an event, so that whatever `between` enqueues (the RPN losses) keeps the GPU busy while the host
-            # is released and builds the proposal lists / box-head launches.  nonzero_static: no sync of its own.
-            cap = min(self.fpn_post_nms_top_n, total) if (L > 1 and training) else total
-            idx_all = torch.nonzero_static(kept, size=cap).squeeze(1)
-            counts = self._counts_to_host(kept.view(N, per_img).sum(1), between)
-            st = 0
-            for n in range(N):
-                ii = idx_all[st:st + counts[n]]
-                st += counts[n]
-                out.append(self._boxlist(boxes, scores, extra, ii, sizes[n]))
-        else:
-            top, ok = order
-            counts = self._counts_to_host(ok.sum(1), between)
-            for n in range(N):
-                ii = top[n, :counts[n]] + n * per_img
-                out.append(self._boxlist(boxes, scores, extra, ii, sizes[n]))
-        if training and targets is not None:  # add_gt_proposals (rpn/inference.py:55-76)
-            res = []
-            for b, t in zip(out, targets):
-                g = BoxList(torch.cat([b.bbox, t.bbox.to(dev)], 0), b.size, "xyxy")
-                g.add_field("objectness", torch.cat([b.get_field("objectness"), torch.ones(len(t), device=dev)], 0))
-                res.append(g)
-            out = res
+        for n in range(N):
+            k = counts[n]
+            b = BoxList(ob[n, :k], sizes[n], "xyxy")
+            b.add_field("objectness", osc[n, :k])
+            if self.is_teacher:
+                b.add_field("box_reg", orr[n, :k])
+                b.add_field("rpn_topk", oi[n, :k])
+                b.add_field("rpn_ancher_level", ol[n, :k].to(torch.int64))
+            out.append(b)
         return out
 
     def _counts_to_host(self, cnt, between):
@@ -209,8 +182,8 @@ class RPNPostProcessor(nn.Module):
                 self.between_result = between()
             return cnt.tolist()
         pin = getattr(self, "_pin", None)
-        if pin is None or pin.numel() < cnt.numel():
-            pin = self._pin = torch.empty(max(16, cnt.numel()), dtype=torch.int64).pin_memory()
+        if pin is None or pin.numel() < cnt.numel() or pin.dtype != cnt.dtype:
+            pin = self._pin = torch.empty(max(16, cnt.numel()), dtype=cnt.dtype).pin_memory()
         pin[:cnt.numel()].copy_(cnt, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -220,15 +193,6 @@ class RPNPostProcessor(nn.Module):
             self.between_result = between()
         ev.synchronize()
         return pin[:cnt.numel()].tolist()
-
-    @staticmethod
-    def _boxlist(boxes, scores, extra, ii, size):
-        b = BoxList(boxes[ii], size, "xyxy")
-        b.add_field("objectness", scores[ii])
-        if extra is not None:
-            for k, v in extra.items():
-                b.add_field(k, v[ii])
-        return b
 
 
 def make_rpn_postprocessor(config, rpn_box_coder, is_train, is_teacher=False):

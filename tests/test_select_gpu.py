@@ -1,0 +1,111 @@
+"""the selection kernels of the proposal pipeline (csrc/select.hip: mmt_rpn_gather_decode,
+mmt_rpn_post_select, mmt_sample_fg_bg) bit for bit against the tensor formulations they replaced
+(tests/tensor_formulations.py), at the full 1024 x 1024 sizes.  Scores / keys are drawn without ties: the order between
+equal values is unspecified in the reference and "lower index first" in the kernels."""
+import numpy as np
+import pytest
+import torch
+
+import tensor_formulations as tf
+
+pytestmark = pytest.mark.gpu
+
+N, A = 2, 3
+GRIDS = [256, 128, 64, 32, 16]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from maskrcnn_benchmark import _hip
+    _hip.lib()
+    return _hip
+
+
+def _heads(seed):
+    g = torch.Generator().manual_seed(seed)
+    heads = []
+    for s in GRIDS:
+        n = s * s * A
+        # distinct logits per (image, level): a random permutation of a fine grid
+        lg = torch.stack([(torch.randperm(n, generator=g).float() / n) * 12.0 - 8.0 for _ in range(N)]).view(N, s, s, A)
+        rg = torch.randn(N, s, s, 4 * A, generator=g) * 0.5
+        h = torch.cat([lg, rg], 3).permute(0, 3, 1, 2)          # (N, 5A, H, W) with NHWC memory
+        heads.append(h.cuda())
+    return heads
+
+
+def _anchors():
+    from maskrcnn_benchmark.config import make_default_cfg
+    from maskrcnn_benchmark.modeling.rpn.anchor_generator import make_anchor_generator
+    ag = make_anchor_generator(make_default_cfg()).cuda()
+    return ag.grid_anchors([(s, s) for s in GRIDS])
+
+
+def test_rpn_gather_decode_and_post_select(hip):
+    import math
+    heads, anchors = _heads(3), _anchors()
+    clip = math.log(1000.0 / 16)
+    lims = torch.tensor([[999.0, 999.0], [899.0, 949.0]]).cuda()
+    obj = [h[:, :A] for h in heads]
+    reg = [h[:, A:] for h in heads]
+    rb, rs, ri, rr, offs = tf.rpn_candidates(obj, reg, anchors, 2000, clip, lims)
+    topks = [o.permute(0, 2, 3, 1).reshape(N, -1).topk(min(2000, o[0].numel()), dim=1, sorted=True)[1] for o in obj]
+    for a, b in zip(topks, [ri[:, offs[l]:offs[l + 1]] for l in range(5)]):
+        assert torch.equal(a, b)
+    b, s, i, r, o2 = hip.rpn_gather_decode(heads, anchors, topks, A, clip, lims)
+    assert o2 == offs and torch.equal(i, ri) and torch.equal(r, rr) and torch.equal(s, rs)
+    # decode: device exp() in both, but the tensor formulation multiplies where the kernel does the same operations fused
+    assert torch.equal(b, rb)
+    sumk = offs[-1]
+    seg = [n * sumk + offs[l] for n in range(N) for l in range(5)] + [N * sumk]
+    keep, cnt = hip.nms_batched(b.view(-1, 4), torch.tensor(seg, dtype=torch.int32).cuda(), 2000, 0.7)
+    g = torch.Generator().manual_seed(5)
+    gt = (torch.rand(19, 4, generator=g) * 500).cuda()
+    gt[:, 2:] += gt[:, :2]
+    gt_off = torch.tensor([0, 12, 19], dtype=torch.int32).cuda()
+    for (own_pre, post_n, fpn, training) in (([2000] * 4 + [768], 2000, 2000, True), ([1000] * 4 + [768], 1000, 1000, False),
+                                             ([2000] * 4 + [768], 2000, 2000, False), ([2000] * 4 + [768], 300, 1000, True)):
+        ref = tf.rpn_post_select(s, keep, cnt, offs, own_pre, post_n, fpn, training)
+        cap = fpn + 12
+        ob, osc, oi, orr, ol, oc = hip.rpn_post_select(b, s, i, r, keep, cnt, offs, own_pre, post_n, fpn, training, cap,
+                                                       gt if training else None, gt_off if training else None)
+        oc = oc.tolist()
+        for n in range(N):
+            ng = (12, 7)[n] if training else 0
+            assert oc[n] == ref[n].numel() + ng, (oc, [x.numel() for x in ref])
+            k = ref[n].numel()
+            assert torch.equal(ob[n, :k], b[n][ref[n]]) and torch.equal(osc[n, :k], s[n][ref[n]])
+            assert torch.equal(oi[n, :k], i[n][ref[n]]) and torch.equal(orr[n, :k], r[n][ref[n]])
+            lvl = torch.bucketize(ref[n], torch.tensor(offs[1:], device="cuda"), right=True)
+            assert torch.equal(ol[n, :k].long(), lvl)
+            if training:
+                g0 = (0, 12)[n]
+                assert torch.equal(ob[n, k:k + ng], gt[g0:g0 + ng]) and bool((osc[n, k:k + ng] == 1).all())
+        if training:
+            assert sum(x.numel() for x in ref) == min(fpn, sum(x.numel() for x in ref))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.int64])
+def test_sample_fg_bg_kernel(hip, dtype):
+    g = torch.Generator().manual_seed(11)
+    lens = [261888, 261888, 2012, 37, 1500]
+    labs, keys = [], []
+    for n in lens:
+        u = torch.rand(n, generator=g)
+        lab = torch.where(u < 0.002, 1 + (torch.arange(n) % 2), torch.where(u < 0.9, 0, -1))
+        if n == 37:
+            lab[:] = 0                                   # fewer negatives than the batch, no positives
+        if n == 1500:
+            lab[:400] = 1                                # more positives than the quota
+        labs.append(lab.to(dtype))
+        keys.append(torch.randperm(n, generator=g).float() / n)   # distinct keys
+    labels, kk = torch.cat(labs).cuda(), torch.cat(keys).cuda()
+    off = torch.tensor(np.cumsum([0] + lens), dtype=torch.int32).cuda()
+    pm, nm, cnt = hip.sample_fg_bg(labels, kk, off, 256, 128)
+    o = 0
+    for i, n in enumerate(lens):
+        rp, rn = tf.sample_fg_bg(labels[o:o + n], kk[o:o + n], 256, 128)
+        assert torch.equal(pm[o:o + n], rp) and torch.equal(nm[o:o + n], rn), i
+        assert cnt[i].tolist() == [int(rp.sum()), int(rn.sum())]
+        o += n
+    assert cnt[3].tolist() == [0, 37] and cnt[4].tolist() == [128, 128]
