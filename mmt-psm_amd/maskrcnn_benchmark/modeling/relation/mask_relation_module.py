@@ -50,12 +50,22 @@ class CIAM_Module(nn.Module):
         self.gamma = nn.Parameter(torch.zeros(1))
         self.topk = cfg.MODEL.RELATION_MASK.TOPK
 
-    def forward(self, x):
+    def forward(self, x, group=None):
+        """x (n, C, H, W).  `group` (n,) int: the attention runs inside every group of equal ids separately -- what the
+        reference gets by calling the module once per (image, class) slice (mask_relation_module.py:82-92), here as ONE pass
+        with the cross-group entries masked out (exp(-inf) = 0 exactly: the same softmax over the same values), so that no
+        group size ever has to reach the host."""
         n, C, Hh, Ww = x.size()
         cw = x.permute(1, 0, 2, 3).reshape(C, n, -1)
         energy = torch.bmm(cw, cw.permute(0, 2, 1))
+        if group is not None:
+            same = group[:, None] == group[None, :]
+            energy = torch.where(same[None], energy, torch.full_like(energy, float("-inf")))
         ne = torch.max(energy, -1, keepdim=True)[0] - energy
-        att = F.softmax(torch.mean(ne, 0), dim=-1)
+        m = torch.mean(ne, 0)
+        if group is not None:
+            m = torch.where(same, m, torch.full_like(m, float("-inf")))
+        att = F.softmax(m, dim=-1)
         out = torch.mm(att, x.reshape(n, -1)).view(n, C, Hh, Ww)
         return self.gamma * out + x
 
@@ -78,19 +88,35 @@ class MaskRelationRefineNet(nn.Module):
         """(ROI features (P,256,14,14), first mask logits (P,3,28,28), BoxList, target) of ONE image
         -> (second mask logits in class-sorted order, [sorted BoxList], target, None)"""
         feat_roi, mask_logits, proposal, target = x
-        labels, obj = proposal.get_field("labels"), proposal.get_field("objectness")
-        order, cls_len = [], []
-        for c in range(self.fg_class):
-            idx = torch.nonzero(labels == (c + 1))[:, 0]
-            idx = idx[torch.sort(obj[idx], descending=True, stable=True)[1]]
-            order.append(idx)
-            cls_len.append(int(idx.numel()))
-        order = torch.cat(order)
+        rel, props = self.forward_batch(feat_roi, mask_logits, [proposal])
+        return rel, props, target, None
+
+    def forward_batch(self, feat_roi, mask_logits, proposals):
+        """all images of the batch in one pass (the reference loops over images, mask_head.py:98-127): instances are
+        ordered by (image, class, objectness descending), the appearance extractor runs once over all of them and CIAM mixes
+        inside every (image, class) group.  No tensor size depends on device data: nothing is read back.
+        -> (second logits in sorted order, [sorted BoxList per image])"""
+        sizes = [len(p) for p in proposals]
+        labels = torch.cat([p.get_field("labels") for p in proposals]) if len(proposals) > 1 else proposals[0].get_field("labels")
+        obj = torch.cat([p.get_field("objectness") for p in proposals]) if len(proposals) > 1 else proposals[0].get_field("objectness")
+        dev = labels.device
+        img = torch.cat([torch.full((n,), i, dtype=torch.int64, device=dev) for i, n in enumerate(sizes)]) \
+            if len(sizes) > 1 else torch.zeros((sizes[0],), dtype=torch.int64, device=dev)
+        group = img * (self.fg_class + 1) + labels
+        # stable sort by objectness (descending), then stable by group: = per (image, class) `idx[sort(obj[idx], desc, stable)]`
+        o1 = torch.sort(obj, descending=True, stable=True)[1]
+        order = o1[torch.sort(group[o1], stable=True)[1]]
         sorted_mask = mask_logits[order]
-        sel = sorted_mask[torch.arange(order.numel(), device=order.device), labels[order]]
+        sel = sorted_mask[torch.arange(order.numel(), device=dev), labels[order]]
         feat = self.appearance_feature_extractor((feat_roi[order], torch.sigmoid(sel)[:, None, :, :]))
-        rel = torch.cat([self.relation_module(f) for f in torch.split(feat, cls_len) if f.shape[0] != 0])
+        rel = self.relation_module(feat, group[order])
         rel = self.deconv_1(rel, relu=True, input_relu=False)
         rel = self.classifier(rel, relu=False, input_relu=True)
-        sorted_fields = proposal.copy_with_fields([f for f in proposal.fields() if f != "mask"])[order]
-        return rel, [sorted_fields], target, None
+        out, st = [], 0
+        for p, n in zip(proposals, sizes):
+            oi = order[st:st + n] - st      # the image's instances stay together (group is image-major)
+            out.append(p.copy_with_fields([f for f in p.fields() if f != "mask"])[oi])
+            st += n
+        return rel, out
+
+

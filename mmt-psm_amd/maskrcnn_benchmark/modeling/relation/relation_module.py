@@ -143,37 +143,44 @@ class DuplicationRemovalNetwork(nn.Module):
 
     # ---- label preparation on the device (relation_module.py:323-391)
     def prepare_reg_label(self, sorted_boxes, sorted_score, targets):
+        """The reference copies to the host and loops over classes with numpy (`eye[argmax]`, `np.intersect1d`).  Here every
+        class works on ALL ground-truth boxes of the image with the other classes' columns masked out, so no shape depends
+        on how many boxes a class has and nothing is read back; numpy's first-index tie rules are kept (`_first_argmax`,
+        first-gt-wins scatter)."""
         labels = targets.get_field("labels")
-        n = sorted_boxes.shape[0]
+        tb = targets.bbox
+        n, G = sorted_boxes.shape[0], tb.shape[0]
         dev = sorted_boxes.device
+        if G == 0:
+            return torch.zeros((n, self.fg_class, len(self.target_thresh)), device=dev)
+        a2 = (tb[:, 2] - tb[:, 0] + 1) * (tb[:, 3] - tb[:, 1] + 1)
+        ar_g = torch.arange(G, device=dev)
         per_cls = []
         for i in range(self.fg_class):
-            tb = targets.bbox[labels == (i + 1)]
-            G = tb.shape[0]
-            if G == 0:
-                per_cls.append(torch.zeros((n, len(self.target_thresh)), device=dev))
-                continue
+            cm = labels == (i + 1)                               # [G] this class's ground truth
             score = sorted_score[:, i:i + 1]
             boxes = sorted_boxes[:, i, :]
             a1 = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
-            a2 = (tb[:, 2] - tb[:, 0] + 1) * (tb[:, 3] - tb[:, 1] + 1)
             lt = torch.max(boxes[:, None, :2], tb[:, :2])
             rb = torch.min(boxes[:, None, 2:], tb[:, 2:])
             wh = (rb - lt + 1).clamp(min=0)
             inter = wh[:, :, 0] * wh[:, :, 1]
             iou = inter / (a1[:, None] + a2 - inter)
-            best_gt = F.one_hot(_first_argmax(iou, 1), G).to(iou.dtype)  # eye[argmax(iou, axis=1)]
+            iou_c = torch.where(cm[None, :], iou, torch.full_like(iou, -1.0))
+            best_gt = F.one_hot(_first_argmax(iou_c, 1), G).to(iou.dtype)  # eye[argmax(iou, axis=1)] among this class
             outs = []
             for th in self.target_thresh:
-                mask = (iou > th).to(iou.dtype)
+                mask = ((iou > th) & cm[None, :]).to(iou.dtype)
                 osc = score * mask * best_gt
                 oiou = iou * mask * best_gt
                 msi = _first_argmax(osc, 0)                       # best-scoring box of every gt   [G]
-                moi = oiou[msi, torch.arange(G, device=dev)]       # its IoU                        [G]
-                valid = mask.sum(1) > 0                            # boxes overlapping any gt
-                # np.intersect1d(msi, valid, return_indices=True): for a box chosen by several gts the FIRST gt wins
-                first = torch.full((n,), G, dtype=torch.long, device=dev)
-                first = first.scatter_reduce(0, msi, torch.arange(G, device=dev), reduce="amin", include_self=True)
+                moi = oiou[msi, ar_g]                             # its IoU                        [G]
+                valid = mask.sum(1) > 0                            # boxes overlapping any gt of the class
+                # np.intersect1d(msi, valid, return_indices=True): for a box chosen by several gts the FIRST gt wins;
+                # other classes' columns scatter into a spill slot
+                first = torch.full((n + 1,), G, dtype=torch.long, device=dev)
+                first = first.scatter_reduce(0, torch.where(cm, msi, torch.full_like(msi, n)), ar_g, reduce="amin",
+                                             include_self=True)[:n]
                 take = valid & (first < G)
                 reg = torch.where(take, moi[first.clamp(max=G - 1)], torch.zeros((), device=dev))
                 outs.append(reg)
@@ -227,21 +234,44 @@ class DuplicationRemovalNetwork(nn.Module):
             s = (sf * (sc3 > self.fg_thread).float())[:, :, min(max(self.merge_method, 0), len(self.target_thresh) - 1)]
             objectness = sbl.get_field("objectness").reshape(-1, fg)
             all_scores = sbl.get_field("all_scores")
+            # nuclei (class index 1, label 2, NMS 0.5) first, then cytoplasm (class 0, label 1, POS_NMS) (:261-312).  Fixed
+            # shapes: every class keeps its n ranked boxes; the ones below FG_THREAD are moved far away with score -1 so they
+            # neither suppress nor survive; both classes go through ONE batched NMS (sorted by the regressed score, as
+            # `_C.nms` sorts internally); survivors are emitted in rank order (`_C.nms` returns ascending indices).
+            order_cls = ((1, 2, 0.5), (0, 1, self.nms))
+            if any(not t for _, _, t in order_cls):
+                raise NotImplementedError("relation NMS: a disabled per-class NMS is not on the shipped recipe")
+            valid = torch.stack([s[:, c] >= self.fg_thread for c, _, _ in order_cls])            # [2, n]
+            cs = torch.stack([s[:, c] for c, _, _ in order_cls])
+            bx = torch.stack([bboxes[:, c, :] for c, _, _ in order_cls])                           # [2, n, 4]
+            key = torch.where(valid, cs, torch.full_like(cs, -1.0))
+            so = torch.sort(key, dim=1, descending=True, stable=True)[1]                           # [2, n]
+            bs = torch.gather(bx, 1, so[:, :, None].expand(-1, -1, 4))
+            vs = torch.gather(valid, 1, so)
+            bs = torch.where(vs[:, :, None], bs, torch.full_like(bs, -1.0e6))
+            from maskrcnn_benchmark import _hip as H
+            from maskrcnn_benchmark.utils.miscellaneous import dev_const
+            seg1 = dev_const([0, n], torch.int32, bs.device)
+            kc = [H.nms_batched(bs[q].contiguous(), seg1, n, thr) for q, (_, _, thr) in enumerate(order_cls)]  # thresholds differ
+            keep, cnt = torch.cat([k for k, _ in kc], 0), torch.cat([c for _, c in kc], 0)
+            kept_sorted = torch.zeros((2, n + 1), dtype=torch.bool, device=bs.device)
+            kj = torch.where(torch.arange(n, device=bs.device)[None, :] < cnt[:, None], keep.long(),
+                             torch.full_like(keep, n, dtype=torch.int64))
+            kept_sorted.scatter_(1, kj, True)
+            kept = torch.zeros((2, n), dtype=torch.bool, device=bs.device)
+            kept.scatter_(1, so, kept_sorted[:, :n] & vs)                                          # back to rank order
+            # the only read-back of the module: how many detections each class keeps (<= 2 n = 180 <= DETECTIONS_PER_IMG)
+            if 2 * n > self.detections_per_img > 0:
+                raise NotImplementedError("relation NMS: FIRST_N * classes > DETECTIONS_PER_IMG needs the kthvalue cut")
+            counts = kept.sum(1).tolist()
             parts = []
-            for cls, lab, thr in ((1, 2, 0.5), (0, 1, self.nms)):  # nuclei first, then cytoplasm (:261-312)
-                index = (s[:, cls] >= self.fg_thread).nonzero()[:, 0]
+            for q, (cls, lab, _) in enumerate(order_cls):
+                index = torch.nonzero_static(kept[q], size=counts[q]).squeeze(1)
                 b = BoxList(bboxes[index, cls, :], p.size, mode="xyxy")
-                cs = s[index, cls]
-                b.add_field("scores", cs)
+                b.add_field("scores", s[index, cls])
                 b.add_field("objectness", objectness[index, cls])
                 b.add_field("all_scores", all_scores[index, cls])
-                if thr and len(b):
-                    b = b[_box_nms(b.bbox, cs, thr)]
-                b.add_field("labels", torch.full((len(b),), lab, dtype=torch.int64, device=s.device))
+                b.add_field("labels", torch.full((counts[q],), lab, dtype=torch.int64, device=s.device))
                 parts.append(b)
             r = cat_boxlist(parts)
-            nd = len(r)
-            if nd > self.detections_per_img > 0:
-                thr_v = torch.kthvalue(r.get_field("scores"), nd - self.detections_per_img + 1)[0]
-                r = r[torch.nonzero(r.get_field("scores") >= thr_v).squeeze(1)]
         return [r], {}

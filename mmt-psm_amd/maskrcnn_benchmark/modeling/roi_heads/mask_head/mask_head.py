@@ -198,20 +198,9 @@ class ROIMaskHead(nn.Module):
         loss_1 = self.loss_evaluator(proposals, mask_logits, targets) if self.training else None
         if self.use_relation:
             # mask_head.py:98-127: per image, instances sorted per class by objectness, second logits from CIAM
-            sizes = [len(p) for p in proposals]
             xr = fused.relu_grad_mask(x)  # x is a fused-ReLU output read by non-fused ops below
-            tg = targets if targets is not None else [None] * len(sizes)
-            logits2, sorted_props = [], []
-            for f, m, p, t in zip(xr.split(sizes), mask_logits.split(sizes), proposals, tg):
-                if len(p) == 0:
-                    logits2.append(m)
-                    sorted_props.append(p)
-                    continue
-                l2, sp, _, _ = self.mask_relation_module((f, m, p, t))
-                logits2.append(l2)
-                sorted_props.extend(sp)
-            mask_logits = torch.cat(logits2) if len(logits2) > 1 else logits2[0]
-            proposals = sorted_props
+            if sum(len(p) for p in proposals) > 0:
+                mask_logits, proposals = self.mask_relation_module.forward_batch(xr, mask_logits, proposals)
         if self.training:
             if self.use_relation:
                 loss_2 = self.loss_evaluator(proposals, mask_logits, targets)
