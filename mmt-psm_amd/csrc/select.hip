@@ -272,13 +272,19 @@ __global__ __launch_bounds__(NT) void rpn_post_kernel(const RpnPostArgs a) {
 // labels: >= 1 positive, 0 negative, < 0 ignored; per image the num_pos = min(#pos, P) positives and
 // num_neg = min(#neg, B - num_pos) negatives with the SMALLEST keys (uniform random keys -> a uniform sample without
 // replacement, balanced_positive_negative_sampler.py:40-60); equal keys: lower index first.
+// Uniform keys make this cheap: the num smallest of m keys all lie below tau = 8 num / m (expected 8 num members there),
+// so ONE pass over the labels collects the members below tau into LDS (<= 4096) and the exact select runs on that list.
+// Any key distribution stays correct: if fewer than num or more than 4096 land below tau the select runs over the whole
+// vector instead (many passes: slow, never seen with uniform keys).
 template <typename LT>
 __global__ __launch_bounds__(NT) void sample_kernel(const LT* __restrict__ labels, const float* __restrict__ keys,
                                                     const int* __restrict__ off, const int batch, const int max_pos,
                                                     unsigned char* __restrict__ pos_mask, unsigned char* __restrict__ neg_mask,
                                                     int* __restrict__ counts) {
+  constexpr int CAP = 4096;
   __shared__ SelShared sh;
-  __shared__ int npos_s, nneg_s;
+  __shared__ unsigned long long list[CAP];
+  __shared__ int npos_s, nneg_s, nl_s;
   const int img = blockIdx.x, tid = threadIdx.x;
   const int o0 = off[img], n = off[img + 1] - o0;
   const LT* lab = labels + o0;
@@ -290,23 +296,43 @@ __global__ __launch_bounds__(NT) void sample_kernel(const LT* __restrict__ label
   if (cp) atomicAdd(&npos_s, cp);
   if (cn) atomicAdd(&nneg_s, cn);
   __syncthreads();
-  const int num_pos = min(npos_s, max_pos), num_neg = min(nneg_s, batch - num_pos);
-  // smallest key first = largest inverted key
-  auto kpos = [&](int i) -> unsigned long long {
-    if (!(lab[i] >= (LT)1)) return 0ull;
+  const int npos = npos_s, nneg = nneg_s;
+  const int num_pos = min(npos, max_pos), num_neg = min(nneg, batch - num_pos);
+  // smallest key first = largest inverted key; the index in the low word makes keys unique (equal keys: lower index first)
+  auto k64 = [&](int i) -> unsigned long long {
     return ((unsigned long long)(~f2ord(ky[i])) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
   };
-  auto kneg = [&](int i) -> unsigned long long {
-    if (!(lab[i] == (LT)0)) return 0ull;
-    return ((unsigned long long)(~f2ord(ky[i])) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+  // threshold key of one class (want_pos: labels >= 1, else labels == 0): members with k64 >= T are sampled
+  auto threshold = [&](const bool want_pos, const int members, const int num) -> unsigned long long {
+    if (num <= 0) return ~0ull;          // nothing
+    if (members <= num) return 1ull;     // everything
+    auto member = [&](int i) { return want_pos ? lab[i] >= (LT)1 : lab[i] == (LT)0; };
+    const float tau = fminf(1.0f, 8.0f * (float)num / (float)members);
+    __syncthreads();
+    if (tid == 0) nl_s = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT)
+      if (member(i) && ky[i] < tau) {
+        const int p = atomicAdd(&nl_s, 1);
+        if (p < CAP) list[p] = k64(i);
+      }
+    __syncthreads();
+    const int nl = nl_s;
+    if (nl >= num && nl <= CAP) {
+      auto lk = [&](int j) -> unsigned long long { return list[j]; };
+      return block_select(lk, nl, num, sh);
+    }
+    auto gk = [&](int i) -> unsigned long long { return member(i) ? k64(i) : 0ull; };
+    return block_select(gk, n, num, sh);
   };
-  const unsigned long long Tp = num_pos > 0 ? block_select(kpos, n, num_pos, sh) : ~0ull;
+  const unsigned long long Tp = threshold(true, npos, num_pos);
+  const unsigned long long Tn = threshold(false, nneg, num_neg);
   __syncthreads();
-  const unsigned long long Tn = num_neg > 0 ? block_select(kneg, n, num_neg, sh) : ~0ull;
   for (int i = tid; i < n; i += NT) {
-    const unsigned long long a = kpos(i), b = kneg(i);
-    pos_mask[o0 + i] = (a != 0ull && a >= Tp) ? 1 : 0;
-    neg_mask[o0 + i] = (b != 0ull && b >= Tn) ? 1 : 0;
+    const LT l = lab[i];
+    const unsigned long long k = k64(i);
+    pos_mask[o0 + i] = (l >= (LT)1 && k >= Tp) ? 1 : 0;
+    neg_mask[o0 + i] = (l == (LT)0 && k >= Tn) ? 1 : 0;
   }
   if (tid == 0) { counts[2 * img] = num_pos; counts[2 * img + 1] = num_neg; }
 }

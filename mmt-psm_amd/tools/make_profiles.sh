@@ -1,21 +1,16 @@
 #!/bin/bash
-# Regenerates profiles/ evidence on the GPU box (writes to gpurun_out/prof; copy what is wanted into profiles/):
-#   rocprofv3 kernel stats of `bench.py`, and two separate PMC passes (FETCH_SIZE / WRITE_SIZE) reduced per kernel.
+# Regenerates profiles/ evidence on the GPU box (writes to gpurun_out/prof; summarize_profiles.py copies what is judged into
+# profiles/r02_*):  un-profiled default bench line, rocprofv3 kernel stats of the same command, two separate PMC passes
+# (FETCH_SIZE / WRITE_SIZE) reduced per kernel, one SQ pass (MFMA busy), per arithmetic mode (3 = default, 0 = fp32 MFMA).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $OUT/bench_default.json 2> /tmp/err_default.txt
 export MMT_BENCH_NO_FP32_LEG=1
-for MODE in 3 0; do
-  export MMT_CONV_PRECISION=$MODE
-  rm -rf /tmp/ps$MODE
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps$MODE -- python $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $OUT/bench_under_rocprof_mode$MODE.json 2> /tmp/err_$MODE.txt
-  cp $(find /tmp/ps$MODE -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_mode$MODE.csv
-  for C in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pp
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pp -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>&1
-    python3 - $(find /tmp/pp -name "*counter_collection.csv" | head -1) $C > $OUT/pmc_${C}_by_kernel_mode$MODE.csv <<'PY'
+reduce() {  # csv of a --pmc pass -> per-kernel table of one counter
+python3 - "$1" "$2" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(sys.argv[1])):
@@ -28,6 +23,34 @@ print("kernel,dispatches,%s_sum,%s_per_dispatch" % (sys.argv[2], sys.argv[2]))
 for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print('"%s",%d,%.1f,%.1f' % (k[:120], n, v, v / n))
 PY
+}
+for MODE in 3 0; do
+  export MMT_CONV_PRECISION=$MODE
+  rm -rf /tmp/ps$MODE
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps$MODE -- python $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 --profile-steps 5 > $OUT/bench_under_rocprof_mode$MODE.json 2> /tmp/err_$MODE.txt
+  cp $(find /tmp/ps$MODE -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_mode$MODE.csv
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pp
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pp -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --profile-steps 1 > /dev/null 2>&1
+    reduce $(find /tmp/pp -name "*counter_collection.csv" | head -1) $C > $OUT/pmc_${C}_by_kernel_mode$MODE.csv
   done
 done
+export MMT_CONV_PRECISION=3
+rm -rf /tmp/pq
+MMT_OVERLAP_TEACHER=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d /tmp/pq -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --profile-steps 1 > /dev/null 2>&1
+python3 - $(find /tmp/pq -name "*counter_collection.csv" | head -1) > $OUT/pmc_mfma_busy.txt <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in csv.DictReader(open(sys.argv[1])):
+    agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+print("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA (one pass, --kernel-trace only) of")
+print("# MMT_OVERLAP_TEACHER=0 python bench.py --no-cpu-baseline --steps 2 --warmup 1; sums over all dispatches of a kernel;")
+print("# MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)")
+rows = sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))[:8]
+for k, c in rows:
+    busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(4 * c.get("SQ_BUSY_CU_CYCLES", 1), 1)
+    print("%s   mfma_busy_fraction %.3f" % (k[:70], busy))
+    for n in sorted(c):
+        print("   %-28s %.4g" % (n, c[n]))
+PY
 ls -la $OUT

@@ -109,3 +109,17 @@ def test_sample_fg_bg_kernel(hip, dtype):
         assert cnt[i].tolist() == [int(rp.sum()), int(rn.sum())]
         o += n
     assert cnt[3].tolist() == [0, 37] and cnt[4].tolist() == [128, 128]
+
+
+def test_sample_fg_bg_any_key_distribution(hip):
+    """keys that are NOT uniform (most below the kernel's pre-filter, or none): the exact select over the whole vector
+    takes over -- same result as the tensor formulation"""
+    g = torch.Generator().manual_seed(12)
+    n = 20000
+    lab = (torch.rand(n, generator=g) < 0.01).long()
+    for keys in ((torch.randperm(n, generator=g).float() / n) * 1e-3,          # everything below tau
+                 0.9 + (torch.randperm(n, generator=g).float() / n) * 0.09):   # nothing below tau
+        off = torch.tensor([0, n], dtype=torch.int32).cuda()
+        pm, nm, cnt = hip.sample_fg_bg(lab.cuda(), keys.cuda(), off, 256, 128)
+        rp, rn = tf.sample_fg_bg(lab.cuda(), keys.cuda(), 256, 128)
+        assert torch.equal(pm, rp) and torch.equal(nm, rn)
