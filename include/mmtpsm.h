@@ -124,6 +124,7 @@ typedef struct {
   int pad;
   const float* gt; const int32_t* gt_off;
   float* out_boxes; float* out_scores; int64_t* out_idx; float* out_reg; int32_t* out_level; int32_t* out_cnt;
+  uint64_t* key_scratch;   /* workspace: N * L * min(post_n + 1, kmax) words */
 } mmt_rpn_post_args;
 int mmt_rpn_post_select(const mmt_rpn_post_args* a /*[host]*/, void* stream);
 /* mmt_sample_fg_bg: BalancedPositiveNegativeSampler (balanced_positive_negative_sampler.py:20-72) for n_images label

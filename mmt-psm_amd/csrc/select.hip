@@ -139,6 +139,7 @@ struct RpnPostArgs {
   int L, N, sumk, kmax, post_n, fpn_post_n, training, cap, min_size_filter, pad;
   const float* gt; const int* gt_off;     // training: ground-truth boxes appended after the selection (or null)
   float* out_boxes; float* out_scores; long* out_idx; float* out_reg; int* out_level; int* out_cnt;  // [N][cap] ..., [N]
+  unsigned long long* key_scratch;        // [N * L * min(post_n + 1, kmax)] words of workspace
 };
 
 // entry e of image n = (level l, rank j < min(post_n, kmax)): valid when j < keep_cnt and its position lies in the
@@ -186,11 +187,17 @@ __global__ __launch_bounds__(NT) void rpn_post_kernel(const RpnPostArgs a) {
     pos = a.seg_off[l] + p;
     return true;
   };
-  auto key = [&](int e) -> unsigned long long {
+  // the key of every entry is computed ONCE (three dependent loads: count, kept position, score) into the caller's scratch
+  // (this block's slice of it); the select and the compaction then stream over that array
+  unsigned long long* const kbuf = a.key_scratch + (long)(a.training ? 0 : blockIdx.x) * a.L * per;
+  for (int e = tid; e < E; e += NT) {
     int img, pos;
-    if (!entry(e, img, pos)) return 0ull;
-    return ((unsigned long long)f2ord(a.scores[(long)img * a.sumk + pos]) << 32) | (unsigned)(0xffffffffu - (unsigned)e);
-  };
+    kbuf[e] = entry(e, img, pos)
+                  ? (((unsigned long long)f2ord(a.scores[(long)img * a.sumk + pos]) << 32) | (unsigned)(0xffffffffu - (unsigned)e))
+                  : 0ull;
+  }
+  __syncthreads();
+  auto key = [&](int e) -> unsigned long long { return kbuf[e]; };
   const unsigned long long T = block_select(key, E, a.fpn_post_n, sh);
   if (!a.training) {
     // descending score order (rpn/inference.py:235-242: topk(sorted=True) then index)
@@ -352,7 +359,8 @@ extern "C" int mmt_rpn_gather_decode(const mmt_rpn_select_args* a, void* stream)
 }
 
 extern "C" int mmt_rpn_post_select(const mmt_rpn_post_args* a, void* stream) {
-  if (!a || a->L < 1 || a->L > 8 || a->N < 1 || !a->keep || !a->keep_cnt || !a->out_boxes || !a->out_cnt) return MMT_EINVAL;
+  if (!a || a->L < 1 || a->L > 8 || a->N < 1 || !a->keep || !a->keep_cnt || !a->out_boxes || !a->out_cnt || !a->key_scratch)
+    return MMT_EINVAL;
   static_assert(sizeof(mmt_rpn_post_args) == sizeof(RpnPostArgs), "argument layout");
   RpnPostArgs k;
   memcpy(&k, a, sizeof(k));

@@ -48,7 +48,8 @@ class RpnPostArgs(ctypes.Structure):
                 ("sumk", c_int), ("kmax", c_int), ("post_n", c_int), ("fpn_post_n", c_int), ("training", c_int),
                 ("cap", c_int), ("min_size_filter", c_int), ("pad", c_int), ("gt", c_void_p), ("gt_off", c_void_p),
                 ("out_boxes", c_void_p), ("out_scores", c_void_p),
-                ("out_idx", c_void_p), ("out_reg", c_void_p), ("out_level", c_void_p), ("out_cnt", c_void_p)]
+                ("out_idx", c_void_p), ("out_reg", c_void_p), ("out_level", c_void_p), ("out_cnt", c_void_p),
+                ("key_scratch", c_void_p)]
 
 
 class MgdTeachers(ctypes.Structure):
@@ -346,6 +347,8 @@ def rpn_post_select(boxes, scores, idx, reg, keep, keep_cnt, level_off, own_pre,
     oc = torch.empty((N,), dtype=torch.int32, device=dev)
     a.out_boxes, a.out_scores, a.out_idx, a.out_reg = ob.data_ptr(), osc.data_ptr(), oi.data_ptr(), orr.data_ptr()
     a.out_level, a.out_cnt = ol.data_ptr(), oc.data_ptr()
+    scratch = torch.empty((N * L * (keep.shape[1] + 1),), dtype=torch.int64, device=dev)
+    a.key_scratch = scratch.data_ptr()
     _check(lib().mmt_rpn_post_select(ctypes.byref(a), _stream()), "mmt_rpn_post_select")
     return ob, osc, oi, orr, ol, oc
 
