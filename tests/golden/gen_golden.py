@@ -234,15 +234,19 @@ def gen_mt_losses():
         w = weight_sum_losses(ld, step, 250, 250, 7000, l=5.0, balanced=bal, start_mt=1000)
         rows.append([step, w["loss_classifier"], w["mt_classifier"], w["mt_fg_loss"], w["nms_loss"]])
     out["wsl"] = np.array(rows, dtype=np.float64)
-    # EMA: 21 steps on a small vector through the reference trainer's update rule
-    t = torch.zeros(5)
+    # EMA: 21 steps on a small vector through the reference trainer's OWN update_teacher (engine/MTtrainer.py:277-281),
+    # called unbound on a stand-in that has the three attributes the method reads
+    from types import SimpleNamespace
+    from maskrcnn_benchmark.engine.MTtrainer import MTtrainer as RefTrainer
+    tp, sp = torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(5))
+    holder = SimpleNamespace(alpha=0.99, teacher=SimpleNamespace(parameters=lambda: [tp]),
+                             student=SimpleNamespace(parameters=lambda: [sp]))
     s0 = torch.arange(5).float()
     tr = []
     for it in range(21):
-        s = s0 * (1 + 0.1 * it)
-        alpha = min(1 - 1 / (it + 1), 0.99)
-        t.mul_(alpha).add_(s, alpha=1 - alpha)
-        tr.append(t.clone())
+        sp.data.copy_(s0 * (1 + 0.1 * it))
+        RefTrainer.update_teacher(holder, it)
+        tr.append(tp.data.clone())
     out["ema_trace"] = torch.stack(tr)
     save("mt_losses", **out)
 
