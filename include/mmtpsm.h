@@ -230,6 +230,10 @@ int mmt_pack_weight_flipped(const float* w, const float* scale, void* planes, lo
 /* x[n] fp32 (n % 8 == 0, 16-byte aligned) -> three bf16 planes planes[q * plane_stride + i], x = p0 + p1 + p2 with
  * round-to-nearest at each level (|x - sum| <= 2^-27 |x|): the activation-side counterpart of mmt_pack_weight */
 int mmt_split_planes(const float* x, void* planes, long plane_stride, long n, void* stream);
+/* mmt_pack_weight_flipped for a whole table of weights in one launch (descs / unit_desc on the device; unit_desc[u] = index
+ * of the descriptor that 512-element unit u belongs to, descs[d].unit0 = its first unit): once per optimiser step */
+typedef struct { const float* w; const float* scale; void* dst; long plane_stride; int Cout, KH, KW, Cin, unit0, pad; } mmt_flip_desc;
+int mmt_pack_weights_flipped(const mmt_flip_desc* descs /*[dev]*/, const int* unit_desc /*[dev]*/, int n_units, void* stream);
 int mmt_pack_weights(const float* base, void* planes, long plane_stride, const mmt_pack_desc* descs /*[dev]*/,
                      const int* unit_desc /*[dev]*/, int n_units, void* stream);
 

@@ -1562,11 +1562,9 @@ __global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__
 
 // packed planes of the DATA-GRADIENT weights straight from w: the matrix wd[ci][(KH-1-kh, KW-1-kw, co)] = w[co][kh][kw][ci]
 // * scale[co] (what weight_flip_kernel materialises in fp32) is never written; needs Cout % 16 == 0
-__global__ __launch_bounds__(256) void pack_flip_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                                        unsigned short* __restrict__ dst, long plane_stride, int Cout,
-                                                        int KH, int KW, int Cin, int n_units) {
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (unit >= n_units) return;
+__device__ __forceinline__ void pack_flip_unit(const float* __restrict__ w, const float* __restrict__ scale,
+                                               unsigned short* __restrict__ dst, long plane_stride, int Cout, int KH, int KW,
+                                               int Cin, int unit, int lane) {
   const int nb32 = (Cin + 31) >> 5;
   const int step = unit / nb32, blk = unit - step * nb32;
   const int r = lane >> 1, h = lane & 1;
@@ -1588,6 +1586,25 @@ __global__ __launch_bounds__(256) void pack_flip_kernel(const float* __restrict_
   for (int q = 0; q < 3; q++)
     *(uint4*)(dst + q * plane_stride + (long)unit * 512 + lane * 8) = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
 }
+
+__global__ __launch_bounds__(256) void pack_flip_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                        unsigned short* __restrict__ dst, long plane_stride, int Cout,
+                                                        int KH, int KW, int Cin, int n_units) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (unit >= n_units) return;
+  pack_flip_unit(w, scale, dst, plane_stride, Cout, KH, KW, Cin, unit, lane);
+}
+
+// all data-gradient weight planes of a model in ONE launch (once per optimiser step): descriptor table on the device
+struct FlipDesc { const float* w; const float* scale; unsigned short* dst; long plane_stride; int Cout, KH, KW, Cin, unit0, pad; };
+__global__ __launch_bounds__(256) void pack_flip_many_kernel(const FlipDesc* __restrict__ descs, const int* __restrict__ unit_desc,
+                                                             int n_units) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (unit >= n_units) return;
+  const FlipDesc d = descs[unit_desc[unit]];
+  pack_flip_unit(d.w, d.scale, d.dst, d.plane_stride, d.Cout, d.KH, d.KW, d.Cin, unit - d.unit0, lane);
+}
+
 
 __global__ __launch_bounds__(256) void pack_many_kernel(const float* __restrict__ base, unsigned short* __restrict__ dst,
                                                         long plane_stride, const PackDesc* __restrict__ descs,
@@ -2645,6 +2662,16 @@ extern "C" int mmt_pack_weight_flipped(const float* w, const float* scale, void*
   const int units = (int)(n / 512);
   hipLaunchKernelGGL(pack_flip_kernel, dim3((units + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, scale,
                      (unsigned short*)planes, plane_stride, Cout, KH, KW, Cin, units);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_pack_weights_flipped(const mmt_flip_desc* descs, const int* unit_desc, int n_units, void* stream) {
+  if (!descs || !unit_desc) return MMT_EINVAL;
+  if (n_units <= 0) return 0;
+  static_assert(sizeof(mmt_flip_desc) == sizeof(FlipDesc), "descriptor layout");
+  hipLaunchKernelGGL(pack_flip_many_kernel, dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const FlipDesc*)descs,
+                     unit_desc, n_units);
   MMT_LAUNCH_CHECK();
   return 0;
 }

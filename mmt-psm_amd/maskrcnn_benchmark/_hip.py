@@ -83,6 +83,7 @@ _SIGS = {
     "mmt_split_planes": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p],
     "mmt_conv_wants_planes": [ctypes.POINTER(ConvArgs)],
     "mmt_pack_weights": [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p],
+    "mmt_pack_weights_flipped": [c_void_p, c_void_p, c_int, c_void_p],
     "mmt_pack_weight_flipped": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_conv_wgrad_splits": [ctypes.POINTER(ConvArgs)],
     "mmt_conv_wgrad": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -560,6 +561,9 @@ def pack_weight_flipped(w, scale=None):
                                          _stream()), "mmt_pack_weight_flipped")
     if key is not None:
         FLIPPED[ptr] = (key, planes)
+        # from the next optimiser step on this weight's data-gradient planes are re-packed together with all the others in
+        # one launch right after the step (engine/flat.py: refresh_planes), instead of one launch per layer in backward
+        flat.register_flipped(w, scale, planes, (Cout, KH, KW, Cin))
     return planes
 
 

@@ -94,6 +94,36 @@ class FlatParams(object):
         H.pack_weights(self.data, self.planes, self._pack_descs, self._pack_units, self._n_units)
         self.plane_versions = {p.data_ptr(): p._version for _, p in self._named if p.dim() >= 2}
         self.plane_epoch = H.PLANES_EPOCH
+        self._repack_flipped()
+
+    def register_flipped(self, w, scale, planes, dims):
+        """a data-gradient weight (w, BN scale) whose packed planes `planes` should follow the parameters from now on"""
+        ent = self.__dict__.setdefault("_flip_entries", {})
+        if w.data_ptr() not in ent or ent[w.data_ptr()][1] is not scale:
+            ent[w.data_ptr()] = (w, scale, planes, dims)
+            self._flip_table = None
+
+    def _repack_flipped(self):
+        from .. import _hip as H
+        ent = self.__dict__.get("_flip_entries")
+        if not ent or H.get_conv_precision() == 0:
+            return
+        if self.__dict__.get("_flip_table") is None:
+            import struct
+            descs, unit_desc, unit0 = [], [], 0
+            for w, scale, planes, (Cout, KH, KW, Cin) in ent.values():
+                units = planes.shape[1] // 512
+                descs.append(struct.pack("qqqqiiiiii", w.data_ptr(), 0 if scale is None else scale.data_ptr(), planes.data_ptr(),
+                                         planes.stride(0), Cout, KH, KW, Cin, unit0, 0))
+                unit_desc += [len(descs) - 1] * units
+                unit0 += units
+            dev = self.data.device
+            self._flip_table = (torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev),
+                                torch.tensor(unit_desc, dtype=torch.int32, device=dev), unit0)
+        d, u, n = self._flip_table
+        H._check(H.lib().mmt_pack_weights_flipped(d.data_ptr(), u.data_ptr(), n, H._stream()), "mmt_pack_weights_flipped")
+        for w, scale, planes, _ in ent.values():
+            H.FLIPPED[w.data_ptr()] = ((id(self), self.plane_gen, H._p(scale), None if scale is None else scale._version), planes)
 
     def active_ranges(self, names, lo, hi):
         """merged [a, b) element ranges inside [lo, hi) of the flat buffer covered by the parameters in `names`
