@@ -2784,8 +2784,10 @@ extern "C" int mmt_conv_wgrad_splits(const mmt_conv_args* a) {
   // all blocks of a launch run equally long: fill the 512 resident slots (256 CUs x 2 blocks) ONCE.  (640 = 1.25
   // rounds cost a second, 20 %-full round: 92 -> 105 TFLOP/s fp32, 103 -> 136 split-bf16 on the FPN 3x3 shapes)
   const long tiles = (long)tx * ty;
-  int split = (int)(tiles >= 512 ? 1 : 512 / tiles);
-  const int max_split = mmt_cdiv(p.M, 512);  // at least 16 k-tiles per block
+  static const int slots = getenv("MMT_WGRAD_SLOTS") ? atoi(getenv("MMT_WGRAD_SLOTS")) : 512;
+  static const int min_px = getenv("MMT_WGRAD_MINPX") ? atoi(getenv("MMT_WGRAD_MINPX")) : 512;
+  int split = (int)(tiles >= slots ? 1 : slots / tiles);
+  const int max_split = mmt_cdiv(p.M, min_px);  // at least min_px / 16 k-tiles per block
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   int mps = mmt_cdiv(p.M, split);
