@@ -114,20 +114,15 @@ class GeneralizedRCNN(nn.Module):
         return result
 
     def _relation_nms(self, x, result, class_logits, box_regression, targets):
-        """generalized_rcnn.py:62-96: per image, learned duplicate removal on the (un-NMS'ed) box-head output"""
+        """generalized_rcnn.py:62-96: learned duplicate removal on the (un-NMS'ed) box-head output -- all images in one pass
+        (modeling/relation/relation_module.py::forward_batch; the reference loops over images)"""
         prob = torch.softmax(class_logits, dim=1)
-        sizes = [len(r) for r in result]
         # `x` is the fused ReLU(+dropout) output of fc7: its consumers mask the gradient (layers/fused.py convention)
         self.relation_nms.in_mask_scale = self.box_heads.box._scale(self.training)
-        outs, losses = [], []
-        tg = targets if targets is not None else [None] * len(sizes)
-        for xi, re, cl, br, t in zip(x.split(sizes), result, prob.split(sizes), box_regression.split(sizes), tg):
-            r, l = self.relation_nms((xi, [re], cl, br, [t]))
-            outs.append(r)
-            losses.append(l)
+        outs, loss = self.relation_nms.forward_batch(x, result, prob, box_regression, targets)
         if self.training:
-            return result, {"nms_loss": torch.mean(torch.stack([l["nms_loss"] for l in losses]))}
-        return [r[0] for r in outs], None
+            return result, loss
+        return outs, None
 
     def forward_teacher(self, images, targets=None):
         if targets is not None:

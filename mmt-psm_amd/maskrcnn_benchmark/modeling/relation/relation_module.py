@@ -210,26 +210,66 @@ class DuplicationRemovalNetwork(nn.Module):
         return b.clip_to_image(remove_empty=False)
 
     def forward(self, x):
+        """one image (the reference's call, generalized_rcnn.py:74-85): (fc7 features, [proposals], class probabilities, box
+        regression, [target]) -> ([detections], {}) in eval / (None, {"nms_loss"}) in training"""
         appearance_feature, proposals, cls_score, box_reg, targets = x
         assert len(proposals) == 1, "called per image (generalized_rcnn.py:74-85)"
-        p, t = proposals[0], targets[0]
-        fg = self.fg_class
+        out, loss = self.forward_batch(appearance_feature, proposals, cls_score, box_reg, targets)
+        return (None, loss) if self.training else (out, {})
+
+    def forward_batch(self, appearance_feature, proposals, cls_score, box_reg, targets):
+        """All images of the batch at once.  The relation attention works per class on the n = FIRST_N ranked boxes of that
+        class, classes never mix -- so the (image, class) pairs of the whole batch are simply more "classes" of one pass:
+        one embedding GEMM over all ROIs, one attention over (n, B * fg), one classifier GEMM (the reference loops over
+        images, generalized_rcnn.py:74-85).  -> (list of detections per image, {}) / (None, {"nms_loss": mean over images})"""
+        fg, T = self.fg_class, len(self.target_thresh)
+        sizes = [len(p) for p in proposals]
+        tg = targets if targets is not None else [None] * len(sizes)
         with torch.no_grad():
-            dec = self.boxcoder.decode(box_reg.detach().view(len(p), -1), p.bbox)
-            sbl = self.filter_results(dec, t, cls_score.detach(), p.size, fg + 1, p.get_field("objectness"))
-        ind, scores = sbl.get_field("sorted_idx"), sbl.get_field("scores")
-        bboxes = sbl.bbox.reshape(-1, fg, 4)
-        n = ind.shape[0]
-        app = self.roi_feat_embedding_fc(appearance_feature, input_relu=True,
-                                         in_mask_scale=getattr(self, "in_mask_scale", 1.0))[ind]
+            sbls = []
+            for p, cs, br, t in zip(proposals, cls_score.split(sizes), box_reg.split(sizes), tg):
+                dec = self.boxcoder.decode(br.detach().reshape(len(p), -1), p.bbox)
+                sbls.append(self.filter_results(dec, t, cs.detach(), p.size, fg + 1, p.get_field("objectness")))
+        ns = [s.get_field("sorted_idx").shape[0] for s in sbls]
+        if len(set(ns)) != 1:  # an image with fewer than FIRST_N proposals: image by image
+            outs, losses, st = [], [], 0
+            for i, n_i in enumerate(sizes):
+                o, l = self._relate(appearance_feature[st:st + n_i], [proposals[i]], [sbls[i]])
+                st += n_i
+                outs += o if o is not None else []
+                losses.append(l)
+            if self.training:
+                return None, {"nms_loss": torch.mean(torch.stack([l["nms_loss"] for l in losses]))}
+            return outs, {}
+        return self._relate(appearance_feature, proposals, sbls)
+
+    def _relate(self, appearance_feature, proposals, sbls):
+        fg, T, B = self.fg_class, len(self.target_thresh), len(sbls)
+        n = sbls[0].get_field("sorted_idx").shape[0]
+        emb = self.roi_feat_embedding_fc(appearance_feature, input_relu=True, in_mask_scale=getattr(self, "in_mask_scale", 1.0))
+        app, st = [], 0
+        for p, s_ in zip(proposals, sbls):
+            app.append(emb[st + s_.get_field("sorted_idx")])        # (n, fg, app_dim)
+            st += len(p)
+        app = torch.cat(app, 1) if B > 1 else app[0]                # (n, B * fg, app_dim)
         rank = self.nms_rank_fc(extract_rank_embedding(n, self.roi_feat_dim, device=app.device))
         sf = app + rank[:, None, :]
-        pos = extract_multi_position_matrix(bboxes, None, self.geo_feature_dim, 1000)
+        bb = [s_.bbox.reshape(-1, fg, 4) for s_ in sbls]
+        pos = extract_multi_position_matrix(torch.cat(bb, 1) if B > 1 else bb[0], None, self.geo_feature_dim, 1000)
         sf = F.relu(sf + self.relation_module(sf, pos, None))
-        sf = self.classifier(sf.reshape(-1, self.app_dim).contiguous()).view(-1, fg, len(self.target_thresh))
-        sc3 = torch.cat([scores[:, :, None]] * len(self.target_thresh), dim=-1)
+        sf_all = self.classifier(sf.reshape(-1, self.app_dim).contiguous()).view(n, B * fg, T)
         if self.training:
-            return None, {"nms_loss": F.mse_loss(sbl.get_field("labels_iou_reg"), sf)}
+            losses = [F.mse_loss(s_.get_field("labels_iou_reg"), sf_all[:, i * fg:(i + 1) * fg]) for i, s_ in enumerate(sbls)]
+            return None, {"nms_loss": torch.mean(torch.stack(losses)) if B > 1 else losses[0]}
+        return [self._detect(p, s_, sf_all[:, i * fg:(i + 1) * fg]) for i, (p, s_) in enumerate(zip(proposals, sbls))], {}
+
+    def _detect(self, p, sbl, sf):
+        """inference tail of one image (relation_module.py:250-321): regressed scores -> per-class NMS -> detections"""
+        fg = self.fg_class
+        scores = sbl.get_field("scores")
+        bboxes = sbl.bbox.reshape(-1, fg, 4)
+        n = scores.shape[0]
+        sc3 = torch.cat([scores[:, :, None]] * len(self.target_thresh), dim=-1)
         with torch.no_grad():
             s = (sf * (sc3 > self.fg_thread).float())[:, :, min(max(self.merge_method, 0), len(self.target_thresh) - 1)]
             objectness = sbl.get_field("objectness").reshape(-1, fg)
@@ -274,4 +314,4 @@ class DuplicationRemovalNetwork(nn.Module):
                 b.add_field("labels", torch.full((counts[q],), lab, dtype=torch.int64, device=s.device))
                 parts.append(b)
             r = cat_boxlist(parts)
-        return [r], {}
+        return r
