@@ -114,6 +114,7 @@ class BucketedAllReduce(object):
 
     def reset(self):
         self.registered, self.fired, self.sent, self.works = {}, {}, set(), []
+        self.expected = None  # backbone passes of this step, when the caller knows it before they are all registered
 
     def install(self):
         self.reset()
@@ -128,7 +129,8 @@ class BucketedAllReduce(object):
             return
         self.fired[stage] = self.fired.get(stage, 0) + 1
         # several backbone passes in one step: the piece is final when the LAST registered pass has fired
-        if stage in self.pieces and stage not in self.sent and self.fired[stage] == self.registered.get(stage, 0):
+        need = self.expected if self.expected is not None else self.registered.get(stage, 0)
+        if stage in self.pieces and stage not in self.sent and self.fired[stage] == need:
             # earlier pieces of the fixed order that this rank never completed go first, so the order stays the same
             for s_ in self.ORDER:
                 if s_ == stage:
@@ -208,6 +210,8 @@ class MTtrainer(object):
         self.overlap_teacher = os.environ.get("MMT_OVERLAP_TEACHER", "1") != "0" and self.device.type == "cuda"
         self.early_sup_backward = os.environ.get("MMT_EARLY_SUP_BACKWARD", "1") != "0"
         self.student_passes = os.environ.get("MMT_STUDENT_PASSES", "split")  # "split" | "batched"
+        self.skipped_pairs = 0  # steps whose consistency branch was skipped (no pseudo box on some image)
+        self.teacher_first = os.environ.get("MMT_TEACHER_FIRST", "0") != "0"
         # priority -1: HIP maps streams of one priority onto a few hardware queues round-robin; once RCCL has created its own
         # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
         # main stream and the overlap silently disappears (measured: 63.7 vs 59.9 ms/step).  A different priority class
@@ -239,18 +243,29 @@ class MTtrainer(object):
         if bucketed is not None:
             bucketed.install()  # the stage hooks are registered by the forward passes below
         feats_s = feats_u = None
-        early, cut = False, None
+        early, cut, late_xu = False, None, None
+        job = None
+        if use_mt and self.overlap_teacher and self.teacher_first:
+            job = self._start_teacher(data_u_list)  # before the student's backbone passes: see __init__
         if use_mt and self.student_bs == 1:
             xs = data_s.tensors.to(self.device)
             xu = data_u_list[-1].tensors.to(self.device)
-            if self.student_passes == "split":
+            if self.student_passes in ("split", "late"):
                 # Two student backbone passes, labeled crops and unlabeled view.  The supervised branch then runs its WHOLE
                 # backward (heads, FPN, backbone) while this thread would otherwise only wait for the teacher -- the teacher is
                 # the critical path of the forward and its launch-bound stretches leave the GPU room -- and only the
                 # consistency branch is left for after the teacher.  (Batching the two passes makes larger GEMMs but keeps
                 # the backbone backward behind the teacher: 50.0 vs 51.8 ms/step.)
+                # "late": the unlabeled view's backbone pass is only needed by the consistency branch -- it is issued after
+                # the supervised backward, so the teacher (which waits for what this stream holds when it starts) begins one
+                # backbone pass earlier.
                 feats_s = tuple(self.student.backbone(xs))
-                feats_u = [tuple(self.student.backbone(xu))]
+                if self.student_passes == "split":
+                    feats_u = [tuple(self.student.backbone(xu))]
+                else:
+                    late_xu = xu
+                    if bucketed is not None:
+                        bucketed.expected = 2  # the second pass registers its hooks after the first one has fired
                 early = True
             elif xs.shape[1:] == xu.shape[1:]:
                 # one pass over [labeled crops ; unlabeled student view]; the two forwards consume their slice of the pyramid
@@ -268,7 +283,8 @@ class MTtrainer(object):
                     feats_u = [tuple(t.detach().requires_grad_(True) for t in feats_u[0])]
                     cut = (roots, feats_s + feats_u[0])
                     early = True
-        job = self._start_teacher(data_u_list) if (use_mt and self.overlap_teacher) else None
+        if job is None and use_mt and self.overlap_teacher:
+            job = self._start_teacher(data_u_list)
         try:
             self.scheduler.step()
             if early:
@@ -277,6 +293,8 @@ class MTtrainer(object):
             if early:
                 losses_dict = self.weight_sum_loss(loss_dict, iteration)
                 sum(v for v in losses_dict.values()).backward()
+                if late_xu is not None:
+                    feats_u = [tuple(self.student.backbone(late_xu))]
                 unl = self.weight_sum_loss(self.forward_unlabel(data_u_list, feats_u, job), iteration)
                 job = None
                 if unl:
@@ -406,6 +424,7 @@ class MTtrainer(object):
                     teacher_results = self.teacher.forward_teacher(teacher_list)
         except ValueError as e:  # no pseudo boxes for an image: the reference skips the pair (bare except)
             self.logger.info("teacher produced no boxes (%s), skip this pair", e)
+            self.skipped_pairs += 1
             return {}
         return self.student.forward_student(student, teacher_results, features=features, embeddings=emb)
 

@@ -4,7 +4,7 @@ ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 sys.path.insert(0, ROOT)
 import bench
 from torch.profiler import profile, ProfilerActivity, record_function
-cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0)
+cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
 import maskrcnn_benchmark.modeling.rpn.rpn as R
 import maskrcnn_benchmark.modeling.roi_heads.box_head.box_head as B
 import maskrcnn_benchmark.modeling.roi_heads.mask_head.mask_head as M

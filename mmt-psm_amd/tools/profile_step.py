@@ -11,7 +11,7 @@ import bench  # noqa: E402
 from maskrcnn_benchmark import _hip  # noqa: E402
 
 torch.cuda.set_device(0)
-cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0)
+cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
 it0 = 1400
 for i in range(2):
     il, tg, ul = batch()

@@ -2,7 +2,7 @@ import sys, os, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/mmt-psm_amd")
 import bench
 from maskrcnn_benchmark import _hip
-cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0)
+cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
 for i in range(2):
     il, tg, ul = batch(); trainer.train_step(1400 + i, il, tg, ul)
 orig = _hip.roi_align_backward

@@ -3,7 +3,7 @@ import os, sys, time, torch
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, ROOT)
 import bench
-cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0)
+cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
 T = {}
 orig_unl = trainer.forward_unlabel
 def unl(data_u_list, features=None, job=None):

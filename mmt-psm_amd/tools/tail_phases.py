@@ -3,7 +3,7 @@ import os, sys, time, torch
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, ROOT)
 import bench
-cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0)
+cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
 ev = {}
 def mark(k):
     e = torch.cuda.Event(enable_timing=True); e.record(); ev[k] = e

@@ -4,7 +4,7 @@ ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 sys.path.insert(0, ROOT)
 import bench
 from torch.profiler import profile, ProfilerActivity
-cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0)
+cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
 for i in range(3):
     il, tg, ul = batch(); trainer.train_step(1400 + i, il, tg, ul)
 torch.cuda.synchronize()
