@@ -114,7 +114,6 @@ class BucketedAllReduce(object):
 
     def reset(self):
         self.registered, self.fired, self.sent, self.works = {}, {}, set(), []
-        self.expected = None  # backbone passes of this step, when the caller knows it before they are all registered
 
     def install(self):
         self.reset()
@@ -129,8 +128,7 @@ class BucketedAllReduce(object):
             return
         self.fired[stage] = self.fired.get(stage, 0) + 1
         # several backbone passes in one step: the piece is final when the LAST registered pass has fired
-        need = self.expected if self.expected is not None else self.registered.get(stage, 0)
-        if stage in self.pieces and stage not in self.sent and self.fired[stage] == need:
+        if stage in self.pieces and stage not in self.sent and self.fired[stage] == self.registered.get(stage, 0):
             # earlier pieces of the fixed order that this rank never completed go first, so the order stays the same
             for s_ in self.ORDER:
                 if s_ == stage:
@@ -211,7 +209,6 @@ class MTtrainer(object):
         self.early_sup_backward = os.environ.get("MMT_EARLY_SUP_BACKWARD", "1") != "0"
         self.student_passes = os.environ.get("MMT_STUDENT_PASSES", "split")  # "split" | "batched"
         self.skipped_pairs = 0  # steps whose consistency branch was skipped (no pseudo box on some image)
-        self.teacher_first = os.environ.get("MMT_TEACHER_FIRST", "0") != "0"
         # priority -1: HIP maps streams of one priority onto a few hardware queues round-robin; once RCCL has created its own
         # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
         # main stream and the overlap silently disappears (measured: 63.7 vs 59.9 ms/step).  A different priority class
@@ -243,29 +240,22 @@ class MTtrainer(object):
         if bucketed is not None:
             bucketed.install()  # the stage hooks are registered by the forward passes below
         feats_s = feats_u = None
-        early, cut, late_xu = False, None, None
+        early, cut = False, None
         job = None
-        if use_mt and self.overlap_teacher and self.teacher_first:
-            job = self._start_teacher(data_u_list)  # before the student's backbone passes: see __init__
         if use_mt and self.student_bs == 1:
             xs = data_s.tensors.to(self.device)
             xu = data_u_list[-1].tensors.to(self.device)
-            if self.student_passes in ("split", "late"):
+            if self.student_passes == "split":
                 # Two student backbone passes, labeled crops and unlabeled view.  The supervised branch then runs its WHOLE
                 # backward (heads, FPN, backbone) while this thread would otherwise only wait for the teacher -- the teacher is
                 # the critical path of the forward and its launch-bound stretches leave the GPU room -- and only the
                 # consistency branch is left for after the teacher.  (Batching the two passes makes larger GEMMs but keeps
                 # the backbone backward behind the teacher: 50.0 vs 51.8 ms/step.)
-                # "late": the unlabeled view's backbone pass is only needed by the consistency branch -- it is issued after
-                # the supervised backward, so the teacher (which waits for what this stream holds when it starts) begins one
-                # backbone pass earlier.
+                # Measured on the stationary bench (46.4 ms): starting the teacher BEFORE these passes 50.5, the unlabeled
+                # view's pass issued after the supervised backward 46.5, batched 48.0, batched + teacher first 49.0 --
+                # between 8 and 37 ms both streams hold convolution work and the step is the sum of the kernel times.
                 feats_s = tuple(self.student.backbone(xs))
-                if self.student_passes == "split":
-                    feats_u = [tuple(self.student.backbone(xu))]
-                else:
-                    late_xu = xu
-                    if bucketed is not None:
-                        bucketed.expected = 2  # the second pass registers its hooks after the first one has fired
+                feats_u = [tuple(self.student.backbone(xu))]
                 early = True
             elif xs.shape[1:] == xu.shape[1:]:
                 # one pass over [labeled crops ; unlabeled student view]; the two forwards consume their slice of the pyramid
@@ -283,7 +273,7 @@ class MTtrainer(object):
                     feats_u = [tuple(t.detach().requires_grad_(True) for t in feats_u[0])]
                     cut = (roots, feats_s + feats_u[0])
                     early = True
-        if job is None and use_mt and self.overlap_teacher:
+        if use_mt and self.overlap_teacher:
             job = self._start_teacher(data_u_list)
         try:
             self.scheduler.step()
@@ -293,8 +283,6 @@ class MTtrainer(object):
             if early:
                 losses_dict = self.weight_sum_loss(loss_dict, iteration)
                 sum(v for v in losses_dict.values()).backward()
-                if late_xu is not None:
-                    feats_u = [tuple(self.student.backbone(late_xu))]
                 unl = self.weight_sum_loss(self.forward_unlabel(data_u_list, feats_u, job), iteration)
                 job = None
                 if unl:

@@ -7,7 +7,9 @@ import bench
 cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
 LOG = []
 def stamp(what):
-    LOG.append((time.perf_counter(), threading.current_thread().name, what))
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()   # on the calling thread's current stream: the device reaches this point when everything queued before is done
+    LOG.append((time.perf_counter(), threading.current_thread().name, what, ev))
 def hook(model, tag):
     for name in ("backbone", "rpn", "box_heads", "mask_heads", "hint_adaptor"):
         m = getattr(model, name, None)
@@ -36,9 +38,11 @@ for rep in range(2):
     il, tg, ul = batch()
     torch.cuda.synchronize()
     del LOG[:]
+    e0 = torch.cuda.Event(enable_timing=True); e0.record()
     t0 = time.perf_counter()
     trainer.train_step(1410 + rep, il, tg, ul)
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print("step: host returns at %.2f ms, device done at %.2f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
-    for t, th, what in LOG:
-        print("  %7.2f ms  %-12s %s" % ((t - t0) * 1e3, th, what))
+    print("  host issue time | device time (when the stream got there) | thread | phase")
+    for t, th, what, ev in LOG:
+        print("  %7.2f ms  %7.2f ms  %-12s %s" % ((t - t0) * 1e3, e0.elapsed_time(ev), th, what))

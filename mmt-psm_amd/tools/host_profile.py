@@ -3,7 +3,7 @@ import cProfile, pstats, sys, os, io, torch
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, ROOT)
 import bench
-cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, len(sys.argv) > 1 and sys.argv[1] == "irnet")
+cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, len(sys.argv) > 1 and sys.argv[1] == "irnet", base_lr=bench.BENCH_BASE_LR)
 for i in range(3):
     il, tg, ul = batch(); trainer.train_step(1400 + i, il, tg, ul)
 torch.cuda.synchronize()
