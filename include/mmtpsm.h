@@ -182,6 +182,12 @@ typedef struct {
    * epilogue, for a following 3x3 convolution that wants x_planes; Cout % 4 == 0, out_stride == 1 */
   void* y_planes;
   long y_plane_stride;
+  /* bf16 STORAGE of activations (mode 1, BASELINE configs[4] "bf16 MFMA path"): bit 0 (1) `x`, bit 1 (2) `y`, bit 2 (4)
+   * `res`, bit 3 (8) `mask` point to bf16 tensors with the indexing of the fp32 tensor they stand for (the pointers keep
+   * their declared type); bit 4 (16): `dy` of mmt_conv_wgrad is bf16.  A bf16 `x` is copied to LDS as it is -- it IS the
+   * one-term plane -- and needs mode 1, w_planes, Cin % 16 == 0, Cout > 32; a bf16 `y` is the fp32 result rounded to
+   * nearest even and replaces the fp32 store.  Values are those of the fp32-storage call on the rounded tensors. */
+  int io_bf16;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
@@ -256,6 +262,8 @@ int mmt_weight_flip_transpose(const float* w, const float* scale /*or NULL*/, fl
 
 /* stem max-pool 3x3 s2 p1 (backbone/resnet.py:292), NHWC */
 int mmt_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* the same on bf16 tensors (bf16 activation storage, see mmt_conv_args.io_bf16) */
+int mmt_maxpool3x3s2_bf16(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------- losses (forward value + gradient in one launch)
  * mask-logit BCE (mask_head/loss.py:177-179): logits [P,28*28,NC] NHWC, labels int32 [P], targets [P,28*28] {0,1};

@@ -41,7 +41,11 @@ struct ConvP {
   const unsigned short* wpl; long wpl_stride;  // pre-split bf16 planes of w (or null)
   const unsigned short* xpl; long xpl_stride;  // pre-split bf16 planes of x, same NHWC indexing as x (or null)
   unsigned short* ypl; long ypl_stride;        // also write y as three bf16 planes (for a 3x3 consumer), or null
+  int io;  // bf16 STORAGE of operands (mode 1): IO_X x, IO_Y y, IO_RES res, IO_MASK mask are bf16 tensors of the same indexing
 };
+constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b);
 
 template <int NS>
 __device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]);
@@ -91,6 +95,16 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
         if (vec) { const f32x4 t = ldg4(q); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
         else { for (int e = 0; e < 4; e++) o[e] = e < nv ? q[e] : 0.f; }
       };
+      // the same for a tensor stored as bf16 (element index = the fp32 tensor's)
+      auto ldh = [&](const float* base, long idx, float* o) {
+        const unsigned short* q = (const unsigned short*)base + idx;
+        if (vec) {
+          const uint2 t = *(const uint2*)q;
+          o[0] = __builtin_bit_cast(float, t.x << 16); o[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+          o[2] = __builtin_bit_cast(float, t.y << 16); o[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+        } else { for (int e = 0; e < 4; e++) o[e] = e < nv ? __builtin_bit_cast(float, (unsigned)q[e] << 16) : 0.f; }
+      };
+      const bool res_h = p.io & IO_RES, mask_h = p.io & IO_MASK;
       // rows in groups of G: every residual / mask / mul load of a group is issued before the first use, so a thread
       // pays one global-load latency per group instead of one per row (the row loop is not unrollable past its stores)
       constexpr int ROWS = BM / RPP, G = ROWS < 4 ? ROWS : 4;
@@ -111,7 +125,8 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             if (p.res_mode == 2) {
               const int h2 = p.Ho >> 1, w2 = p.Wo >> 1;
-              ld(p.res + (((long)img * h2 + (ho >> 1)) * w2 + (wo >> 1)) * p.Cout + c, ur[g]);
+              const long ri = (((long)img * h2 + (ho >> 1)) * w2 + (wo >> 1)) * p.Cout + c;
+              if (res_h) ldh(p.res, ri, ur[g]); else ld(p.res + ri, ur[g]);
             } else if (p.res_mode == 3) {
               const int h2 = p.Ho * 2, w2 = p.Wo * 2;
               const float* rp = p.res + (((long)img * h2 + 2 * ho) * w2 + 2 * wo) * p.Cout + c;
@@ -121,8 +136,8 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
             if (p.out_stride > 1)
               oidx[g] = (((long)img * p.out_H + ho * p.out_stride) * p.out_W + wo * p.out_stride) * p.Cout + c;
           }
-          if (p.res_mode == 1) ld(p.res + (long)m * p.Cout + c, ur[g]);
-          if (p.mask) ld(p.mask + oidx[g], um[g]);
+          if (p.res_mode == 1) { if (res_h) ldh(p.res, (long)m * p.Cout + c, ur[g]); else ld(p.res + (long)m * p.Cout + c, ur[g]); }
+          if (p.mask) { if (mask_h) ldh(p.mask, oidx[g], um[g]); else ld(p.mask + oidx[g], um[g]); }
           if (p.mul) ld(p.mul + (long)m * p.Cout + c, ul[g]);
         }
 #pragma unroll
@@ -149,6 +164,14 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
           if (p.mul) {
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] *= ul[g][e];
+          }
+          if (p.io & IO_Y) {  // y is a bf16 tensor: round to nearest even, nothing else is written
+            unsigned short* yh = (unsigned short*)p.y + oidx[g];
+            const unsigned lo = pk_bf16(v[0], v[1]), hi = pk_bf16(v[2], v[3]);
+            if (vec) *(uint2*)yh = uint2{lo, hi};
+            else { const unsigned short h4[4] = {(unsigned short)lo, (unsigned short)(lo >> 16), (unsigned short)hi, (unsigned short)(hi >> 16)};
+                   for (int e = 0; e < nv; e++) yh[e] = h4[e]; }
+            continue;
           }
           if (vec) *(f32x4*)(p.y + oidx[g]) = f32x4{v[0], v[1], v[2], v[3]};
           else for (int e = 0; e < nv; e++) p.y[oidx[g] + e] = v[e];
@@ -1992,7 +2015,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p,
 // the end load nothing (predicated to offset 0) and store zeros into a buffer nobody reads.
 // MODE = pixel decode: 0 divisions, 1 carry-select per pixel (Ho, Wo >= 8), 2 per thread (+ Wo % 4 == 0);
 // VEC4 = Cout % 4 == 0 (16-byte dy loads)
-template <int NS, int MODE, bool VEC4>
+// BF (mode 1, bf16 storage): bit 0 = x is a bf16 tensor, bit 1 = dy is; the loads fetch 8 bytes per 4 channels and widen
+// them (exact), everything after the load is unchanged -- the one-term "split" of a bf16 value is the value itself
+template <int NS, int MODE, bool VEC4, int BF = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, const float* __restrict__ dy,
                                                                  const float* __restrict__ rowscale,
                                                                  float* __restrict__ dw, int m_per_split,
@@ -2054,10 +2079,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
     // Loads are raw buffer loads: 32-bit byte offset against a scalar descriptor (no 64-bit address arithmetic), and
     // lanes outside the tensor / in the halo get offset 2^31 >= num_records, for which the hardware returns zeros.
     constexpr unsigned OOB = 0x80000000u;
+    constexpr bool HALF = RB ? (BF & 1) != 0 : (BF & 2) != 0;  // this role's tensor is stored as bf16
+    static_assert(!HALF || VEC4, "bf16 storage: 4-channel loads");
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(RB ? p.x : dy), 0, (int)((RB ? (long)p.N * p.H * p.W * p.Cin : (long)p.M * p.Cout) * 4), 0x00020000);
-    auto bload = [&](unsigned voff) {
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+        (void*)(RB ? p.x : dy), 0, (int)((RB ? (long)p.N * p.H * p.W * p.Cin : (long)p.M * p.Cout) * (HALF ? 2 : 4)), 0x00020000);
+    auto bload = [&](unsigned voff) {   // voff: byte offset in the fp32 tensor (OOB = 2^31: beyond either size)
+      if constexpr (HALF) {
+        const uint2 t = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff >> 1), 0, 0));
+        return f32x4{__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
+                     __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u)};
+      } else {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+      }
     };
     // MODE 2 (Wo % 4 == 0): the thread's four pixels share an output row, so one (ih, iw, offset) triple is carried
     // per thread, with the tap folded into the wrap limits; stepping 16 pixels wraps at most once in each direction
@@ -2323,6 +2356,7 @@ __global__ void weight_flip_kernel(const float* __restrict__ w, const float* __r
   }
 }
 
+template <bool HALF>  // HALF: x and y are bf16 tensors (max of bf16 values is a bf16 value: exact)
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
                                                       int H, int W, int C, int Ho, int Wo) {
   const long total = (long)N * Ho * Wo * (C / 4);
@@ -2339,12 +2373,22 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
       for (int dwi = 0; dwi < 3; dwi++) {
         const int iw = wo * 2 - 1 + dwi;
         if ((unsigned)iw >= (unsigned)W) continue;
-        const f32x4 v = ldg4(x + (((long)n * H + ih) * W + iw) * C + c4 * 4);
+        const long xi = (((long)n * H + ih) * W + iw) * C + c4 * 4;
+        f32x4 v;
+        if (HALF) {
+          const uint2 t = *(const uint2*)((const unsigned short*)x + xi);
+          v = f32x4{__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
+                    __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u)};
+        } else {
+          v = ldg4(x + xi);
+        }
 #pragma unroll
         for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
       }
     }
-    *(f32x4*)(y + (((long)n * Ho + ho) * Wo + wo) * C + c4 * 4) = m;
+    const long yi = (((long)n * Ho + ho) * Wo + wo) * C + c4 * 4;
+    if (HALF) *(uint2*)((unsigned short*)y + yi) = uint2{pk_bf16(m[0], m[1]), pk_bf16(m[2], m[3])};
+    else *(f32x4*)(y + yi) = m;
   }
 }
 
@@ -2359,6 +2403,13 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.wpl = (const unsigned short*)a->w_planes; p.wpl_stride = a->w_plane_stride;
   p.xpl = (const unsigned short*)a->x_planes; p.xpl_stride = a->x_plane_stride;
   p.ypl = (unsigned short*)a->y_planes; p.ypl_stride = a->y_plane_stride;
+  p.io = a->io_bf16;
+  if (p.io & ~(IO_X | IO_Y | IO_RES | IO_MASK | IO_DY)) return MMT_EINVAL;
+  if (p.io & IO_X) {  // x itself is the (only) bf16 plane: the all-planes kernels with one term
+    if (p.xpl || ((size_t)a->x & 15)) return MMT_EINVAL;
+    p.xpl = (const unsigned short*)a->x; p.xpl_stride = 0;
+  }
+  if ((p.io & IO_Y) && (p.ypl || a->mul)) return MMT_EINVAL;
   if (p.ypl && ((a->Cout & 3) || ((size_t)p.ypl & 7) || (p.ypl_stride & 3) || a->out_stride > 1)) return MMT_EINVAL;
   if ((long)p.N * p.Ho * p.Wo > 0x7fffffffL) return MMT_EINVAL;
   if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL || (long)p.N * p.Ho * p.Wo * p.Cout >= 0x7fffffffL ||
@@ -2526,9 +2577,9 @@ static int strip_tw(const ConvP& p, bool need_planes = true) {
   return strip_ksplit(p, tw) ? tw : 0;
 }
 
-template <int TW>
+template <int TW, int NS = 3>
 int launch_strip(const ConvP& p, hipStream_t s) {
-  constexpr int NS = 3, R = 256 / TW, SW = TW + 32;
+  constexpr int R = 256 / TW, SW = TW + 32;
   const size_t ring = (size_t)2 * (NS * R * SW * 32 + 3 * NS * 128 * 32), epi = (size_t)256 * 128 * sizeof(float);
   const size_t lds = ring > epi ? ring : epi;
   const int ksplit = strip_ksplit(p, TW);
@@ -2586,7 +2637,7 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
   const char* rows_env = getenv("MMT_ROWS");  // read per call: the parity tests switch it
   const int rows = rows_env ? atoi(rows_env) : 1;
   static const int rows_min = getenv("MMT_ROWS_MIN") ? atoi(getenv("MMT_ROWS_MIN")) : 256;  // blocks of 128 rows
-  if (rows && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * rows_min &&
+  if (rows && !p.io && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * rows_min &&
       (p.Cout & 3) == 0 && p.res_mode <= 1 && !p.mask && !p.mul && p.out_stride == 1 &&
       (long)p.M * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31)) {
     static const int bn64 = getenv("MMT_ROWS_BN") ? atoi(getenv("MMT_ROWS_BN")) : 32;
@@ -2599,6 +2650,20 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
     if (tw == 64) return launch_strip<64>(p, s);
   }
   const int ksplit = pick_ksplit(p);
+  if (p.io & IO_X) {  // x stored as bf16 (mode 1 only, checked by the caller): both operands are DMA-copied as they are
+    if constexpr (NS == 1) {
+      const int tw = strip_tw(p);
+      if (tw == 128) return launch_strip<128, 1>(p, s);
+      if (tw == 64) return launch_strip<64, 1>(p, s);
+      if (ksplit > 1) return launch_pp<128, 128, 2, 2, 1, 3>(p, s, ksplit);
+      switch (variant) {
+        case 1: return launch_pp<128, 128, 2, 2, 1, 3>(p, s);
+        case 3: return launch_pp<128, 64, 2, 2, 1, 3>(p, s);
+        default: return launch_pp<64, 64, 2, 2, 1, 3>(p, s);
+      }
+    }
+    return MMT_EINVAL;
+  }
   // activations pre-split into planes by the caller: the all-planes kernel (128 x 128 tiles, 2 x 2 waves)
   static const int use_pp = getenv("MMT_PP") ? atoi(getenv("MMT_PP")) : 0;  // measured: no faster than the kernel below
   if (use_pp && p.xpl && NS == 3 && (ksplit > 1 || variant == 1) && !((size_t)p.xpl & 15) && !(p.xpl_stride & 7))
@@ -2754,6 +2819,7 @@ extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int variant = pick_variant(p);
   const int prec = precision();
+  if ((p.io & IO_X) && !(prec == 1 && variant != 0 && (p.Cin & 15) == 0 && p.wpl)) return MMT_EINVAL;  // bf16 x: DMA kernels only
   if (!p.w && !(prec > 0 && variant != 0 && (p.Cin & 15) == 0 && p.wpl)) return MMT_EINVAL;  // planes-only call
   if (prec > 0 && variant != 0 && (p.Cin & 15) == 0 && p.wpl) {
     if (((size_t)p.wpl & 15) || (p.wpl_stride & 7)) return MMT_EINVAL;
@@ -2812,6 +2878,11 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   float* ws = split > 1 ? workspace : nullptr;
   const bool fast = (p.Cout & 3) == 0 && p.Wo >= 8 && p.Ho >= 8;
   const int prec = precision();
+  // bf16 storage of x (IO_X) / dy (IO_DY): mode 1, the pipelined kernel with 4-channel loads only
+  const int bf = ((p.io & IO_X) ? 1 : 0) | ((p.io & IO_DY) ? 2 : 0);
+  if (bf && !(prec == 1 && (p.Cout & 3) == 0 && (mps & 15) == 0 && (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) &&
+              (long)p.M * p.Cout * 4 < (1L << 31)))
+    return MMT_EINVAL;
   static const int pipe_any = getenv("MMT_WGRAD_PIPE") ? atoi(getenv("MMT_WGRAD_PIPE")) : 1;
   const bool small_t = (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31);
   if (prec > 0 && ((p.Cout & 3) == 0 || (pipe_any && small_t)) && (mps & 15) == 0) {
@@ -2821,13 +2892,15 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
     const bool small = (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31);
     const int mode = !(p.Wo >= 8 && p.Ho >= 8) ? 0 : ((p.Wo & 3) == 0 ? 2 : 1);
     const bool vec4 = (p.Cout & 3) == 0;
-#define WGP(NS, MODE) do { if (vec4) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<NS, MODE, true>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias); else hipLaunchKernelGGL((conv_wgrad_pipe_kernel<NS, MODE, false>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias); } while (0)
+#define WGPL(K) hipLaunchKernelGGL(K, grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)
+#define WGP(NS, MODE) do { if (bf && NS == 1) { if (bf == 1) WGPL((conv_wgrad_pipe_kernel<1, MODE, true, 1>)); else if (bf == 2) WGPL((conv_wgrad_pipe_kernel<1, MODE, true, 2>)); else WGPL((conv_wgrad_pipe_kernel<1, MODE, true, 3>)); } else if (vec4) WGPL((conv_wgrad_pipe_kernel<NS, MODE, true>)); else WGPL((conv_wgrad_pipe_kernel<NS, MODE, false>)); } while (0)
 #define WGP3(NS) do { if (mode == 2) WGP(NS, 2); else if (mode == 1) WGP(NS, 1); else WGP(NS, 0); } while (0)
-#define WGS(NS, INC) do { if (pipe && small) WGP3(NS); else hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias); } while (0)
+#define WGS(NS, INC) do { if ((pipe && small) || bf) WGP3(NS); else hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias); } while (0)
     if (fast) { if (prec == 1) WGS(1, true); else if (prec == 2) WGS(2, true); else WGS(3, true); }
     else { if (prec == 1) WGS(1, false); else if (prec == 2) WGS(2, false); else WGS(3, false); }
 #undef WGP3
 #undef WGP
+#undef WGPL
 #undef WGS
     dbias = nullptr;  // summed inside the kernel
   } else if (fast)
@@ -2877,7 +2950,19 @@ extern "C" int mmt_maxpool3x3s2(const float* x, float* y, int N, int H, int W, i
   if (total == 0) return 0;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, Ho, Wo);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_maxpool3x3s2_bf16(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+  if (C & 3) return MMT_EINVAL;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  if (total == 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(maxpool_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W,
+                     C, Ho, Wo);
   MMT_LAUNCH_CHECK();
   return 0;
 }

@@ -28,7 +28,10 @@ class ConvArgs(ctypes.Structure):
                 ("relu", c_int), ("res_mode", c_int), ("out_stride", c_int), ("out_H", c_int), ("out_W", c_int),
                 ("mask_scale", c_float), ("w_planes", c_void_p), ("w_plane_stride", ctypes.c_long),
                 ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long),
-                ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long)]
+                ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long), ("io_bf16", c_int)]
+
+
+IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
 
 
 class RpnLevel(ctypes.Structure):
@@ -90,6 +93,7 @@ _SIGS = {
     "mmt_colsum": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "mmt_weight_flip_transpose": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mmt_maxpool3x3s2_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_mask_bce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_mgd_level_forward": [c_void_p, ctypes.POINTER(MgdTeachers), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_mgd_level_backward": [c_void_p, ctypes.POINTER(MgdTeachers), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
@@ -110,6 +114,19 @@ PROFILE = None
 PROFILE_ALL = False
 # eligible 3x3 convolutions split their input into bf16 planes first and run on conv3x3_strip_kernel (csrc/conv_igemm.hip)
 AUTO_PLANES = os.environ.get("MMT_AUTO_PLANES", "1") != "0"
+# bf16 STORAGE of the ResNet body's activations and activation gradients (BASELINE configs[4] "bf16 MFMA path"): only with
+# the bf16 arithmetic (mode 1).  The producers in layers/fused.py ask `bf16_storage()`; every consumer goes by the dtype
+# of the tensor it is handed.
+_BF16_STORAGE = os.environ.get("MMT_BF16_STORAGE", "0") != "0"
+
+
+def set_bf16_storage(on):
+    global _BF16_STORAGE
+    _BF16_STORAGE = bool(on)
+
+
+def bf16_storage():
+    return _BF16_STORAGE and get_conv_precision() == 1
 
 
 def lib():
@@ -163,8 +180,8 @@ def nhwc(x):
     _dev(x)
     if x.dim() != 4:
         raise RuntimeError("expected a 4-D activation")
-    if x.dtype != torch.float32:
-        raise RuntimeError("fp32 activations only")
+    if x.dtype != torch.float32 and x.dtype != torch.bfloat16:
+        raise RuntimeError("fp32 (or, with bf16 storage, bf16) activations only")
     if not x.permute(0, 2, 3, 1).is_contiguous():
         x = x.contiguous(memory_format=torch.channels_last)
         if not x.permute(0, 2, 3, 1).is_contiguous():  # C==1 / H==W==1 corner cases of torch's format logic
@@ -172,9 +189,9 @@ def nhwc(x):
     return x
 
 
-def empty_nhwc(n, c, h, w, device, zero=False):
+def empty_nhwc(n, c, h, w, device, zero=False, dtype=torch.float32):
     f = torch.zeros if zero else torch.empty
-    return f((n, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+    return f((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
 # ------------------------------------------------------------------------------------------ ROIAlign
@@ -427,16 +444,24 @@ def planes_of(x):
 
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
                  mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0,
-                 w_shape=None, planes=None, out_size=None, x_planes=None, want_planes=False):
+                 w_shape=None, planes=None, out_size=None, x_planes=None, want_planes=False, out_dtype=None):
     """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory).
     y_out/y_offset (elements): write into an existing NHWC tensor at a shifted base (transposed-conv taps).
     w=None with w_shape + planes: the weight exists only as packed bf16 planes (pack_weight_flipped).
     out_size=(Ho, Wo): fewer output rows / columns than `pad` on both sides would give, i.e. a smaller pad at the
-    bottom / right (taps that fall outside the input read zeros either way)."""
+    bottom / right (taps that fall outside the input read zeros either way).
+    bf16 storage (mode 1): a bf16 `x`, `res`, `mask` is taken as it is; out_dtype=torch.bfloat16 makes y a bf16 tensor."""
     if x_planes is None:
         x_planes = planes_of(x)
     x = nhwc(x)
     N, Cin, H, W = x.shape
+    io = IO_X if x.dtype == torch.bfloat16 else 0
+    out_dtype = torch.float32 if out_dtype is None else out_dtype
+    if y_out is not None:
+        out_dtype = y_out.dtype
+    if out_dtype == torch.bfloat16:
+        io |= IO_Y
+    esz = 2 if out_dtype == torch.bfloat16 else 4
     if w is None:
         Cout, Cin_w, KH, KW = w_shape
         if Cin_w != Cin:
@@ -462,16 +487,16 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         _keep = _weight_planes(w, a)  # noqa: F841  (keeps a per-call plane buffer alive until the launch is queued)
     if out_stride > 1:
         oh, ow = out_hw
-        y = y_out if y_out is not None else empty_nhwc(N, Cout, oh, ow, x.device, zero=True)
+        y = y_out if y_out is not None else empty_nhwc(N, Cout, oh, ow, x.device, zero=True, dtype=out_dtype)
         a.out_stride, a.out_H, a.out_W = out_stride, oh, ow
     else:
-        y = y_out if y_out is not None else empty_nhwc(N, Cout, Ho, Wo, x.device)
-    a.y = y.data_ptr() + 4 * int(y_offset)
+        y = y_out if y_out is not None else empty_nhwc(N, Cout, Ho, Wo, x.device, dtype=out_dtype)
+    a.y = y.data_ptr() + esz * int(y_offset)
     y_planes = None
-    if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0:
+    if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0 and not io:
         y_planes = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=x.device)
         a.y_planes, a.y_plane_stride = y_planes.data_ptr(), y_planes.stride(0)
-    auto_split = (x_planes is None and AUTO_PLANES and a.KH == 3 and a.w_planes
+    auto_split = (x_planes is None and AUTO_PLANES and a.KH == 3 and a.w_planes and not io
                   and lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1)
     if auto_split:
         # one pass over x; the 3x3 kernel then reads bf16 planes (9 taps x Cout/128 re-reads).  Allocated here, filled
@@ -484,9 +509,14 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if res is not None:
         res = nhwc(res)
         a.res, a.res_mode = res.data_ptr(), res_mode
+        if res.dtype == torch.bfloat16:
+            io |= IO_RES
     if mask is not None:
         mask = nhwc(mask)
-        a.mask, a.mask_scale = mask.data_ptr() + 4 * int(y_offset), float(mask_scale)
+        a.mask, a.mask_scale = mask.data_ptr() + mask.element_size() * int(y_offset), float(mask_scale)
+        if mask.dtype == torch.bfloat16:
+            io |= IO_MASK
+    a.io_bf16 = io
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
@@ -615,6 +645,7 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
     a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
     a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
     a.out_stride = 1
+    a.io_bf16 = (IO_X if x.dtype == torch.bfloat16 else 0) | (IO_DY if dy.dtype == torch.bfloat16 else 0)
     splits = lib().mmt_conv_wgrad_splits(ctypes.byref(a))
     ws = torch.empty((splits * Cout * KH * KW * Cin,), dtype=torch.float32, device=x.device) if splits > 1 else None
     if PROFILE is not None and PROFILE_ALL:
@@ -648,8 +679,11 @@ def maxpool3x3s2(x):
     x = nhwc(x)
     N, C, H, W = x.shape
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-    y = empty_nhwc(N, C, Ho, Wo, x.device)
-    _check(lib().mmt_maxpool3x3s2(_p(x), _p(y), N, H, W, C, Ho, Wo, _stream()), "mmt_maxpool3x3s2")
+    y = empty_nhwc(N, C, Ho, Wo, x.device, dtype=x.dtype)
+    if x.dtype == torch.bfloat16:
+        _check(lib().mmt_maxpool3x3s2_bf16(_p(x), _p(y), N, H, W, C, Ho, Wo, _stream()), "mmt_maxpool3x3s2_bf16")
+    else:
+        _check(lib().mmt_maxpool3x3s2(_p(x), _p(y), N, H, W, C, Ho, Wo, _stream()), "mmt_maxpool3x3s2")
     return y
 
 

@@ -48,8 +48,10 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
     return (None if dst_w is not None else dw), (None if (dst_b is not None or not with_bias) else db)
 
 
-def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, res=None, res_mode=0, want_planes=False):
-    """data gradient of y = conv(x, w) (* scale[co]) w.r.t. x, with optional fused (x>0) mask / residual add"""
+def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, res=None, res_mode=0, want_planes=False,
+           out_dtype=None):
+    """data gradient of y = conv(x, w) (* scale[co]) w.r.t. x, with optional fused (x>0) mask / residual add;
+    out_dtype: the storage type of x (autograd wants the gradient in the tensor's own type: bf16 storage)"""
     kh = w.shape[2]
     if stride != 1 and kh != 1:
         raise RuntimeError("strided data-gradient is implemented for 1x1 convolutions (STRIDE_IN_1X1) only")
@@ -60,9 +62,9 @@ def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, re
     wd = None if planes is not None else H.weight_flip_transpose(w, scale)
     if stride == 1:
         return H.conv_forward(g, wd, stride=1, pad=kh - 1 - pad, mask=mask, mask_scale=mask_scale, res=res,
-                              res_mode=res_mode, want_planes=want_planes, **kw)
+                              res_mode=res_mode, want_planes=want_planes, out_dtype=out_dtype, **kw)
     return H.conv_forward(g, wd, out_stride=stride, out_hw=tuple(x_shape[2:]), mask=mask, mask_scale=mask_scale,
-                          res=res, res_mode=res_mode, **kw)
+                          res=res, res_mode=res_mode, out_dtype=out_dtype, **kw)
 
 
 class ConvFn(torch.autograd.Function):
@@ -86,7 +88,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw, db = _wgrad(x, g, w, stride, pad, None, has_b, *ctx.dst)
         if ctx.needs_input_grad[0]:
-            dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None)
+            dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None, out_dtype=x.dtype)
         return dx, dw, db, None, None, None, None
 
 
@@ -142,10 +144,11 @@ class BottleneckFn(torch.autograd.Function):
         mid = w1.shape[0]
         ho, wo = (x.shape[2] + stride - 1) // stride, (x.shape[3] + stride - 1) // stride
         wp = H.planes_wanted_3x3(x.shape[0], mid, ho, wo, w2.shape[0])
-        o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True, want_planes=wp)
-        o2 = H.conv_forward(o1, w2, s2, b2, 1, 1, relu=True)
-        r = x if wd is None else H.conv_forward(x, wd, sd, bd, stride, 0)
-        out = H.conv_forward(o2, w3, s3, b3, 1, 0, relu=True, res=r, res_mode=1)
+        od = torch.bfloat16 if H.bf16_storage() else None   # bf16 activation storage (mode 1): every tensor of the block
+        o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True, want_planes=wp, out_dtype=od)
+        o2 = H.conv_forward(o1, w2, s2, b2, 1, 1, relu=True, out_dtype=od)
+        r = x if wd is None else H.conv_forward(x, wd, sd, bd, stride, 0, out_dtype=od)
+        out = H.conv_forward(o2, w3, s3, b3, 1, 0, relu=True, res=r, res_mode=1, out_dtype=od)
         ctx.save_for_backward(x, o1, o2, w1, w2, w3, wd if wd is not None else x.new_zeros(()))
         ctx.bn = (s1, s2, s3, sd)
         ctx.stride = stride
@@ -161,21 +164,21 @@ class BottleneckFn(torch.autograd.Function):
         g = H.nhwc(g)  # masked by (out > 0) by the consumer
         d1, d2, d3, dd = ctx.dst
         dw3, _ = _wgrad(o2, g, w3, 1, 0, s3, dst_w=d3)
-        d_o2 = _dgrad(g, w3, o2.shape, 1, 0, s3, mask=o2,
+        d_o2 = _dgrad(g, w3, o2.shape, 1, 0, s3, mask=o2, out_dtype=o2.dtype,
                       want_planes=H.planes_wanted_3x3(o2.shape[0], o2.shape[1], o2.shape[2], o2.shape[3], w2.shape[1]))
         dw2, _ = _wgrad(o1, d_o2, w2, 1, 1, s2, dst_w=d2)
-        d_o1 = _dgrad(d_o2, w2, o1.shape, 1, 1, s2, mask=o1)
+        d_o1 = _dgrad(d_o2, w2, o1.shape, 1, 1, s2, mask=o1, out_dtype=o1.dtype)
         dw1, _ = _wgrad(x, d_o1, w1, stride, 0, s1, dst_w=d1)
         dwd = dx = None
         if ctx.has_ds:
             dwd, _ = _wgrad(x, g, wd, stride, 0, sd, dst_w=dd)
         if ctx.needs_input_grad[0]:
             if ctx.has_ds:
-                t = _dgrad(d_o1, w1, (x.shape[0], x.shape[1], g.shape[2], g.shape[3]), 1, 0, s1)  # compact Ho x Wo
-                dx = _dgrad(g, wd, x.shape, stride, 0, sd, mask=x, res=t, res_mode=1) if stride > 1 else \
-                    _dgrad(g, wd, x.shape, 1, 0, sd, mask=x, res=t, res_mode=1)
+                t = _dgrad(d_o1, w1, (x.shape[0], x.shape[1], g.shape[2], g.shape[3]), 1, 0, s1, out_dtype=x.dtype)  # compact Ho x Wo
+                dx = _dgrad(g, wd, x.shape, stride, 0, sd, mask=x, res=t, res_mode=1, out_dtype=x.dtype) if stride > 1 else \
+                    _dgrad(g, wd, x.shape, 1, 0, sd, mask=x, res=t, res_mode=1, out_dtype=x.dtype)
             else:
-                dx = _dgrad(d_o1, w1, x.shape, 1, 0, s1, mask=x, res=g, res_mode=1)
+                dx = _dgrad(d_o1, w1, x.shape, 1, 0, s1, mask=x, res=g, res_mode=1, out_dtype=x.dtype)
         return dx, dw1, dw2, dw3, dwd, None, None
 
 
@@ -215,7 +218,7 @@ class FPNFn(torch.autograd.Function):
         for k in range(4):
             dwi[k], dbi[k] = _wgrad(cs[k], d_in[k], wi[k], 1, 0, None, True, *ctx.dst[0][k])
             if ctx.needs_input_grad[k]:
-                dcs[k] = _dgrad(d_in[k], wi[k], cs[k].shape, 1, 0, None, mask=cs[k])  # C_k is a ReLU output
+                dcs[k] = _dgrad(d_in[k], wi[k], cs[k].shape, 1, 0, None, mask=cs[k], out_dtype=cs[k].dtype)  # C_k is a ReLU output
         out = list(dcs)
         for k in range(4):
             out += [dwi[k], dbi[k]]

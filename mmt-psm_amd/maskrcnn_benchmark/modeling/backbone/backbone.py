@@ -46,14 +46,15 @@ class StemWithFixedBatchNorm(nn.Module):
             z = x.new_zeros((n, h // 2, w // 2, 2, 2, 4))
             z[..., :3] = x.view(n, c, h // 2, 2, w // 2, 2).permute(0, 2, 4, 3, 5, 1)
             y = H.conv_forward(z.view(n, h // 2, w // 2, 16).permute(0, 3, 1, 2), self._s2d_weight(), s, b, 1, 2,
-                               relu=True, out_size=(h // 2, w // 2))
+                               relu=True, out_size=(h // 2, w // 2), out_dtype=torch.bfloat16 if H.bf16_storage() else None)
             return H.maxpool3x3s2(y)
         # odd sizes: pad RGB -> 4 channels (zero weight on the 4th), fp32-input kernel
         x4 = x.new_zeros((n, h, w, 4))
         x4[..., :3] = x.permute(0, 2, 3, 1)
         w4 = self.conv1.weight.new_zeros((self.conv1.out_channels, 7, 7, 4))
         w4[..., :3] = self.conv1.weight.detach().permute(0, 2, 3, 1)
-        y = H.conv_forward(x4.permute(0, 3, 1, 2), w4.permute(0, 3, 1, 2), s, b, 2, 3, relu=True)
+        y = H.conv_forward(x4.permute(0, 3, 1, 2), w4.permute(0, 3, 1, 2), s, b, 2, 3, relu=True,
+                           out_dtype=torch.bfloat16 if H.bf16_storage() else None)
         return H.maxpool3x3s2(y)
 
 
