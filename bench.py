@@ -151,7 +151,7 @@ KERNEL_NAMES = {
     "fwd1": lambda mode: ("conv_fwd_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)" if mode == 0 else
                           "conv_fwd_glds_kernel<128,128,4,1,%d,3> (v_mfma_f32_32x32x16_bf16 x %d products)" % (mode, PRODUCTS[mode])),
     "fwd4": lambda mode: "conv3x3_strip_kernel<TW,3> (256x128 tiles on 8 waves, pre-split planes, v_mfma_f32_32x32x16_bf16 x 6 "
-                         "products; the bracket includes the plane-split pass of its input)",
+                         "products; brackets hold the kernel and, in its split-K form, the finish launch)",
 }
 
 
@@ -326,6 +326,14 @@ def main():
                        "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}},
             "roofline": roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dtp, npf, dom),
         }
+        pres = [q[5] for q in prof if len(q) > 5 and q[5] is not None]
+        if pres:
+            # launches whose input planes no producing epilogue had written: one split pass over the input in front of them
+            ps = sum(a_.elapsed_time(b_) for a_, b_ in pres)
+            out["roofline"]["plane_split_pass"] = {
+                "launches_per_step": len(pres) // npf, "ms_per_step": round(ps / npf, 4),
+                "achieved_with_it": round(flops / ((ms + ps) * 1e-3) / 1e12, 2),
+                "frac_with_it": round(flops / ((ms + ps) * 1e-3) / 1e12 / out["roofline"]["peak"], 4)}
         if other:
             fo, mo = total(other)
             out["roofline"]["other_large_tile_kernel"] = {

@@ -46,6 +46,10 @@ typedef struct {
 
 int mmt_roi_align_forward(const mmt_pyramid* pyr /*[host]*/, const float* rois, const int32_t* levels,
                           int K, int PH, int PW, int sampling_ratio, float* out, void* stream);
+/* the same with the pyramid levels stored as bf16 tensors (feat[l] point to bf16, C % 4 == 0): bf16 activation storage of
+ * the bf16 arithmetic mode (mmt_conv_args.io_bf16); taps are widened exactly, arithmetic and output are fp32 */
+int mmt_roi_align_forward_bf16(const mmt_pyramid* pyr /*[host]*/, const float* rois, const int32_t* levels,
+                               int K, int PH, int PW, int sampling_ratio, float* out, void* stream);
 /* grad_feat[l] must be zero-initialised by the caller; accumulates with fp32 atomics */
 int mmt_roi_align_backward(const mmt_pyramid* pyr /*[host]*/, const float* rois, const int32_t* levels,
                            int K, int PH, int PW, int sampling_ratio, const float* grad_out, void* stream);

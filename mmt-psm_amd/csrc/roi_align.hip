@@ -43,7 +43,9 @@ __device__ __forceinline__ Bilin bilin(int H, int W, float y, float x) {
   return b;
 }
 
-template <bool BWD, int VEC>
+// HALF (forward only, VEC == 4): the pyramid levels are bf16 tensors (bf16 activation storage, mode 1); taps are widened
+// exactly, arithmetic and output stay fp32
+template <bool BWD, int VEC, bool HALF = false>
 __global__ __launch_bounds__(256) void roi_align_kernel(Pyr p, const float* __restrict__ rois,
                                                         const int* __restrict__ levels, int K, int PH, int PW,
                                                         int sr, float* __restrict__ out_or_gout) {
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(Pyr p, const float* __re
   const int gh = sr > 0 ? sr : (int)ceilf(rh / PH);
   const int gw = sr > 0 ? sr : (int)ceilf(rw / PW);
   const float count = (float)(gh * gw);
-  const float* feat = p.feat[lv] + (long)b * H * W * C;
+  const float* feat = HALF ? (const float*)((const unsigned short*)p.feat[lv] + (long)b * H * W * C) : p.feat[lv] + (long)b * H * W * C;
   float* gfeat = BWD ? p.grad[lv] + (long)b * H * W * C : nullptr;
   float* o = out_or_gout + bin * C;
 
@@ -141,7 +143,15 @@ __global__ __launch_bounds__(256) void roi_align_kernel(Pyr p, const float* __re
         const long o3 = ((long)q.yh * W + q.xl) * C + c0, o4 = ((long)q.yh * W + q.xh) * C + c0;
         if (!BWD) {
           float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
-          if (VEC == 4) {
+          if (VEC == 4 && HALF) {
+            const unsigned short* fh = (const unsigned short*)feat;
+            const uint2 h1 = *(const uint2*)(fh + o1), h2 = *(const uint2*)(fh + o2), h3 = *(const uint2*)(fh + o3), h4 = *(const uint2*)(fh + o4);
+            auto wide = [](const uint2 t, float (&v)[VEC]) {
+              v[0] = __builtin_bit_cast(float, t.x << 16); v[1 % VEC] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+              v[2 % VEC] = __builtin_bit_cast(float, t.y << 16); v[3 % VEC] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+            };
+            wide(h1, v1); wide(h2, v2); wide(h3, v3); wide(h4, v4);
+          } else if (VEC == 4) {
             const f32x4 a1 = *(const f32x4*)(feat + o1), a2 = *(const f32x4*)(feat + o2);
             const f32x4 a3 = *(const f32x4*)(feat + o3), a4 = *(const f32x4*)(feat + o4);
 #pragma unroll
@@ -193,6 +203,20 @@ extern "C" int mmt_roi_align_forward(const mmt_pyramid* pyr, const float* rois, 
   else
     hipLaunchKernelGGL((roi_align_kernel<false, 4>), dim3(mmt_cdiv(nbins, 4)), dim3(256), 0, (hipStream_t)stream, q,
                        rois, levels, K, PH, PW, sampling_ratio, out);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_roi_align_forward_bf16(const mmt_pyramid* pyr, const float* rois, const int32_t* levels, int K,
+                                          int PH, int PW, int sampling_ratio, float* out, void* stream) {
+  Pyr q;
+  int e = fill(q, pyr);
+  if (e) return e;
+  if (q.C & 3) return MMT_EINVAL;
+  long nbins = (long)K * PH * PW;
+  if (nbins == 0) return 0;
+  hipLaunchKernelGGL((roi_align_kernel<false, 4, true>), dim3(mmt_cdiv(nbins, 4)), dim3(256), 0, (hipStream_t)stream, q,
+                     rois, levels, K, PH, PW, sampling_ratio, out);
   MMT_LAUNCH_CHECK();
   return 0;
 }

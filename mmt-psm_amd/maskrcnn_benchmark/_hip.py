@@ -62,6 +62,7 @@ class MgdTeachers(ctypes.Structure):
 _SIGS = {
     "mmt_version": [],
     "mmt_roi_align_forward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mmt_roi_align_forward_bf16": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_roi_align_backward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_nms_batched": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_resample_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
@@ -216,8 +217,14 @@ def roi_align_forward(feats, scales, rois, levels, ph, pw, sr):
     out = empty_nhwc(K, feats[0].shape[1], ph, pw, rois.device)
     if K:
         p = _pyramid(feats, scales)
-        _check(lib().mmt_roi_align_forward(ctypes.byref(p), _p(rois), _p(levels), K, ph, pw, sr, _p(out), _stream()),
-               "mmt_roi_align_forward")
+        if feats[0].dtype == torch.bfloat16:  # bf16 activation storage: levels as stored, pooled output fp32
+            if any(f.dtype != torch.bfloat16 for f in feats):
+                raise RuntimeError("roi_align_forward: pyramid levels of mixed storage types")
+            _check(lib().mmt_roi_align_forward_bf16(ctypes.byref(p), _p(rois), _p(levels), K, ph, pw, sr, _p(out), _stream()),
+                   "mmt_roi_align_forward_bf16")
+        else:
+            _check(lib().mmt_roi_align_forward(ctypes.byref(p), _p(rois), _p(levels), K, ph, pw, sr, _p(out), _stream()),
+                   "mmt_roi_align_forward")
     return out
 
 
@@ -524,14 +531,18 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         var = lib().mmt_conv_variant(ctypes.byref(a))
         if var in (1, 4) or PROFILE_ALL:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            if auto_split:
+            pre = None
+            if auto_split:  # the plane-split pass of the input (when no producer wrote the planes): its own bracket
+                pre = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                pre[0].record()
                 split_planes(x, x_planes)
+                pre[1].record()
+            e0.record()
             _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
             e1.record()
             PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1,
                             ("fwd%d" % var, N, H, W, Cin, Cout, KH, stride, out_stride),
-                            lib().mmt_conv_ksplit(ctypes.byref(a))))
+                            lib().mmt_conv_ksplit(ctypes.byref(a)), pre))
             if y_planes is not None:
                 y._mmt_planes = (y_planes, y._version)
             return y

@@ -195,10 +195,11 @@ class FPNFn(torch.autograd.Function):
         inner = [None] * 4
         # inner_k feeds the 3x3 output convolution, P_k the 3x3 RPN head convolution: planes from the producing epilogues
         wp = [H.planes_wanted_3x3(c.shape[0], wi[k].shape[0], c.shape[2], c.shape[3], wl[k].shape[0]) for k, c in enumerate(cs)]
-        inner[3] = H.conv_forward(cs[3], wi[3], None, bi[3], want_planes=wp[3])
+        od = torch.bfloat16 if H.bf16_storage() else None   # bf16 activation storage: laterals and pyramid levels too
+        inner[3] = H.conv_forward(cs[3], wi[3], None, bi[3], want_planes=wp[3], out_dtype=od)
         for k in (2, 1, 0):
-            inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2, want_planes=wp[k])
-        outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes) for k in range(4)]
+            inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2, want_planes=wp[k], out_dtype=od)
+        outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes, out_dtype=od) for k in range(4)]
         ctx.save_for_backward(*cs, *inner, *wi, *wl)
         ctx.dst = ([(_dst(wi[k]), _dst(bi[k])) for k in range(4)], [(_dst(wl[k]), _dst(bl[k])) for k in range(4)])
         return tuple(outs)
@@ -280,13 +281,16 @@ class RoiAlignFpnFn(torch.autograd.Function):
         out = H.roi_align_forward(feats, scales, rois, levels, res, res, sr)
         ctx.save_for_backward(rois, levels)
         ctx.cfgv = (res, scales, sr, [tuple(f.shape) for f in feats])
+        ctx.fdt = feats[0].dtype
         return out
 
     @staticmethod
     def backward(ctx, g):
         rois, levels = ctx.saved_tensors
         res, scales, sr, shapes = ctx.cfgv
-        grads = H.roi_align_backward(g, shapes, scales, rois, levels, res, res, sr)
+        grads = H.roi_align_backward(g, shapes, scales, rois, levels, res, res, sr)   # fp32 atomics
+        if ctx.fdt != torch.float32:
+            grads = [gr.to(ctx.fdt) for gr in grads]   # bf16 storage: the gradient in the level's own type
         return (None, None, None, None, None) + tuple(
             gr if ctx.needs_input_grad[5 + i] else None for i, gr in enumerate(grads))
 

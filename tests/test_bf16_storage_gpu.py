@@ -204,6 +204,7 @@ def test_detector_bf16_storage_vs_oracle(mode1):
         ptg.append(b)
     seen = []
     hook = student.backbone.body.layer3.register_forward_hook(lambda m, i, o: seen.append(o.dtype))
+    hook2 = student.backbone.register_forward_hook(lambda m, i, o: seen.extend(t.dtype for t in o))   # P2..P6
     H.set_bf16_storage(True)
     try:
         student.set_replay(Replay(taps, substitute_lists=True))
@@ -213,7 +214,8 @@ def test_detector_bf16_storage_vs_oracle(mode1):
     finally:
         H.set_bf16_storage(False)
         hook.remove()
-    assert seen and all(d == BF for d in seen), seen
+        hook2.remove()
+    assert len(seen) >= 6 and all(d == BF for d in seen), seen
     dev = {k: abs(out[k].item() - ref[k].item()) / max(abs(ref[k].item()), 1e-6) for k in ref}
     assert all(v == v for v in dev.values())
     for k, v in dev.items():
