@@ -208,6 +208,13 @@ class MTtrainer(object):
         self.overlap_teacher = os.environ.get("MMT_OVERLAP_TEACHER", "1") != "0" and self.device.type == "cuda"
         self.early_sup_backward = os.environ.get("MMT_EARLY_SUP_BACKWARD", "1") != "0"
         self.student_passes = os.environ.get("MMT_STUDENT_PASSES", "split")  # "split" | "batched"
+        # hipGraph capture of the three backbone passes (engine/graphs.py); MMT_GRAPHS=0 runs them launch by launch
+        self.use_graphs = os.environ.get("MMT_GRAPHS", "0") != "0" and self.device.type == "cuda"
+        if self.use_graphs:
+            from maskrcnn_benchmark.engine.graphs import BackboneGraphs
+            which = os.environ.get("MMT_GRAPHS", "1")   # 1 both models, 2 student only, 3 teacher only (tuning)
+            self.student.graphs = BackboneGraphs(self.student, self.flat_s) if which in ("1", "2") else None
+            self.teacher.graphs = BackboneGraphs(self.teacher, None) if which in ("1", "3") else None
         self.skipped_pairs = 0  # steps whose consistency branch was skipped (no pseudo box on some image)
         # priority -1: HIP maps streams of one priority onto a few hardware queues round-robin; once RCCL has created its own
         # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
@@ -254,8 +261,10 @@ class MTtrainer(object):
                 # Measured on the stationary bench (46.4 ms): starting the teacher BEFORE these passes 50.5, the unlabeled
                 # view's pass issued after the supervised backward 46.5, batched 48.0, batched + teacher first 49.0 --
                 # between 8 and 37 ms both streams hold convolution work and the step is the sum of the kernel times.
-                feats_s = tuple(self.student.backbone(xs))
-                feats_u = [tuple(self.student.backbone(xu))]
+                if self.use_graphs:
+                    self._capture_graphs(xs, xu, data_u_list)
+                feats_s = self.student.run_backbone(xs, 0)
+                feats_u = [self.student.run_backbone(xu, 1)]
                 early = True
             elif xs.shape[1:] == xu.shape[1:]:
                 # one pass over [labeled crops ; unlabeled student view]; the two forwards consume their slice of the pyramid
@@ -316,6 +325,22 @@ class MTtrainer(object):
             if self.teacher_check_period > 0 and iteration % self.teacher_check_period == 0:
                 check_teacher_identity(self.flat_t)
         return losses_dict
+
+    def _capture_graphs(self, xs, xu, data_u_list):
+        """first step with these shapes: capture the two student passes and the teacher's view batch on this thread, before
+        the teacher thread exists (a capture must not see launches of another thread)"""
+        gs, gt = getattr(self.student, "graphs", None), getattr(self.teacher, "graphs", None)
+        if gs is not None and gs.usable():
+            gs.prepare(xs, 0)
+            gs.prepare(xu, 1)
+        tl = data_u_list[:self.teacher_bs]
+        shapes = {tuple(f.tensors.shape) for f in tl}
+        if gt is not None and len(shapes) == 1 and gt.usable():
+            n = tl[0].tensors.shape[0]
+            shape = (2 * len(tl) * n,) + tuple(tl[0].tensors.shape[1:])
+            with torch.no_grad():
+                if gt.key_of(shape, 0) not in gt.table:
+                    gt.prepare(torch.zeros(shape, device=self.device), 0)
 
     def _pad_mt_keys(self, losses):
         """A rank whose teacher found no boxes skips the consistency branch (reference: bare except, MTtrainer.py:258-265)

@@ -43,6 +43,12 @@ class GeneralizedRCNN(nn.Module):
         self.taps = None  # dict: records stage outputs (tests / debugging)
 
     # ---- test instrumentation: replay of recorded random decisions (sampler index sets, dropout masks); see utils/replay.py
+    def run_backbone(self, x, slot=0):
+        """backbone(x); as a captured hipGraph when the engine enabled that (engine/graphs.py: `self.graphs`), `slot`
+        telling apart the passes of one step that are alive at the same time"""
+        g = getattr(self, "graphs", None)
+        return g(x, slot) if g is not None else tuple(self.backbone(x))
+
     def set_replay(self, replay):
         self._replay = replay
         fa = (lambda tag: replay.take_all(tag)) if replay is not None else None
@@ -180,7 +186,7 @@ class GeneralizedRCNN(nn.Module):
                 views.append(img.tensors)
             n = views[0].shape[0]
             if all(v.shape == views[0].shape for v in views):
-                pyr = self.backbone(torch.cat(views, 0))
+                pyr = self.run_backbone(torch.cat(views, 0))
                 self._batched_pyr = (pyr, n, len(views))
                 feats = [tuple(level[i * n:(i + 1) * n] for level in pyr) for i in range(len(views))]
             else:
