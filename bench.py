@@ -145,13 +145,16 @@ ARITH = {0: "fp32-input MFMA (IEEE fp32 products)",
          3: "fp32 tensors; products on the bf16 matrix pipe as a 3-term bf16 split (6 MFMAs, fp32 accumulate): error vs fp64 "
             "<= the fp32-input MFMA's (profiles/r01_precision.txt); MMT_CONV_PRECISION=0 selects the fp32-input MFMA",
          2: "fp32 tensors; 2-term bf16 split (3 MFMAs)", 1: "fp32 tensors; bf16 products, fp32 accumulate"}
+ARITH_BF16_STORAGE = ("bf16 products, fp32 accumulate; activations and activation gradients of the ResNet body and the FPN "
+                      "stored as bf16 (weights: bf16 planes of fp32 masters; heads, losses, weight gradients fp32)")
 
 
 KERNEL_NAMES = {
     "fwd1": lambda mode: ("conv_fwd_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)" if mode == 0 else
                           "conv_fwd_glds_kernel<128,128,4,1,%d,3> (v_mfma_f32_32x32x16_bf16 x %d products)" % (mode, PRODUCTS[mode])),
-    "fwd4": lambda mode: "conv3x3_strip_kernel<TW,3> (256x128 tiles on 8 waves, pre-split planes, v_mfma_f32_32x32x16_bf16 x 6 "
-                         "products; brackets hold the kernel and, in its split-K form, the finish launch)",
+    "fwd4": lambda mode: "conv3x3_strip_kernel<TW,%d> (256x128 tiles on 8 waves, %s, v_mfma_f32_32x32x16_bf16 x %d "
+                         "products; brackets hold the kernel and, in its split-K form, the finish launch)" % (
+                             mode, "pre-split planes" if mode == 3 else "bf16 tensors as stored", PRODUCTS[mode]),
 }
 
 
@@ -185,6 +188,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the separate event-bracketed leg (roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--irnet", action="store_true", help="IR-Net on (BASELINE configs[4] in fp32); not the headline line")
+    ap.add_argument("--bf16", action="store_true", help="BASELINE configs[4]'s arithmetic: bf16 products (fp32 accumulate) and bf16 "
+                    "activation storage in the backbone + FPN (MMT_CONV_PRECISION=1 MMT_BF16_STORAGE=1); not the headline line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,6 +206,9 @@ def main():
 
     from maskrcnn_benchmark import _hip
     _hip.lib()
+    if args.bf16:
+        _hip.set_conv_precision(1)
+        _hip.set_bf16_storage(True)
     cfg, trainer, batch = build(device, rank, args.irnet, base_lr=BENCH_BASE_LR)
     it0 = cfg.MT.START_MT + cfg.MT.RAMPUP_STEP + 100  # mean-teacher branch active, consistency weight = lambda
 
@@ -316,7 +324,7 @@ def main():
                                     round(sorted(per_step)[(len(per_step) * 9) // 10 - (1 if len(per_step) >= 10 else 0)], 3)],
             "imgs_per_sec_at_median": round(imgs_per_step / (med * 1e-3), 4),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if mode == 1 else "f32", "data": "synthetic",
             "config": {"workload": "MMT-PSM mean-teacher step (BASELINE configs[2]; configs[3] when n_gpus>1): per GPU 2 "
                                    "labeled + 2 unlabeled 1000x1000x3 crops, AUG_K=2 + flip, AUG_S=1, MT.LAMBDA 5, "
                                    "PSM+MGD, EMA teacher, fwd+bwd+SGD, R50-FPN fp32, IR-Net %s" % (
@@ -348,7 +356,7 @@ def main():
             out["roofline"]["unsplit_k_launches"] = {
                 "launches_per_step": len(uns) // max(npf, 1), "achieved": round(fu / (mu * 1e-3) / 1e12, 2),
                 "frac": round(fu / (mu * 1e-3) / 1e12 / out["roofline"]["peak"], 4), "avg_launch_ms": round(mu / len(uns), 4)}
-        out["config"]["conv_arithmetic"] = ARITH[mode]
+        out["config"]["conv_arithmetic"] = ARITH_BF16_STORAGE if _hip.bf16_storage() else ARITH[mode]
         if single is not None:
             # `achieved` above is bracketed on the launch stream while the teacher's stream shares the GPU; this is the same
             # kernel, same shapes, in a single-stream run of the same step (MMT_OVERLAP_TEACHER=0)

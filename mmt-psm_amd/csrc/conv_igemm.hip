@@ -2787,7 +2787,8 @@ extern "C" int mmt_conv_variant(const mmt_conv_args* a) {
   int e = fill(p, a);
   if (e) return e;
   const int v = pick_variant(p);
-  if (v != 0 && precision() == 3 && strip_tw(p)) return 4;  // conv3x3_strip_kernel (x_planes given)
+  // conv3x3_strip_kernel: mode 3 with x_planes given, mode 1 with x stored as bf16
+  if (v != 0 && (precision() == 3 || (precision() == 1 && (p.io & IO_X))) && strip_tw(p)) return 4;
   // the split-K form runs on the 128 x 128 kernel whatever the tile variant would have been
   if (v != 0 && precision() > 0 && (p.Cin & 15) == 0 && p.wpl && pick_ksplit(p) > 1) return 1;
   return v;
@@ -2805,7 +2806,7 @@ extern "C" int mmt_conv_ksplit(const mmt_conv_args* a) {
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
-  if (pick_variant(p) != 0 && precision() == 3 && strip_tw(p)) return 1;
+  if (pick_variant(p) != 0 && (precision() == 3 || (precision() == 1 && (p.io & IO_X))) && strip_tw(p)) return 1;
   if (pick_variant(p) != 0 && precision() > 0 && (p.Cin & 15) == 0 && p.wpl) return pick_ksplit(p);
   return 1;
 }
