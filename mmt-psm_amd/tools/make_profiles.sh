@@ -53,4 +53,16 @@ for k, c in rows:
     for n in sorted(c):
         print("   %-28s %.4g" % (n, c[n]))
 PY
+# how the step is put together (no profiler unless noted): per-shape convolution table, host / device phase times, the
+# two-stream occupancy per ms (rocprofv3 kernel trace), the per-step series with the recipe's learning rate (why the bench
+# freezes it), the bf16 configuration
+unset MMT_CONV_PRECISION
+python $R/mmt-psm_amd/tools/conv_table.py > $OUT/conv_table.txt 2>/dev/null
+python $R/mmt-psm_amd/tools/host_phases.py 2>/dev/null | tail -36 > $OUT/host_device_phases.txt
+bash $R/mmt-psm_amd/tools/prof_timeline.sh > $OUT/stream_timeline.txt 2>/dev/null
+RECIPE_LR=1 STEPS=120 python $R/mmt-psm_amd/tools/step_series.py 2>/dev/null | tail -3 > $OUT/step_series_recipe_lr.txt
+STEPS=120 python $R/mmt-psm_amd/tools/step_series.py 2>/dev/null | tail -3 > $OUT/step_series_bench.txt
+python $R/bench.py --bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2>/dev/null
+python $R/bench.py --bf16 --irnet --no-cpu-baseline > $OUT/bench_bf16_irnet.json 2>/dev/null
+python $R/bench.py --irnet --no-cpu-baseline > $OUT/bench_irnet.json 2>/dev/null
 ls -la $OUT

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 torch.cuda.set_device(0)
-cfg, tr, batch = bench.build(torch.device("cuda", 0), 0)
+cfg, tr, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
 it0 = 1400
 
 

@@ -28,18 +28,20 @@ if pin:
     print("pinned to", len(os.sched_getaffinity(0)), "cpus")
 if os.environ.get("SWITCH"):
     sys.setswitchinterval(float(os.environ["SWITCH"]))
-cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
+# RECIPE_LR=1: the recipe's BASE_LR instead of the bench's frozen one -- the run in which the teacher loses its detections
+cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=None if os.environ.get("RECIPE_LR") else bench.BENCH_BASE_LR)
 N = int(os.environ.get("STEPS", "200"))
 rows = []
 for i in range(N):
     il, tg, ul = batch()
     trainer.train_step(1400 + i, il, tg, ul)
     torch.cuda.synchronize()
-    rows.append((time.perf_counter(), getcpu(), open("/proc/loadavg").read().split()[0]))
+    rows.append((time.perf_counter(), getcpu(), open("/proc/loadavg").read().split()[0], trainer.skipped_pairs))
 dts = [(rows[i][0] - rows[i - 1][0]) * 1e3 for i in range(1, N)]
 line = ""
 for i in range(1, N):
-    line += "%d:%.0f(c%d,l%s) " % (i, dts[i - 1], rows[i][1], rows[i][2])
+    line += "%d:%.1f%s " % (i, dts[i - 1], "*" if rows[i][3] > rows[i - 1][3] else "")
+print("per-step ms (* = consistency branch skipped: the teacher found no box on some unlabeled image):")
 print(line)
 d = sorted(dts[5:])
 print("PIN=%r SWITCH=%r: median %.2f  p10 %.2f  p90 %.2f  mean %.2f  fast(<41) %d of %d" % (
