@@ -87,13 +87,36 @@ for mode in (3, 0):
                 "%.1f MB), WRITE_SIZE %.0f KB -> fabric traffic %.1f MB%s." % (
                     name + ("...>" if name.endswith("<") else ""), avg_us,
                     (" vs %.1f us measured live by bench.py with events on the launch stream, same command%s" % (
-                        live, " (its brackets also hold the plane-split pass / split-K finish launch of the call)")) if live else "",
+                        live, " (its brackets also hold the split-K finish launch of the call)")) if live else "",
                     nd, fkb, 2 * fkb * 1024 / 1e6, wkb, tb / 1e6,
                     (" vs %.1f MB algorithmic (input + weights + output once)" % (alg / 1e6)) if live and alg else "")]
     if mode == 3 and "traffic_bytes_per_launch_fwd1" in tm:
         tm["traffic_bytes_per_launch"] = tm["traffic_bytes_per_launch_fwd1"]
     out.append("")
 json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+# how the step is put together + the other configurations (text files of tools/, copied as they are)
+extra = [("conv_table.txt", "every convolution call of a step by shape (single-stream, event-bracketed): time, TFLOP/s, MFMA / HBM bound"),
+         ("host_device_phases.txt", "host issue time and device arrival time of every phase of one overlapped step (no profiler)"),
+         ("stream_timeline.txt", "occupancy of the two streams per ms of one step (rocprofv3 kernel trace; slower than un-profiled)"),
+         ("step_series_recipe_lr.txt", "per-step ms over 120 steps at the RECIPE's learning rate (* = consistency branch skipped)"),
+         ("step_series_bench.txt", "the same with the bench's frozen learning rate"),
+         ("bench_bf16.json", "`python bench.py --bf16`: bf16 products + bf16 activation storage"),
+         ("bench_bf16_irnet.json", "`python bench.py --bf16 --irnet` = BASELINE configs[4] on one GPU"),
+         ("bench_irnet.json", "`python bench.py --irnet`: IR-Net on, fp32-grade arithmetic")]
+out += ["## How the step is put together; other configurations", ""]
+for f, what in extra:
+    if os.path.exists(os.path.join(SRC, f)):
+        shutil.copy(os.path.join(SRC, f), os.path.join(DST, TAG + f))
+        line = "* `profiles/%s%s` -- %s" % (TAG, f, what)
+        if f.endswith(".json"):
+            try:
+                j = json.loads(open(os.path.join(SRC, f)).read().strip().splitlines()[-1])
+                line += ": **%.1f imgs/s, %.2f ms/step** (median %.2f; skipped-branch steps %s)" % (
+                    j["value"], j["ms_per_step"], j["median_ms_per_step"], j["config"].get("consistency_branch_skipped_steps"))
+            except Exception as e:
+                line += " (unreadable: %s)" % e
+        out.append(line)
+out.append("")
 out += ["## MFMA-busy (single-stream SQ pass)", "", "```"] + [l.rstrip() for l in open(os.path.join(SRC, "pmc_mfma_busy.txt")) if "mfma_busy_fraction" in l or l.startswith("#")] + ["```", ""]
 hist = open(os.path.join(DST, "r02_history.md")).read() if os.path.exists(os.path.join(DST, "r02_history.md")) else ""
 open(os.path.join(DST, "r02_summary.md"), "w").write("\n".join(out) + "\n" + hist)
