@@ -207,7 +207,8 @@ class MTtrainer(object):
         # glue, and vice versa.  MMT_OVERLAP_TEACHER=0 restores the serial order.
         self.overlap_teacher = os.environ.get("MMT_OVERLAP_TEACHER", "1") != "0" and self.device.type == "cuda"
         self.early_sup_backward = os.environ.get("MMT_EARLY_SUP_BACKWARD", "1") != "0"
-        self.student_passes = os.environ.get("MMT_STUDENT_PASSES", "split")  # "split" | "batched"
+        # "pair" (one N = 4 forward, two autograd graphs) | "split" (two passes) | "batched" (one pass, one graph)
+        self.student_passes = os.environ.get("MMT_STUDENT_PASSES", "pair")
         # hipGraph capture of the three backbone passes (engine/graphs.py); MMT_GRAPHS=0 runs them launch by launch
         self.use_graphs = os.environ.get("MMT_GRAPHS", "0") != "0" and self.device.type == "cuda"
         if self.use_graphs:
@@ -252,7 +253,14 @@ class MTtrainer(object):
         if use_mt and self.student_bs == 1:
             xs = data_s.tensors.to(self.device)
             xu = data_u_list[-1].tensors.to(self.device)
-            if self.student_passes == "split":
+            if self.student_passes == "pair" and xs.shape == xu.shape and not self.use_graphs:
+                # one set of forward launches for both passes (N = 4), two autograd graphs (modeling/backbone/backbone.py:
+                # forward_pair): the schedule below is that of "split"
+                from maskrcnn_benchmark.modeling.backbone.backbone import forward_pair
+                feats_s, fu = forward_pair(self.student.backbone, xs, xu)
+                feats_u = [fu]
+                early = True
+            elif self.student_passes in ("split", "pair"):
                 # Two student backbone passes, labeled crops and unlabeled view.  The supervised branch then runs its WHOLE
                 # backward (heads, FPN, backbone) while this thread would otherwise only wait for the teacher -- the teacher is
                 # the critical path of the forward and its launch-bound stretches leave the GPU room -- and only the

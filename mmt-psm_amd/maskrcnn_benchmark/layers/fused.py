@@ -132,23 +132,42 @@ def linear(x, w, b=None, relu=False, input_relu=False, in_mask_scale=1.0, mul=No
     return LinearFn.apply(x, w, b, relu, input_relu, in_mask_scale, mul)
 
 
+def batch_slice(t, lo, hi):
+    """images lo..hi of an NHWC-dense (N,C,H,W) tensor: a dense view; the bf16 planes a producer attached go along"""
+    v = t[lo:hi]
+    pl = H.planes_of(t)
+    if pl is not None:
+        per = t.numel() // t.shape[0]
+        v._mmt_planes = (pl[:, lo * per:hi * per], v._version)
+    return v
+
+
+def bottleneck_forward(x, w1, w2, w3, wd, bn, stride):
+    """the 3-4 launches of a bottleneck -> (o1, o2, out)"""
+    s1, b1, s2, b2, s3, b3, sd, bd = bn
+    # o1 feeds one 3x3 convolution: where that runs on bf16 planes, conv1's epilogue writes them (no split pass)
+    mid = w1.shape[0]
+    ho, wo = (x.shape[2] + stride - 1) // stride, (x.shape[3] + stride - 1) // stride
+    wp = H.planes_wanted_3x3(x.shape[0], mid, ho, wo, w2.shape[0])
+    od = torch.bfloat16 if H.bf16_storage() else None   # bf16 activation storage (mode 1): every tensor of the block
+    o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True, want_planes=wp, out_dtype=od)
+    o2 = H.conv_forward(o1, w2, s2, b2, 1, 1, relu=True, out_dtype=od)
+    r = x if wd is None else H.conv_forward(x, wd, sd, bd, stride, 0, out_dtype=od)
+    out = H.conv_forward(o2, w3, s3, b3, 1, 0, relu=True, res=r, res_mode=1, out_dtype=od)
+    return o1, o2, out
+
+
 class BottleneckFn(torch.autograd.Function):
     """BottleneckWithFixedBatchNorm.forward (backbone/resnet.py:254-274) as 3-4 fused launches:
-    conv1x1(s)+BN+ReLU -> conv3x3+BN+ReLU -> conv1x1+BN (+ downsample 1x1(s)+BN) + residual + ReLU."""
+    conv1x1(s)+BN+ReLU -> conv3x3+BN+ReLU -> conv1x1+BN (+ downsample 1x1(s)+BN) + residual + ReLU.
+    `pre` = (o1, o2, out) already computed for this input (backbone.py::forward_pair: one N = 4 forward for the two student
+    passes of a step): the node then only records what its backward needs."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, w3, wd, bn, stride):
+    def forward(ctx, x, w1, w2, w3, wd, bn, stride, pre=None):
         s1, b1, s2, b2, s3, b3, sd, bd = bn
         x = H.nhwc(x)
-        # o1 feeds one 3x3 convolution: where that runs on bf16 planes, conv1's epilogue writes them (no split pass)
-        mid = w1.shape[0]
-        ho, wo = (x.shape[2] + stride - 1) // stride, (x.shape[3] + stride - 1) // stride
-        wp = H.planes_wanted_3x3(x.shape[0], mid, ho, wo, w2.shape[0])
-        od = torch.bfloat16 if H.bf16_storage() else None   # bf16 activation storage (mode 1): every tensor of the block
-        o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True, want_planes=wp, out_dtype=od)
-        o2 = H.conv_forward(o1, w2, s2, b2, 1, 1, relu=True, out_dtype=od)
-        r = x if wd is None else H.conv_forward(x, wd, sd, bd, stride, 0, out_dtype=od)
-        out = H.conv_forward(o2, w3, s3, b3, 1, 0, relu=True, res=r, res_mode=1, out_dtype=od)
+        o1, o2, out = pre if pre is not None else bottleneck_forward(x, w1, w2, w3, wd, bn, stride)
         ctx.save_for_backward(x, o1, o2, w1, w2, w3, wd if wd is not None else x.new_zeros(()))
         ctx.bn = (s1, s2, s3, sd)
         ctx.stride = stride
@@ -179,7 +198,20 @@ class BottleneckFn(torch.autograd.Function):
                     _dgrad(g, wd, x.shape, 1, 0, sd, mask=x, res=t, res_mode=1, out_dtype=x.dtype)
             else:
                 dx = _dgrad(d_o1, w1, x.shape, 1, 0, s1, mask=x, res=g, res_mode=1, out_dtype=x.dtype)
-        return dx, dw1, dw2, dw3, dwd, None, None
+        return dx, dw1, dw2, dw3, dwd, None, None, None
+
+
+def fpn_forward(cs, wi, bi, wl, bl, out_planes=True):
+    """the 8 launches of the FPN -> (inner[4], outs[4])"""
+    inner = [None] * 4
+    # inner_k feeds the 3x3 output convolution, P_k the 3x3 RPN head convolution: planes from the producing epilogues
+    wp = [H.planes_wanted_3x3(c.shape[0], wi[k].shape[0], c.shape[2], c.shape[3], wl[k].shape[0]) for k, c in enumerate(cs)]
+    od = torch.bfloat16 if H.bf16_storage() else None   # bf16 activation storage: laterals and pyramid levels too
+    inner[3] = H.conv_forward(cs[3], wi[3], None, bi[3], want_planes=wp[3], out_dtype=od)
+    for k in (2, 1, 0):
+        inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2, want_planes=wp[k], out_dtype=od)
+    outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes, out_dtype=od) for k in range(4)]
+    return inner, outs
 
 
 class FPNFn(torch.autograd.Function):
@@ -188,18 +220,11 @@ class FPNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, c2, c3, c4, c5, wi1, bi1, wi2, bi2, wi3, bi3, wi4, bi4, wl1, bl1, wl2, bl2, wl3, bl3, wl4, bl4,
-                out_planes=True):
+                out_planes=True, pre=None):
         cs = [H.nhwc(c) for c in (c2, c3, c4, c5)]
         wi, bi = (wi1, wi2, wi3, wi4), (bi1, bi2, bi3, bi4)
         wl, bl = (wl1, wl2, wl3, wl4), (bl1, bl2, bl3, bl4)
-        inner = [None] * 4
-        # inner_k feeds the 3x3 output convolution, P_k the 3x3 RPN head convolution: planes from the producing epilogues
-        wp = [H.planes_wanted_3x3(c.shape[0], wi[k].shape[0], c.shape[2], c.shape[3], wl[k].shape[0]) for k, c in enumerate(cs)]
-        od = torch.bfloat16 if H.bf16_storage() else None   # bf16 activation storage: laterals and pyramid levels too
-        inner[3] = H.conv_forward(cs[3], wi[3], None, bi[3], want_planes=wp[3], out_dtype=od)
-        for k in (2, 1, 0):
-            inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2, want_planes=wp[k], out_dtype=od)
-        outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes, out_dtype=od) for k in range(4)]
+        inner, outs = pre if pre is not None else fpn_forward(cs, wi, bi, wl, bl, out_planes)
         ctx.save_for_backward(*cs, *inner, *wi, *wl)
         ctx.dst = ([(_dst(wi[k]), _dst(bi[k])) for k in range(4)], [(_dst(wl[k]), _dst(bl[k])) for k in range(4)])
         return tuple(outs)
@@ -225,7 +250,7 @@ class FPNFn(torch.autograd.Function):
             out += [dwi[k], dbi[k]]
         for k in range(4):
             out += [dwl[k], dbl[k]]
-        return tuple(out) + (None,)
+        return tuple(out) + (None, None)
 
 
 class DeconvFn(torch.autograd.Function):

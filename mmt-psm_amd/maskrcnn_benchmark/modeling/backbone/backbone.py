@@ -75,7 +75,7 @@ class BottleneckWithFixedBatchNorm(nn.Module):
         self.bn3 = FrozenBatchNorm2d(out_channels)
         self.stride = stride
 
-    def forward(self, x):
+    def _args(self):
         s1, b1 = self.bn1.folded()
         s2, b2 = self.bn2.folded()
         s3, b3 = self.bn3.folded()
@@ -83,8 +83,15 @@ class BottleneckWithFixedBatchNorm(nn.Module):
         if self.downsample is not None:
             wd = self.downsample[0].weight
             sd, bd = self.downsample[1].folded()
-        return fused.BottleneckFn.apply(x, self.conv1.weight, self.conv2.weight, self.conv3.weight, wd,
-                                        (s1, b1, s2, b2, s3, b3, sd, bd), self.stride)
+        return self.conv1.weight, self.conv2.weight, self.conv3.weight, wd, (s1, b1, s2, b2, s3, b3, sd, bd), self.stride
+
+    def forward(self, x, pre=None):
+        return fused.BottleneckFn.apply(x, *self._args(), pre)
+
+    def forward_raw(self, x):
+        """no autograd: (o1, o2, out) of this block for `x` (forward_pair)"""
+        w1, w2, w3, wd, bn, stride = self._args()
+        return fused.bottleneck_forward(H.nhwc(x), w1.detach(), w2.detach(), w3.detach(), None if wd is None else wd.detach(), bn, stride)
 
 
 class ResNet(nn.Module):
@@ -126,12 +133,76 @@ class ResNet(nn.Module):
                     x = getattr(self, name)(x)
             else:
                 x = getattr(self, name)(x)
-                cb = self.grad_ready
-                if cb is not None and x.requires_grad:
-                    cb(name, "registered")
-                    x.register_hook(lambda g, name=name, cb=cb: cb(name, "fired"))
+                _stage_hook(self, name, x)
             outs.append(x)
         return outs
+
+
+def _stage_hook(body, name, x):
+    cb = body.grad_ready
+    if cb is not None and x.requires_grad:
+        cb(name, "registered")
+        x.register_hook(lambda g, name=name, cb=cb: cb(name, "fired"))
+
+
+def forward_pair(backbone, xa, xb):
+    """backbone(xa), backbone(xb) for two equally shaped batches that need SEPARATE autograd graphs (the labeled and the
+    unlabeled student pass of a mean-teacher step: the supervised backward runs before the consistency branch exists) with
+    ONE set of forward launches on the concatenated batch: N = 4 instead of 2 x N = 2 fills the chip better on the few-tile
+    layers (fewer split-K ranges, fewer finish launches).  The forward runs without autograd; each half then gets its own
+    chain of the same nodes (`pre=`: the node only records the tensors its backward reads, all of them dense views of the
+    N = 4 results).  -> (pyramid of xa, pyramid of xb), each exactly what backbone(x) returns."""
+    body, fpn = backbone.body, backbone.fpn
+    n = xa.shape[0]
+    halves = ((0, n), (n, 2 * n))
+    with torch.no_grad():
+        x = body.stem(torch.cat([xa, xb], 0))
+        raw = {}     # block -> (o1, o2, out) on the concatenated batch
+        frozen = []
+        for i, name in enumerate(body.stages, 1):
+            for bi, blk in enumerate(getattr(body, name)):
+                if i < body.freeze_at:
+                    x = blk(x)
+                else:
+                    raw[(name, bi)] = blk.forward_raw(x)
+                    x = raw[(name, bi)][2]
+            if i < body.freeze_at:
+                frozen.append(x)
+        cs_cat = frozen + [raw[(name, len(getattr(body, name)) - 1)][2] for i, name in enumerate(body.stages, 1) if i >= body.freeze_at]
+        wi = [getattr(fpn, nm).weight for nm in fpn.inner_blocks]
+        bi_ = [getattr(fpn, nm).bias for nm in fpn.inner_blocks]
+        wl = [getattr(fpn, nm).weight for nm in fpn.layer_blocks]
+        bl = [getattr(fpn, nm).bias for nm in fpn.layer_blocks]
+        inner_cat, outs_cat = fused.fpn_forward([H.nhwc(c) for c in cs_cat], wi, bi_, wl, bl, getattr(fpn, "out_planes", True))
+    res = []
+    for lo, hi in halves:
+        outs = []
+        x = None
+        for i, name in enumerate(body.stages, 1):
+            if i < body.freeze_at:
+                x = fused.batch_slice(frozen[i - 1], lo, hi)
+            else:
+                for bi, blk in enumerate(getattr(body, name)):
+                    x = blk(x, pre=tuple(fused.batch_slice(t, lo, hi) for t in raw[(name, bi)]))
+                _stage_hook(body, name, x)
+            outs.append(x)
+        args = list(outs)
+        for nm in fpn.inner_blocks:
+            m = getattr(fpn, nm)
+            args += [m.weight, m.bias]
+        for nm in fpn.layer_blocks:
+            m = getattr(fpn, nm)
+            args += [m.weight, m.bias]
+        pre = ([fused.batch_slice(t, lo, hi) for t in inner_cat], [fused.batch_slice(t, lo, hi) for t in outs_cat])
+        pyr = list(fused.FPNFn.apply(*args, getattr(fpn, "out_planes", True), pre))
+        for p_, o_ in zip(pyr, pre[1]):  # the node's outputs are new tensor objects: the planes of the slices go along
+            pl = H.planes_of(o_)
+            if pl is not None:
+                p_._mmt_planes = (pl, p_._version)
+        if fpn.top_blocks is not None:
+            pyr.extend(fpn.top_blocks(pyr[-1]))
+        res.append(tuple(pyr))
+    return res[0], res[1]
 
 
 class FPN(nn.Module):

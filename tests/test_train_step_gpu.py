@@ -196,16 +196,19 @@ def _close(a, b, tol, what):
     assert err < tol, (what, err)
 
 
+BENCH_PASSES = "pair"   # MTtrainer's default student-pass mode = what bench.py times
+
+
 def _schedule_equivalence(trainer, batch):
     snap = _snapshot(trainer)
     keep = (trainer.overlap_teacher, trainer.student_passes, trainer.early_sup_backward)
     old_env = os.environ.get("MMT_SPLITK")
     try:
-        _run_schedule(trainer, batch, 1400, True, "split", True, 3)   # warm-up: allocator, caches, plane packing
+        _run_schedule(trainer, batch, 1400, True, BENCH_PASSES, True, 3)   # warm-up: allocator, caches, plane packing
         _restore(trainer, snap)
-        bench_l, bench_g, bench_s, bench_t = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
+        bench_l, bench_g, bench_s, bench_t = _run_schedule(trainer, batch, 1400, True, BENCH_PASSES, True, 11)
         _restore(trainer, snap)
-        same_l, same_g, same_s, same_t = _run_schedule(trainer, batch, 1400, False, "split", True, 11)
+        same_l, same_g, same_s, same_t = _run_schedule(trainer, batch, 1400, False, BENCH_PASSES, True, 11)
         _restore(trainer, snap)
         # Second comparison, against ONE batched student pass and ONE backward after everything.  A batch of 4 instead of
         # 2 + 2 changes the tile count of the deep layers and with it their number of split-K ranges, i.e. the ORDER of
@@ -216,7 +219,7 @@ def _schedule_equivalence(trainer, batch):
         # (test_fullsize_properties.py::test_conv_fullsize_linearity_and_batch_invariance).
         os.environ["MMT_SPLITK"] = "0"
         os.environ["MMT_STRIP"] = "0"   # the tap-strip 3x3 kernel sums K as (kh, slab, kw) and is chosen by block count
-        b2_l, b2_g, b2_s, b2_t = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
+        b2_l, b2_g, b2_s, b2_t = _run_schedule(trainer, batch, 1400, True, BENCH_PASSES, True, 11)
         _restore(trainer, snap)
         ser_l, ser_g, ser_s, ser_t = _run_schedule(trainer, batch, 1400, False, "batched", False, 11)
         _restore(trainer, snap)
@@ -242,6 +245,49 @@ def _schedule_equivalence(trainer, batch):
     _close(b2_s - snap["s"], ser_s - snap["s"], 1e-3, "student update")
     _close(b2_t - snap["t"], ser_t - snap["t"], 1e-3, "teacher update")
     assert (bench_s != snap["s"]).any() and (bench_t != snap["t"]).any()
+
+
+def test_pair_forward_equals_batched_forward_and_split_backward(small):
+    """modeling/backbone/backbone.py::forward_pair: ONE N = 4 forward for the two student passes, two autograd graphs.
+    Its pyramids are bit for bit those of the batched pass (same launches), and the step it gives equals the two-pass step up
+    to the summation order of the few-tile layers (split-K ranges depend on the batch: both arms run with MMT_SPLITK=0 /
+    MMT_STRIP=0, where every convolution is batch-invariant) and of the atomics."""
+    from maskrcnn_benchmark.modeling.backbone.backbone import forward_pair
+    _, trainer, batch = small
+    il, tg, ul = batch()
+    xs, xu = il.tensors.cuda(), ul[-1].tensors.cuda()
+    with torch.no_grad():
+        cat = trainer.student.backbone(torch.cat([xs, xu], 0))
+    pa, pb = forward_pair(trainer.student.backbone, xs, xu)
+    n = xs.shape[0]
+    for c, a, b in zip(cat, pa, pb):
+        assert torch.equal(c[:n], a.detach()) and torch.equal(c[n:], b.detach())
+    assert all(t.requires_grad for t in pa + pb)
+    snap = _snapshot(trainer)
+    keep = (trainer.overlap_teacher, trainer.student_passes, trainer.early_sup_backward)
+    old = {k: os.environ.get(k) for k in ("MMT_SPLITK", "MMT_STRIP")}
+    try:
+        os.environ["MMT_SPLITK"] = "0"
+        os.environ["MMT_STRIP"] = "0"
+        _run_schedule(trainer, batch, 1400, True, "pair", True, 3)
+        _restore(trainer, snap)
+        p_l, p_g, p_s, p_t = _run_schedule(trainer, batch, 1400, True, "pair", True, 11)
+        _restore(trainer, snap)
+        s_l, s_g, s_s, s_t = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
+        _restore(trainer, snap)
+    finally:
+        trainer.overlap_teacher, trainer.student_passes, trainer.early_sup_backward = keep
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert "mt_classifier" in p_l and "mt_fg_loss" in p_l
+    for k in s_l:
+        assert p_l[k] == pytest.approx(s_l[k], rel=1e-6), k
+    _close(p_g, s_g, 1e-4, "gradient, pair vs split")
+    _close(p_s - snap["s"], s_s - snap["s"], 1e-4, "student update")
+    _close(p_t - snap["t"], s_t - snap["t"], 1e-4, "teacher update")
 
 
 def test_graph_captured_backbone_equals_eager(small):
