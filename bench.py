@@ -141,6 +141,63 @@ def cpu_baseline():
                       "%.1f s (%s)" % (times[0], dt, ", ".join("%.1f" % t for t in times[1:]))}
 
 
+NOMINAL_SCLK_MHZ = 2400.0  # the clock the dense matrix peaks are quoted at
+
+
+class ClockSampler(object):
+    """shader clock / board power of this process's GPU from its sysfs hwmon node, sampled every 10 ms by a helper thread
+    (used in the bracketed profile leg only, never in the headline leg).  The MFMA peak scales with the clock, and under
+    bf16 MFMA load this part runs at its board power limit well below the nominal clock (tools/clock_under_load.py:
+    1.63 GHz and 1400 W under the dominant kernel back to back; 2.39 GHz under the fp32-input MFMA kernel)."""
+
+    def __init__(self, device_index):
+        import glob
+        self.node = None
+        try:
+            bus = torch.cuda.get_device_properties(device_index).pci_bus_id
+            dev = [d for d in glob.glob("/sys/bus/pci/devices/*") if d.lower().endswith(":%02x:00.0" % bus)]
+            hw = glob.glob(dev[0] + "/hwmon/hwmon*/") if dev else []
+            if hw and os.path.exists(hw[0] + "freq1_input"):
+                self.node = hw[0]
+        except Exception:
+            self.node = None
+        self.samples, self._stop, self._th = [], False, None
+
+    def _read(self, name):
+        try:
+            return float(open(self.node + name).read())
+        except Exception:
+            return None
+
+    def _run(self):
+        pw = "power1_input" if os.path.exists(self.node + "power1_input") else "power1_average"
+        while not self._stop:
+            f, p = self._read("freq1_input"), self._read(pw)
+            if f is not None:
+                self.samples.append((f / 1e6, None if p is None else p / 1e6))
+            time.sleep(0.01)
+
+    def __enter__(self):
+        if self.node is not None:
+            import threading
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th is not None:
+            self._th.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        f = sorted(x[0] for x in self.samples)
+        p = sorted(x[1] for x in self.samples if x[1] is not None)
+        return {"sclk_mhz_median": round(f[len(f) // 2], 0), "sclk_mhz_p10_p90": [round(f[len(f) // 10], 0), round(f[len(f) * 9 // 10], 0)],
+                "board_power_w_median": round(p[len(p) // 2], 0) if p else None, "samples": len(f)}
+
+
 ARITH = {0: "fp32-input MFMA (IEEE fp32 products)",
          3: "fp32 tensors; products on the bf16 matrix pipe as a 3-term bf16 split (6 MFMAs, fp32 accumulate): error vs fp64 "
             "<= the fp32-input MFMA's (profiles/r01_precision.txt); MMT_CONV_PRECISION=0 selects the fp32-input MFMA",
@@ -262,7 +319,8 @@ def main():
         skipped = int(t.item())
     nxt = args.warmup + args.steps
     npf = max(1, min(args.profile_steps, args.steps))
-    dtp, groups, _, _ = timed(nxt, npf, True)
+    with ClockSampler(local) as clock:
+        dtp, groups, _, _ = timed(nxt, npf, True)
     nxt += npf
 
     def total(g):
@@ -342,6 +400,16 @@ def main():
                 "launches_per_step": len(pres) // npf, "ms_per_step": round(ps / npf, 4),
                 "achieved_with_it": round(flops / ((ms + ps) * 1e-3) / 1e12, 2),
                 "frac_with_it": round(flops / ((ms + ps) * 1e-3) / 1e12 / out["roofline"]["peak"], 4)}
+        ck = clock.summary()
+        if ck is not None and mode != 0:
+            # what the part clocked at during the bracketed leg (whole step, all kernels): the matrix peak at that clock
+            ck["peak_at_median_sclk"] = round(out["roofline"]["peak"] * ck["sclk_mhz_median"] / NOMINAL_SCLK_MHZ, 1)
+            ck["frac_of_peak_at_median_sclk"] = round(out["roofline"]["achieved"] / ck["peak_at_median_sclk"], 4)
+            ck["note"] = ("sysfs hwmon of this GPU, 10 ms samples over the bracketed leg; `peak` above is quoted at %d MHz, under "
+                          "bf16 MFMA load the part sits at its board power limit below that (profiles/r02_clock_under_load.txt)"
+                          % NOMINAL_SCLK_MHZ)
+        if ck is not None:
+            out["roofline"]["clock"] = ck
         if other:
             fo, mo = total(other)
             out["roofline"]["other_large_tile_kernel"] = {

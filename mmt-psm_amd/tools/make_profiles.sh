@@ -65,4 +65,5 @@ STEPS=120 python $R/mmt-psm_amd/tools/step_series.py 2>/dev/null | tail -3 > $OU
 python $R/bench.py --bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2>/dev/null
 python $R/bench.py --bf16 --irnet --no-cpu-baseline > $OUT/bench_bf16_irnet.json 2>/dev/null
 python $R/bench.py --irnet --no-cpu-baseline > $OUT/bench_irnet.json 2>/dev/null
+python $R/mmt-psm_amd/tools/clock_under_load.py 2>/dev/null | grep -v amdgpu.ids > $OUT/clock_under_load.txt
 ls -la $OUT

@@ -100,6 +100,7 @@ extra = [("conv_table.txt", "every convolution call of a step by shape (single-s
          ("stream_timeline.txt", "occupancy of the two streams per ms of one step (rocprofv3 kernel trace; slower than un-profiled)"),
          ("step_series_recipe_lr.txt", "per-step ms over 120 steps at the RECIPE's learning rate (* = consistency branch skipped)"),
          ("step_series_bench.txt", "the same with the bench's frozen learning rate"),
+         ("clock_under_load.txt", "shader clock and board power of the GPU under the dominant kernel back to back, the fp32-input MFMA kernel, an HBM copy, the bench step"),
          ("bench_bf16.json", "`python bench.py --bf16`: bf16 products + bf16 activation storage"),
          ("bench_bf16_irnet.json", "`python bench.py --bf16 --irnet` = BASELINE configs[4] on one GPU"),
          ("bench_irnet.json", "`python bench.py --irnet`: IR-Net on, fp32-grade arithmetic")]
