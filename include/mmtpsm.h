@@ -219,6 +219,22 @@ int mmt_conv_wants_planes(const mmt_conv_args* a /*[host]*/);
  * Tensors stay fp32 in HBM in every mode.  Shapes the split kernels do not cover (Cin % 16 != 0 or Cout <= 32 forward,
  * Cout % 4 != 0 weight gradient) always run in mode 0.  Returns MMT_EINVAL for an unknown mode. */
 int mmt_set_conv_precision(int mode);
+/* EXPERIMENT (not used by the product path; mmt-psm_amd/tools/bench_f16x2.py): the tap-strip 3x3 kernel on
+ * a TWO-term fp16 split -- x * s = h + l, 22 significant bits, 3 matrix products per multiply instead of 6.  The caller
+ * scales each operand tensor by a power of two (largest magnitude near 2^14), passes the two fp16 planes of the input
+ * (mmt_split_planes_f16) and of the packed weight (mmt_pack_weight_f16 / _flipped_f16) in x_planes / w_planes; the scales are
+ * device scalars derived on the device from mmt_amax (no host round trip), the epilogue divides the sum by s_x s_w.
+ * Strip shapes only (mmt_conv_wants_planes).  Opt-in from Python with MMT_F16X2=1. */
+int mmt_amax(const float* x, long n, const float* rowscale, long inner, int rows, float* amax /*device, zeroed*/, void* stream);
+int mmt_split_planes_f16(const float* x, void* planes, long plane_stride, long n, float scale, const float* amax /*device or NULL*/,
+                         float* scale_out /*device or NULL*/, float* amax_next /*device or NULL: max |x| of THIS tensor is
+                         accumulated here, for the scale of the next tensor in the same role (delayed scaling)*/,
+                         float* zero_slot /*device or NULL: set to 0 (the accumulator of the call after this one)*/, void* stream);
+int mmt_pack_weight_f16(const float* w, void* planes, long plane_stride, int Cout, int K, float scale, const float* amax,
+                        float* scale_out, void* stream);
+int mmt_pack_weight_flipped_f16(const float* w, const float* scale, void* planes, long plane_stride, int Cout, int KH, int KW,
+                                int Cin, const float* amax, float* scale_out, void* stream);
+int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a /*[host]*/, const float* s_x /*device*/, const float* s_w /*device*/, void* stream);
 int mmt_get_conv_precision(void);
 /* Packed bf16 planes of a weight matrix w[Cout][K] (K = KH*KW*Cin in the weight's own memory order, K % 16 == 0) for
  * the split-bf16 modes.  Plane q (q = 0..2, at planes + q*plane_stride bf16 elements) holds the q-th term of the

@@ -41,6 +41,7 @@ struct ConvP {
   const unsigned short* wpl; long wpl_stride;  // pre-split bf16 planes of w (or null)
   const unsigned short* xpl; long xpl_stride;  // pre-split bf16 planes of x, same NHWC indexing as x (or null)
   unsigned short* ypl; long ypl_stride;        // also write y as three bf16 planes (for a 3x3 consumer), or null
+  const float* f16_sx; const float* f16_sw;  // fp16 two-term split (experiment): device scalars s_x, s_w; the epilogue divides by s_x s_w
   int io;  // bf16 STORAGE of operands (mode 1): IO_X x, IO_Y y, IO_RES res, IO_MASK mask are bf16 tensors of the same indexing
 };
 constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;
@@ -104,6 +105,11 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
           o[2] = __builtin_bit_cast(float, t.y << 16); o[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
         } else { for (int e = 0; e < 4; e++) o[e] = e < nv ? __builtin_bit_cast(float, (unsigned)q[e] << 16) : 0.f; }
       };
+      if (p.f16_sx) {  // operands were scaled by powers of two: exact rescale of the accumulated sum
+        const float inv = 1.f / (*p.f16_sx * *p.f16_sw);
+#pragma unroll
+        for (int e = 0; e < 4; e++) sc[e] *= inv;
+      }
       const bool res_h = p.io & IO_RES, mask_h = p.io & IO_MASK;
       // rows in groups of G: every residual / mask / mul load of a group is issued before the first use, so a thread
       // pays one global-load latency per group instead of one per row (the row loop is not unrollable past its stores)
@@ -407,6 +413,24 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]) {
       r3 -= __builtin_bit_cast(float, b & 0xffff0000u);
     }
   }
+}
+
+// ---- EXPERIMENT (mmt_conv3x3_strip_f16x2, tools/bench_f16x2.py): two-term fp16 split of a pre-scaled value, x * s = h + l
+// with h = fp16(x s), l = fp16(x s - h) (the residual is exact in fp32): 22 significant bits, |x s - h - l| <= 2^-22 |x s|.
+// The caller scales each tensor by a power of two so that its largest magnitude sits near 2^14: h is then a normal fp16
+// number down to 2^-28 of the tensor's maximum and l down to 2^-17 of it (below that l turns subnormal: absolute error
+// <= 2^-25 in scaled units, i.e. <= 2^-39 of the maximum).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4h(const f32x4 v, const float s, uint2 (&o)[2]) {
+  float r[4] = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
+#pragma unroll
+  for (int e = 0; e < 4; e++) r[e] = fminf(fmaxf(r[e], -65504.f), 65504.f);   // a scale from an older tensor may be too large: saturate
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) { h[e] = (_Float16)r[e]; l[e] = (_Float16)(r[e] - (float)h[e]); }
+  o[0] = uint2{__builtin_bit_cast(unsigned, f16x2{h[0], h[1]}), __builtin_bit_cast(unsigned, f16x2{h[2], h[3]})};
+  o[1] = uint2{__builtin_bit_cast(unsigned, f16x2{l[0], l[1]}), __builtin_bit_cast(unsigned, f16x2{l[2], l[3]})};
 }
 
 template <int BM, int BN, int WM, int WN, int NS>
@@ -1092,7 +1116,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
 // K order: (kh, channel slab, kw) -- the packed weight planes are indexed, not re-packed.  One barrier per super-step
 // (three taps = 72 MFMAs per wave), placed before the last tap: the fragments of that tap are in registers by then, so the
 // stage is free for the copies of super-step s + 2 while tap 0 of s + 1 is pre-read from the other stage.
-template <int TW, int NS, int DBG = 0>  // DBG (timing experiments): 1 no copies in the loop, 2 no fragment reads, 4 no barrier / waits
+template <int TW, int NS, int DBG = 0, bool F16 = false>  // DBG (timing experiments): 1 no copies in the loop, 2 no fragment reads, 4 no barrier / waits; F16: the planes hold fp16 terms (experiment)
 __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, const int ksplit, float* __restrict__ ws) {
   constexpr int BM = 256, BN = 128, R = BM / TW, SW = TW + 32, TM = 2, TN = 2;
   constexpr int PA = R * SW * 32;              // bytes of one A plane of a stage (strip rows x 32 B)
@@ -1264,7 +1288,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
         for (int a = 0; a < TM; a++)
 #pragma unroll
           for (int b = 0; b < TN; b++) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
+            if constexpr (F16)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[qa][a]), __builtin_bit_cast(f16x8, fb[qb][b]), acc[a][b], 0, 0, 0);
+            else
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
             j++;
             if (ri < (j * NF + NRD - 1) / NRD && ri < NF) { if (do_read && !(DBG & 2)) read_tap(sg_next, kw_next, fan, fbn, ri); ri++; }
             if (di < (j * ndma + NM - 1) / NM && di < ndma) { if (do_dma && !(DBG & 1)) issue_slot(dma0 + di, stage_fill); di++; }
@@ -1352,6 +1379,69 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     for (int q = 0; q < NS; q++)
       ((uint4*)(pl + q * plane_stride))[i] = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
   }
+}
+
+// power-of-two scale that puts the largest magnitude `amax` into [2^13, 2^14] (an all-zero tensor: 1)
+__device__ __forceinline__ float f16_scale_of(const float amax) {
+  if (!(amax > 0.f)) return 1.f;
+  int e;
+  frexpf(amax, &e);                      // amax = m 2^e, m in [0.5, 1)
+  e = 14 - e;
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.f, e);
+}
+
+// one atomic per BLOCK, and only when the block's maximum beats what is already there (atomics on one address serialise
+// at the L2: 32 k of them cost milliseconds): wave reduce, LDS reduce over the 4 waves, test, atomicMax
+__device__ __forceinline__ void block_amax_commit(float m, unsigned* __restrict__ out) {
+  __shared__ float wmax[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const unsigned bits = __builtin_bit_cast(unsigned, m);
+    if (m > 0.f && bits > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, bits);
+  }
+}
+
+// out[0] = max(out[0], max |x[i] * rowscale[(i / inner) % rows]|) as a float (non-negative floats order like their bits)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, const long n4, const float* __restrict__ rowscale,
+                                                   const long inner4, const int rows, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)x)[i];
+    const float rs = rowscale ? fabsf(rowscale[(i / inner4) % rows]) : 1.f;
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * rs);
+  }
+  block_amax_commit(m, out);
+}
+
+__global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __restrict__ x, unsigned short* __restrict__ pl,
+                                                               const long plane_stride, const long n8, const float s_host,
+                                                               const float* __restrict__ amax, float* __restrict__ s_out,
+                                                               unsigned* __restrict__ amax_next, float* __restrict__ zero_slot) {
+  const float s = amax ? f16_scale_of(*amax) : s_host;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (s_out) *s_out = s;
+    if (zero_slot) *zero_slot = 0.f;   // the accumulator of the NEXT call in this role (nobody touches it during this one)
+  }
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const f32x4 v0 = ((const f32x4*)x)[2 * i], v1 = ((const f32x4*)x)[2 * i + 1];
+    if (amax_next) {
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))));
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+    }
+    uint2 o0[2], o1[2];
+    split4h(v0, s, o0);
+    split4h(v1, s, o1);
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      ((uint4*)(pl + q * plane_stride))[i] = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+  }
+  if (amax_next) block_amax_commit(m, amax_next);   // the maximum of THIS tensor, for the scale of the next one in this role
 }
 
 // one block per QUARTER tile (BM / 4 rows): four times the blocks of the main launch's tile count, or this small kernel is a
@@ -1583,6 +1673,34 @@ __global__ __launch_bounds__(256) void pack_one_kernel(const float* __restrict__
   if (unit < n_units) pack_unit(w, dst, plane_stride, Cout, K, unit, threadIdx.x & 63);
 }
 
+// the same tiling with the two fp16 terms of w * s (experiment, see split4h)
+__global__ __launch_bounds__(256) void pack_one_f16_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst,
+                                                           long plane_stride, int Cout, int K, int n_units, float s_host,
+                                                           const float* __restrict__ amax, float* __restrict__ s_out) {
+  const float s = amax ? f16_scale_of(*amax) : s_host;
+  if (s_out && blockIdx.x == 0 && threadIdx.x == 0) *s_out = s;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;
+  const int lane = threadIdx.x & 63;
+  const int nb32 = (Cout + 31) >> 5;
+  const int step = unit / nb32, blk = unit - step * nb32;
+  const int r = lane >> 1, h = lane & 1;
+  const int n = blk * 32 + r;
+  const int lh = h ^ ((r >> 3) & 1);
+  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+  if (n < Cout) {
+    const float* src = w + (long)n * K + step * 16 + lh * 8;
+    v0 = ldg4(src);
+    v1 = ldg4(src + 4);
+  }
+  uint2 o0[2], o1[2];
+  split4h(v0, s, o0);
+  split4h(v1, s, o1);
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+    *(uint4*)(dst + q * plane_stride + (long)unit * 512 + lane * 8) = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+}
+
 // packed planes of the DATA-GRADIENT weights straight from w: the matrix wd[ci][(KH-1-kh, KW-1-kw, co)] = w[co][kh][kw][ci]
 // * scale[co] (what weight_flip_kernel materialises in fp32) is never written; needs Cout % 16 == 0
 __device__ __forceinline__ void pack_flip_unit(const float* __restrict__ w, const float* __restrict__ scale,
@@ -1607,6 +1725,38 @@ __device__ __forceinline__ void pack_flip_unit(const float* __restrict__ w, cons
   split4<3>(f32x4{v[4], v[5], v[6], v[7]}, o1);
 #pragma unroll
   for (int q = 0; q < 3; q++)
+    *(uint4*)(dst + q * plane_stride + (long)unit * 512 + lane * 8) = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+}
+
+// data-gradient weights (see pack_flip_unit) as the two fp16 terms of wd * s, s from the device-side maximum (experiment)
+__global__ __launch_bounds__(256) void pack_flip_f16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                            unsigned short* __restrict__ dst, long plane_stride, int Cout,
+                                                            int KH, int KW, int Cin, int n_units,
+                                                            const float* __restrict__ amax, float* __restrict__ s_out) {
+  const float s = f16_scale_of(*amax);
+  if (s_out && blockIdx.x == 0 && threadIdx.x == 0) *s_out = s;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;
+  const int lane = threadIdx.x & 63;
+  const int nb32 = (Cin + 31) >> 5;
+  const int step = unit / nb32, blk = unit - step * nb32;
+  const int r = lane >> 1, h = lane & 1;
+  const int ci = blk * 32 + r;
+  const int lh = h ^ ((r >> 3) & 1);
+  const int k0 = step * 16 + lh * 8;
+  const int ft = k0 / Cout, co0 = k0 - ft * Cout;
+  const int tap = KH * KW - 1 - ft;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int co = co0 + j;
+    v[j] = ci < Cin ? w[((long)co * KH * KW + tap) * Cin + ci] * (scale ? scale[co] : 1.f) : 0.f;
+  }
+  uint2 o0[2], o1[2];
+  split4h(f32x4{v[0], v[1], v[2], v[3]}, s, o0);
+  split4h(f32x4{v[4], v[5], v[6], v[7]}, s, o1);
+#pragma unroll
+  for (int q = 0; q < 2; q++)
     *(uint4*)(dst + q * plane_stride + (long)unit * 512 + lane * 8) = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
 }
 
@@ -2403,6 +2553,7 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.wpl = (const unsigned short*)a->w_planes; p.wpl_stride = a->w_plane_stride;
   p.xpl = (const unsigned short*)a->x_planes; p.xpl_stride = a->x_plane_stride;
   p.ypl = (unsigned short*)a->y_planes; p.ypl_stride = a->y_plane_stride;
+  p.f16_sx = p.f16_sw = nullptr;
   p.io = a->io_bf16;
   if (p.io & ~(IO_X | IO_Y | IO_RES | IO_MASK | IO_DY)) return MMT_EINVAL;
   if (p.io & IO_X) {  // x itself is the (only) bf16 plane: the all-planes kernels with one term
@@ -2749,6 +2900,94 @@ extern "C" int mmt_pack_weights(const float* base, void* planes, long plane_stri
   hipLaunchKernelGGL(pack_many_kernel, dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream, base,
                      (unsigned short*)planes, plane_stride, (const PackDesc*)descs, unit_desc, n_units);
   MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- experiment: 3x3 convolution on the tap-strip kernel with a two-term fp16 split (3 products instead of 6)
+// amax[0] = max(amax[0], max |x * rowscale|) (amax zeroed by the caller); rowscale indexes rows of `inner` elements
+extern "C" int mmt_amax(const float* x, long n, const float* rowscale, long inner, int rows, float* amax, void* stream) {
+  if (!x || !amax || n < 0 || (n & 3) || ((size_t)x & 15) || (rowscale && (inner <= 0 || (inner & 3) || rows <= 0))) return MMT_EINVAL;
+  if (n == 0) return 0;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(amax_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n / 4, rowscale, rowscale ? inner / 4 : 1,
+                     rowscale ? rows : 1, (unsigned*)amax);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+// scale: the power of two to use, or -- with `amax` (device) -- derived from it on the device and written to scale_out (device)
+extern "C" int mmt_split_planes_f16(const float* x, void* planes, long plane_stride, long n, float scale, const float* amax,
+                                    float* scale_out, float* amax_next, float* zero_slot, void* stream) {
+  if (!x || !planes || n < 0 || (n & 7) || plane_stride < n || (plane_stride & 7) || ((size_t)planes & 15) || ((size_t)x & 15))
+    return MMT_EINVAL;
+  if (n == 0) return 0;
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(split_planes_f16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes,
+                     plane_stride, n / 8, scale, amax, scale_out, (unsigned*)amax_next, zero_slot);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_pack_weight_f16(const float* w, void* planes, long plane_stride, int Cout, int K, float scale, const float* amax,
+                                   float* scale_out, void* stream) {
+  const long n = mmt_packed_weight_elems(Cout, K);
+  if (!w || !planes || n < 0 || plane_stride < n || (plane_stride & 7) || ((size_t)planes & 15)) return MMT_EINVAL;
+  const int units = (int)(n / 512);
+  hipLaunchKernelGGL(pack_one_f16_kernel, dim3((units + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)planes,
+                     plane_stride, Cout, K, units, scale, amax, scale_out);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+// data-gradient weights of conv(x, w) (* scale[co]), as mmt_pack_weight_flipped; amax = device max of |w scale| (mmt_amax)
+extern "C" int mmt_pack_weight_flipped_f16(const float* w, const float* scale, void* planes, long plane_stride, int Cout, int KH,
+                                           int KW, int Cin, const float* amax, float* scale_out, void* stream) {
+  const long n = mmt_packed_weight_elems(Cin, KH * KW * Cout);
+  if (!w || !planes || !amax || n < 0 || (Cout & 15) || plane_stride < n || (plane_stride & 7) || ((size_t)planes & 15)) return MMT_EINVAL;
+  const int units = (int)(n / 512);
+  hipLaunchKernelGGL(pack_flip_f16_kernel, dim3((units + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, scale,
+                     (unsigned short*)planes, plane_stride, Cout, KH, KW, Cin, units, amax, scale_out);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+// x_planes / w_planes: the two fp16 planes of x * s_x and of the packed weight * s_w; s_x, s_w: device scalars
+extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x, const float* s_w, void* stream) {
+  ConvP p;
+  int e = fill(p, a);
+  if (e) return e;
+  if (!p.y || !p.xpl || !p.wpl || !s_x || !s_w || p.io || p.ypl) return MMT_EINVAL;
+  p.f16_sx = s_x; p.f16_sw = s_w;
+  const int tw = strip_tw(p);
+  if (!tw) return MMT_EINVAL;
+  const int ksplit = strip_ksplit(p, tw);
+  constexpr int NS = 2;
+  hipStream_t s = (hipStream_t)stream;
+  SplitWs w{nullptr};
+  if (ksplit > 1) {
+    w = split_workspace(s);
+    if (!w.ws) return MMT_EINVAL;
+  }
+  const int tiles = p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
+  auto go = [&](auto kern, int TW) {
+    const int R = 256 / TW, SW = TW + 32;
+    const size_t ring = (size_t)2 * (NS * R * SW * 32 + 3 * NS * 128 * 32), epi = (size_t)256 * 128 * sizeof(float);
+    const size_t lds = ring > epi ? ring : epi;
+    const hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (er != hipSuccess) return (int)er;
+    hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit, w.ws);
+    return 0;
+  };
+  if (tw == 128) e = go(conv3x3_strip_kernel<128, NS, 0, true>, 128);
+  else e = go(conv3x3_strip_kernel<64, NS, 0, true>, 64);
+  if (e) return e;
+  MMT_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    hipLaunchKernelGGL((conv_splitk_finish_kernel<256, 128>), dim3(tiles * 4), dim3(256), (size_t)64 * 128 * 4, s, p, ksplit, w.ws);
+    MMT_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -5,6 +5,7 @@ an op is not a CUDA/HIP tensor, the call raises.  PyTorch is used for device mem
 autograd bookkeeping only; tensors cross the boundary as raw device pointers.
 """
 import ctypes
+import weakref
 import os
 
 import torch
@@ -94,6 +95,11 @@ _SIGS = {
     "mmt_colsum": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "mmt_weight_flip_transpose": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mmt_amax": [c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p],
+    "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "mmt_pack_weight_flipped_f16": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mmt_conv3x3_strip_f16x2": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p],
     "mmt_maxpool3x3s2_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_mask_bce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_mgd_level_forward": [c_void_p, ctypes.POINTER(MgdTeachers), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
@@ -119,6 +125,74 @@ AUTO_PLANES = os.environ.get("MMT_AUTO_PLANES", "1") != "0"
 # the bf16 arithmetic (mode 1).  The producers in layers/fused.py ask `bf16_storage()`; every consumer goes by the dtype
 # of the tensor it is handed.
 _BF16_STORAGE = os.environ.get("MMT_BF16_STORAGE", "0") != "0"
+
+
+# EXPERIMENT (opt-in, MMT_F16X2=1): 3x3 convolutions that run on the tap-strip kernel take a TWO-term fp16
+# split of both operands (3 matrix products per multiply instead of 6), each tensor scaled by a power of two derived on the
+# device from its largest magnitude.  Error against fp64 no larger than the shipped 3-term bf16 split's (tools/bench_f16x2.py).
+F16X2 = os.environ.get("MMT_F16X2", "0") != "0"
+F16X2_DELAYED = os.environ.get("MMT_F16X2_DELAYED", "1") != "0"
+_F16W = {}   # weight address -> (key, planes, device scale)
+
+
+def set_f16x2(on):
+    global F16X2
+    F16X2 = bool(on)
+    _F16W.clear()
+    _F16SITE.clear()
+
+
+_F16SITE = {}   # role of a tensor (consumer weight address, flipped) -> [device state (scale, a0, a1, a2), calls so far]
+
+
+def f16_split(x, site=None):
+    """x (dense fp32) -> ((2, numel) fp16 planes of x * s, device tensor holding s at [0]), no host sync.
+    Without `site`: one reduction pass for max |x|, one split pass.  With `site` (a key naming the ROLE of x: the weight that
+    consumes it): delayed scaling -- call k scales by the maximum of the tensor of call k-1 (slot (k-1) % 3), records its own
+    in slot k % 3 and clears slot (k+1) % 3: one pass; the first tensor of a role takes the two-pass route.  A power-of-two
+    scale does not change the represented value unless a term leaves the fp16 range: 4x headroom above the previous maximum,
+    saturating beyond."""
+    n = x.numel()
+    xp = torch.empty((2, n), dtype=torch.float16, device=x.device)
+    ent = _F16SITE.get(site) if site is not None else None
+    if ent is None:
+        st = torch.zeros((4,), dtype=torch.float32, device=x.device)
+        _check(lib().mmt_amax(x.data_ptr(), n, None, 0, 0, st.data_ptr() + 4, _stream()), "mmt_amax")
+        _check(lib().mmt_split_planes_f16(x.data_ptr(), xp.data_ptr(), xp.stride(0), n, 1.0, st.data_ptr() + 4, st.data_ptr(),
+                                          None, None, _stream()), "mmt_split_planes_f16")
+        if site is not None:
+            _F16SITE[site] = [st, 1]
+        return xp, st
+    st, k = ent
+    base = st.data_ptr() + 4
+    _check(lib().mmt_split_planes_f16(x.data_ptr(), xp.data_ptr(), xp.stride(0), n, 1.0, base + 4 * ((k - 1) % 3), st.data_ptr(),
+                                      base + 4 * (k % 3), base + 4 * ((k + 1) % 3), _stream()), "mmt_split_planes_f16")
+    ent[1] = k + 1
+    return xp, st
+
+
+def f16_weight_planes(w, flip_scale=None, flipped=False):
+    """packed fp16 planes (+ device scale) of a forward weight, or of its data-gradient form (taps flipped, transposed,
+    rows scaled by flip_scale); cached until the weight (or the scale vector) is modified"""
+    # valid for THIS tensor object only (an address is reused by the allocator; parameters are long-lived objects)
+    key = (w._version, tuple(w.shape), _p(flip_scale), None if flip_scale is None else flip_scale._version, PLANES_EPOCH)
+    hit = _F16W.get((w.data_ptr(), flipped))
+    if hit is not None and hit[0] == key and hit[3]() is w:
+        return hit[1], hit[2]
+    Cout, Cin, KH, KW = w.shape
+    am = torch.zeros((2,), dtype=torch.float32, device=w.device)
+    K = Cin * KH * KW
+    _check(lib().mmt_amax(w.data_ptr(), w.numel(), _p(flip_scale) if flipped else None, K, Cout, am.data_ptr(), _stream()), "mmt_amax")
+    if flipped:
+        pl = torch.empty((2, packed_elems(Cin, KH * KW * Cout)), dtype=torch.float16, device=w.device)
+        _check(lib().mmt_pack_weight_flipped_f16(w.data_ptr(), _p(flip_scale), pl.data_ptr(), pl.stride(0), Cout, KH, KW, Cin,
+                                                 am.data_ptr(), am.data_ptr() + 4, _stream()), "mmt_pack_weight_flipped_f16")
+    else:
+        pl = torch.empty((2, packed_elems(Cout, K)), dtype=torch.float16, device=w.device)
+        _check(lib().mmt_pack_weight_f16(w.data_ptr(), pl.data_ptr(), pl.stride(0), Cout, K, 1.0, am.data_ptr(), am.data_ptr() + 4,
+                                         _stream()), "mmt_pack_weight_f16")
+    _F16W[(w.data_ptr(), flipped)] = (key, pl, am, weakref.ref(w))
+    return pl, am
 
 
 def set_bf16_storage(on):
@@ -451,7 +525,7 @@ def planes_of(x):
 
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
                  mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0,
-                 w_shape=None, planes=None, out_size=None, x_planes=None, want_planes=False, out_dtype=None):
+                 w_shape=None, planes=None, out_size=None, x_planes=None, want_planes=False, out_dtype=None, f16_src=None):
     """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory).
     y_out/y_offset (elements): write into an existing NHWC tensor at a shifted base (transposed-conv taps).
     w=None with w_shape + planes: the weight exists only as packed bf16 planes (pack_weight_flipped).
@@ -500,10 +574,20 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         y = y_out if y_out is not None else empty_nhwc(N, Cout, Ho, Wo, x.device, dtype=out_dtype)
     a.y = y.data_ptr() + esz * int(y_offset)
     y_planes = None
+    f16 = None   # (weight source, flipped?, row scale): this call runs on the two-term fp16 split (experiment)
+    if (F16X2 and not io and a.KH == 3 and a.w_planes and out_stride == 1 and y_out is None and mul is None
+            and get_conv_precision() == 3 and lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1):
+        if w is not None:
+            f16 = (w, False, None)
+        elif f16_src is not None:
+            f16 = (nhwc(f16_src[0]), True, f16_src[1])
+    if f16 is not None:
+        want_planes = False   # a strip consumer in this mode splits its input itself
+        x_planes = None
     if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0 and not io:
         y_planes = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=x.device)
         a.y_planes, a.y_plane_stride = y_planes.data_ptr(), y_planes.stride(0)
-    auto_split = (x_planes is None and AUTO_PLANES and a.KH == 3 and a.w_planes and not io
+    auto_split = (x_planes is None and AUTO_PLANES and a.KH == 3 and a.w_planes and not io and f16 is None
                   and lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1)
     if auto_split:
         # one pass over x; the 3x3 kernel then reads bf16 planes (9 taps x Cout/128 re-reads).  Allocated here, filled
@@ -527,6 +611,25 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
+    if f16 is not None:
+        rec = PROFILE is not None
+        if rec:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        xp16, sx = f16_split(x, (f16[0].data_ptr(), f16[1]) if F16X2_DELAYED else None)
+        wp16, sw = f16_weight_planes(f16[0], f16[2], f16[1])
+        a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+        a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
+        if rec:
+            ev[1].record()
+            ev[2].record()
+        _check(lib().mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr() + 4, _stream()),
+               "mmt_conv3x3_strip_f16x2")
+        if rec:
+            ev[3].record()
+            PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, ev[2], ev[3],
+                            ("fwd4", N, H, W, Cin, Cout, KH, stride, out_stride), 1, (ev[0], ev[1])))
+        return y
     if PROFILE is not None:
         var = lib().mmt_conv_variant(ctypes.byref(a))
         if var in (1, 4) or PROFILE_ALL:

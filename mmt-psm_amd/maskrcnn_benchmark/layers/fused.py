@@ -58,7 +58,7 @@ def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, re
     # the transposed / tap-flipped / BN-scaled weights: straight into packed bf16 planes when the DMA-fed kernels take the
     # data gradient (one launch, nothing materialised in fp32), else as an fp32 tensor
     planes = H.pack_weight_flipped(w, scale)
-    kw = dict(w_shape=(w.shape[1], w.shape[0], kh, w.shape[3]), planes=planes) if planes is not None else {}
+    kw = dict(w_shape=(w.shape[1], w.shape[0], kh, w.shape[3]), planes=planes, f16_src=(w, scale)) if planes is not None else {}
     wd = None if planes is not None else H.weight_flip_transpose(w, scale)
     if stride == 1:
         return H.conv_forward(g, wd, stride=1, pad=kh - 1 - pad, mask=mask, mask_scale=mask_scale, res=res,

@@ -91,7 +91,7 @@ class BottleneckWithFixedBatchNorm(nn.Module):
     def forward_raw(self, x):
         """no autograd: (o1, o2, out) of this block for `x` (forward_pair)"""
         w1, w2, w3, wd, bn, stride = self._args()
-        return fused.bottleneck_forward(H.nhwc(x), w1.detach(), w2.detach(), w3.detach(), None if wd is None else wd.detach(), bn, stride)
+        return fused.bottleneck_forward(H.nhwc(x), w1, w2, w3, wd, bn, stride)   # (the caller runs this under no_grad)
 
 
 class ResNet(nn.Module):
