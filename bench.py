@@ -215,13 +215,25 @@ KERNEL_NAMES = {
 }
 
 
+def products_of(mode, dom):
+    """matrix products per algorithmic multiply-add of a bracketed kernel group"""
+    from maskrcnn_benchmark import _hip
+    if dom == "fwd4" and mode == 3 and _hip.F16X2:
+        return 3   # conv3x3_strip_kernel on the two-term fp16 split
+    return PRODUCTS[mode]
+
+
 def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, nsteps, dom="fwd1"):
     """dominant kernel = the 128x128 forward tile (also runs every stride-1 data gradient).  `achieved` is algorithmic
     FLOP/s (2*M*N*K per launch / event-bracketed launch time); `peak` is the matrix-pipe peak available to that
     arithmetic: the fp32-input MFMA peak in mode 0, the bf16 dense peak divided by the products per multiply-add else."""
     n = max(len(prof), 1)
-    peak = PEAK_FP32_MFMA_TFLOPS if mode == 0 else PEAK_BF16_MFMA_TFLOPS / PRODUCTS[mode]
+    nprod = products_of(mode, dom)
+    peak = PEAK_FP32_MFMA_TFLOPS if mode == 0 else PEAK_BF16_MFMA_TFLOPS / nprod
     kern = KERNEL_NAMES[dom](mode)
+    if nprod == 3 and dom == "fwd4":
+        kern = ("conv3x3_strip_kernel<TW,2,0,true> (256x128 tiles on 8 waves, two fp16 planes per operand scaled per tensor, "
+                "v_mfma_f32_32x32x16_f16 x 3 products; brackets hold the kernel and, in its split-K form, the finish launch)")
     r = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
          "frac": round(ach / peak, 4), "traffic": traffic,
          "algorithmic_bytes_per_launch": round(alg_bytes / n, 1), "algorithmic_flop_per_launch": round(flops / n, 1),
@@ -230,9 +242,9 @@ def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, nsteps, dom="fw
          "measured_in": "a separate leg of %d steps with an event pair around every launch of this kernel on its launch "
                         "stream (%.2f ms/step with the brackets); the headline leg carries no brackets" % (nsteps, dt / nsteps * 1e3)}
     if mode != 0:
-        r["executed_mfma_tflops"] = round(ach * PRODUCTS[mode], 1)
-        r["peak_note"] = "%.0f TFLOP/s bf16 dense / %d products; the same work on the fp32-input MFMA is capped at %.1f" % (
-            PEAK_BF16_MFMA_TFLOPS, PRODUCTS[mode], PEAK_FP32_MFMA_TFLOPS)
+        r["executed_mfma_tflops"] = round(ach * nprod, 1)
+        r["peak_note"] = "%.0f TFLOP/s bf16 / fp16 dense / %d products; the same work on the fp32-input MFMA is capped at %.1f" % (
+            PEAK_BF16_MFMA_TFLOPS, nprod, PEAK_FP32_MFMA_TFLOPS)
         r["vs_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
     return r
 
@@ -245,6 +257,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the separate event-bracketed leg (roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--irnet", action="store_true", help="IR-Net on (BASELINE configs[4] in fp32); not the headline line")
+    ap.add_argument("--f16x2", action="store_true", help="the 3x3 convolutions of the tap-strip kernel on the two-term fp16 split "
+                    "(3 matrix products instead of 6; MMT_F16X2=1): fp32-grade like the default, measured beside it")
     ap.add_argument("--bf16", action="store_true", help="BASELINE configs[4]'s arithmetic: bf16 products (fp32 accumulate) and bf16 "
                     "activation storage in the backbone + FPN (MMT_CONV_PRECISION=1 MMT_BF16_STORAGE=1); not the headline line")
     args = ap.parse_args()
@@ -266,6 +280,8 @@ def main():
     if args.bf16:
         _hip.set_conv_precision(1)
         _hip.set_bf16_storage(True)
+    if args.f16x2:
+        _hip.set_f16x2(True)
     cfg, trainer, batch = build(device, rank, args.irnet, base_lr=BENCH_BASE_LR)
     it0 = cfg.MT.START_MT + cfg.MT.RAMPUP_STEP + 100  # mean-teacher branch active, consistency weight = lambda
 
@@ -412,9 +428,12 @@ def main():
             out["roofline"]["clock"] = ck
         if other:
             fo, mo = total(other)
+            odom = "fwd4" if dom == "fwd1" else "fwd1"
+            opeak = PEAK_FP32_MFMA_TFLOPS if mode == 0 else PEAK_BF16_MFMA_TFLOPS / products_of(mode, odom)
             out["roofline"]["other_large_tile_kernel"] = {
-                "kernel": KERNEL_NAMES["fwd4" if dom == "fwd1" else "fwd1"](mode), "launches_per_step": len(other) // npf,
-                "achieved": round(fo / (mo * 1e-3) / 1e12, 2), "frac": round(fo / (mo * 1e-3) / 1e12 / out["roofline"]["peak"], 4),
+                "kernel": KERNEL_NAMES[odom](mode) + (" [two-term fp16 split: 3 products, peak %.0f]" % opeak if products_of(mode, odom) == 3 else ""),
+                "launches_per_step": len(other) // npf,
+                "achieved": round(fo / (mo * 1e-3) / 1e12, 2), "frac": round(fo / (mo * 1e-3) / 1e12 / opeak, 4),
                 "avg_launch_ms": round(mo / len(other), 4), "share_of_step_time": round(mo / (dtp * 1e3), 4)}
         # the launches of that kernel with an un-split K (the large FPN / layer1-2 shapes); the others are the few-tile,
         # long-K layers, whose bracketed duration also contains their small finish launch
@@ -425,6 +444,10 @@ def main():
                 "launches_per_step": len(uns) // max(npf, 1), "achieved": round(fu / (mu * 1e-3) / 1e12, 2),
                 "frac": round(fu / (mu * 1e-3) / 1e12 / out["roofline"]["peak"], 4), "avg_launch_ms": round(mu / len(uns), 4)}
         out["config"]["conv_arithmetic"] = ARITH_BF16_STORAGE if _hip.bf16_storage() else ARITH[mode]
+        if _hip.F16X2 and mode == 3:
+            out["config"]["conv_arithmetic"] += (" | 3x3 convolutions of the tap-strip kernel: two-term fp16 split of both operands, each "
+                                                 "tensor scaled by a power of two from its largest magnitude (3 MFMAs, fp32 accumulate): "
+                                                 "error vs fp64 below the 3-term bf16 split's (profiles/r02_precision_f16x2.txt)")
         if single is not None:
             # `achieved` above is bracketed on the launch stream while the teacher's stream shares the GPU; this is the same
             # kernel, same shapes, in a single-stream run of the same step (MMT_OVERLAP_TEACHER=0)

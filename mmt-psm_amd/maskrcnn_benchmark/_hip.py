@@ -131,7 +131,7 @@ _BF16_STORAGE = os.environ.get("MMT_BF16_STORAGE", "0") != "0"
 # split of both operands (3 matrix products per multiply instead of 6), each tensor scaled by a power of two derived on the
 # device from its largest magnitude.  Error against fp64 no larger than the shipped 3-term bf16 split's (tools/bench_f16x2.py).
 F16X2 = os.environ.get("MMT_F16X2", "0") != "0"
-F16X2_DELAYED = os.environ.get("MMT_F16X2_DELAYED", "1") != "0"
+F16X2_DELAYED = os.environ.get("MMT_F16X2_DELAYED", "0") != "0"   # scale from the previous tensor of the role (one pass less)
 _F16W = {}   # weight address -> (key, planes, device scale)
 
 

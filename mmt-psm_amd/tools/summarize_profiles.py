@@ -101,6 +101,8 @@ extra = [("conv_table.txt", "every convolution call of a step by shape (single-s
          ("step_series_recipe_lr.txt", "per-step ms over 120 steps at the RECIPE's learning rate (* = consistency branch skipped)"),
          ("step_series_bench.txt", "the same with the bench's frozen learning rate"),
          ("clock_under_load.txt", "shader clock and board power of the GPU under the dominant kernel back to back, the fp32-input MFMA kernel, an HBM copy, the bench step"),
+         ("bench_f16x2.json", "`python bench.py --f16x2`: the strip kernel's 3x3 convolutions on the two-term fp16 split (3 products), everything else as the default"),
+         ("precision_f16x2.txt", "time and error against fp64 of that arithmetic, the default 3-term bf16 split and the fp32-input MFMA on the strip shapes, for activation-like, gradient-like, extreme-scale and outlier-laden operands"),
          ("bench_bf16.json", "`python bench.py --bf16`: bf16 products + bf16 activation storage"),
          ("bench_bf16_irnet.json", "`python bench.py --bf16 --irnet` = BASELINE configs[4] on one GPU"),
          ("bench_irnet.json", "`python bench.py --irnet`: IR-Net on, fp32-grade arithmetic")]

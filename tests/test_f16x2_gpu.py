@@ -1,0 +1,196 @@
+"""The opt-in two-term fp16 split of the tap-strip 3x3 convolutions (include/mmtpsm.h: mmt_conv3x3_strip_f16x2;
+`_hip.set_f16x2(True)` / MMT_F16X2=1): three matrix products per multiply instead of six.
+
+  * kernel level, forward and data gradient, every epilogue operand, both strip widths, the split-K form: error against an
+    fp64 convolution no larger than the shipped 3-term bf16 split's in the mean (rms <= 1.1 x) and within its own bound
+    at the worst element (<= 2 x, far inside the mode's tolerance), for activation-like,
+    signed, gradient-like (six decades) and extreme-scale (1e-20, 1e15) operands -- the scale of each tensor is derived on
+    the device from its own largest magnitude, so the magnitude of a tensor is irrelevant;
+  * the weight-plane cache belongs to ONE tensor object (an address reused by the allocator must not hit);
+  * the detector: supervised losses against the fp32 CPU oracle at the tolerance of the default arithmetic (1e-4), gradients
+    of the parameters against the default arithmetic's."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mmt-psm_amd"))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture()
+def hip():
+    from maskrcnn_benchmark import _hip as H
+    H.lib()
+    prev = H.get_conv_precision()
+    H.set_conv_precision(3)
+    yield H
+    H.set_f16x2(False)
+    H.set_conv_precision(prev)
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _inputs(kind, shape, g):
+    t = torch.randn(shape, generator=g)
+    if kind == "act":
+        t = t.relu()
+    elif kind == "signed50":
+        t = t * 50.0
+    elif kind == "grad":
+        t = t * torch.exp(torch.randn(shape, generator=g) * 2.0) * 1e-5
+    elif kind == "tiny":
+        t = t * 1e-20
+    elif kind == "huge":
+        t = t * 1e15
+    return _cl(t.cuda())
+
+
+CASES = [  # N, Cin, H, W, Cout, input kind, epilogue
+    (2, 128, 128, 128, 192, "act", "res"), (8, 256, 64, 64, 256, "signed50", "relu"), (32, 128, 32, 64, 128, "act", "mask"),
+    (2, 256, 64, 64, 256, "grad", ""), (2, 128, 128, 128, 128, "grad", "mask"), (2, 256, 64, 64, 256, "tiny", ""),
+    (2, 256, 128, 128, 256, "huge", "relu"), (2, 256, 256, 256, 256, "act", "relu"),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_strip_f16x2_error_not_above_bf16x3(hip, case):
+    H = hip
+    N, C, Hh, W, Co, kind, opts = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = _inputs(kind, (N, C, Hh, W), g)
+    w = _cl((torch.randn(Co, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda())
+    mag = x.abs().max().item() * 0.3
+    sc, sh = (torch.rand(Co, generator=g) + 0.5).cuda(), (torch.randn(Co, generator=g) * 0.1 * mag).cuda()
+    res = _cl((torch.randn(N, Co, Hh, W, generator=g) * mag).cuda()) if opts == "res" else None
+    mask = _cl(torch.randn(N, Co, Hh, W, generator=g).cuda()) if opts == "mask" else None
+    kw = dict(relu=opts in ("res", "relu"), res=res, res_mode=1 if res is not None else 0, mask=mask, mask_scale=2.0)
+    H.set_f16x2(False)
+    y3 = H.conv_forward(x, w, sc, sh, 1, 1, **kw)
+    H.set_f16x2(True)
+    yh = H.conv_forward(x, w, sc, sh, 1, 1, **kw)
+    H.set_f16x2(False)
+    ref = F.conv2d(x[:1].double(), w.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if res is not None:
+        ref = ref + res[:1].double()
+    if kw["relu"]:
+        ref = F.relu(ref)
+    if mask is not None:
+        ref = torch.where(mask[:1] > 0, ref * 2.0, torch.zeros_like(ref))
+    scale = ref.abs().max().item()
+    e3 = (y3[:1].double() - ref).abs().max().item() / scale
+    eh = (yh[:1].double() - ref).abs().max().item() / scale
+    r3 = (y3[:1].double() - ref).pow(2).mean().sqrt().item() / scale
+    rh = (yh[:1].double() - ref).pow(2).mean().sqrt().item() / scale
+    assert not torch.equal(y3, yh)                 # it really ran the other arithmetic
+    assert eh < 1e-5, (case, eh)                   # the tolerance of the default mode (tests/test_hip_kernels.py: MODE_TOL[3])
+    assert rh <= 1.1 * r3 + 1e-9, (case, rh, r3)   # no worse than it in the mean ...
+    assert eh <= 2.0 * e3 + 1e-7, (case, eh, e3)   # ... nor at the worst element (the bound the strip kernel's own test uses)
+
+
+def test_strip_f16x2_data_gradient(hip):
+    """the data gradient of a 3x3 convolution (flipped, transposed, BN-scaled weights packed as fp16 terms on the device)"""
+    H = hip
+    from maskrcnn_benchmark.layers import fused
+    g = torch.Generator().manual_seed(9)
+    N, C, S, Co = 2, 256, 64, 256
+    w = _cl((torch.randn(Co, C, 3, 3, generator=g) * 0.02).cuda())
+    bn = (torch.rand(Co, generator=g) + 0.5).cuda()
+    dy = _inputs("grad", (N, Co, S, S), g)
+    act = _inputs("act", (N, C, S, S), g)
+    outs = {}
+    for on in (False, True):
+        H.set_f16x2(on)
+        outs[on] = fused._dgrad(dy, w, (N, C, S, S), 1, 1, bn, mask=act)
+    H.set_f16x2(False)
+    wd = (w.double() * bn.double().view(-1, 1, 1, 1)).flip(2, 3).transpose(0, 1)
+    ref = F.conv2d(dy[:1].double(), wd, None, 1, 1) * (act[:1] > 0)
+    scale = ref.abs().max().item()
+    e3 = (outs[False][:1].double() - ref).abs().max().item() / scale
+    eh = (outs[True][:1].double() - ref).abs().max().item() / scale
+    assert not torch.equal(outs[False], outs[True])
+    assert eh < 1e-5 and eh <= 2.0 * e3 + 1e-7, (eh, e3)
+
+
+def test_f16_weight_cache_is_per_tensor_object(hip):
+    """two different weights that the allocator places at the same address must not share packed planes"""
+    H = hip
+    g = torch.Generator().manual_seed(2)
+    x = _inputs("act", (2, 128, 64, 64), g)
+    H.set_f16x2(True)
+    ys = []
+    for i in range(3):
+        w = _cl((torch.randn(128, 128, 3, 3, generator=g) * 0.05).cuda())
+        y = H.conv_forward(x, w, None, None, 1, 1)
+        ref = F.conv2d(x[:1].double(), w.double(), None, 1, 1)
+        assert (y[:1].double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item(), i
+        ys.append(y)
+        del w
+    H.set_f16x2(False)
+
+
+def test_detector_f16x2_vs_oracle(hip):
+    """supervised forward + backward of the detector with the strip convolutions on the fp16 split: losses against the fp32
+    CPU oracle at 1e-4, parameter gradients against the default arithmetic's run"""
+    H = hip
+    import synthetic
+    from oracle import model as om
+    from maskrcnn_benchmark.config import make_default_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    from maskrcnn_benchmark.utils.replay import Replay
+    SIZE = 256   # P2 = 64 x 64: the FPN output and RPN head convolutions on P2 run on the strip kernel (split-K form)
+    cfg = make_default_cfg()
+    torch.manual_seed(0)
+    student = build_detection_model(cfg, is_student=True)
+    shapes = {k: tuple(v.shape) for k, v in student.state_dict().items()}
+    weights = synthetic.make_weights(shapes, seed=0)
+    student.load_state_dict(weights, strict=False)
+    student.cuda().train()
+    imgs, tgs = synthetic.make_labeled(2, SIZE, 4, seed=1234)
+    otg = [om.Boxes(t["boxes"], t["size"], {"labels": t["labels"], "masks": t["polys"]}) for t in tgs]
+    taps = {}
+    torch.manual_seed(99)
+    with torch.no_grad():
+        ref = om.forward_supervised(weights, om.default_cfg(), imgs, otg, taps)
+    ptg = []
+    for t in tgs:
+        b = BoxList(t["boxes"].cuda(), t["size"], "xyxy")
+        b.add_field("labels", t["labels"].cuda())
+        b.add_field("masks", SegmentationMask([[p for p in inst] for inst in t["polys"]], t["size"], mode="poly"))
+        ptg.append(b)
+    grads, losses = {}, {}
+    used = []
+    orig = H.f16_split
+    try:
+        for on in (False, True):
+            H.set_f16x2(on)
+            H.f16_split = lambda x, site=None: (used.append(tuple(x.shape)), orig(x, site))[1]
+            for p in student.parameters():
+                p.grad = None
+            student.set_replay(Replay(taps))
+            out = student(to_image_list(list(imgs.cuda()), 32), ptg)
+            student.set_replay(None)
+            sum(out.values()).backward()
+            losses[on] = {k: v.item() for k, v in out.items()}
+            grads[on] = {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
+    finally:
+        H.f16_split = orig
+        H.set_f16x2(False)
+    assert len(used) >= 4, used   # their forward and data-gradient launches went through the fp16 path
+    for k in ref:
+        assert losses[True][k] == pytest.approx(ref[k].item(), rel=1e-4, abs=1e-6), (k, losses[True][k], ref[k].item())
+    worst = 0.0
+    for n, g3 in grads[False].items():
+        d = (grads[True][n] - g3).norm().item() / max(g3.norm().item(), 1e-12)
+        worst = max(worst, d)
+    assert worst < 2e-4, worst
