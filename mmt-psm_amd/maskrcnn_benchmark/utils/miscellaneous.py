@@ -33,6 +33,7 @@ def sigmoid_rampdown(gap_time, rampdown_length):
 
 
 _DEV_CONST = {}
+_DEV_CONST_OLD = {}   # the previous generation: kept referenced, kernels already queued on EITHER stream may still read them
 
 
 def dev_const(values, dtype, device):
@@ -45,6 +46,10 @@ def dev_const(values, dtype, device):
     t = _DEV_CONST.get(key)
     if t is None:
         if len(_DEV_CONST) > 4096:
+            # never free on overflow: a constant may be in use by launches queued on the other stream (the teacher thread
+            # shares this table), and the allocator would hand its memory to the next allocation of the creating stream
+            _DEV_CONST_OLD.clear()
+            _DEV_CONST_OLD.update(_DEV_CONST)
             _DEV_CONST.clear()
         t = torch.tensor(values, dtype=dtype, device=device)
         _DEV_CONST[key] = t
