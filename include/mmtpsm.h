@@ -192,6 +192,9 @@ typedef struct {
    * one-term plane -- and needs mode 1, w_planes, Cin % 16 == 0, Cout > 32; a bf16 `y` is the fp32 result rounded to
    * nearest even and replaces the fp32 store.  Values are those of the fp32-storage call on the rounded tensors. */
   int io_bf16;
+  /* optional: device float, zeroed by the caller, into which max |y| of this launch's output is accumulated (the scale of a
+   * consumer on the two-term fp16 split, mmt_conv3x3_strip_f16x2, without a reduction pass of its own) */
+  void* y_amax;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);

@@ -41,6 +41,7 @@ struct ConvP {
   const unsigned short* wpl; long wpl_stride;  // pre-split bf16 planes of w (or null)
   const unsigned short* xpl; long xpl_stride;  // pre-split bf16 planes of x, same NHWC indexing as x (or null)
   unsigned short* ypl; long ypl_stride;        // also write y as three bf16 planes (for a 3x3 consumer), or null
+  unsigned* amax_out;  // device float (bits) accumulating max |y| of this launch's output, or null (fp16 split: the consumer's scale)
   const float* f16_sx; const float* f16_sw;  // fp16 two-term split (experiment): device scalars s_x, s_w; the epilogue divides by s_x s_w
   int io;  // bf16 STORAGE of operands (mode 1): IO_X x, IO_Y y, IO_RES res, IO_MASK mask are bf16 tensors of the same indexing
 };
@@ -78,6 +79,7 @@ __device__ __forceinline__ void conv_epilogue_stage(f32x16 (&acc)[BM / (32 * WM)
 template <int BM, int BN>
 __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds, const int m0, const int n0, const int tid,
                                                      const int HoWo) {
+  float amx = 0.f;   // max |y| over what this thread stores (p.amax_out)
   {
     float* ct = lds;  // [BM][BN]
     constexpr int C4 = BN / 4, RPP = 256 / C4;
@@ -171,6 +173,10 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] *= ul[g][e];
           }
+          if (p.amax_out) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) amx = fmaxf(amx, e < nv ? fabsf(v[e]) : 0.f);
+          }
           if (p.io & IO_Y) {  // y is a bf16 tensor: round to nearest even, nothing else is written
             unsigned short* yh = (unsigned short*)p.y + oidx[g];
             const unsigned lo = pk_bf16(v[0], v[1]), hi = pk_bf16(v[2], v[3]);
@@ -190,6 +196,13 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
         }
       }
     }
+  }
+  if (p.amax_out) {   // one atomic per wave, and only when it beats the value already there (see block_amax_commit)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+    const unsigned bits = __builtin_bit_cast(unsigned, amx);
+    if ((tid & 63) == 0 && amx > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(p.amax_out, bits);
   }
 }
 
@@ -2554,6 +2567,7 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.xpl = (const unsigned short*)a->x_planes; p.xpl_stride = a->x_plane_stride;
   p.ypl = (unsigned short*)a->y_planes; p.ypl_stride = a->y_plane_stride;
   p.f16_sx = p.f16_sw = nullptr;
+  p.amax_out = (unsigned*)a->y_amax;
   p.io = a->io_bf16;
   if (p.io & ~(IO_X | IO_Y | IO_RES | IO_MASK | IO_DY)) return MMT_EINVAL;
   if (p.io & IO_X) {  // x itself is the (only) bf16 plane: the all-planes kernels with one term
@@ -2788,7 +2802,7 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
   const char* rows_env = getenv("MMT_ROWS");  // read per call: the parity tests switch it
   const int rows = rows_env ? atoi(rows_env) : 1;
   static const int rows_min = getenv("MMT_ROWS_MIN") ? atoi(getenv("MMT_ROWS_MIN")) : 256;  // blocks of 128 rows
-  if (rows && !p.io && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * rows_min &&
+  if (rows && !p.io && !p.amax_out && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * rows_min &&
       (p.Cout & 3) == 0 && p.res_mode <= 1 && !p.mask && !p.mul && p.out_stride == 1 &&
       (long)p.M * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31)) {
     static const int bn64 = getenv("MMT_ROWS_BN") ? atoi(getenv("MMT_ROWS_BN")) : 32;

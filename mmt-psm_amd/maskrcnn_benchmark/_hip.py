@@ -29,7 +29,7 @@ class ConvArgs(ctypes.Structure):
                 ("relu", c_int), ("res_mode", c_int), ("out_stride", c_int), ("out_H", c_int), ("out_W", c_int),
                 ("mask_scale", c_float), ("w_planes", c_void_p), ("w_plane_stride", ctypes.c_long),
                 ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long),
-                ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long), ("io_bf16", c_int)]
+                ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long), ("io_bf16", c_int), ("y_amax", c_void_p)]
 
 
 IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
@@ -142,6 +142,19 @@ def set_f16x2(on):
     _F16SITE.clear()
 
 
+_AMAX_POOL = {}   # (device, stream) -> [zeroed float tensor, next free index]: slots for the producers' max |y|
+
+
+def _amax_slot(device):
+    key = (str(device), _stream())
+    ent = _AMAX_POOL.get(key)
+    if ent is None or ent[1] >= ent[0].numel():
+        ent = _AMAX_POOL[key] = [torch.zeros((4096,), dtype=torch.float32, device=device), 0]
+    i = ent[1]
+    ent[1] = i + 1
+    return ent[0][i:i + 1]
+
+
 _F16SITE = {}   # role of a tensor (consumer weight address, flipped) -> [device state (scale, a0, a1, a2), calls so far]
 
 
@@ -154,6 +167,13 @@ def f16_split(x, site=None):
     saturating beyond."""
     n = x.numel()
     xp = torch.empty((2, n), dtype=torch.float16, device=x.device)
+    am = getattr(x, "_mmt_amax", None)
+    if am is not None and am[1] == x._version:
+        # the convolution that produced x recorded max |x| in its epilogue (mmt_conv_args.y_amax): the split pass alone
+        st = torch.empty((1,), dtype=torch.float32, device=x.device)
+        _check(lib().mmt_split_planes_f16(x.data_ptr(), xp.data_ptr(), xp.stride(0), n, 1.0, am[0].data_ptr(), st.data_ptr(),
+                                          None, None, _stream()), "mmt_split_planes_f16")
+        return xp, st
     ent = _F16SITE.get(site) if site is not None else None
     if ent is None:
         st = torch.zeros((4,), dtype=torch.float32, device=x.device)
@@ -582,8 +602,12 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         elif f16_src is not None:
             f16 = (nhwc(f16_src[0]), True, f16_src[1])
     if f16 is not None:
-        want_planes = False   # a strip consumer in this mode splits its input itself
         x_planes = None
+    want_amax = False
+    if F16X2 and want_planes and get_conv_precision() == 3:
+        # the consumer of y is a strip convolution on the fp16 split: it scales and splits y itself -- no bf16 planes from this
+        # epilogue, but max |y| recorded on the way saves it the reduction pass
+        want_amax, want_planes = True, False
     if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0 and not io:
         y_planes = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=x.device)
         a.y_planes, a.y_plane_stride = y_planes.data_ptr(), y_planes.stride(0)
@@ -608,6 +632,10 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if mask.dtype == torch.bfloat16:
             io |= IO_MASK
     a.io_bf16 = io
+    amax_slot = None
+    if want_amax and not io and y_out is None and out_stride == 1:
+        amax_slot = _amax_slot(x.device)
+        a.y_amax = amax_slot.data_ptr()
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
@@ -629,6 +657,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             ev[3].record()
             PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, ev[2], ev[3],
                             ("fwd4", N, H, W, Cin, Cout, KH, stride, out_stride), 1, (ev[0], ev[1])))
+        if amax_slot is not None:
+            y._mmt_amax = (amax_slot, y._version)
         return y
     if PROFILE is not None:
         var = lib().mmt_conv_variant(ctypes.byref(a))
@@ -648,12 +678,16 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
                             lib().mmt_conv_ksplit(ctypes.byref(a)), pre))
             if y_planes is not None:
                 y._mmt_planes = (y_planes, y._version)
+            if amax_slot is not None:
+                y._mmt_amax = (amax_slot, y._version)
             return y
     if auto_split:
         split_planes(x, x_planes)
     _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
     if y_planes is not None:
         y._mmt_planes = (y_planes, y._version)
+    if amax_slot is not None:
+        y._mmt_amax = (amax_slot, y._version)
     return y
 
 

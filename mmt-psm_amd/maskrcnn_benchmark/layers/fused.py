@@ -139,6 +139,9 @@ def batch_slice(t, lo, hi):
     if pl is not None:
         per = t.numel() // t.shape[0]
         v._mmt_planes = (pl[:, lo * per:hi * per], v._version)
+    am = getattr(t, "_mmt_amax", None)
+    if am is not None and am[1] == t._version:
+        v._mmt_amax = (am[0], v._version)   # max over the whole batch: an upper bound for the slice (fp16 split scale)
     return v
 
 
