@@ -222,3 +222,33 @@ def test_detector_bf16_storage_vs_oracle(mode1):
         assert v < 5e-2, dev
     gr = [p.grad for n, p in student.named_parameters() if p.grad is not None and "layer3" in n]
     assert gr and all(torch.isfinite(t).all().item() for t in gr) and any(t.abs().max().item() > 0 for t in gr)
+
+
+def test_pair_forward_with_bf16_storage(mode1):
+    """the N = 4 forward of the two student passes (backbone.py::forward_pair) hands out dense bf16 slices: pyramids equal to
+    the batched pass, and a backward through one half reaches the weights"""
+    H = mode1
+    import synthetic
+    from maskrcnn_benchmark.config import make_default_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    from maskrcnn_benchmark.modeling.backbone.backbone import forward_pair
+    cfg = make_default_cfg()
+    torch.manual_seed(0)
+    model = build_detection_model(cfg, is_student=True)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(synthetic.make_weights(shapes, seed=0), strict=False)
+    model.cuda().train()
+    g = torch.Generator().manual_seed(4)
+    xa, xb = (torch.randn(2, 3, 192, 192, generator=g) * 50).cuda(), (torch.randn(2, 3, 192, 192, generator=g) * 50).cuda()
+    H.set_bf16_storage(True)
+    try:
+        with torch.no_grad():
+            cat = model.backbone(torch.cat([xa, xb], 0))
+        pa, pb = forward_pair(model.backbone, xa, xb)
+        for c, a, b in zip(cat, pa, pb):
+            assert a.dtype == BF and torch.equal(c[:2], a.detach()) and torch.equal(c[2:], b.detach())
+        sum(t.float().mean() for t in pa).backward()
+    finally:
+        H.set_bf16_storage(False)
+    w = model.backbone.body.layer3[0].conv2.weight
+    assert w.grad is not None and torch.isfinite(w.grad).all().item() and w.grad.abs().max().item() > 0
