@@ -221,7 +221,8 @@ class MTtrainer(object):
         # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
         # main stream and the overlap silently disappears (measured: 63.7 vs 59.9 ms/step).  A different priority class
         # has its own queues.
-        self.t_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.overlap_teacher else None
+        self.t_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MMT_TEACHER_PRIORITY", "-1"))) \
+            if self.overlap_teacher else None
         self._bucketed = None  # BucketedAllReduce, built lazily when enabled (see _bucketed_allreduce)
         # One random stream per model: the teacher's forward runs in a helper thread beside the student's, and with the
         # global generator the interleaving of their draws (fg/bg sampler keys, dropout) would depend on thread timing.
