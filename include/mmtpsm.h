@@ -195,6 +195,10 @@ typedef struct {
   /* optional: device float, zeroed by the caller, into which max |y| of this launch's output is accumulated (the scale of a
    * consumer on the two-term fp16 split, mmt_conv3x3_strip_f16x2, without a reduction pass of its own) */
   void* y_amax;
+  /* mmt_conv_wgrad only, optional, mode 3: device floats holding max |x| and max |dy| (e.g. recorded through y_amax by the
+   * launches that produced them): the weight gradient then runs on the two-term fp16 split (3 products instead of 6) */
+  const void* f16_x_amax;
+  const void* f16_dy_amax;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);

@@ -2180,7 +2180,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p,
 // VEC4 = Cout % 4 == 0 (16-byte dy loads)
 // BF (mode 1, bf16 storage): bit 0 = x is a bf16 tensor, bit 1 = dy is; the loads fetch 8 bytes per 4 channels and widen
 // them (exact), everything after the load is unchanged -- the one-term "split" of a bf16 value is the value itself
-template <int NS, int MODE, bool VEC4, int BF = 0>
+// F16 (opt-in fp16 two-term split, NS == 2): both operands are scaled by the power of two of their recorded maximum
+// (p.f16_sx -> max |x|, p.f16_sw -> max |dy|, device scalars), split into two fp16 terms, multiplied with 3 f16 MFMAs, and the
+// tile is divided by s_x s_dy where it is stored (directly, or in wgrad_reduce_kernel for the split form)
+template <int NS, int MODE, bool VEC4, int BF = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, const float* __restrict__ dy,
                                                                  const float* __restrict__ rowscale,
                                                                  float* __restrict__ dw, int m_per_split,
@@ -2234,10 +2237,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
   const int lr = lane & 31, kh2 = lane >> 5;
   const int froff = kh2 * 2048 + lr * 16;
   const int ntile = (me - ms + 15) / 16;
+  float f16_s[2] = {1.f, 1.f};   // F16: scale of dy (role A) / of x (role B)
+  if constexpr (F16) { f16_s[0] = f16_scale_of(*p.f16_sw); f16_s[1] = f16_scale_of(*p.f16_sx); }
 
   // the whole pipeline once per staging role (wave-uniform), so that each copy is straight-line code
   auto run = [&](auto role_tag) {
     constexpr bool RB = decltype(role_tag)::value;
+    const float f16_role = f16_s[RB ? 1 : 0];
     int m_load = ms + pg * 4;  // first pixel of this thread's next load (advances 16 per step)
     // Loads are raw buffer loads: 32-bit byte offset against a scalar descriptor (no 64-bit address arithmetic), and
     // lanes outside the tensor / in the halo get offset 2^31 >= num_records, for which the hardware returns zeros.
@@ -2330,20 +2336,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
 #pragma unroll
       for (int e = 0; e < 4; e++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) sv[e][j] = rg[j][e];
+        for (int j = 0; j < 4; j++) sv[e][j] = F16 ? rg[j][e] * f16_role : rg[j][e];
     };
     auto split_cvt = [&](int e, int q, char* base) {
-      su[e][0] = pk_bf16(sv[e][0], sv[e][1]);
-      su[e][1] = pk_bf16(sv[e][2], sv[e][3]);
+      if constexpr (F16) {
+        su[e][0] = __builtin_bit_cast(unsigned, f16x2{(_Float16)sv[e][0], (_Float16)sv[e][1]});
+        su[e][1] = __builtin_bit_cast(unsigned, f16x2{(_Float16)sv[e][2], (_Float16)sv[e][3]});
+      } else {
+        su[e][0] = pk_bf16(sv[e][0], sv[e][1]);
+        su[e][1] = pk_bf16(sv[e][2], sv[e][3]);
+      }
       *(uint2*)(base + q * PL + e * 512) = uint2{su[e][0], su[e][1]};
     };
     // plain v_sub_f32: the compiler would pair these into v_pk_add_f32, which is the slower choice beside MFMAs
     auto fsub = [](float a, unsigned b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
     auto split_sub = [&](int e) {
-      sv[e][0] = fsub(sv[e][0], su[e][0] << 16);
-      sv[e][1] = fsub(sv[e][1], su[e][0] & 0xffff0000u);
-      sv[e][2] = fsub(sv[e][2], su[e][1] << 16);
-      sv[e][3] = fsub(sv[e][3], su[e][1] & 0xffff0000u);
+      if constexpr (F16) {
+        const f16x2 h0 = __builtin_bit_cast(f16x2, su[e][0]), h1 = __builtin_bit_cast(f16x2, su[e][1]);
+        sv[e][0] -= (float)h0[0]; sv[e][1] -= (float)h0[1]; sv[e][2] -= (float)h1[0]; sv[e][3] -= (float)h1[1];
+      } else {
+        sv[e][0] = fsub(sv[e][0], su[e][0] << 16);
+        sv[e][1] = fsub(sv[e][1], su[e][0] & 0xffff0000u);
+        sv[e][2] = fsub(sv[e][2], su[e][1] << 16);
+        sv[e][3] = fsub(sv[e][3], su[e][1] & 0xffff0000u);
+      }
     };
     constexpr int SPL = 2 * NS - 1;          // cvt, (sub, cvt) x (NS-1) per channel
     constexpr int NMICRO = 4 + 1 + 4 * SPL;  // split_begin, 4 pixel loads, 4 channels x SPL pieces
@@ -2382,7 +2398,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
           for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int b = 0; b < 2; b++) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
+              if constexpr (F16)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[qa][a]), __builtin_bit_cast(f16x8, fb[qb][b]), acc[a][b], 0, 0, 0);
+              else
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
               j++;
 #pragma unroll
               for (int r = 0; r < (NMICRO + NM - 1) / NM; r++)
@@ -2446,7 +2465,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
         f32x4 v = *(const f32x4*)(ct + row * 128 + cc * 4);
         float* q = dst + (long)co * NP + n;
         if (direct) {
-          const float sc = rowscale ? rowscale[co] : 1.f;
+          const float sc = (rowscale ? rowscale[co] : 1.f) * (F16 ? 1.f / (f16_s[0] * f16_s[1]) : 1.f);
           const f32x4 o = *(const f32x4*)q;
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = o[e] + v[e] * sc;
@@ -2460,7 +2479,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
 // dw[co][n] += rowscale[co] * sum_s ws[s][co][n]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Cout, int NP,
                                                            const float* __restrict__ rowscale,
-                                                           float* __restrict__ dw) {
+                                                           float* __restrict__ dw, const float* __restrict__ f16_ax = nullptr,
+                                                           const float* __restrict__ f16_ady = nullptr) {
+  const float f16_inv = f16_ax ? 1.f / (f16_scale_of(*f16_ax) * f16_scale_of(*f16_ady)) : 1.f;   // fp16 split: the slabs hold scaled sums
   const long n4 = (long)Cout * NP / 4;
   const long slab = (long)Cout * NP;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -2476,7 +2497,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       for (int u = 0; u < 8; u++) a += b[u];
     }
     for (; s < splits; s++) a += *(const f32x4*)(ws + s * slab + i * 4);
-    const float sc = rowscale ? rowscale[(int)((i * 4) / NP)] : 1.f;
+    const float sc = (rowscale ? rowscale[(int)((i * 4) / NP)] : 1.f) * f16_inv;
 #pragma unroll
     for (int e = 0; e < 4; e++) o[e] += a[e] * sc;
     ((f32x4*)dw)[i] = o;
@@ -3134,6 +3155,28 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   const int prec = precision();
   // bf16 storage of x (IO_X) / dy (IO_DY): mode 1, the pipelined kernel with 4-channel loads only
   const int bf = ((p.io & IO_X) ? 1 : 0) | ((p.io & IO_DY) ? 2 : 0);
+  // opt-in fp16 two-term split (mode 3 only): x_amax / dy_amax = device maxima of the two operands
+  const bool f16 = a->f16_x_amax && a->f16_dy_amax;
+  if (f16) {
+    if (prec != 3 || bf || (p.Cout & 3) || (mps & 15) || !((long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31)))
+      return MMT_EINVAL;
+    p.f16_sx = (const float*)a->f16_x_amax;
+    p.f16_sw = (const float*)a->f16_dy_amax;
+    const dim3 grid(tx, ty, split);
+    const int mode = !(p.Wo >= 8 && p.Ho >= 8) ? 0 : ((p.Wo & 3) == 0 ? 2 : 1);
+#define WGF(MODE) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<2, MODE, true, 0, true>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)
+    if (mode == 2) WGF(2); else if (mode == 1) WGF(1); else WGF(0);
+#undef WGF
+    MMT_LAUNCH_CHECK();
+    if (split > 1) {
+      const long n4 = (long)p.Cout * NP / 4;
+      int blocks = (int)((n4 + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, split, p.Cout, NP, rowscale, dw, p.f16_sx, p.f16_sw);
+      MMT_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   if (bf && !(prec == 1 && (p.Cout & 3) == 0 && (mps & 15) == 0 && (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) &&
               (long)p.M * p.Cout * 4 < (1L << 31)))
     return MMT_EINVAL;

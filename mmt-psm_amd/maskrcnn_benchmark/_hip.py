@@ -29,7 +29,8 @@ class ConvArgs(ctypes.Structure):
                 ("relu", c_int), ("res_mode", c_int), ("out_stride", c_int), ("out_H", c_int), ("out_W", c_int),
                 ("mask_scale", c_float), ("w_planes", c_void_p), ("w_plane_stride", ctypes.c_long),
                 ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long),
-                ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long), ("io_bf16", c_int), ("y_amax", c_void_p)]
+                ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long), ("io_bf16", c_int), ("y_amax", c_void_p),
+                ("f16_x_amax", c_void_p), ("f16_dy_amax", c_void_p)]
 
 
 IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
@@ -132,6 +133,7 @@ _BF16_STORAGE = os.environ.get("MMT_BF16_STORAGE", "0") != "0"
 # device from its largest magnitude.  Error against fp64 no larger than the shipped 3-term bf16 split's (tools/bench_f16x2.py).
 F16X2 = os.environ.get("MMT_F16X2", "0") != "0"
 F16X2_DELAYED = os.environ.get("MMT_F16X2_DELAYED", "0") != "0"   # scale from the previous tensor of the role (one pass less)
+F16_STATS = {"wgrad": 0, "conv": 0, "amax_pass": 0}   # launches that took the fp16 path (tools, tests)
 _F16W = {}   # weight address -> (key, planes, device scale)
 
 
@@ -176,12 +178,15 @@ def f16_split(x, site=None):
         return xp, st
     ent = _F16SITE.get(site) if site is not None else None
     if ent is None:
+        F16_STATS["amax_pass"] += 1
         st = torch.zeros((4,), dtype=torch.float32, device=x.device)
         _check(lib().mmt_amax(x.data_ptr(), n, None, 0, 0, st.data_ptr() + 4, _stream()), "mmt_amax")
         _check(lib().mmt_split_planes_f16(x.data_ptr(), xp.data_ptr(), xp.stride(0), n, 1.0, st.data_ptr() + 4, st.data_ptr(),
                                           None, None, _stream()), "mmt_split_planes_f16")
         if site is not None:
             _F16SITE[site] = [st, 1]
+        else:
+            x._mmt_amax = (st[1:2], x._version)   # other consumers of this tensor (its weight gradient) need no pass of their own
         return xp, st
     st, k = ent
     base = st.data_ptr() + 4
@@ -644,6 +649,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if rec:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
+        F16_STATS["conv"] += 1
         xp16, sx = f16_split(x, (f16[0].data_ptr(), f16[1]) if F16X2_DELAYED else None)
         wp16, sw = f16_weight_planes(f16[0], f16[2], f16[1])
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
@@ -794,6 +800,12 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
     a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
     a.out_stride = 1
     a.io_bf16 = (IO_X if x.dtype == torch.bfloat16 else 0) | (IO_DY if dy.dtype == torch.bfloat16 else 0)
+    if F16X2 and not a.io_bf16 and Cout % 4 == 0 and get_conv_precision() == 3:
+        ax, ad = getattr(x, "_mmt_amax", None), getattr(dy, "_mmt_amax", None)
+        if ax is not None and ad is not None and ax[1] == x._version and ad[1] == dy._version:
+            # both operands carry their recorded maximum: two-term fp16 split (3 products instead of 6), no extra pass
+            a.f16_x_amax, a.f16_dy_amax = ax[0].data_ptr(), ad[0].data_ptr()
+            F16_STATS["wgrad"] += 1
     splits = lib().mmt_conv_wgrad_splits(ctypes.byref(a))
     ws = torch.empty((splits * Cout * KH * KW * Cin,), dtype=torch.float32, device=x.device) if splits > 1 else None
     if PROFILE is not None and PROFILE_ALL:

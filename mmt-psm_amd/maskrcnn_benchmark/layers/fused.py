@@ -85,10 +85,10 @@ class ConvFn(torch.autograd.Function):
         stride, pad, input_relu, has_b = ctx.cfgv
         g = H.nhwc(g)
         dx = dw = db = None
+        if ctx.needs_input_grad[0]:   # first: on the fp16 split it records max |g|, which the weight gradient then reuses
+            dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None, out_dtype=x.dtype)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw, db = _wgrad(x, g, w, stride, pad, None, has_b, *ctx.dst)
-        if ctx.needs_input_grad[0]:
-            dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None, out_dtype=x.dtype)
         return dx, dw, db, None, None, None, None
 
 
@@ -241,9 +241,9 @@ class FPNFn(torch.autograd.Function):
         d_in = [None] * 4
         dwl, dbl, dwi, dbi, dcs = [None] * 4, [None] * 4, [None] * 4, [None] * 4, [None] * 4
         for k in range(4):  # finest first: d_inner_k = dgrad(layer_k) + 2x2-sum(d_inner_{k-1})
-            dwl[k], dbl[k] = _wgrad(inner[k], gs[k], wl[k], 1, 1, None, True, *ctx.dst[1][k])
             d_in[k] = _dgrad(gs[k], wl[k], inner[k].shape, 1, 1, None, res=d_in[k - 1] if k > 0 else None,
                              res_mode=3 if k > 0 else 0)
+            dwl[k], dbl[k] = _wgrad(inner[k], gs[k], wl[k], 1, 1, None, True, *ctx.dst[1][k])
         for k in range(4):
             dwi[k], dbi[k] = _wgrad(cs[k], d_in[k], wi[k], 1, 0, None, True, *ctx.dst[0][k])
             if ctx.needs_input_grad[k]:

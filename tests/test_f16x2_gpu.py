@@ -119,6 +119,37 @@ def test_strip_f16x2_data_gradient(hip):
     assert eh < 1e-5 and eh <= 2.0 * e3 + 1e-7, (eh, e3)
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 64, 64, 128, 3, "act", "grad"), (2, 256, 64, 64, 256, 3, "act", "grad"),
+                                   (2, 256, 128, 128, 256, 3, "signed50", "tiny"), (8, 128, 32, 32, 128, 3, "act", "act")])
+def test_wgrad_f16x2(hip, shape):
+    """weight gradient with both operands carrying their recorded maximum (`_mmt_amax`, as the producing launches attach it):
+    two-term fp16 split, 3 products; error against fp64 within the default's bound, split and un-split accumulation"""
+    H = hip
+    N, Cin, Hh, W, Cout, k, kx, kd = shape
+    g = torch.Generator().manual_seed(sum(shape[:6]))
+    x = _inputs(kx, (N, Cin, Hh, W), g)
+    dy = _inputs(kd, (N, Cout, Hh, W), g)
+    rs = (torch.rand(Cout, generator=g) + 0.5).cuda()
+
+    def run(on):
+        H.set_f16x2(on)
+        if on:
+            x._mmt_amax = (x.abs().max().reshape(1), x._version)
+            dy._mmt_amax = (dy.abs().max().reshape(1), dy._version)
+        dw = _cl(torch.zeros((Cout, Cin, k, k), device="cuda"))
+        H.conv_wgrad(x, dy, (Cout, Cin, k, k), 1, k // 2, dw, rs, None)
+        H.set_f16x2(False)
+        return dw
+    d3, dh = run(False), run(True)
+    xu = F.unfold(x.double(), k, padding=k // 2)                      # (N, Cin k k, HW)
+    ref = torch.einsum("nco,nko->ck", dy.double().flatten(2), xu).view(Cout, Cin, k, k) * rs.double().view(-1, 1, 1, 1)
+    scale = ref.abs().max().item()
+    e3 = (d3.double() - ref).abs().max().item() / scale
+    eh = (dh.double() - ref).abs().max().item() / scale
+    assert not torch.equal(d3, dh)
+    assert eh < 2e-5 and eh <= 2.0 * e3 + 1e-7, (shape, eh, e3)
+
+
 def test_f16_weight_cache_is_per_tensor_object(hip):
     """two different weights that the allocator places at the same address must not share packed planes"""
     H = hip
