@@ -242,6 +242,9 @@ int mmt_pack_weight_f16(const float* w, void* planes, long plane_stride, int Cou
 int mmt_pack_weight_flipped_f16(const float* w, const float* scale, void* planes, long plane_stride, int Cout, int KH, int KW,
                                 int Cin, const float* amax, float* scale_out, void* stream);
 int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a /*[host]*/, const float* s_x /*device*/, const float* s_w /*device*/, void* stream);
+/* the same arithmetic for every other shape of the DMA-fed kernel (1x1, strided, 3x3 on small maps): raw fp32 x, split in
+ * registers after its scaling by the power of two of x_amax (device: max |x|, e.g. recorded through y_amax) */
+int mmt_conv_forward_f16x2(const mmt_conv_args* a /*[host]*/, const float* x_amax /*device*/, const float* s_w /*device*/, void* stream);
 int mmt_get_conv_precision(void);
 /* Packed bf16 planes of a weight matrix w[Cout][K] (K = KH*KW*Cin in the weight's own memory order, K % 16 == 0) for
  * the split-bf16 modes.  Plane q (q = 0..2, at planes + q*plane_stride bf16 elements) holds the q-th term of the

@@ -42,12 +42,22 @@ struct ConvP {
   const unsigned short* xpl; long xpl_stride;  // pre-split bf16 planes of x, same NHWC indexing as x (or null)
   unsigned short* ypl; long ypl_stride;        // also write y as three bf16 planes (for a 3x3 consumer), or null
   unsigned* amax_out;  // device float (bits) accumulating max |y| of this launch's output, or null (fp16 split: the consumer's scale)
+  int f16_ax;  // f16_sx points to max |x| (the scale is derived from it) instead of to the scale itself
   const float* f16_sx; const float* f16_sw;  // fp16 two-term split (experiment): device scalars s_x, s_w; the epilogue divides by s_x s_w
   int io;  // bf16 STORAGE of operands (mode 1): IO_X x, IO_Y y, IO_RES res, IO_MASK mask are bf16 tensors of the same indexing
 };
 constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b);
+// power-of-two scale that puts the largest magnitude `amax` into [2^13, 2^14] (an all-zero tensor: 1)
+__device__ __forceinline__ float f16_scale_of_fwd(const float amax) {
+  if (!(amax > 0.f)) return 1.f;
+  int e;
+  frexpf(amax, &e);
+  e = 14 - e;
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.f, e);
+}
 
 template <int NS>
 __device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]);
@@ -108,7 +118,7 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
         } else { for (int e = 0; e < 4; e++) o[e] = e < nv ? __builtin_bit_cast(float, (unsigned)q[e] << 16) : 0.f; }
       };
       if (p.f16_sx) {  // operands were scaled by powers of two: exact rescale of the accumulated sum
-        const float inv = 1.f / (*p.f16_sx * *p.f16_sw);
+        const float inv = 1.f / ((p.f16_ax ? f16_scale_of_fwd(*p.f16_sx) : *p.f16_sx) * *p.f16_sw);
 #pragma unroll
         for (int e = 0; e < 4; e++) sc[e] *= inv;
       }
@@ -607,7 +617,9 @@ __device__ __forceinline__ void dma16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_ptr_t)l, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int S>
+// F16 (opt-in, NS == 2): the weight planes hold the two fp16 terms of w * s_w; the activations are scaled by the power of
+// two of their recorded maximum (p.f16_sx -> max |x|, a device scalar) and split into two fp16 terms in registers; 3 products
+template <int BM, int BN, int WM, int WN, int NS, int S, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, const unsigned short* __restrict__ wpl,
                                                                const long wpl_stride, const int ksplit,
                                                                float* __restrict__ ws) {
@@ -747,16 +759,29 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
   f32x4 va[TM][2];        // raw fp32 A fragment halves of the next step; turned into residuals by the split levels
   unsigned ua[TM][2][2];  // packed bf16 pairs of the level being produced
   uint2 oa[TM][2][NS];    // bf16 terms of the A fragment halves
+  float f16_sx = 1.f;
+  if constexpr (F16) f16_sx = f16_scale_of_fwd(*p.f16_sx);
   auto split_cvt = [&](int a, int h, int q) {
-    ua[a][h][0] = pk_bf16(va[a][h][0], va[a][h][1]);
-    ua[a][h][1] = pk_bf16(va[a][h][2], va[a][h][3]);
+    if constexpr (F16) {
+      if (q == 0) va[a][h] *= f16_sx;
+      ua[a][h][0] = __builtin_bit_cast(unsigned, f16x2{(_Float16)va[a][h][0], (_Float16)va[a][h][1]});
+      ua[a][h][1] = __builtin_bit_cast(unsigned, f16x2{(_Float16)va[a][h][2], (_Float16)va[a][h][3]});
+    } else {
+      ua[a][h][0] = pk_bf16(va[a][h][0], va[a][h][1]);
+      ua[a][h][1] = pk_bf16(va[a][h][2], va[a][h][3]);
+    }
     oa[a][h][q] = uint2{ua[a][h][0], ua[a][h][1]};
   };
   auto split_sub = [&](int a, int h) {
-    va[a][h][0] -= __builtin_bit_cast(float, ua[a][h][0] << 16);
-    va[a][h][1] -= __builtin_bit_cast(float, ua[a][h][0] & 0xffff0000u);
-    va[a][h][2] -= __builtin_bit_cast(float, ua[a][h][1] << 16);
-    va[a][h][3] -= __builtin_bit_cast(float, ua[a][h][1] & 0xffff0000u);
+    if constexpr (F16) {
+      const f16x2 h0 = __builtin_bit_cast(f16x2, ua[a][h][0]), h1 = __builtin_bit_cast(f16x2, ua[a][h][1]);
+      va[a][h][0] -= (float)h0[0]; va[a][h][1] -= (float)h0[1]; va[a][h][2] -= (float)h1[0]; va[a][h][3] -= (float)h1[1];
+    } else {
+      va[a][h][0] -= __builtin_bit_cast(float, ua[a][h][0] << 16);
+      va[a][h][1] -= __builtin_bit_cast(float, ua[a][h][0] & 0xffff0000u);
+      va[a][h][2] -= __builtin_bit_cast(float, ua[a][h][1] << 16);
+      va[a][h][3] -= __builtin_bit_cast(float, ua[a][h][1] & 0xffff0000u);
+    }
   };
   auto pack_a = [&](bf16x8 (&fa)[NS][TM]) {
 #pragma unroll
@@ -818,7 +843,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
         for (int a = 0; a < TM; a++)
 #pragma unroll
           for (int b = 0; b < TN; b++) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
+            if constexpr (F16)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[qa][a]), __builtin_bit_cast(f16x8, fb[qb][b]), acc[a][b], 0, 0, 0);
+            else
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
             j++;
 #pragma unroll
             for (int r = 0; r < (NMICRO + NM - 1) / NM; r++)
@@ -1508,6 +1536,7 @@ struct PackDesc { long src_off, dst_off; int Cout, K, unit0, pad; };
 template <int KT, int BN, int NS>
 __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, const unsigned short* __restrict__ wpl,
                                                               const long wpl_stride) {
+  float amx = 0.f;   // max |y| over what this thread stores (p.amax_out)
   constexpr int TN = BN / 32;
   constexpr int PIECES = KT * NS * TN;       // 1 KiB DMA pieces per panel: [kt][plane][32-column block]
   constexpr int BBUF = PIECES * 1024;
@@ -1652,9 +1681,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
         }
+        if (p.amax_out) amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         *(f32x4*)(p.y + (long)m * p.Cout + c) = f32x4{v[0], v[1], v[2], v[3]};
       }
     }
+  }
+  if (p.amax_out) {   // as in conv_epilogue_finish: one conditional atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+    const unsigned bits = __builtin_bit_cast(unsigned, amx);
+    if ((threadIdx.x & 63) == 0 && amx > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(p.amax_out, bits);
   }
 }
 
@@ -2588,6 +2625,7 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.xpl = (const unsigned short*)a->x_planes; p.xpl_stride = a->x_plane_stride;
   p.ypl = (unsigned short*)a->y_planes; p.ypl_stride = a->y_plane_stride;
   p.f16_sx = p.f16_sw = nullptr;
+  p.f16_ax = 0;
   p.amax_out = (unsigned*)a->y_amax;
   p.io = a->io_bf16;
   if (p.io & ~(IO_X | IO_Y | IO_RES | IO_MASK | IO_DY)) return MMT_EINVAL;
@@ -2823,7 +2861,7 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
   const char* rows_env = getenv("MMT_ROWS");  // read per call: the parity tests switch it
   const int rows = rows_env ? atoi(rows_env) : 1;
   static const int rows_min = getenv("MMT_ROWS_MIN") ? atoi(getenv("MMT_ROWS_MIN")) : 256;  // blocks of 128 rows
-  if (rows && !p.io && !p.amax_out && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * rows_min &&
+  if (rows && !p.io && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * rows_min &&
       (p.Cout & 3) == 0 && p.res_mode <= 1 && !p.mask && !p.mul && p.out_stride == 1 &&
       (long)p.M * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31)) {
     static const int bn64 = getenv("MMT_ROWS_BN") ? atoi(getenv("MMT_ROWS_BN")) : 32;
@@ -3023,6 +3061,47 @@ extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x,
     hipLaunchKernelGGL((conv_splitk_finish_kernel<256, 128>), dim3(tiles * 4), dim3(256), (size_t)64 * 128 * 4, s, p, ksplit, w.ws);
     MMT_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+static int pick_variant(const ConvP& p);
+// any convolution the DMA-fed kernel takes (Cin % 16 == 0, Cout > 32), raw fp32 x: x_amax = device max |x|, w_planes = the two
+// fp16 planes of the packed weight, s_w their device scale
+extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_amax, const float* s_w, void* stream) {
+  ConvP p;
+  int e = fill(p, a);
+  if (e) return e;
+  if (!p.y || !p.wpl || !x_amax || !s_w || p.io || p.ypl || (p.Cin & 15) || ((size_t)p.wpl & 15) || (p.wpl_stride & 7)) return MMT_EINVAL;
+  if (p.M == 0 || p.Cout == 0) return 0;
+  const int variant = pick_variant(p);
+  if (variant == 0) return MMT_EINVAL;
+  p.f16_sx = x_amax; p.f16_sw = s_w; p.f16_ax = 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int ksplit = pick_ksplit(p);
+  auto go = [&](auto kern, int BM, int BN, int ks) -> int {
+    const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN) * ks;
+    SplitWs w{nullptr};
+    if (ks > 1) {
+      w = split_workspace(s);
+      if (!w.ws || tiles > 1024) return MMT_EINVAL;
+    }
+    const size_t ring = (size_t)3 * (BM * 64 + 2 * BN * 32), epi = (size_t)BM * BN * sizeof(float);
+    const size_t lds = ring > epi ? ring : epi;
+    if (lds > 65536) {
+      const hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (er != hipSuccess) return (int)er;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, p, p.wpl, p.wpl_stride, ks, w.ws);
+    if (ks > 1)
+      hipLaunchKernelGGL((conv_splitk_finish_kernel<128, 128>), dim3(tiles / ks * 4), dim3(256), epi / 4, s, p, ks, w.ws);
+    return 0;
+  };
+  if (ksplit > 1) e = go(conv_fwd_glds_kernel<128, 128, 4, 1, 2, 3, true>, 128, 128, ksplit);
+  else if (variant == 1) e = go(conv_fwd_glds_kernel<128, 128, 4, 1, 2, 3, true>, 128, 128, 1);
+  else if (variant == 3) e = go(conv_fwd_glds_kernel<128, 64, 4, 1, 2, 3, true>, 128, 64, 1);
+  else e = go(conv_fwd_glds_kernel<64, 64, 2, 2, 2, 3, true>, 64, 64, 1);
+  if (e) return e;
+  MMT_LAUNCH_CHECK();
   return 0;
 }
 

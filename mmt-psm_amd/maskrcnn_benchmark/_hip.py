@@ -101,6 +101,7 @@ _SIGS = {
     "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_flipped_f16": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mmt_conv3x3_strip_f16x2": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p],
+    "mmt_conv_forward_f16x2": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p],
     "mmt_maxpool3x3s2_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_mask_bce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_mgd_level_forward": [c_void_p, ctypes.POINTER(MgdTeachers), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
@@ -132,8 +133,9 @@ _BF16_STORAGE = os.environ.get("MMT_BF16_STORAGE", "0") != "0"
 # split of both operands (3 matrix products per multiply instead of 6), each tensor scaled by a power of two derived on the
 # device from its largest magnitude.  Error against fp64 no larger than the shipped 3-term bf16 split's (tools/bench_f16x2.py).
 F16X2 = os.environ.get("MMT_F16X2", "0") != "0"
+F16X2_TILED = os.environ.get("MMT_F16X2_TILED", "1") != "0"   # also the tiled kernel (1x1, small-map 3x3, fc), not only the strip kernel
 F16X2_DELAYED = os.environ.get("MMT_F16X2_DELAYED", "0") != "0"   # scale from the previous tensor of the role (one pass less)
-F16_STATS = {"wgrad": 0, "conv": 0, "amax_pass": 0}   # launches that took the fp16 path (tools, tests)
+F16_STATS = {"wgrad": 0, "conv": 0, "tiled": 0, "amax_pass": 0}   # launches that took the fp16 path (tools, tests)
 _F16W = {}   # weight address -> (key, planes, device scale)
 
 
@@ -608,11 +610,18 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             f16 = (nhwc(f16_src[0]), True, f16_src[1])
     if f16 is not None:
         x_planes = None
+    f16t = None   # the same arithmetic on the tiled DMA kernel (1x1 layers, 3x3 on small maps, fc): x split in registers
     want_amax = False
-    if F16X2 and want_planes and get_conv_precision() == 3:
-        # the consumer of y is a strip convolution on the fp16 split: it scales and splits y itself -- no bf16 planes from this
-        # epilogue, but max |y| recorded on the way saves it the reduction pass
+    if F16X2 and not io and get_conv_precision() == 3:
+        # consumers on the fp16 split scale y themselves: no bf16 planes from this epilogue, max |y| recorded on the way
         want_amax, want_planes = True, False
+        rows_shape = (a.KH == 1 and stride == 1 and Cin in (64, 128) and N * Ho * Wo >= 128 * 256 and res_mode <= 1
+                      and mask is None and mul is None and out_stride == 1)   # the row-resident 1x1 kernel keeps these
+        if (f16 is None and F16X2_TILED and a.w_planes and Cout > 32 and Cin % 16 == 0 and y_out is None and not rows_shape):
+            if w is not None:
+                f16t = (w, False, None)
+            elif f16_src is not None:
+                f16t = (nhwc(f16_src[0]), True, f16_src[1])
     if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0 and not io:
         y_planes = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=x.device)
         a.y_planes, a.y_plane_stride = y_planes.data_ptr(), y_planes.stride(0)
@@ -644,6 +653,31 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
+    if f16t is not None:
+        am = getattr(x, "_mmt_amax", None)
+        if am is None or am[1] != x._version:
+            F16_STATS["amax_pass"] += 1
+            slot = _amax_slot(x.device)
+            _check(lib().mmt_amax(x.data_ptr(), x.numel(), None, 0, 0, slot.data_ptr(), _stream()), "mmt_amax")
+            am = (slot, x._version)
+            x._mmt_amax = am
+        wp16, sw = f16_weight_planes(f16t[0], f16t[2], f16t[1])
+        a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
+        a.x_planes = None
+        F16_STATS["tiled"] += 1
+        rec = PROFILE is not None and (PROFILE_ALL or lib().mmt_conv_variant(ctypes.byref(a)) == 1)
+        if rec:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _check(lib().mmt_conv_forward_f16x2(ctypes.byref(a), am[0].data_ptr(), sw.data_ptr() + 4, _stream()), "mmt_conv_forward_f16x2")
+        if rec:
+            e1.record()
+            PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1,
+                            ("fwd%d" % lib().mmt_conv_variant(ctypes.byref(a)), N, H, W, Cin, Cout, KH, stride, out_stride),
+                            lib().mmt_conv_ksplit(ctypes.byref(a)), None))
+        if amax_slot is not None:
+            y._mmt_amax = (amax_slot, y._version)
+        return y
     if f16 is not None:
         rec = PROFILE is not None
         if rec:
