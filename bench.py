@@ -218,8 +218,8 @@ KERNEL_NAMES = {
 def products_of(mode, dom):
     """matrix products per algorithmic multiply-add of a bracketed kernel group"""
     from maskrcnn_benchmark import _hip
-    if dom == "fwd4" and mode == 3 and _hip.F16X2:
-        return 3   # conv3x3_strip_kernel on the two-term fp16 split
+    if mode == 3 and _hip.F16X2 and (dom == "fwd4" or _hip.F16X2_TILED):
+        return 3   # the two-term fp16 split: the strip kernel, and (F16X2_TILED) the tiled kernel too
     return PRODUCTS[mode]
 
 
@@ -231,6 +231,8 @@ def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, nsteps, dom="fw
     nprod = products_of(mode, dom)
     peak = PEAK_FP32_MFMA_TFLOPS if mode == 0 else PEAK_BF16_MFMA_TFLOPS / nprod
     kern = KERNEL_NAMES[dom](mode)
+    if nprod == 3 and dom == "fwd1":
+        kern = "conv_fwd_glds_kernel<128,128,4,1,2,3,true> (activations split into two fp16 terms in registers, v_mfma_f32_32x32x16_f16 x 3 products)"
     if nprod == 3 and dom == "fwd4":
         kern = ("conv3x3_strip_kernel<TW,2,0,true> (256x128 tiles on 8 waves, two fp16 planes per operand scaled per tensor, "
                 "v_mfma_f32_32x32x16_f16 x 3 products; brackets hold the kernel and, in its split-K form, the finish launch)")

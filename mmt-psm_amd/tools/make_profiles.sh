@@ -68,4 +68,6 @@ python $R/bench.py --irnet --no-cpu-baseline > $OUT/bench_irnet.json 2>/dev/null
 python $R/mmt-psm_amd/tools/clock_under_load.py 2>/dev/null | grep -v amdgpu.ids > $OUT/clock_under_load.txt
 python $R/bench.py --f16x2 --no-cpu-baseline > $OUT/bench_f16x2.json 2>/dev/null
 python $R/mmt-psm_amd/tools/bench_f16x2.py 2>/dev/null | grep -v amdgpu.ids > $OUT/precision_f16x2.txt
+python $R/mmt-psm_amd/tools/bench_f16x2_glds.py 2>/dev/null | grep -v amdgpu.ids >> $OUT/precision_f16x2.txt
+python $R/mmt-psm_amd/tools/f16_stats.py 2>/dev/null | grep -v amdgpu.ids >> $OUT/precision_f16x2.txt
 ls -la $OUT
