@@ -11,8 +11,11 @@ crops x AUG_K=2 views x flip (+ coarse inference on view 0's pyramid), [C] stude
 [D] weighted loss, backward, (RCCL all-reduce of the flat student gradient when N > 1), SGD, [E] EMA teacher.
 img = one source crop consumed per step (2 labeled + 2 unlabeled = 4 per GPU per step); weak scaling.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: conv_fwd_kernel<128,128,2,2>, fp32 MFMA) and
-`cpu_baseline` (the CPU oracle timed on this node's host cores on a bounded sample; baseline only).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the large-tile convolution kernel with the most
+event-bracketed time in a separate leg: conv3x3_strip_kernel or conv_fwd_glds_kernel<128,128>, on the matrix pipe through
+the two-term fp16 split -- 3 MFMA products per multiply, peak 2500 / 3 TFLOP/s; the 6-product line of the 3-term bf16
+split and the fp32-input MFMA peak are quoted beside it) and `cpu_baseline` (the CPU oracle timed on this node's host
+cores on a bounded sample; baseline only).
 """
 import argparse
 import json
@@ -248,6 +251,10 @@ def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, nsteps, dom="fw
         r["peak_note"] = "%.0f TFLOP/s bf16 / fp16 dense / %d products; the same work on the fp32-input MFMA is capped at %.1f" % (
             PEAK_BF16_MFMA_TFLOPS, nprod, PEAK_FP32_MFMA_TFLOPS)
         r["vs_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
+    if nprod == 3:
+        # the line the previous rounds were quoted on: the same algorithmic FLOP/s against the 6-product ceiling
+        r["six_product_line"] = {"peak": round(PEAK_BF16_MFMA_TFLOPS / 6, 1), "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4),
+                                 "note": "3-term bf16 split (round-2 default, now the per-tensor fall-back; python bench.py --bf16x3)"}
     return r
 
 
@@ -259,8 +266,10 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the separate event-bracketed leg (roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--irnet", action="store_true", help="IR-Net on (BASELINE configs[4] in fp32); not the headline line")
-    ap.add_argument("--f16x2", action="store_true", help="the 3x3 convolutions of the tap-strip kernel on the two-term fp16 split "
-                    "(3 matrix products instead of 6; MMT_F16X2=1): fp32-grade like the default, measured beside it")
+    ap.add_argument("--f16x2", action="store_true", help="(default since round 3; kept for old command lines) convolutions on the "
+                    "two-term fp16 split: 3 matrix products per multiply instead of 6")
+    ap.add_argument("--bf16x3", action="store_true", help="the round-2 default arithmetic, now the per-tensor fall-back: 3-term bf16 "
+                    "split, 6 matrix products per multiply (MMT_F16X2=0)")
     ap.add_argument("--bf16", action="store_true", help="BASELINE configs[4]'s arithmetic: bf16 products (fp32 accumulate) and bf16 "
                     "activation storage in the backbone + FPN (MMT_CONV_PRECISION=1 MMT_BF16_STORAGE=1); not the headline line")
     args = ap.parse_args()
@@ -284,6 +293,8 @@ def main():
         _hip.set_bf16_storage(True)
     if args.f16x2:
         _hip.set_f16x2(True)
+    if args.bf16x3:
+        _hip.set_f16x2(False)
     cfg, trainer, batch = build(device, rank, args.irnet, base_lr=BENCH_BASE_LR)
     it0 = cfg.MT.START_MT + cfg.MT.RAMPUP_STEP + 100  # mean-teacher branch active, consistency weight = lambda
 
@@ -447,9 +458,13 @@ def main():
                 "frac": round(fu / (mu * 1e-3) / 1e12 / out["roofline"]["peak"], 4), "avg_launch_ms": round(mu / len(uns), 4)}
         out["config"]["conv_arithmetic"] = ARITH_BF16_STORAGE if _hip.bf16_storage() else ARITH[mode]
         if _hip.F16X2 and mode == 3:
-            out["config"]["conv_arithmetic"] += (" | 3x3 convolutions of the tap-strip kernel: two-term fp16 split of both operands, each "
-                                                 "tensor scaled by a power of two from its largest magnitude (3 MFMAs, fp32 accumulate): "
-                                                 "error vs fp64 below the 3-term bf16 split's (profiles/r02_precision_f16x2.txt)")
+            out["config"]["conv_arithmetic"] = (
+                "fp32 tensors; products on the fp16 matrix pipe as a two-term fp16 split of both operands, each tensor scaled by a "
+                "power of two derived on the device from its largest magnitude (3 MFMAs per multiply, fp32 accumulate): error vs "
+                "fp64 <= the 3-term bf16 split's and the fp32-input MFMA's (profiles/r03_precision_f16x2.txt); tensors whose crest "
+                "factor max/mean exceeds 2^17 fall back to the 3-term bf16 split (6 MFMAs) per consuming site; "
+                "MMT_F16X2=0 / --bf16x3 selects that split everywhere, MMT_CONV_PRECISION=0 the fp32-input MFMA")
+            out["config"]["f16_split_launches"] = dict(_hip.F16_STATS)
         if single is not None:
             # `achieved` above is bracketed on the launch stream while the teacher's stream shares the GPU; this is the same
             # kernel, same shapes, in a single-stream run of the same step (MMT_OVERLAP_TEACHER=0)

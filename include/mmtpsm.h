@@ -199,6 +199,12 @@ typedef struct {
    * launches that produced them): the weight gradient then runs on the two-term fp16 split (3 products instead of 6) */
   const void* f16_x_amax;
   const void* f16_dy_amax;
+  /* nonzero: y_amax points to a 33-float slot (zeroed by the caller); besides slot[0] = max |y| the launch accumulates,
+   * over a sample of its tiles (every 64th block), sum |y| into slot[1 .. 16] and the number of sampled elements into
+   * slot[17 .. 32].  max / mean = the crest factor of the tensor, by which the host decides
+   * whether its consumers keep the two-term fp16 split or fall back to the three-term bf16 split (fp16 has 5 exponent
+   * bits: a tensor dominated by a few huge elements pushes everything else below the range of the low term) */
+  int y_amax_stats;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
@@ -233,6 +239,10 @@ int mmt_set_conv_precision(int mode);
  * device scalars derived on the device from mmt_amax (no host round trip), the epilogue divides the sum by s_x s_w.
  * Strip shapes only (mmt_conv_wants_planes).  Opt-in from Python with MMT_F16X2=1. */
 int mmt_amax(const float* x, long n, const float* rowscale, long inner, int rows, float* amax /*device, zeroed*/, void* stream);
+/* the same reduction into a 33-float statistics slot (device, zeroed): slot[0] = max |x|, slot[1..16] += sums of |x| over a
+ * sample of the tensor, slot[17..32] += the sample's element counts
+ * (what mmt_conv_args.y_amax_stats makes a producing convolution record about its output) */
+int mmt_amax_stats(const float* x, long n, float* slot /*device, zeroed*/, void* stream);
 int mmt_split_planes_f16(const float* x, void* planes, long plane_stride, long n, float scale, const float* amax /*device or NULL*/,
                          float* scale_out /*device or NULL*/, float* amax_next /*device or NULL: max |x| of THIS tensor is
                          accumulated here, for the scale of the next tensor in the same role (delayed scaling)*/,
@@ -272,6 +282,15 @@ typedef struct { const float* w; const float* scale; void* dst; long plane_strid
 int mmt_pack_weights_flipped(const mmt_flip_desc* descs /*[dev]*/, const int* unit_desc /*[dev]*/, int n_units, void* stream);
 int mmt_pack_weights(const float* base, void* planes, long plane_stride, const mmt_pack_desc* descs /*[dev]*/,
                      const int* unit_desc /*[dev]*/, int n_units, void* stream);
+/* the same two tables for the two-term fp16 split (the default arithmetic of mode 3): planes = two fp16 planes of
+ * w_d * s_d, s_d the power of two that puts max |w_d| into [2^13, 2^14], derived on the device (a reduction launch and a
+ * packing launch); stat[2 d] <- max |w_d| (x scale), stat[2 d + 1] <- s_d, the device scalar the convolutions take as s_w.
+ * Replaces nothing in the reference: it keeps the packed form of engine/flat.py's parameter buffer current after
+ * solver/build.py's SGD step and MTtrainer.py:277-281's EMA. */
+int mmt_pack_weights_f16(const float* base, void* planes, long plane_stride, const mmt_pack_desc* descs /*[dev]*/,
+                         const int* unit_desc /*[dev]*/, int n_units, int n_descs, float* stat /*[dev][n_descs][2]*/, void* stream);
+int mmt_pack_weights_flipped_f16(const mmt_flip_desc* descs /*[dev]*/, const int* unit_desc /*[dev]*/, int n_units, int n_descs,
+                                 float* stat /*[dev][n_descs][2]*/, void* stream);
 
 /* weight gradient: dw[co,kh,kw,ci] += rowscale[co] * sum_{n,ho,wo} dy[n,ho,wo,co] * x[n,ho*s+kh-p,wo*s+kw-p,ci]
  * (dw = the caller's gradient buffer, same layout as the weight; Cin % 4 == 0); optional dbias[co] += sum dy[..,co].

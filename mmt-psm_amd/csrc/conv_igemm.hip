@@ -42,6 +42,8 @@ struct ConvP {
   const unsigned short* xpl; long xpl_stride;  // pre-split bf16 planes of x, same NHWC indexing as x (or null)
   unsigned short* ypl; long ypl_stride;        // also write y as three bf16 planes (for a 3x3 consumer), or null
   unsigned* amax_out;  // device float (bits) accumulating max |y| of this launch's output, or null (fp16 split: the consumer's scale)
+  int amax_stats;      // amax_out is a 33-float slot: every 64th block adds sum |y| of what it stores to [1 + k] and the element count
+                       // to [17 + k], k = (block >> 6) & 15 (crest factor max / mean of a SAMPLE: the fp16 split's fall-back test)
   int f16_ax;  // f16_sx points to max |x| (the scale is derived from it) instead of to the scale itself
   const float* f16_sx; const float* f16_sw;  // fp16 two-term split (experiment): device scalars s_x, s_w; the epilogue divides by s_x s_w
   int io;  // bf16 STORAGE of operands (mode 1): IO_X x, IO_Y y, IO_RES res, IO_MASK mask are bf16 tensors of the same indexing
@@ -89,7 +91,7 @@ __device__ __forceinline__ void conv_epilogue_stage(f32x16 (&acc)[BM / (32 * WM)
 template <int BM, int BN>
 __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds, const int m0, const int n0, const int tid,
                                                      const int HoWo) {
-  float amx = 0.f;   // max |y| over what this thread stores (p.amax_out)
+  float amx = 0.f, asum = 0.f, acnt = 0.f;   // max |y| / sum |y| / count over what this thread stores (p.amax_out)
   {
     float* ct = lds;  // [BM][BN]
     constexpr int C4 = BN / 4, RPP = 256 / C4;
@@ -185,7 +187,8 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
           }
           if (p.amax_out) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) amx = fmaxf(amx, e < nv ? fabsf(v[e]) : 0.f);
+            for (int e = 0; e < 4; e++) { const float av = e < nv ? fabsf(v[e]) : 0.f; amx = fmaxf(amx, av); asum += av; }
+            acnt += (float)nv;
           }
           if (p.io & IO_Y) {  // y is a bf16 tensor: round to nearest even, nothing else is written
             unsigned short* yh = (unsigned short*)p.y + oidx[g];
@@ -213,6 +216,17 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
     const unsigned bits = __builtin_bit_cast(unsigned, amx);
     if ((tid & 63) == 0 && amx > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       atomicMax(p.amax_out, bits);
+    // mean |y| from a SAMPLE of the tiles (every 64th block; atomics on the two cache lines of a slot serialise at the L2:
+    // one per wave of EVERY block doubled the time of the large launches)
+    if (p.amax_stats && (blockIdx.x & 63) == 0) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { asum += __shfl_xor(asum, o, 64); acnt += __shfl_xor(acnt, o, 64); }
+      if ((tid & 63) == 0 && acnt > 0.f) {
+        const int k = (blockIdx.x >> 6) & 15;
+        atomicAdd((float*)p.amax_out + 1 + k, asum);
+        atomicAdd((float*)p.amax_out + 17 + k, acnt);
+      }
+    }
   }
 }
 
@@ -1448,15 +1462,26 @@ __device__ __forceinline__ void block_amax_commit(float m, unsigned* __restrict_
 }
 
 // out[0] = max(out[0], max |x[i] * rowscale[(i / inner) % rows]|) as a float (non-negative floats order like their bits)
+template <bool STATS>  // STATS: out is a 33-float slot, sum |x| and count of every 16th block's share added to it (see ConvP.amax_stats)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, const long n4, const float* __restrict__ rowscale,
                                                    const long inner4, const int rows, unsigned* __restrict__ out) {
-  float m = 0.f;
+  float m = 0.f, sum = 0.f, cnt = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const f32x4 v = ((const f32x4*)x)[i];
     const float rs = rowscale ? fabsf(rowscale[(i / inner4) % rows]) : 1.f;
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * rs);
+    if (STATS) { sum += ((fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]))) * rs; cnt += 4.f; }
   }
   block_amax_commit(m, out);
+  if (STATS && (blockIdx.x & 15) == 0) {   // the grid-stride loop gives every block a share spread over the whole tensor
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+    if ((threadIdx.x & 63) == 0 && cnt > 0.f) {
+      const int k = (blockIdx.x >> 4) & 15;
+      atomicAdd((float*)out + 1 + k, sum);
+      atomicAdd((float*)out + 17 + k, cnt);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __restrict__ x, unsigned short* __restrict__ pl,
@@ -1536,7 +1561,7 @@ struct PackDesc { long src_off, dst_off; int Cout, K, unit0, pad; };
 template <int KT, int BN, int NS>
 __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, const unsigned short* __restrict__ wpl,
                                                               const long wpl_stride) {
-  float amx = 0.f;   // max |y| over what this thread stores (p.amax_out)
+  float amx = 0.f, asum = 0.f, acnt = 0.f;   // max |y| / sum |y| / count over what this thread stores (p.amax_out)
   constexpr int TN = BN / 32;
   constexpr int PIECES = KT * NS * TN;       // 1 KiB DMA pieces per panel: [kt][plane][32-column block]
   constexpr int BBUF = PIECES * 1024;
@@ -1681,7 +1706,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
         }
-        if (p.amax_out) amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        if (p.amax_out) {
+          amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+          asum += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
+          acnt += 4.f;
+        }
         *(f32x4*)(p.y + (long)m * p.Cout + c) = f32x4{v[0], v[1], v[2], v[3]};
       }
     }
@@ -1692,6 +1721,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
     const unsigned bits = __builtin_bit_cast(unsigned, amx);
     if ((threadIdx.x & 63) == 0 && amx > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       atomicMax(p.amax_out, bits);
+    if (p.amax_stats && (blockIdx.x & 63) == 0) {   // a sample of the row blocks, as in conv_epilogue_finish
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { asum += __shfl_xor(asum, o, 64); acnt += __shfl_xor(acnt, o, 64); }
+      if ((threadIdx.x & 63) == 0 && acnt > 0.f) {
+        const int k = (blockIdx.x >> 6) & 15;
+        atomicAdd((float*)p.amax_out + 1 + k, asum);
+        atomicAdd((float*)p.amax_out + 17 + k, acnt);
+      }
+    }
   }
 }
 
@@ -1836,6 +1874,94 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const float* __restrict_
   if (unit >= n_units) return;
   const PackDesc d = descs[unit_desc[unit]];
   pack_unit(base + d.src_off, dst + d.dst_off, plane_stride, d.Cout, d.K, unit - d.unit0, threadIdx.x & 63);
+}
+
+// ---- fp16 two-term planes (the default arithmetic of mode 3) of EVERY weight matrix of a model, once per optimiser / EMA
+// step like pack_many_kernel: launch 1 reduces max |w| per matrix into stat[2 d] (one conditional atomic per 1 KiB unit),
+// launch 2 derives the matrix's power-of-two scale from it, leaves it in stat[2 d + 1] and writes the planes of w * scale.
+__device__ __forceinline__ void load_pack_unit(const float* __restrict__ w, int Cout, int K, int unit, int lane, f32x4& v0, f32x4& v1) {
+  const int nb32 = (Cout + 31) >> 5;
+  const int step = unit / nb32, blk = unit - step * nb32;
+  const int r = lane >> 1, h = lane & 1;
+  const int n = blk * 32 + r;
+  const int lh = h ^ ((r >> 3) & 1);
+  v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+  v1 = v0;
+  if (n < Cout) {
+    const float* src = w + (long)n * K + step * 16 + lh * 8;
+    v0 = ldg4(src);
+    v1 = ldg4(src + 4);
+  }
+}
+
+__device__ __forceinline__ void load_flip_unit(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int KH, int KW,
+                                               int Cin, int unit, int lane, f32x4& v0, f32x4& v1) {
+  const int nb32 = (Cin + 31) >> 5;
+  const int step = unit / nb32, blk = unit - step * nb32;
+  const int r = lane >> 1, h = lane & 1;
+  const int ci = blk * 32 + r;
+  const int lh = h ^ ((r >> 3) & 1);
+  const int k0 = step * 16 + lh * 8;
+  const int ft = k0 / Cout, co0 = k0 - ft * Cout;
+  const int tap = KH * KW - 1 - ft;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int co = co0 + j;
+    v[j] = ci < Cin ? w[((long)co * KH * KW + tap) * Cin + ci] * (scale ? scale[co] : 1.f) : 0.f;
+  }
+  v0 = f32x4{v[0], v[1], v[2], v[3]};
+  v1 = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+__device__ __forceinline__ void unit_amax_commit(const f32x4 v0, const f32x4 v1, unsigned* __restrict__ out) {
+  float m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                  fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const unsigned bits = __builtin_bit_cast(unsigned, m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f && bits > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, bits);
+}
+
+__device__ __forceinline__ void store_unit_f16(const f32x4 v0, const f32x4 v1, const float s, unsigned short* __restrict__ dst,
+                                               long plane_stride, int unit, int lane) {
+  uint2 o0[2], o1[2];
+  split4h(v0, s, o0);
+  split4h(v1, s, o1);
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+    *(uint4*)(dst + q * plane_stride + (long)unit * 512 + lane * 8) = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
+}
+
+template <bool PACK>  // false: the reduction launch, true: the packing launch
+__global__ __launch_bounds__(256) void pack_many_f16_kernel(const float* __restrict__ base, unsigned short* __restrict__ dst,
+                                                            long plane_stride, const PackDesc* __restrict__ descs,
+                                                            const int* __restrict__ unit_desc, int n_units, float* __restrict__ stat) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (unit >= n_units) return;
+  const int di = unit_desc[unit];
+  const PackDesc d = descs[di];
+  f32x4 v0, v1;
+  load_pack_unit(base + d.src_off, d.Cout, d.K, unit - d.unit0, lane, v0, v1);
+  if (!PACK) { unit_amax_commit(v0, v1, (unsigned*)stat + 2 * di); return; }
+  const float s = f16_scale_of(stat[2 * di]);
+  if (unit == d.unit0 && lane == 0) stat[2 * di + 1] = s;
+  store_unit_f16(v0, v1, s, dst + d.dst_off, plane_stride, unit - d.unit0, lane);
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void pack_flip_many_f16_kernel(const FlipDesc* __restrict__ descs, const int* __restrict__ unit_desc,
+                                                                 int n_units, float* __restrict__ stat) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (unit >= n_units) return;
+  const int di = unit_desc[unit];
+  const FlipDesc d = descs[di];
+  f32x4 v0, v1;
+  load_flip_unit(d.w, d.scale, d.Cout, d.KH, d.KW, d.Cin, unit - d.unit0, lane, v0, v1);
+  if (!PACK) { unit_amax_commit(v0, v1, (unsigned*)stat + 2 * di); return; }
+  const float s = f16_scale_of(stat[2 * di]);
+  if (unit == d.unit0 && lane == 0) stat[2 * di + 1] = s;
+  store_unit_f16(v0, v1, s, d.dst, d.plane_stride, unit - d.unit0, lane);
 }
 
 // ------------------------------------------------------------------------------------ weight gradient
@@ -2627,6 +2753,7 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.f16_sx = p.f16_sw = nullptr;
   p.f16_ax = 0;
   p.amax_out = (unsigned*)a->y_amax;
+  p.amax_stats = a->y_amax_stats;
   p.io = a->io_bf16;
   if (p.io & ~(IO_X | IO_Y | IO_RES | IO_MASK | IO_DY)) return MMT_EINVAL;
   if (p.io & IO_X) {  // x itself is the (only) bf16 plane: the all-planes kernels with one term
@@ -2976,6 +3103,36 @@ extern "C" int mmt_pack_weights(const float* base, void* planes, long plane_stri
   return 0;
 }
 
+// the two fp16 planes of w * s_d for every matrix d of the table (see pack_many_f16_kernel); stat[2 d] <- max |w_d|,
+// stat[2 d + 1] <- s_d (what mmt_conv_forward_f16x2 / mmt_conv3x3_strip_f16x2 take as s_w)
+extern "C" int mmt_pack_weights_f16(const float* base, void* planes, long plane_stride, const mmt_pack_desc* descs,
+                                    const int* unit_desc, int n_units, int n_descs, float* stat, void* stream) {
+  if (!base || !planes || !descs || !unit_desc || !stat || (plane_stride & 7) || ((size_t)planes & 15)) return MMT_EINVAL;
+  if (n_units <= 0 || n_descs <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(stat, 0, (size_t)n_descs * 2 * sizeof(float), s) != hipSuccess) return MMT_EINVAL;
+  hipLaunchKernelGGL(pack_many_f16_kernel<false>, dim3((n_units + 3) / 4), dim3(256), 0, s, base, (unsigned short*)planes, plane_stride,
+                     (const PackDesc*)descs, unit_desc, n_units, stat);
+  hipLaunchKernelGGL(pack_many_f16_kernel<true>, dim3((n_units + 3) / 4), dim3(256), 0, s, base, (unsigned short*)planes, plane_stride,
+                     (const PackDesc*)descs, unit_desc, n_units, stat);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_pack_weights_flipped_f16(const mmt_flip_desc* descs, const int* unit_desc, int n_units, int n_descs, float* stat,
+                                            void* stream) {
+  if (!descs || !unit_desc || !stat) return MMT_EINVAL;
+  if (n_units <= 0 || n_descs <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(stat, 0, (size_t)n_descs * 2 * sizeof(float), s) != hipSuccess) return MMT_EINVAL;
+  hipLaunchKernelGGL(pack_flip_many_f16_kernel<false>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const FlipDesc*)descs, unit_desc,
+                     n_units, stat);
+  hipLaunchKernelGGL(pack_flip_many_f16_kernel<true>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const FlipDesc*)descs, unit_desc,
+                     n_units, stat);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- experiment: 3x3 convolution on the tap-strip kernel with a two-term fp16 split (3 products instead of 6)
 // amax[0] = max(amax[0], max |x * rowscale|) (amax zeroed by the caller); rowscale indexes rows of `inner` elements
 extern "C" int mmt_amax(const float* x, long n, const float* rowscale, long inner, int rows, float* amax, void* stream) {
@@ -2983,8 +3140,20 @@ extern "C" int mmt_amax(const float* x, long n, const float* rowscale, long inne
   if (n == 0) return 0;
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(amax_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n / 4, rowscale, rowscale ? inner / 4 : 1,
+  hipLaunchKernelGGL(amax_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n / 4, rowscale, rowscale ? inner / 4 : 1,
                      rowscale ? rows : 1, (unsigned*)amax);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same reduction into a 33-float statistics slot (zeroed by the caller): slot[0] = max |x|, slot[1..32] = partial sums of |x|
+extern "C" int mmt_amax_stats(const float* x, long n, float* slot, void* stream) {
+  if (!x || !slot || n < 0 || (n & 3) || ((size_t)x & 15)) return MMT_EINVAL;
+  if (n == 0) return 0;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(amax_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n / 4, (const float*)nullptr, 1L, 1,
+                     (unsigned*)slot);
   MMT_LAUNCH_CHECK();
   return 0;
 }

@@ -292,6 +292,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(const LT* __restrict__ label
   __shared__ SelShared sh;
   __shared__ unsigned long long list[CAP];
   __shared__ int npos_s, nneg_s, nl_s;
+  __shared__ unsigned long long lmin_s;
   const int img = blockIdx.x, tid = threadIdx.x;
   const int o0 = off[img], n = off[img + 1] - o0;
   const LT* lab = labels + o0;
@@ -325,9 +326,20 @@ __global__ __launch_bounds__(NT) void sample_kernel(const LT* __restrict__ label
       }
     __syncthreads();
     const int nl = nl_s;
-    if (nl >= num && nl <= CAP) {
+    if (nl > num && nl <= CAP) {
       auto lk = [&](int j) -> unsigned long long { return list[j]; };
       return block_select(lk, nl, num, sh);
+    }
+    if (nl == num && nl <= CAP) {
+      // exactly `num` members below tau: they ARE the sample, and the threshold is the smallest key of the list
+      // (block_select's "<= k candidates: everything" answer would be read against ALL members of the class below)
+      if (tid == 0) lmin_s = ~0ull;
+      __syncthreads();
+      unsigned long long m = ~0ull;
+      for (int j = tid; j < nl; j += NT) m = list[j] < m ? list[j] : m;
+      if (m != ~0ull) atomicMin(&lmin_s, m);
+      __syncthreads();
+      return lmin_s;
     }
     auto gk = [&](int i) -> unsigned long long { return member(i) ? k64(i) : 0ull; };
     return block_select(gk, n, num, sh);
@@ -364,7 +376,12 @@ extern "C" int mmt_rpn_post_select(const mmt_rpn_post_args* a, void* stream) {
   static_assert(sizeof(mmt_rpn_post_args) == sizeof(RpnPostArgs), "argument layout");
   RpnPostArgs k;
   memcpy(&k, a, sizeof(k));
-  if (k.fpn_post_n < 1 || (!k.training && k.fpn_post_n > 2048) || k.cap < k.fpn_post_n || k.N * k.L > 64) return MMT_EINVAL;
+  // bad_rank[] holds one entry per segment of a block: all N * L segments in training (one block), L per image in inference
+  // capacity: an image can receive at most L * post entries of the selection (the caller adds room for its gt boxes)
+  const int post = k.post_n > 0 && k.post_n < k.kmax ? k.post_n : k.kmax;
+  const int per_image = k.fpn_post_n < k.L * post ? k.fpn_post_n : k.L * post;
+  if (k.fpn_post_n < 1 || (!k.training && k.fpn_post_n > 2048) || k.cap < per_image || (k.training && k.N * k.L > 64))
+    return MMT_EINVAL;
   hipLaunchKernelGGL(rpn_post_kernel, dim3(k.training ? 1 : k.N), dim3(NT), 0, (hipStream_t)stream, k);
   MMT_LAUNCH_CHECK();
   return 0;

@@ -30,7 +30,7 @@ class ConvArgs(ctypes.Structure):
                 ("mask_scale", c_float), ("w_planes", c_void_p), ("w_plane_stride", ctypes.c_long),
                 ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long),
                 ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long), ("io_bf16", c_int), ("y_amax", c_void_p),
-                ("f16_x_amax", c_void_p), ("f16_dy_amax", c_void_p)]
+                ("f16_x_amax", c_void_p), ("f16_dy_amax", c_void_p), ("y_amax_stats", c_int)]
 
 
 IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
@@ -90,6 +90,8 @@ _SIGS = {
     "mmt_conv_wants_planes": [ctypes.POINTER(ConvArgs)],
     "mmt_pack_weights": [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p],
     "mmt_pack_weights_flipped": [c_void_p, c_void_p, c_int, c_void_p],
+    "mmt_pack_weights_f16": [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "mmt_pack_weights_flipped_f16": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "mmt_pack_weight_flipped": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_conv_wgrad_splits": [ctypes.POINTER(ConvArgs)],
     "mmt_conv_wgrad": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -97,6 +99,7 @@ _SIGS = {
     "mmt_weight_flip_transpose": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_amax": [c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p],
+    "mmt_amax_stats": [c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_flipped_f16": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
@@ -129,34 +132,153 @@ AUTO_PLANES = os.environ.get("MMT_AUTO_PLANES", "1") != "0"
 _BF16_STORAGE = os.environ.get("MMT_BF16_STORAGE", "0") != "0"
 
 
-# EXPERIMENT (opt-in, MMT_F16X2=1): 3x3 convolutions that run on the tap-strip kernel take a TWO-term fp16
-# split of both operands (3 matrix products per multiply instead of 6), each tensor scaled by a power of two derived on the
-# device from its largest magnitude.  Error against fp64 no larger than the shipped 3-term bf16 split's (tools/bench_f16x2.py).
-F16X2 = os.environ.get("MMT_F16X2", "0") != "0"
+# DEFAULT arithmetic of mode 3 since round 3 (MMT_F16X2=0 / set_f16x2(False) selects the 3-term bf16 split, which is also the
+# per-tensor fall-back): convolutions take a TWO-term fp16 split of both operands (3 matrix products per
+# multiply instead of 6), each tensor scaled by a power of two derived on the device from its largest magnitude.  Error
+# against fp64 no larger than the 3-term bf16 split's (tools/bench_f16x2.py, profiles/r03_precision_f16x2.txt).
+F16X2_DEFAULT = os.environ.get("MMT_F16X2", "1") != "0"
+F16X2 = F16X2_DEFAULT
 F16X2_TILED = os.environ.get("MMT_F16X2_TILED", "1") != "0"   # also the tiled kernel (1x1, small-map 3x3, fc), not only the strip kernel
 F16X2_DELAYED = os.environ.get("MMT_F16X2_DELAYED", "0") != "0"   # scale from the previous tensor of the role (one pass less)
-F16_STATS = {"wgrad": 0, "conv": 0, "tiled": 0, "amax_pass": 0}   # launches that took the fp16 path (tools, tests)
+F16_STATS = {"wgrad": 0, "conv": 0, "tiled": 0, "amax_pass": 0, "fallback": 0, "weight_pack": 0}   # launches that took the fp16 path (tools, tests)
+WGRAD_F16_MIN_ELEMS = int(os.environ.get("MMT_WGRAD_F16_MIN", str(1 << 22)))
 _F16W = {}   # weight address -> (key, planes, device scale)
 
 
 def set_f16x2(on):
+    """True / False; None restores the process default (MMT_F16X2, on unless set to 0)"""
     global F16X2
-    F16X2 = bool(on)
+    F16X2 = F16X2_DEFAULT if on is None else bool(on)
     _F16W.clear()
     _F16SITE.clear()
+    _SITES.clear()
 
 
-_AMAX_POOL = {}   # (device, stream) -> [zeroed float tensor, next free index]: slots for the producers' max |y|
+# ---- per-tensor statistics of the fp16 split: every producing launch records max |y| AND sum |y| of its output in a slot of
+# a device pool (mmt_conv_args.y_amax / y_amax_stats; tensors that come from elsewhere take one mmt_amax_stats pass).  The
+# maximum gives the consumer its power-of-two scale on the device, with no host round trip.  max / mean -- the crest factor
+# -- tells whether fp16's 5 exponent bits can hold the tensor at all: when one element is 10^8 x the rest, everything else
+# falls below the range of the low term (outputs built only from such values then carry 2e-5 instead of 2e-6 of sum |a||b|,
+# profiles/r02_precision_f16x2.txt).  That decision needs the host (it picks the kernel), so it is LAGGED: a full pool is
+# copied to pinned memory asynchronously, each consuming site (a weight, forward or data-gradient form) looks at the
+# statistics of one of its recent input tensors when they have arrived, and falls back to the 3-term bf16 split -- exact
+# for any dynamic range -- from then on, until the crest factor is back below F16_CREST_LO.  No call ever waits.
+STAT_W = 40            # floats per slot: [0] max |x|, [1..16] sums of |x| over a sample, [17..32] the sample's counts, padding
+_POOL_SLOTS = 2048     # ~6 steps of the detector
+F16_CREST_HI, F16_CREST_LO = 2.0 ** 17, 2.0 ** 15
+
+
+class _StatPool(object):
+    __slots__ = ("dev", "host", "event", "next", "gen", "host_gen", "base")
+
+    def __init__(self, device):
+        self.dev = torch.zeros((_POOL_SLOTS, STAT_W), dtype=torch.float32, device=device)
+        self.host = torch.zeros((_POOL_SLOTS, STAT_W), dtype=torch.float32).pin_memory()
+        self.event, self.next, self.gen, self.host_gen = None, 0, 0, -1
+        self.base = self.dev.data_ptr()
+
+    def retire(self):
+        """full: its statistics travel to the host (asynchronously, on the stream that filled it)"""
+        self.host.copy_(self.dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.host_gen = self.gen
+
+    def reuse(self):
+        if self.event is not None:
+            self.event.synchronize()   # two rotations later: long done
+        self.dev.zero_()
+        self.gen += 1
+        self.next = 0
+
+
+_AMAX_POOL = {}   # (device, stream) -> [ring of 3 pools, index of the current one]
+_SITES = {}       # consuming site -> [fp16 split allowed, pending (pool, generation, slot, numel) or None]
+
+
+class _Slot(object):
+    """one zeroed statistics slot of a pool: what a launch is handed as y_amax and what `tensor._mmt_amax[0]` holds (anything
+    with a data_ptr() works there: tests attach plain one-element tensors)"""
+    __slots__ = ("ptr", "pool", "gen", "idx")
+
+    def __init__(self, pool, idx):
+        self.pool, self.gen, self.idx = pool, pool.gen, idx
+        self.ptr = pool.base + idx * (4 * STAT_W)
+
+    def data_ptr(self):
+        return self.ptr
 
 
 def _amax_slot(device):
+    """-> a zeroed statistics slot of the current pool of this (device, stream)"""
     key = (str(device), _stream())
     ent = _AMAX_POOL.get(key)
-    if ent is None or ent[1] >= ent[0].numel():
-        ent = _AMAX_POOL[key] = [torch.zeros((4096,), dtype=torch.float32, device=device), 0]
-    i = ent[1]
-    ent[1] = i + 1
-    return ent[0][i:i + 1]
+    if ent is None:
+        ent = _AMAX_POOL[key] = [[_StatPool(device)], 0]
+    pool = ent[0][ent[1]]
+    if pool.next >= _POOL_SLOTS:
+        pool.retire()
+        ent[1] = (ent[1] + 1) % 3
+        if ent[1] >= len(ent[0]):
+            ent[0].append(_StatPool(device))
+        pool = ent[0][ent[1]]
+        if pool.next:
+            pool.reuse()
+    i = pool.next
+    pool.next = i + 1
+    return _Slot(pool, i)
+
+
+def f16_flush_stats():
+    """tests / tools: send the statistics recorded so far to the host now (a pool normally travels when it is full)"""
+    torch.cuda.synchronize()
+    for ent in _AMAX_POOL.values():
+        pool = ent[0][ent[1]]
+        if pool.next:
+            pool.retire()
+            pool.next = _POOL_SLOTS   # nothing more goes into this generation
+    torch.cuda.synchronize()
+
+
+def _site_ok(site, x):
+    """may the consumer `site` take `x` on the two-term fp16 split?  (lagged crest-factor test, see above)"""
+    ent = _SITES.get(site)
+    if ent is None:
+        ent = _SITES[site] = [True, None]
+    pend = ent[1]
+    if pend is not None:
+        pool, gen = pend.pool, pend.gen
+        if pool.host_gen == gen:
+            if pool.event.query():
+                row = pool.host[pend.idx]
+                amax, tot, cnt = float(row[0]), float(row[1:17].sum()), float(row[17:33].sum())
+                if tot > 0.0:
+                    crest = amax * cnt / tot if amax == amax and amax != float("inf") else float("inf")
+                    if crest > F16_CREST_HI:
+                        ent[0] = False
+                    elif crest < F16_CREST_LO:
+                        ent[0] = True
+                ent[1] = None
+        elif pool.gen > gen + 1:
+            ent[1] = None    # overwritten before anybody looked
+    if ent[1] is None:
+        am = getattr(x, "_mmt_amax", None)
+        if am is not None and am[1] == x._version and type(am[0]) is _Slot:
+            ent[1] = am[0]
+    if not ent[0]:
+        F16_STATS["fallback"] = F16_STATS.get("fallback", 0) + 1
+    return ent[0]
+
+
+def _amax_of(x):
+    """the recorded (statistics slot, version) of x, taking one reduction pass when nobody recorded it"""
+    am = getattr(x, "_mmt_amax", None)
+    if am is None or am[1] != x._version:
+        F16_STATS["amax_pass"] += 1
+        slot = _amax_slot(x.device)
+        _check(lib().mmt_amax_stats(x.data_ptr(), x.numel(), slot.ptr, _stream()), "mmt_amax_stats")
+        am = x._mmt_amax = (slot, x._version)
+    return am
 
 
 _F16SITE = {}   # role of a tensor (consumer weight address, flipped) -> [device state (scale, a0, a1, a2), calls so far]
@@ -179,16 +301,19 @@ def f16_split(x, site=None):
                                           None, None, _stream()), "mmt_split_planes_f16")
         return xp, st
     ent = _F16SITE.get(site) if site is not None else None
+    if ent is None and site is None:
+        am = _amax_of(x)   # one reduction pass; other consumers of this tensor (its weight gradient) then need none of their own
+        st = torch.empty((1,), dtype=torch.float32, device=x.device)
+        _check(lib().mmt_split_planes_f16(x.data_ptr(), xp.data_ptr(), xp.stride(0), n, 1.0, am[0].data_ptr(), st.data_ptr(),
+                                          None, None, _stream()), "mmt_split_planes_f16")
+        return xp, st
     if ent is None:
         F16_STATS["amax_pass"] += 1
         st = torch.zeros((4,), dtype=torch.float32, device=x.device)
         _check(lib().mmt_amax(x.data_ptr(), n, None, 0, 0, st.data_ptr() + 4, _stream()), "mmt_amax")
         _check(lib().mmt_split_planes_f16(x.data_ptr(), xp.data_ptr(), xp.stride(0), n, 1.0, st.data_ptr() + 4, st.data_ptr(),
                                           None, None, _stream()), "mmt_split_planes_f16")
-        if site is not None:
-            _F16SITE[site] = [st, 1]
-        else:
-            x._mmt_amax = (st[1:2], x._version)   # other consumers of this tensor (its weight gradient) need no pass of their own
+        _F16SITE[site] = [st, 1]
         return xp, st
     st, k = ent
     base = st.data_ptr() + 4
@@ -199,27 +324,50 @@ def f16_split(x, site=None):
 
 
 def f16_weight_planes(w, flip_scale=None, flipped=False):
-    """packed fp16 planes (+ device scale) of a forward weight, or of its data-gradient form (taps flipped, transposed,
-    rows scaled by flip_scale); cached until the weight (or the scale vector) is modified"""
+    """packed fp16 planes + a one-element device view holding their scale, of a forward weight or of its data-gradient form
+    (taps flipped, transposed, rows scaled by flip_scale).  Parameters of a flattened model (engine/flat.py) are packed in
+    bulk after every SGD / EMA step (raw-pointer updates that no version counter sees) and only looked up here; anything else
+    is packed per call and cached until the tensor (or the scale vector) is modified."""
+    ptr = w.data_ptr()
+    ent = PLANES.get(ptr)
+    flat = ent[0]() if ent is not None else None
+    gen = None
+    if flat is not None and ent[2] == w.numel():
+        gen = flat.plane_gen
+        if flat.plane_versions.get(ptr) == w._version and flat.plane_epoch >= PLANES_EPOCH:
+            if flipped:
+                hit = flat.flipped16(w, flip_scale)
+                if hit is not None:
+                    return hit
+            elif flat.f16_gen == gen and len(ent) > 3:
+                hit = flat.views16.get(ptr)   # the views never change: planes16 / stat16 are allocated once
+                if hit is None:
+                    n = packed_elems(w.shape[0], w.numel() // w.shape[0])
+                    hit = flat.views16[ptr] = (flat.planes16[:, ent[1]:ent[1] + n], flat.stat16[ent[3], 1:2])
+                return hit
     # valid for THIS tensor object only (an address is reused by the allocator; parameters are long-lived objects)
-    key = (w._version, tuple(w.shape), _p(flip_scale), None if flip_scale is None else flip_scale._version, PLANES_EPOCH)
-    hit = _F16W.get((w.data_ptr(), flipped))
+    key = (w._version, tuple(w.shape), _p(flip_scale), None if flip_scale is None else flip_scale._version, PLANES_EPOCH, gen)
+    hit = _F16W.get((ptr, flipped))
     if hit is not None and hit[0] == key and hit[3]() is w:
-        return hit[1], hit[2]
+        return hit[1], hit[2][1:2]
     Cout, Cin, KH, KW = w.shape
     am = torch.zeros((2,), dtype=torch.float32, device=w.device)
     K = Cin * KH * KW
+    F16_STATS["weight_pack"] = F16_STATS.get("weight_pack", 0) + 1
     _check(lib().mmt_amax(w.data_ptr(), w.numel(), _p(flip_scale) if flipped else None, K, Cout, am.data_ptr(), _stream()), "mmt_amax")
     if flipped:
         pl = torch.empty((2, packed_elems(Cin, KH * KW * Cout)), dtype=torch.float16, device=w.device)
         _check(lib().mmt_pack_weight_flipped_f16(w.data_ptr(), _p(flip_scale), pl.data_ptr(), pl.stride(0), Cout, KH, KW, Cin,
                                                  am.data_ptr(), am.data_ptr() + 4, _stream()), "mmt_pack_weight_flipped_f16")
+        if flat is not None and gen is not None and flat.plane_versions.get(ptr) == w._version:
+            # from the next optimiser step on these planes follow the parameters in the bulk launch (engine/flat.py)
+            flat.register_flipped16(w, flip_scale, pl, (Cout, KH, KW, Cin))
     else:
         pl = torch.empty((2, packed_elems(Cout, K)), dtype=torch.float16, device=w.device)
         _check(lib().mmt_pack_weight_f16(w.data_ptr(), pl.data_ptr(), pl.stride(0), Cout, K, 1.0, am.data_ptr(), am.data_ptr() + 4,
                                          _stream()), "mmt_pack_weight_f16")
-    _F16W[(w.data_ptr(), flipped)] = (key, pl, am, weakref.ref(w))
-    return pl, am
+    _F16W[(ptr, flipped)] = (key, pl, am, weakref.ref(w))
+    return pl, am[1:2]
 
 
 def set_bf16_storage(on):
@@ -608,8 +756,6 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             f16 = (w, False, None)
         elif f16_src is not None:
             f16 = (nhwc(f16_src[0]), True, f16_src[1])
-    if f16 is not None:
-        x_planes = None
     f16t = None   # the same arithmetic on the tiled DMA kernel (1x1 layers, 3x3 on small maps, fc): x split in registers
     want_amax = False
     if F16X2 and not io and get_conv_precision() == 3:
@@ -622,6 +768,11 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
                 f16t = (w, False, None)
             elif f16_src is not None:
                 f16t = (nhwc(f16_src[0]), True, f16_src[1])
+        sel = f16 if f16 is not None else f16t
+        if sel is not None and not _site_ok((sel[0].data_ptr(), sel[1]), x):
+            f16 = f16t = None   # this input's dynamic range defeats fp16 (lagged crest-factor test): 3-term bf16 split
+    if f16 is not None:
+        x_planes = None
     if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0 and not io:
         y_planes = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=x.device)
         a.y_planes, a.y_plane_stride = y_planes.data_ptr(), y_planes.stride(0)
@@ -649,18 +800,12 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     amax_slot = None
     if want_amax and not io and y_out is None and out_stride == 1:
         amax_slot = _amax_slot(x.device)
-        a.y_amax = amax_slot.data_ptr()
+        a.y_amax, a.y_amax_stats = amax_slot.ptr, 1
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
     if f16t is not None:
-        am = getattr(x, "_mmt_amax", None)
-        if am is None or am[1] != x._version:
-            F16_STATS["amax_pass"] += 1
-            slot = _amax_slot(x.device)
-            _check(lib().mmt_amax(x.data_ptr(), x.numel(), None, 0, 0, slot.data_ptr(), _stream()), "mmt_amax")
-            am = (slot, x._version)
-            x._mmt_amax = am
+        am = _amax_of(x)
         wp16, sw = f16_weight_planes(f16t[0], f16t[2], f16t[1])
         a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
         a.x_planes = None
@@ -669,7 +814,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if rec:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _check(lib().mmt_conv_forward_f16x2(ctypes.byref(a), am[0].data_ptr(), sw.data_ptr() + 4, _stream()), "mmt_conv_forward_f16x2")
+        _check(lib().mmt_conv_forward_f16x2(ctypes.byref(a), am[0].data_ptr(), sw.data_ptr(), _stream()), "mmt_conv_forward_f16x2")
         if rec:
             e1.record()
             PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1,
@@ -691,7 +836,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if rec:
             ev[1].record()
             ev[2].record()
-        _check(lib().mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr() + 4, _stream()),
+        _check(lib().mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), _stream()),
                "mmt_conv3x3_strip_f16x2")
         if rec:
             ev[3].record()
@@ -836,8 +981,14 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
     a.io_bf16 = (IO_X if x.dtype == torch.bfloat16 else 0) | (IO_DY if dy.dtype == torch.bfloat16 else 0)
     if F16X2 and not a.io_bf16 and Cout % 4 == 0 and get_conv_precision() == 3:
         ax, ad = getattr(x, "_mmt_amax", None), getattr(dy, "_mmt_amax", None)
-        if ax is not None and ad is not None and ax[1] == x._version and ad[1] == dy._version:
-            # both operands carry their recorded maximum: two-term fp16 split (3 products instead of 6), no extra pass
+        big = N * H * W * Cin >= WGRAD_F16_MIN_ELEMS   # where 3 products instead of 6 pay for a reduction pass over an operand
+        if big and (ax is None or ax[1] != x._version):
+            ax = _amax_of(x)
+        if big and (ad is None or ad[1] != dy._version):
+            ad = _amax_of(dy)
+        if (ax is not None and ad is not None and ax[1] == x._version and ad[1] == dy._version
+                and _site_ok(("wgx", dw.data_ptr()), x) and _site_ok(("wgd", dw.data_ptr()), dy)):
+            # both operands carry their recorded maximum: two-term fp16 split (3 products instead of 6)
             a.f16_x_amax, a.f16_dy_amax = ax[0].data_ptr(), ad[0].data_ptr()
             F16_STATS["wgrad"] += 1
     splits = lib().mmt_conv_wgrad_splits(ctypes.byref(a))

@@ -70,6 +70,21 @@ def allreduce_gradients(flat):
             flat.grad.mul_(1.0 / ws)
 
 
+def sync_touched(flat):
+    """Which parameters "have a gradient" this step must be the same on every rank: the all-reduce hands every rank the same
+    averaged gradient, but `flat.touched` (what FlatSGD.step updates, torch SGD's `p.grad is None: continue`) is filled by
+    THIS rank's backward nodes.  A rank whose teacher found no boxes skipped the consistency branch and never touched the
+    hint adaptors while the others did; updating them on some ranks only would let the students -- and with them the EMA
+    teachers -- drift apart for good.  The update set is therefore the UNION over ranks: one MAX all-reduce of
+    a per-parameter flag vector (a few hundred bytes) and one read-back, only when there is somebody to differ from."""
+    if get_world_size() < 2:
+        return
+    names = [n for n, (o, _) in sorted(flat.index.items(), key=lambda kv: kv[1][0]) if o < flat.n_trainable]
+    flags = torch.tensor([1 if n in flat.touched else 0 for n in names], dtype=torch.int32, device=flat.grad.device)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    flat.touched.update(n for n, f in zip(names, flags.tolist()) if f)
+
+
 class BucketedAllReduce(object):
     """The same exchange, started while the backward pass is still running.  The flat gradient is cut at the stage
     boundaries of the backbone ([layer2 | layer3 | layer4 | FPN + heads]: the weights region of engine/flat.py is in
@@ -328,6 +343,7 @@ class MTtrainer(object):
                 bucketed.finish()
         if bucketed is None:
             allreduce_gradients(self.flat_s)
+        sync_touched(self.flat_s)
         self.optimizer.step()
         if self.lambda_value > 0 and iteration > (self.start_mt - 10):
             self.update_teacher(iteration - (self.start_mt - 10))

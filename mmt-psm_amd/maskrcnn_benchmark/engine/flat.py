@@ -56,6 +56,9 @@ class FlatParams(object):
                 H.GRAD_SLOTS[p.grad.data_ptr()] = (me, n)
                 p.register_post_accumulate_grad_hook(lambda q, n=n, me=me: me() is not None and me().touched.add(n))
         self.planes = None
+        self.planes16 = self.stat16 = None   # fp16 two-term planes of the same matrices + (max, scale) per matrix
+        self.f16_gen = -1
+        self.views16 = {}                    # weight address -> (its slice of planes16, its scale in stat16)
         self.plane_versions = {}
         self.plane_epoch = -1
         self.plane_gen = 0
@@ -83,7 +86,7 @@ class FlatParams(object):
                 elems = H.packed_elems(cout, k)
                 descs.append(struct.pack("qqiiii", o, off, cout, k, unit0, 0))
                 unit_desc += [len(descs) - 1] * (elems // 512)
-                H.PLANES[p.data_ptr()] = (weakref.ref(self), off, p.numel())
+                H.PLANES[p.data_ptr()] = (weakref.ref(self), off, p.numel(), len(descs) - 1)
                 off += elems
                 unit0 += elems // 512
             dev = self.data.device
@@ -91,7 +94,20 @@ class FlatParams(object):
             self._pack_descs = torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev)
             self._pack_units = torch.tensor(unit_desc, dtype=torch.int32, device=dev)
             self._n_units = unit0
+            self._n_descs = len(descs)
+            self.planes16 = self.stat16 = None
+            self.views16 = {}
         H.pack_weights(self.data, self.planes, self._pack_descs, self._pack_units, self._n_units)
+        if H.F16X2 and H.get_conv_precision() == 3 and self._n_descs:
+            # the default arithmetic's form of the same matrices: two fp16 planes of w * s, s per matrix from its maximum
+            # (reduction launch + packing launch over the same tables); stat16[d] = (max |w_d|, s_d)
+            if self.planes16 is None:
+                self.planes16 = torch.empty((2, self.planes.shape[1]), dtype=torch.float16, device=self.data.device)
+                self.stat16 = torch.zeros((self._n_descs, 2), dtype=torch.float32, device=self.data.device)
+            H._check(H.lib().mmt_pack_weights_f16(self.data.data_ptr(), self.planes16.data_ptr(), self.planes16.stride(0),
+                                                  self._pack_descs.data_ptr(), self._pack_units.data_ptr(), self._n_units,
+                                                  self._n_descs, self.stat16.data_ptr(), H._stream()), "mmt_pack_weights_f16")
+            self.f16_gen = self.plane_gen
         self.plane_versions = {p.data_ptr(): p._version for _, p in self._named if p.dim() >= 2}
         self.plane_epoch = H.PLANES_EPOCH
         self._repack_flipped()
@@ -103,8 +119,53 @@ class FlatParams(object):
             ent[w.data_ptr()] = (w, scale, planes, dims)
             self._flip_table = None
 
+    def register_flipped16(self, w, scale, planes, dims):
+        """the same for the fp16 two-term planes of a data-gradient weight (default arithmetic of mode 3)"""
+        ent = self.__dict__.setdefault("_flip16_entries", {})
+        if w.data_ptr() not in ent or ent[w.data_ptr()][1] is not scale:
+            ent[w.data_ptr()] = (w, scale, planes, dims)
+            self._flip16_table = None
+
+    def flipped16(self, w, scale):
+        """(planes, scale view) of a registered data-gradient weight packed for THIS parameter generation, or None"""
+        t = self.__dict__.get("_flip16_table")
+        if t is None or self.__dict__.get("_flip16_gen") != self.plane_gen:
+            return None
+        e = self._flip16_entries.get(w.data_ptr())
+        if e is None or e[1] is not scale or e[0] is not w:
+            return None
+        v = t[5].get(w.data_ptr())
+        if v is None:
+            v = t[5][w.data_ptr()] = (e[2], t[4][t[3][w.data_ptr()], 1:2])
+        return v
+
+    def _repack_flipped16(self):
+        from .. import _hip as H
+        ent = self.__dict__.get("_flip16_entries")
+        if not ent or H.get_conv_precision() != 3 or not H.F16X2:
+            return
+        if self.__dict__.get("_flip16_table") is None:
+            import struct
+            descs, unit_desc, unit0, idx = [], [], 0, {}
+            for w, scale, planes, (Cout, KH, KW, Cin) in ent.values():
+                units = planes.shape[1] // 512
+                idx[w.data_ptr()] = len(descs)
+                descs.append(struct.pack("qqqqiiiiii", w.data_ptr(), 0 if scale is None else scale.data_ptr(), planes.data_ptr(),
+                                         planes.stride(0), Cout, KH, KW, Cin, unit0, 0))
+                unit_desc += [len(descs) - 1] * units
+                unit0 += units
+            dev = self.data.device
+            self._flip16_table = (torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev),
+                                  torch.tensor(unit_desc, dtype=torch.int32, device=dev), unit0, idx,
+                                  torch.zeros((len(descs), 2), dtype=torch.float32, device=dev), {})
+        d, u, n, idx, stat, _ = self._flip16_table
+        H._check(H.lib().mmt_pack_weights_flipped_f16(d.data_ptr(), u.data_ptr(), n, len(idx), stat.data_ptr(), H._stream()),
+                 "mmt_pack_weights_flipped_f16")
+        self._flip16_gen = self.plane_gen
+
     def _repack_flipped(self):
         from .. import _hip as H
+        self._repack_flipped16()
         ent = self.__dict__.get("_flip_entries")
         if not ent or H.get_conv_precision() == 0:
             return

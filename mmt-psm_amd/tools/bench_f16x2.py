@@ -24,7 +24,7 @@ def f16x2(x, w, scale, shift, relu, pre=None):
     y = H.empty_nhwc(N, Cout, Hh, W, x.device)
     a.y, a.scale, a.shift, a.relu = y.data_ptr(), H._p(scale), H._p(shift), 1 if relu else 0
     a.x_planes, a.x_plane_stride, a.w_planes, a.w_plane_stride = xp.data_ptr(), xp.stride(0), wp.data_ptr(), wp.stride(0)
-    H._check(L.mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr() + 4, H._stream()), "strip f16x2")
+    H._check(L.mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), H._stream()), "strip f16x2")
     return y, ((xp, sx), (wp, sw))
 g = torch.Generator().manual_seed(0)
 def act(shape): return cl(torch.randn(shape, generator=g).relu_().cuda())                       # post-ReLU activations

@@ -49,3 +49,13 @@ def weights(synth, state_shapes):
 
 def T(a):
     return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(autouse=True)
+def _restore_conv_arithmetic(request):
+    """GPU tests switch the convolution arithmetic (`_hip.set_f16x2`, `set_conv_precision`): the next test starts from
+    the process default again (mode 3 on the two-term fp16 split)"""
+    yield
+    if request.node.get_closest_marker("gpu") is not None and torch.cuda.is_available():
+        from maskrcnn_benchmark import _hip as H
+        H.set_f16x2(None)

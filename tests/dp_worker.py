@@ -148,6 +148,19 @@ def main():
     res["reduced_keys"] = sorted(red)
     MT.BucketedAllReduce._send = orig_send
 
+    # ---- (2b) ADVICE r2: a REAL step (SGD + EMA) with rank 1 skipping its consistency branch.  Rank 1 never touched the hint
+    # adaptors, rank 0 did; the update set is the union over ranks (MTtrainer.sync_touched), so both students move the same
+    if rank == 1:
+        pp.score_thresh = 2.0
+    step(True)
+    pp.score_thresh = thr
+    cs = gathered(torch.stack([MT.teacher_checksum(trainer.flat_t), MT.teacher_checksum(trainer.flat_s)]))
+    res["skip_step_students_equal"] = bool(all(int(c[1]) == int(cs[0][1]) for c in cs))
+    res["skip_step_teachers_equal"] = bool(all(int(c[0]) == int(cs[0][0]) for c in cs))
+    o_, k_ = trainer.flat_s.index["hint_adaptor.adapter_1.weight"]
+    res["skip_step_adaptor_moved"] = bool((trainer.flat_s.data[o_:o_ + k_] != sn[0][o_:o_ + k_]).any())
+    restore(sn)
+
     # ---- (3) a real step: identical students and teachers afterwards, checksum collective passes
     step(True)
     cs = gathered(torch.stack([MT.teacher_checksum(trainer.flat_t), MT.teacher_checksum(trainer.flat_s)]))

@@ -28,6 +28,8 @@ def test_two_rank_train_step_on_one_device(tmp_path):
         assert r["seq_equal_when_skipping"] and r["seq_equal_across_ranks"], r
         assert r["teacher_checksums_equal"] and r["student_checksums_equal"] and r["teacher_moved"], r
         assert r["check_passes"] and r["check_detects_divergence"], r
+        # one rank skipped its consistency branch in a real step: the update set is the union over ranks, nobody drifts
+        assert r["skip_step_students_equal"] and r["skip_step_teachers_equal"] and r["skip_step_adaptor_moved"], r
         assert r["reduced_keys"] == r["skip_keys_dp"], r
     # rank 1 skipped the consistency branch; its loss dict still carries the mt_* keys (zeros) for the logging reduce
     assert "mt_classifier" in res[1]["skip_keys"] and "mt_fg_loss" in res[1]["skip_keys"], res[1]

@@ -1,5 +1,6 @@
-"""The opt-in two-term fp16 split of the tap-strip 3x3 convolutions (include/mmtpsm.h: mmt_conv3x3_strip_f16x2;
-`_hip.set_f16x2(True)` / MMT_F16X2=1): three matrix products per multiply instead of six.
+"""The two-term fp16 split (default arithmetic of mode 3 since round 3; include/mmtpsm.h: mmt_conv3x3_strip_f16x2,
+mmt_conv_forward_f16x2; `_hip.set_f16x2(False)` / MMT_F16X2=0 selects the 3-term bf16 split it falls back to): three matrix
+products per multiply instead of six.
 
   * kernel level, forward and data gradient, every epilogue operand, both strip widths, the split-K form: error against an
     fp64 convolution no larger than the shipped 3-term bf16 split's in the mean (rms <= 1.1 x) and within its own bound
@@ -30,7 +31,7 @@ def hip():
     prev = H.get_conv_precision()
     H.set_conv_precision(3)
     yield H
-    H.set_f16x2(False)
+    H.set_f16x2(None)
     H.set_conv_precision(prev)
 
 
@@ -165,6 +166,50 @@ def test_f16_weight_cache_is_per_tensor_object(hip):
         ys.append(y)
         del w
     H.set_f16x2(False)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 64, 64, 256, 3), (2, 256, 64, 64, 512, 1)])
+def test_fallback_to_bf16x3_when_the_dynamic_range_defeats_fp16(hip, shape):
+    """ONE element 10^8 x the rest (profiles/r02_precision_f16x2.txt's weak spot): every other value sits below the range of
+    the fp16 low term.  The producing side records max and sum |x| per tensor; when the statistics have reached the host
+    the consuming site sees a crest factor max / mean > 2^17 and runs the 3-term bf16 split (bit-identical to
+    set_f16x2(False)) until tensors with an ordinary range come by again.  Strip kernel (3x3) and tiled kernel (1x1)."""
+    H = hip
+    N, C, S, _, Co, k = shape
+    g = torch.Generator().manual_seed(77 + k)
+    x = _inputs("act", (N, C, S, S), g)
+    x[1, 17, 30, 31] = 1.0e8
+    x2 = _inputs("act", (N, C, S, S), g)
+    w = _cl((torch.randn(Co, C, k, k, generator=g) * 0.05).cuda())
+    H.set_f16x2(False)
+    y_ref = H.conv_forward(x, w, None, None, 1, k // 2)
+    H.set_f16x2(True)
+    kind = "conv" if k == 3 else "tiled"
+    c0, f0 = H.F16_STATS[kind], H.F16_STATS["fallback"]
+    y1 = H.conv_forward(x, w, None, None, 1, k // 2)      # nothing known about this site's inputs yet: fp16 split
+    y1b = H.conv_forward(x, w, None, None, 1, k // 2)     # (the site now waits for the statistics of this tensor)
+    assert H.F16_STATS[kind] == c0 + 2 and H.F16_STATS["fallback"] == f0 and not torch.equal(y1, y_ref)
+    assert torch.equal(y1, y1b)
+    H.f16_flush_stats()
+    y2 = H.conv_forward(x, w, None, None, 1, k // 2)
+    assert H.F16_STATS["fallback"] == f0 + 1 and H.F16_STATS[kind] == c0 + 2
+    assert torch.equal(y2, y_ref)                          # the fall-back IS the 3-term bf16 split
+    # what the fall-back buys: outputs that do not see the outlier, against fp64
+    ref = F.conv2d(x[:1].double(), w.double(), None, 1, k // 2)
+    den = F.conv2d(x[:1].double().abs(), w.double().abs(), None, 1, k // 2)
+    e_f16 = ((y1[:1].double() - ref).abs() / den).max().item()
+    e_fb = ((y2[:1].double() - ref).abs() / den).max().item()
+    assert e_fb < 3e-6 and e_fb < e_f16, (e_fb, e_f16)
+    # ordinary tensors again: after their statistics arrive the site returns to the fp16 split
+    H.conv_forward(x2, w, None, None, 1, k // 2)           # still falling back; the amax pass of the fallback-less path is
+    x2._mmt_amax = H._amax_of(x2)                          # not run there, so record the statistics the way a producer would
+    H.conv_forward(x2, w, None, None, 1, k // 2)
+    H.f16_flush_stats()
+    c1 = H.F16_STATS[kind]
+    y3 = H.conv_forward(x2, w, None, None, 1, k // 2)
+    assert H.F16_STATS[kind] == c1 + 1
+    ref3 = F.conv2d(x2[:1].double(), w.double(), None, 1, k // 2)
+    assert (y3[:1].double() - ref3).abs().max().item() < 1e-5 * ref3.abs().max().item()
 
 
 def test_detector_f16x2_vs_oracle(hip):

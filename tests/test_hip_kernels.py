@@ -18,6 +18,15 @@ def hip():
     return _hip
 
 
+@pytest.fixture(params=["f16x2", "bf16x3"])
+def arith(request, hip):
+    """mode 3 in both of its arithmetics: the default two-term fp16 split (3 products) and the three-term bf16 split
+    (6 products) that it falls back to per tensor -- same tolerances"""
+    hip.set_f16x2(request.param == "f16x2")
+    yield request.param
+    hip.set_f16x2(None)
+
+
 def cl(x):  # NCHW cpu tensor -> NHWC-dense cuda tensor
     return x.cuda().contiguous(memory_format=torch.channels_last)
 
@@ -112,7 +121,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_forward_epilogues(hip, case):
+def test_conv_forward_epilogues(hip, arith, case):
     N, Cin, H, W, Cout, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
     if Cin == 12544:
@@ -131,7 +140,7 @@ def test_conv_forward_epilogues(hip, case):
     assert (y2.cpu().double() - ref2).abs().max().item() < 2e-5 * max(scl, 1.0)
 
 
-def test_conv_fpn_residual_modes_and_scatter(hip):
+def test_conv_fpn_residual_modes_and_scatter(hip, arith):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 64, 16, 24, generator=g)
     w = torch.randn(32, 64, 1, 1, generator=g) / 8
@@ -161,7 +170,7 @@ def test_conv_fpn_residual_modes_and_scatter(hip):
 @pytest.mark.parametrize("case", [(2, 128, 20, 24, 128, 3, 1, 1), (2, 256, 24, 24, 128, 1, 2, 0),
                                   (2, 256, 16, 20, 15, 1, 1, 0), (3, 32, 9, 11, 40, 3, 1, 1),
                                   (64, 1024, 1, 1, 12, 1, 1, 0)])
-def test_conv_wgrad_and_dgrad(hip, case):
+def test_conv_wgrad_and_dgrad(hip, arith, case):
     N, Cin, H, W, Cout, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
@@ -358,7 +367,7 @@ MODE_TOL = {0: 1e-5, 3: 1e-5, 2: 6e-5, 1: 2e-2}  # max |err| / max |ref| against
 @pytest.mark.parametrize("case", [(2, 64, 24, 24, 96, 3, 1, 1), (3, 128, 30, 30, 160, 1, 2, 0), (1, 48, 17, 23, 64, 3, 1, 1),
                                   (2, 256, 64, 64, 256, 3, 1, 1), (2, 16, 40, 40, 64, 1, 1, 0), (8, 32, 64, 64, 64, 1, 1, 0),
                                   (300, 1024, 1, 1, 1024, 1, 1, 0), (2, 256, 32, 32, 256, 3, 1, 1), (200, 4096, 1, 1, 256, 1, 1, 0)])
-def test_conv_arithmetic_modes_forward(hip, restore_mode, case):
+def test_conv_arithmetic_modes_forward(hip, restore_mode, arith, case):
     """every arithmetic mode of mmt_conv_forward against fp64, with and without pre-packed weight planes; the 3-term
     split (default) must be as accurate as the fp32-input MFMA"""
     N, Cin, H, W, Cout, k, s, p = case
@@ -384,7 +393,7 @@ def test_conv_arithmetic_modes_forward(hip, restore_mode, case):
                                   (1000, 256, 1, 1, 512, 1, 1, 0), (2, 20, 12, 12, 36, 3, 1, 1), (20, 256, 14, 14, 256, 3, 1, 1),
                                   (2, 32, 40, 40, 64, 3, 2, 1), (2, 32, 40, 36, 64, 3, 2, 1), (3, 64, 16, 12, 128, 3, 1, 1),
                                   (2, 64, 32, 32, 15, 1, 1, 0), (600, 1024, 1, 1, 15, 1, 1, 0), (2, 32, 20, 20, 30, 3, 1, 1)])
-def test_conv_arithmetic_modes_wgrad(hip, restore_mode, case):
+def test_conv_arithmetic_modes_wgrad(hip, restore_mode, arith, case):
     """the three pixel-decode variants of the pipelined kernel are all here: Wo % 4 == 0 (one carried position per
     thread, strides 1 and 2), other Wo >= 8 (one per pixel), and 1 x 1 / tiny maps (divisions); Cout % 4 != 0 (the
     15-channel predictors) takes the element-wise dy loads"""
@@ -413,6 +422,7 @@ def test_conv1x1_rows_kernel(hip, restore_mode, case, residual):
     """1x1 layers with K = 64 / 128 and >= 64k rows run on conv1x1_rows_kernel (one block per 128 rows, all Cout
     panels): bit-identical to the tiled kernel (MMT_ROWS=0), fp32-grade against fp64; ragged M and Cout included"""
     import os
+    hip.set_f16x2(False)   # this kernel and the tiled kernel it is compared with: the 3-term bf16 split (bit-identical there)
     N, Cin, H, W, Cout = case
     g = torch.Generator().manual_seed(sum(case))
     x, w = cl(torch.randn(N, Cin, H, W, generator=g)), cl(torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05)
@@ -437,7 +447,7 @@ def test_conv1x1_rows_kernel(hip, restore_mode, case, residual):
             os.environ["MMT_ROWS"] = old
 
 
-def test_packed_weight_planes_bookkeeping(hip, restore_mode):
+def test_packed_weight_planes_bookkeeping(hip, restore_mode, arith):
     """engine/flat.py keeps one packed copy of all weight matrices; a convolution must never use a stale one"""
     from torch import nn
     from maskrcnn_benchmark.layers import Conv2d
@@ -568,6 +578,7 @@ def test_conv3x3_strip_kernel_planes(hip, restore_mode):
     Both strip widths, image borders, a Cout that is not a multiple of 128, every epilogue operand."""
     import os
     hip.set_conv_precision(3)
+    hip.set_f16x2(False)   # the bf16-plane form of the kernel (the fall-back arithmetic); its fp16 form: tests/test_f16x2_gpu.py
     g = torch.Generator().manual_seed(31)
     taken = 0  # shapes the library ran on the strip kernel: full grids, and the split-K form (few tiles, Wo == strip width)
     for (N, C, H, W, Co, opts) in ((2, 128, 128, 128, 192, "res"), (8, 256, 64, 64, 256, "relu"), (32, 128, 32, 64, 128, "mask"),

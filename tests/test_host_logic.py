@@ -297,6 +297,11 @@ assert a == c == d
 # the padded loss dict reduces with the same keys everywhere
 red = MT.reduce_loss_dict({"loss": torch.tensor(1.0), "mt_fg_loss": torch.tensor(float(rank))})
 assert sorted(red) == ["loss", "mt_fg_loss"]
+# ADVICE r2: the set of parameters FlatSGD updates is the union over ranks of what each rank's backward touched
+flat.touched.clear()
+flat.touched.update(["rpn.weight", "backbone.fpn.weight"] if rank == 0 else ["rpn.weight", "backbone.body.layer4.bias"])
+MT.sync_touched(flat)
+assert flat.touched == {"rpn.weight", "backbone.fpn.weight", "backbone.body.layer4.bias"}, flat.touched
 # teacher identity checksum: equal buffers pass, a divergent rank is caught on every rank
 t = FlatParams(Net())
 t.data.copy_(flat.data)
