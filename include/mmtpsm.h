@@ -113,6 +113,14 @@ typedef struct {
   float* boxes; float* scores; int64_t* idx; float* box_reg;
 } mmt_rpn_select_args;
 int mmt_rpn_gather_decode(const mmt_rpn_select_args* a /*[host]*/, void* stream);
+/* mmt_rpn_topk: torch.topk(objectness, k, sorted=True)[1] of every (image, level) segment (rpn/inference.py:94-96) for all
+ *   levels and images of a call in five launches (multi-block radix select + one sorting block per segment): topk [N][k]
+ *   int64 indices px * A + a into the level's H*W*A logits (head = fused NHWC head output with C = 5A channels, logits
+ *   first), descending by value, equal values: lower index first.  k <= 2048.  workspace: mmt_rpn_topk_workspace_bytes()
+ *   bytes, 16-byte aligned. */
+typedef struct { const float* head; int64_t* topk; int HW; int k; } mmt_rpn_topk_level;
+long mmt_rpn_topk_workspace_bytes(int N, int L, long anchors_per_image);
+int mmt_rpn_topk(const mmt_rpn_topk_level* levels /*[host][L]*/, int L, int N, int A, void* workspace, void* stream);
 /* mmt_rpn_post_select: after mmt_nms_batched over the N*L segments (keep [N*L,kmax], keep_cnt [N*L]): a kept candidate
  *   survives when its rank in its segment is < post_n and its position < own_pre[level] (rpn/inference.py:130-135); of the
  *   survivors the best fpn_post_n of the WHOLE BATCH (training: rpn/inference.py:223-234, written per image in (level,
@@ -145,6 +153,12 @@ int mmt_sample_fg_bg(const void* labels, int labels_are_float, const float* keys
 int mmt_box_decode(const float* codes, const float* boxes, int R, int ncls, float wx, float wy, float ww, float wh, float clip,
                    const int32_t* row_off /*[n_img+1] or NULL*/, const float* lim /*[n_img,2] or NULL*/, int n_img, float* out,
                    void* stream);
+/* Pooler.convert_to_roi_format + LevelMapper (modeling/poolers.py:11-32, 91-104) for the boxes of all images of a call
+ * (host arrays of n_img <= 32 device pointers to [count_i, 4] xyxy boxes, 16-byte aligned): rois [K, 5] = (image, box) and, when
+ * `levels` is given, levels [K] = clamp(floor(lvl0 + log2(sqrt(area) / s0 + eps)), k_min, k_max) - k_min in the tensor
+ * code's fp32 expression order (replaces ~40 elementwise / cat launches per pooler call) */
+int mmt_roi_format_levels(const float* const* boxes /*[host]*/, const int32_t* counts /*[host]*/, int n_img, float s0, float lvl0,
+                          float eps, int k_min, int k_max, float* rois, int32_t* levels /*or NULL*/, void* stream);
 int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
                       const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total, int shared_cand,
                       float high, float low, int allow_low_quality, float wx, float wy, float ww, float wh, uint32_t* top_ws,

@@ -1914,15 +1914,6 @@ __device__ __forceinline__ void load_flip_unit(const float* __restrict__ w, cons
   v1 = f32x4{v[4], v[5], v[6], v[7]};
 }
 
-__device__ __forceinline__ void unit_amax_commit(const f32x4 v0, const f32x4 v1, unsigned* __restrict__ out) {
-  float m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
-                  fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  const unsigned bits = __builtin_bit_cast(unsigned, m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f && bits > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, bits);
-}
-
 __device__ __forceinline__ void store_unit_f16(const f32x4 v0, const f32x4 v1, const float s, unsigned short* __restrict__ dst,
                                                long plane_stride, int unit, int lane) {
   uint2 o0[2], o1[2];
@@ -1933,7 +1924,40 @@ __device__ __forceinline__ void store_unit_f16(const f32x4 v0, const f32x4 v1, c
     *(uint4*)(dst + q * plane_stride + (long)unit * 512 + lane * 8) = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
 }
 
-template <bool PACK>  // false: the reduction launch, true: the packing launch
+// wave-level running maximum over a contiguous run of units: committed (one conditional atomic) when the run moves on to the
+// next matrix and at its end -- one atomic per 1 KiB unit made this launch 5x slower than the packing launch itself
+__device__ __forceinline__ void wave_amax_commit(float m, unsigned* __restrict__ out) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const unsigned bits = __builtin_bit_cast(unsigned, m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f && bits > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, bits);
+}
+__device__ __forceinline__ float amax8(const f32x4 v0, const f32x4 v1) {
+  return fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+               fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+}
+constexpr int PACK_RUN = 32;   // units per wave in the reduction launches
+
+__global__ __launch_bounds__(256) void pack_many_amax_kernel(const float* __restrict__ base, const PackDesc* __restrict__ descs,
+                                                             const int* __restrict__ unit_desc, int n_units, float* __restrict__ stat) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int u0 = wave * PACK_RUN, u1 = min(u0 + PACK_RUN, n_units);
+  int cur = -1;
+  float m = 0.f;
+  PackDesc d{};
+  for (int unit = u0; unit < u1; unit++) {
+    const int di = unit_desc[unit];
+    if (di != cur) {
+      if (cur >= 0) wave_amax_commit(m, (unsigned*)stat + 2 * cur);
+      cur = di; m = 0.f; d = descs[di];
+    }
+    f32x4 v0, v1;
+    load_pack_unit(base + d.src_off, d.Cout, d.K, unit - d.unit0, lane, v0, v1);
+    m = fmaxf(m, amax8(v0, v1));
+  }
+  if (cur >= 0) wave_amax_commit(m, (unsigned*)stat + 2 * cur);
+}
+
 __global__ __launch_bounds__(256) void pack_many_f16_kernel(const float* __restrict__ base, unsigned short* __restrict__ dst,
                                                             long plane_stride, const PackDesc* __restrict__ descs,
                                                             const int* __restrict__ unit_desc, int n_units, float* __restrict__ stat) {
@@ -1943,13 +1967,31 @@ __global__ __launch_bounds__(256) void pack_many_f16_kernel(const float* __restr
   const PackDesc d = descs[di];
   f32x4 v0, v1;
   load_pack_unit(base + d.src_off, d.Cout, d.K, unit - d.unit0, lane, v0, v1);
-  if (!PACK) { unit_amax_commit(v0, v1, (unsigned*)stat + 2 * di); return; }
   const float s = f16_scale_of(stat[2 * di]);
   if (unit == d.unit0 && lane == 0) stat[2 * di + 1] = s;
   store_unit_f16(v0, v1, s, dst + d.dst_off, plane_stride, unit - d.unit0, lane);
 }
 
-template <bool PACK>
+__global__ __launch_bounds__(256) void pack_flip_many_amax_kernel(const FlipDesc* __restrict__ descs, const int* __restrict__ unit_desc,
+                                                                  int n_units, float* __restrict__ stat) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int u0 = wave * PACK_RUN, u1 = min(u0 + PACK_RUN, n_units);
+  int cur = -1;
+  float m = 0.f;
+  FlipDesc d{};
+  for (int unit = u0; unit < u1; unit++) {
+    const int di = unit_desc[unit];
+    if (di != cur) {
+      if (cur >= 0) wave_amax_commit(m, (unsigned*)stat + 2 * cur);
+      cur = di; m = 0.f; d = descs[di];
+    }
+    f32x4 v0, v1;
+    load_flip_unit(d.w, d.scale, d.Cout, d.KH, d.KW, d.Cin, unit - d.unit0, lane, v0, v1);
+    m = fmaxf(m, amax8(v0, v1));
+  }
+  if (cur >= 0) wave_amax_commit(m, (unsigned*)stat + 2 * cur);
+}
+
 __global__ __launch_bounds__(256) void pack_flip_many_f16_kernel(const FlipDesc* __restrict__ descs, const int* __restrict__ unit_desc,
                                                                  int n_units, float* __restrict__ stat) {
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1958,10 +2000,9 @@ __global__ __launch_bounds__(256) void pack_flip_many_f16_kernel(const FlipDesc*
   const FlipDesc d = descs[di];
   f32x4 v0, v1;
   load_flip_unit(d.w, d.scale, d.Cout, d.KH, d.KW, d.Cin, unit - d.unit0, lane, v0, v1);
-  if (!PACK) { unit_amax_commit(v0, v1, (unsigned*)stat + 2 * di); return; }
   const float s = f16_scale_of(stat[2 * di]);
   if (unit == d.unit0 && lane == 0) stat[2 * di + 1] = s;
-  store_unit_f16(v0, v1, s, d.dst, d.plane_stride, unit - d.unit0, lane);
+  store_unit_f16(v0, v1, s, (unsigned short*)d.dst, d.plane_stride, unit - d.unit0, lane);
 }
 
 // ------------------------------------------------------------------------------------ weight gradient
@@ -3111,9 +3152,9 @@ extern "C" int mmt_pack_weights_f16(const float* base, void* planes, long plane_
   if (n_units <= 0 || n_descs <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(stat, 0, (size_t)n_descs * 2 * sizeof(float), s) != hipSuccess) return MMT_EINVAL;
-  hipLaunchKernelGGL(pack_many_f16_kernel<false>, dim3((n_units + 3) / 4), dim3(256), 0, s, base, (unsigned short*)planes, plane_stride,
-                     (const PackDesc*)descs, unit_desc, n_units, stat);
-  hipLaunchKernelGGL(pack_many_f16_kernel<true>, dim3((n_units + 3) / 4), dim3(256), 0, s, base, (unsigned short*)planes, plane_stride,
+  hipLaunchKernelGGL(pack_many_amax_kernel, dim3(mmt_cdiv(n_units, 4 * PACK_RUN)), dim3(256), 0, s, base, (const PackDesc*)descs, unit_desc,
+                     n_units, stat);
+  hipLaunchKernelGGL(pack_many_f16_kernel, dim3((n_units + 3) / 4), dim3(256), 0, s, base, (unsigned short*)planes, plane_stride,
                      (const PackDesc*)descs, unit_desc, n_units, stat);
   MMT_LAUNCH_CHECK();
   return 0;
@@ -3125,9 +3166,9 @@ extern "C" int mmt_pack_weights_flipped_f16(const mmt_flip_desc* descs, const in
   if (n_units <= 0 || n_descs <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(stat, 0, (size_t)n_descs * 2 * sizeof(float), s) != hipSuccess) return MMT_EINVAL;
-  hipLaunchKernelGGL(pack_flip_many_f16_kernel<false>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const FlipDesc*)descs, unit_desc,
+  hipLaunchKernelGGL(pack_flip_many_amax_kernel, dim3(mmt_cdiv(n_units, 4 * PACK_RUN)), dim3(256), 0, s, (const FlipDesc*)descs, unit_desc,
                      n_units, stat);
-  hipLaunchKernelGGL(pack_flip_many_f16_kernel<true>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const FlipDesc*)descs, unit_desc,
+  hipLaunchKernelGGL(pack_flip_many_f16_kernel, dim3((n_units + 3) / 4), dim3(256), 0, s, (const FlipDesc*)descs, unit_desc,
                      n_units, stat);
   MMT_LAUNCH_CHECK();
   return 0;

@@ -131,6 +131,152 @@ __global__ __launch_bounds__(256) void rpn_gather_kernel(const RpnSelArgs a) {
   *(f32x4*)(a.box_reg + (long)t * 4) = f32x4{d[0], d[1], d[2], d[3]};
 }
 
+// ------------------------------------------------------------------------------------------------ per-level top-k
+// torch.topk(objectness, k, sorted=True) of every (image, level) segment (rpn/inference.py:94-96) for ALL levels and
+// images of a call in five launches (a library top-k is ~8 launches PER LEVEL): a multi-block radix select over the
+// order-preserving 32-bit image of the logits, 11 + 11 + 10 bits,
+//   hist<0>   keys of every element written densely to scratch (the head output is read once, strided), histogram of the
+//             top 11 bits per segment (LDS histogram per 8192-element chunk, then global atomics on the non-empty bins)
+//   hist<1|2> every block re-derives the selected bin(s) of its segment from the earlier histograms (a 2048-bin scan) and
+//             histograms the next digit of the matching keys
+//   compact   threshold key T = value of the k-th largest: every element with key >= T becomes a candidate (value ||
+//             ~index as one 64-bit word; equal values -> lower index first, as everywhere in this file)
+//   final     one block per segment: bitonic sort of the <= 4096 candidates, the first k indices are the result.  More
+//             than 4096 candidates = thousands of logits EQUAL to the threshold (blank images): exact 64-bit select over
+//             the whole segment instead (slow, correct).
+constexpr int TK_BINS = 2048, TK_CHUNK = 8192, TK_CAP = 4096;
+struct TopkLevel { const float* head; long* out; int HW; int k; int chunk0; int key_off; };   // key_off: offset of the level in an image's dense keys
+struct TopkArgs {
+  TopkLevel lv[8];
+  int L, N, A, C, chunks, keys_per_image;
+  unsigned* hist;              // [N*L][3][TK_BINS], zeroed
+  unsigned* keys;              // [N][keys_per_image]
+  unsigned long long* cand;    // [N*L][TK_CAP]
+  int* cnt;                    // [N*L], zeroed
+};
+
+// largest bin b with sum_{j >= b} h[j] >= want; want <- want - sum_{j > b} h[j].  256 threads, h in global memory.
+__device__ __forceinline__ void tk_scan(const unsigned* __restrict__ h, int& bin, int& want, int* sh /*[8]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned v[8];
+  int mine = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { v[j] = h[TK_BINS - 1 - (tid * 8 + j)]; mine += (int)v[j]; }   // thread t: bins descending
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+  __syncthreads();
+  if (lane == 63) sh[wv] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wv; w++) base += sh[w];
+  const int before = base + incl - mine;   // elements in bins above this thread's
+  __syncthreads();
+  if (before < want && before + mine >= want) {
+    int acc = before;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (acc < want && acc + (int)v[j] >= want) { sh[4] = TK_BINS - 1 - (tid * 8 + j); sh[5] = want - acc; }
+      acc += (int)v[j];
+    }
+  }
+  __syncthreads();
+  bin = sh[4];
+  want = sh[5];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void tk_locate(const TopkArgs& a, int& l, int& img, int& chunk) {
+  const int b = blockIdx.x % a.chunks;
+  img = blockIdx.x / a.chunks;
+  l = 0;
+  while (l + 1 < a.L && b >= a.lv[l + 1].chunk0) l++;
+  chunk = b - a.lv[l].chunk0;
+}
+
+template <int PASS>  // 0, 1, 2: histogram of digit PASS; 3: candidate compaction
+__global__ __launch_bounds__(256) void topk_pass_kernel(const TopkArgs a) {
+  __shared__ unsigned lh[TK_BINS];
+  __shared__ int sh[8];
+  int l, img, chunk;
+  tk_locate(a, l, img, chunk);
+  const TopkLevel lv = a.lv[l];
+  const int n = lv.HW * a.A, seg = img * a.L + l, tid = threadIdx.x;
+  const int i0 = chunk * TK_CHUNK, i1 = min(i0 + TK_CHUNK, n);
+  unsigned* keys = a.keys + (long)img * a.keys_per_image + lv.key_off;
+  const unsigned* h = a.hist + (long)seg * 3 * TK_BINS;
+  unsigned prefix = 0, mask = 0;
+  int want = min(lv.k, n);
+  if (PASS >= 1) { int b; tk_scan(h, b, want, sh); prefix = (unsigned)b << 21; mask = 0xffe00000u; }
+  if (PASS >= 2) { int b; tk_scan(h + TK_BINS, b, want, sh); prefix |= (unsigned)b << 10; mask = 0xfffffc00u; }
+  if (PASS == 3) {
+    int b;
+    tk_scan(h + 2 * TK_BINS, b, want, sh);
+    const unsigned T = prefix | (unsigned)b;
+    for (int i = i0 + tid; i < i1; i += 256) {
+      const unsigned kk = keys[i];
+      if (kk >= T) {
+        const int p = atomicAdd(a.cnt + seg, 1);
+        if (p < TK_CAP) a.cand[(long)seg * TK_CAP + p] = ((unsigned long long)kk << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+      }
+    }
+    return;
+  }
+  for (int j = tid; j < TK_BINS; j += 256) lh[j] = 0;
+  __syncthreads();
+  if (PASS == 0) {
+    const float* hd = lv.head + (long)img * lv.HW * a.C;
+    for (int i = i0 + tid; i < i1; i += 256) {
+      const int px = i / a.A, an = i - px * a.A;
+      const unsigned kk = f2ord(hd[(long)px * a.C + an]);
+      keys[i] = kk;
+      atomicAdd(&lh[kk >> 21], 1u);
+    }
+  } else {
+    const int shift = PASS == 1 ? 10 : 0;
+    const unsigned dm = PASS == 1 ? 0x7ffu : 0x3ffu;
+    for (int i = i0 + tid; i < i1; i += 256) {
+      const unsigned kk = keys[i];
+      if ((kk & mask) == prefix) atomicAdd(&lh[(kk >> shift) & dm], 1u);
+    }
+  }
+  __syncthreads();
+  unsigned* gh = a.hist + ((long)seg * 3 + PASS) * TK_BINS;
+  for (int j = tid; j < TK_BINS; j += 256)
+    if (lh[j]) atomicAdd(gh + j, lh[j]);
+}
+
+__global__ __launch_bounds__(NT) void topk_final_kernel(const TopkArgs a) {
+  __shared__ SelShared sh;
+  __shared__ unsigned long long list[TK_CAP];
+  __shared__ int n_list;
+  const int seg = blockIdx.x, img = seg / a.L, l = seg % a.L, tid = threadIdx.x;
+  const TopkLevel lv = a.lv[l];
+  const int n = lv.HW * a.A, k = min(lv.k, n);
+  int c = a.cnt[seg];
+  if (c > TK_CAP) {   // massive ties at the threshold: exact select with the index in the key, over the whole segment
+    const unsigned* keys = a.keys + (long)img * a.keys_per_image + lv.key_off;
+    auto k64 = [&](int i) -> unsigned long long { return ((unsigned long long)keys[i] << 32) | (unsigned)(0xffffffffu - (unsigned)i); };
+    const unsigned long long T = block_select(k64, n, k, sh);
+    if (tid == 0) n_list = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+      const unsigned long long kk = k64(i);
+      if (kk >= T) { const int p = atomicAdd(&n_list, 1); if (p < TK_CAP) list[p] = kk; }
+    }
+    __syncthreads();
+    c = n_list;
+  } else {
+    for (int j = tid; j < c; j += NT) list[j] = a.cand[(long)seg * TK_CAP + j];
+  }
+  int P = 2;
+  while (P < c) P <<= 1;
+  for (int j = c + tid; j < P; j += NT) list[j] = 0ull;
+  block_sort_desc(list, P);
+  long* out = lv.out + (long)img * lv.k;
+  for (int j = tid; j < k; j += NT) out[j] = (long)(0xffffffffu - (unsigned)list[j]);
+}
+
 // ------------------------------------------------------------------------------------------------ after the NMS
 struct RpnPostArgs {
   const float* boxes; const float* scores; const long* idx; const float* box_reg;   // candidates [N][sumk]
@@ -397,6 +543,43 @@ extern "C" int mmt_sample_fg_bg(const void* labels, int labels_are_float, const 
   else
     hipLaunchKernelGGL(sample_kernel<long>, dim3(n_images), dim3(NT), 0, (hipStream_t)stream, (const long*)labels, keys, off,
                        batch_size_per_image, max_pos, pos_mask, neg_mask, counts);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" long mmt_rpn_topk_workspace_bytes(int N, int L, long anchors_per_image) {
+  if (N < 1 || L < 1 || L > 8 || anchors_per_image < 1) return -1;
+  const long segs = (long)N * L;
+  return segs * 3 * TK_BINS * 4 + segs * 4 + ((long)N * anchors_per_image * 4 + 15) / 16 * 16 + segs * TK_CAP * 8 + 64;
+}
+
+extern "C" int mmt_rpn_topk(const mmt_rpn_topk_level* levels, int L, int N, int A, void* workspace, void* stream) {
+  if (!levels || L < 1 || L > 8 || N < 1 || A < 1 || !workspace || ((size_t)workspace & 15)) return MMT_EINVAL;
+  TopkArgs a;
+  a.L = L; a.N = N; a.A = A; a.C = 5 * A;
+  int chunks = 0, koff = 0;
+  for (int l = 0; l < L; l++) {
+    if (!levels[l].head || !levels[l].topk || levels[l].HW < 1 || levels[l].k < 1 || levels[l].k > TK_CAP / 2) return MMT_EINVAL;
+    a.lv[l].head = levels[l].head; a.lv[l].out = (long*)levels[l].topk; a.lv[l].HW = levels[l].HW; a.lv[l].k = levels[l].k;
+    a.lv[l].chunk0 = chunks; a.lv[l].key_off = koff;
+    chunks += mmt_cdiv((long)levels[l].HW * A, TK_CHUNK);
+    koff += levels[l].HW * A;
+  }
+  a.chunks = chunks; a.keys_per_image = koff;
+  const long segs = (long)N * L;
+  char* w = (char*)workspace;
+  a.hist = (unsigned*)w;                      w += segs * 3 * TK_BINS * 4;
+  a.cnt = (int*)w;                            w += (segs * 4 + 15) / 16 * 16;
+  a.keys = (unsigned*)w;                      w += ((long)N * koff * 4 + 15) / 16 * 16;
+  a.cand = (unsigned long long*)w;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, (size_t)(segs * 3 * TK_BINS * 4 + (segs * 4 + 15) / 16 * 16), s) != hipSuccess) return MMT_EINVAL;
+  const dim3 grid(chunks * N);
+  hipLaunchKernelGGL(topk_pass_kernel<0>, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(topk_pass_kernel<1>, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(topk_pass_kernel<2>, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(topk_pass_kernel<3>, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(topk_final_kernel, dim3((int)segs), dim3(NT), 0, s, a);
   MMT_LAUNCH_CHECK();
   return 0;
 }

@@ -146,6 +146,27 @@ __global__ __launch_bounds__(256) void box_decode_kernel(const float* __restrict
   }
   *(f32x4*)(out + i * 4) = o;
 }
+
+// Pooler.convert_to_roi_format + LevelMapper (modeling/poolers.py:29-32, 91-104) for the boxes of all images of a call in one
+// launch: rois[r] = (image, x1, y1, x2, y2), levels[r] = clamp(floor(lvl0 + log2(sqrt(area) / s0 + eps)), k_min, k_max) - k_min
+// in the tensor code's fp32 expression order (area with the +1 convention; built with -ffp-contract=off).
+struct RoiFmtArgs { const float* boxes[32]; int off[33]; int n_img; float s0, lvl0, eps, k_min, k_max; float* rois; int* levels; };
+__global__ __launch_bounds__(256) void roi_format_kernel(const RoiFmtArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.off[a.n_img]) return;
+  int n = 0;
+  while (n + 1 < a.n_img && r >= a.off[n + 1]) n++;
+  const f32x4 b = *(const f32x4*)(a.boxes[n] + (long)(r - a.off[n]) * 4);
+  float* o = a.rois + (long)r * 5;
+  o[0] = (float)n; o[1] = b[0]; o[2] = b[1]; o[3] = b[2]; o[4] = b[3];
+  if (a.levels) {
+    const float area = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+    const float s = sqrtf(area);
+    float lv = floorf(a.lvl0 + log2f(s / a.s0 + a.eps));
+    lv = fminf(fmaxf(lv, a.k_min), a.k_max);   // torch.clamp: NaN (area < 0 never occurs for xyxy boxes with x2 >= x1 - 1) aside
+    a.levels[r] = (int)(long)lv - (int)a.k_min;
+  }
+}
 }  // namespace
 
 extern "C" int mmt_box_decode(const float* codes, const float* boxes, int R, int ncls, float wx, float wy, float ww, float wh,
@@ -178,6 +199,25 @@ extern "C" int mmt_match_targets(const float* cand, const int32_t* cand_off, con
   hipLaunchKernelGGL(match_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_off, gt, gt_off, gt_labels, visible, N, A_total,
                      shared_cand, high, low, allow_low_quality ? top_ws : (const unsigned*)nullptr, wx, wy, ww, wh, matches,
                      labels_f, labels_i, reg);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_roi_format_levels(const float* const* boxes, const int32_t* counts, int n_img, float s0, float lvl0, float eps,
+                                     int k_min, int k_max, float* rois, int32_t* levels, void* stream) {
+  if (!boxes || !counts || n_img < 1 || n_img > 32 || !rois) return MMT_EINVAL;
+  RoiFmtArgs a;
+  a.off[0] = 0;
+  for (int i = 0; i < n_img; i++) {
+    if (counts[i] < 0 || (counts[i] > 0 && (!boxes[i] || ((size_t)boxes[i] & 15)))) return MMT_EINVAL;
+    a.boxes[i] = boxes[i];
+    a.off[i + 1] = a.off[i] + counts[i];
+  }
+  a.n_img = n_img; a.s0 = s0; a.lvl0 = lvl0; a.eps = eps; a.k_min = (float)k_min; a.k_max = (float)k_max;
+  a.rois = rois; a.levels = levels;
+  const int total = a.off[n_img];
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(roi_format_kernel, dim3(mmt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
   MMT_LAUNCH_CHECK();
   return 0;
 }

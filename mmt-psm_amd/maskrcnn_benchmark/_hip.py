@@ -41,6 +41,10 @@ class RpnLevel(ctypes.Structure):
                 ("out_off", c_int), ("pad", c_int)]
 
 
+class RpnTopkLevel(ctypes.Structure):
+    _fields_ = [("head", c_void_p), ("topk", c_void_p), ("HW", c_int), ("k", c_int)]
+
+
 class RpnSelectArgs(ctypes.Structure):
     _fields_ = [("lv", RpnLevel * 8), ("L", c_int), ("N", c_int), ("A", c_int), ("C", c_int), ("sumk", c_int),
                 ("clipv", c_float), ("lim", c_void_p), ("boxes", c_void_p), ("scores", c_void_p), ("idx", c_void_p),
@@ -72,6 +76,7 @@ _SIGS = {
                       c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
     "mmt_aug_erase": [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float),
                       c_void_p],
+    "mmt_roi_format_levels": [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mmt_match_targets": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                           c_float, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p],
@@ -81,6 +86,7 @@ _SIGS = {
     "mmt_set_conv_precision": [ctypes.c_int],
     "mmt_get_conv_precision": [],
     "mmt_pack_weight": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p],
+    "mmt_rpn_topk": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_rpn_gather_decode": [ctypes.POINTER(RpnSelectArgs), c_void_p],
     "mmt_rpn_post_select": [ctypes.POINTER(RpnPostArgs), c_void_p],
     "mmt_sample_fg_bg": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -275,6 +281,14 @@ def _amax_of(x):
     am = getattr(x, "_mmt_amax", None)
     if am is None or am[1] != x._version:
         F16_STATS["amax_pass"] += 1
+        if AMAX_LOG is not None:   # tools/f16_stats.py: who needed a reduction pass of its own
+            import sys
+            f = sys._getframe(1)
+            chain = []
+            while f is not None and len(chain) < 5:
+                chain.append("%s:%d" % (f.f_code.co_name, f.f_lineno))
+                f = f.f_back
+            AMAX_LOG.append((tuple(x.shape), " < ".join(chain)))
         slot = _amax_slot(x.device)
         _check(lib().mmt_amax_stats(x.data_ptr(), x.numel(), slot.ptr, _stream()), "mmt_amax_stats")
         am = x._mmt_amax = (slot, x._version)
@@ -565,6 +579,58 @@ def match_targets(cand, cand_off, gt, gt_off, n_images, high, low, allow_low_qua
                                    float(wy), float(ww), float(wh), _p(top), _p(matches), _p(lf), _p(li), _p(reg), _stream()),
            "mmt_match_targets")
     return matches, (lf if rpn_labels else li), reg
+
+
+def roi_format_levels(boxes, s0=None, lvl0=None, eps=None, k_min=0, k_max=0):
+    """boxes: per-image (n_i, 4) xyxy tensors -> rois (K, 5) = (image, box) and, with a level mapper's constants, the FPN
+    level of every roi as int32 (include/mmtpsm.h: mmt_roi_format_levels); one launch"""
+    n = len(boxes)
+    if n > 32:
+        raise RuntimeError("roi_format_levels: at most 32 images per call")
+    bs = [_dev(b, "boxes") if (b.is_contiguous() and b.dtype == torch.float32 and not (b.data_ptr() & 15)) else
+          _dev(b, "boxes").float().contiguous().clone() for b in boxes]
+    K = sum(b.shape[0] for b in bs)
+    dev = bs[0].device
+    rois = torch.empty((K, 5), dtype=torch.float32, device=dev)
+    levels = torch.empty((K,), dtype=torch.int32, device=dev) if s0 is not None else None
+    if K == 0:
+        return rois, levels
+    ptrs = (c_void_p * n)(*[b.data_ptr() if b.shape[0] else None for b in bs])
+    cnts = (c_int * n)(*[b.shape[0] for b in bs])
+    _check(lib().mmt_roi_format_levels(ptrs, cnts, n, float(s0 or 1.0), float(lvl0 or 0.0), float(eps or 0.0), int(k_min), int(k_max),
+                                       _p(rois), _p(levels), _stream()), "mmt_roi_format_levels")
+    return rois, levels
+
+
+AMAX_LOG = None
+_TOPK_WS = {}   # (device, stream) -> workspace of mmt_rpn_topk (kernels of a stream run in order and may share it)
+
+
+def rpn_topk(heads, ks, A):
+    """heads[l]: fused RPN head output of level l, (N, 5A, H, W) NHWC-dense -> [topk indices (N, k_l) int64 per level]:
+    torch.topk(logits, k_l, sorted=True)[1] of every (image, level) in five launches (include/mmtpsm.h: mmt_rpn_topk)"""
+    L, N = len(heads), heads[0].shape[0]
+    dev = heads[0].device
+    lv = (RpnTopkLevel * L)()
+    outs, keep, total = [], [], 0
+    for l, (h, k) in enumerate(zip(heads, ks)):
+        h = nhwc(h)
+        if h.shape[1] != 5 * A or h.dtype != torch.float32:
+            raise RuntimeError("rpn_topk: the fused fp32 head output (A logits + 4A deltas per pixel) is expected")
+        o = torch.empty((N, k), dtype=torch.int64, device=dev)
+        lv[l].head, lv[l].topk, lv[l].HW, lv[l].k = h.data_ptr(), o.data_ptr(), h.shape[2] * h.shape[3], k
+        total += h.shape[2] * h.shape[3] * A
+        outs.append(o)
+        keep.append(h)
+    fn = lib().mmt_rpn_topk_workspace_bytes
+    fn.restype, fn.argtypes = ctypes.c_long, [c_int, c_int, ctypes.c_long]
+    need = fn(N, L, total)
+    key = (str(dev), _stream())
+    ws = _TOPK_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _TOPK_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    _check(lib().mmt_rpn_topk(ctypes.addressof(lv), L, N, A, ws.data_ptr(), _stream()), "mmt_rpn_topk")
+    return outs
 
 
 def rpn_gather_decode(heads, anchors, topks, A, clip, lim):
@@ -967,6 +1033,15 @@ def get_conv_precision():
     return lib().mmt_get_conv_precision()
 
 
+def wgrad_prepare(x, dy):
+    """the reduction passes conv_wgrad would take for large operands without a recorded maximum, taken on the CURRENT stream
+    (layers/fused.py launches the weight gradient itself on a side stream; a maximum recorded there would race with the
+    data-gradient launch that reads it here)"""
+    if F16X2 and x.dtype == torch.float32 and dy.dtype == torch.float32 and x.numel() >= WGRAD_F16_MIN_ELEMS and get_conv_precision() == 3:
+        _amax_of(nhwc(x))
+        _amax_of(nhwc(dy))
+
+
 def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
     """accumulates into dw (same memory layout as the weight) and dbias"""
     x = nhwc(x)
@@ -1055,12 +1130,13 @@ def _teachers(ts, flips):
     return T
 
 
-def mgd_level_forward(s, ts, flips, m):
-    """-> acc (nt+1,) = [num_i..., msum]"""
+def mgd_level_forward(s, ts, flips, m, acc=None):
+    """-> acc (nt+1,) = [num_i..., msum]; `acc`: a zeroed row to accumulate into (one tensor for all levels of a call)"""
     s = nhwc(s)
     ts = [nhwc(t) for t in ts]
     N, C, H, W = s.shape
-    acc = torch.zeros((len(ts) + 1,), dtype=torch.float32, device=s.device)
+    if acc is None:
+        acc = torch.zeros((len(ts) + 1,), dtype=torch.float32, device=s.device)
     T = _teachers(ts, flips)
     _check(lib().mmt_mgd_level_forward(_p(s), ctypes.byref(T), _p(m), N, H, W, C, _p(acc), _stream()),
            "mmt_mgd_level_forward")
@@ -1073,7 +1149,8 @@ def mgd_level_backward(s, ts, flips, m, coef):
     N, C, H, W = s.shape
     g = empty_nhwc(N, C, H, W, s.device)
     T = _teachers(ts, flips)
-    coef = coef.float().contiguous()
+    if coef.dtype != torch.float32 or not coef.is_contiguous():
+        coef = coef.float().contiguous()
     _check(lib().mmt_mgd_level_backward(_p(s), ctypes.byref(T), _p(m), N, H, W, C, _p(coef), _p(g), _stream()),
            "mmt_mgd_level_backward")
     return g

@@ -135,6 +135,8 @@ class BucketedAllReduce(object):
         self.body.grad_ready = self._event
 
     def _send(self, lo, hi):
+        from maskrcnn_benchmark.layers.fused import join_wgrads
+        join_wgrads()   # weight gradients run on a side stream (layers/fused.py): the piece is final when they are done
         self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def _event(self, stage, what):
@@ -266,6 +268,8 @@ class MTtrainer(object):
         feats_s = feats_u = None
         early, cut = False, None
         job = None
+        if use_mt and self.overlap_teacher and os.environ.get("MMT_TEACHER_FIRST") == "1":   # schedule experiment (tools)
+            job = self._start_teacher(data_u_list)
         if use_mt and self.student_bs == 1:
             xs = data_s.tensors.to(self.device)
             xu = data_u_list[-1].tensors.to(self.device)
@@ -306,7 +310,7 @@ class MTtrainer(object):
                     feats_u = [tuple(t.detach().requires_grad_(True) for t in feats_u[0])]
                     cut = (roots, feats_s + feats_u[0])
                     early = True
-        if use_mt and self.overlap_teacher:
+        if use_mt and self.overlap_teacher and job is None:
             job = self._start_teacher(data_u_list)
         try:
             self.scheduler.step()
@@ -341,6 +345,8 @@ class MTtrainer(object):
                 torch.cuda.current_stream().wait_stream(self.t_stream)
             if bucketed is not None:
                 bucketed.finish()
+        from maskrcnn_benchmark.layers.fused import join_wgrads
+        join_wgrads()   # the weight gradients of this step (side stream) before anything reads the flat gradient
         if bucketed is None:
             allreduce_gradients(self.flat_s)
         sync_touched(self.flat_s)

@@ -20,6 +20,16 @@ import torch
 from .. import _hip as H
 
 
+_NONE = {}   # device -> an empty tensor standing for "no downsample weight" among the saved tensors (no fill launch per block)
+
+
+def _none_like(x):
+    t = _NONE.get(x.device)
+    if t is None:
+        t = _NONE[x.device] = torch.empty((0,), dtype=torch.float32, device=x.device)
+    return t
+
+
 def _dst(t):
     """the parameter's slot in the flat gradient buffer (engine/flat.py), if the model has been flattened"""
     return getattr(t, "_flat_grad", None) if t is not None else None
@@ -35,6 +45,34 @@ def _touch(*slots):
                 ent[0]().touched.add(ent[1])
 
 
+# Weight gradients on a SIDE stream (MMT_WGRAD_STREAM=1, default): a backward pass is a chain of data gradients with one
+# weight gradient hanging off every link -- nothing downstream reads it before the optimiser.  The student's layer3 / layer4
+# calls are few-tile launches that leave most of the 256 CUs idle (profiles/r02_conv_table.txt: 40-65 us each against a
+# 10 us bound), so the weight gradients run beside the chain instead of inside it: every one waits for the event that marks
+# its operands ready, and whoever reads the flat gradient buffer (SGD, the all-reduce pieces) joins first (`join_wgrads`).
+# Only gradients that land in the flat buffer go there (dst_w given); their operands are kept alive by record_stream.
+import os as _os
+_WG_ON = _os.environ.get("MMT_WGRAD_STREAM", "1") != "0"
+_WG = {}   # device -> [side stream, launches since the last join, end-of-backward callback queued]
+
+
+def _wg_stream(dev):
+    ent = _WG.get(dev)
+    if ent is None:
+        ent = _WG[dev] = [torch.cuda.Stream(device=dev, priority=int(_os.environ.get("MMT_WGRAD_PRIORITY", "0"))), 0, False]
+    return ent
+
+
+def join_wgrads(device=None):
+    """the current stream waits for every weight gradient issued on the side stream so far (queued as an end-of-backward
+    callback by the first side-stream launch of a pass, so `.backward()` returns with the gradients ordered on its stream)"""
+    for dev, ent in _WG.items():
+        ent[2] = False
+        if ent[1] and (device is None or dev == device):
+            torch.cuda.current_stream(dev).wait_stream(ent[0])
+            ent[1] = 0
+
+
 def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst_b=None):
     """weight (and bias) gradient.  With flat storage the split-K atomics of `mmt_conv_wgrad` accumulate straight
     into the gradient buffer and None is returned to autograd (no zero-fill, no `grad += dw` pass); otherwise a
@@ -43,7 +81,21 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
     db = None
     if with_bias:
         db = dst_b if dst_b is not None else torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
-    H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
+    if _WG_ON and dst_w is not None and (dst_b is not None or not with_bias) and not (H.PROFILE is not None and H.PROFILE_ALL):
+        ent = _wg_stream(x.device)
+        side, cur = ent[0], torch.cuda.current_stream(x.device)
+        H.wgrad_prepare(x, g)            # reduction passes for operands nobody recorded a maximum of: on THIS stream
+        if not ent[2]:
+            ent[2] = True
+            torch.autograd.Variable._execution_engine.queue_callback(join_wgrads)
+        side.wait_stream(cur)            # operands (x, g) and everything before them on this stream
+        with torch.cuda.stream(side):
+            H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
+        x.record_stream(side)
+        g.record_stream(side)
+        ent[1] += 1
+    else:
+        H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
     _touch(dst_w, dst_b if with_bias else None)
     return (None if dst_w is not None else dw), (None if (dst_b is not None or not with_bias) else db)
 
@@ -171,7 +223,7 @@ class BottleneckFn(torch.autograd.Function):
         s1, b1, s2, b2, s3, b3, sd, bd = bn
         x = H.nhwc(x)
         o1, o2, out = pre if pre is not None else bottleneck_forward(x, w1, w2, w3, wd, bn, stride)
-        ctx.save_for_backward(x, o1, o2, w1, w2, w3, wd if wd is not None else x.new_zeros(()))
+        ctx.save_for_backward(x, o1, o2, w1, w2, w3, wd if wd is not None else _none_like(x))
         ctx.bn = (s1, s2, s3, sd)
         ctx.stride = stride
         ctx.has_ds = wd is not None
@@ -357,24 +409,27 @@ class MGDLossFn(torch.autograd.Function):
         students = [H.nhwc(e) for e in embs[:n_levels]]
         nt = (len(embs) - n_levels) // n_levels
         teachers = [[H.nhwc(embs[n_levels + i * n_levels + l]) for i in range(nt)] for l in range(n_levels)]
-        terms, saved = [], []
+        C = students[0].shape[1]
+        acc = torch.zeros((n_levels, nt + 1), dtype=torch.float32, device=students[0].device)   # one fill for all levels
+        masks = []
         for l, s in enumerate(students):
+            if s.shape[1] != C:
+                raise RuntimeError("MGD: the embeddings of all levels have the same width")
             m = H.mask_pool(seg, s.shape[2], s.shape[3])
-            acc = H.mgd_level_forward(s, teachers[l], flips, m)
-            den = acc[nt] * s.shape[1] + 1e-7
-            terms.append(acc[:nt] / den)
-            saved.append((m, den))
-        ctx.students, ctx.teachers, ctx.saved, ctx.flips = students, teachers, saved, flips
+            H.mgd_level_forward(s, teachers[l], flips, m, acc[l])
+            masks.append(m)
+        den = acc[:, nt] * C + 1e-7                       # per level; the same expressions as the per-level form, batched
+        ctx.students, ctx.teachers, ctx.masks, ctx.den, ctx.flips = students, teachers, masks, den, flips
         ctx.n_terms = nt * n_levels
         # reference order: for teacher: for level -> mean is order independent up to rounding
-        return torch.stack(terms, 1).reshape(-1).mean()
+        return (acc[:, :nt] / den[:, None]).reshape(-1).mean()
 
     @staticmethod
     def backward(ctx, g):
-        grads = []
-        for s, ts, (m, den) in zip(ctx.students, ctx.teachers, ctx.saved):
-            coef = (g / ctx.n_terms / den).expand(len(ts)).contiguous()
-            grads.append(H.mgd_level_backward(s, ts, ctx.flips, m, coef))
+        nt = len(ctx.teachers[0])
+        coef = (g / ctx.n_terms / ctx.den)[:, None].expand(-1, nt).contiguous()   # [level][teacher]
+        grads = [H.mgd_level_backward(s, ts, ctx.flips, m, coef[l])
+                 for l, (s, ts, m) in enumerate(zip(ctx.students, ctx.teachers, ctx.masks))]
         return (None, None, None) + tuple(grads) + (None,) * (len(ctx.teachers[0]) * len(ctx.students))
 
 

@@ -5,6 +5,7 @@ import math
 import torch
 from torch import nn
 
+from maskrcnn_benchmark import _hip as H
 from maskrcnn_benchmark.layers import fused
 
 
@@ -34,9 +35,16 @@ class Pooler(nn.Module):
 
     def forward(self, x, boxes):
         """x: per-level feature maps (N,C,H,W); boxes: list[BoxList] -> (R, C, res, res) NHWC-dense"""
-        rois = self.convert_to_roi_format(boxes)
         n_lv = len(self.scales)
-        levels = self.map_levels(boxes).to(torch.int32) if n_lv > 1 else torch.zeros(
-            (rois.shape[0],), dtype=torch.int32, device=rois.device)
+        m = self.map_levels
+        if all(b.mode == "xyxy" for b in boxes) and len(boxes) <= 32 and boxes[0].bbox.is_cuda:
+            # roi format and level of every box of the call in ONE launch (same fp32 expressions as the tensor code below)
+            rois, levels = H.roi_format_levels([b.bbox for b in boxes], m.s0, m.lvl0, m.eps, m.k_min, m.k_max)
+            if n_lv == 1:
+                levels.zero_()
+        else:
+            rois = self.convert_to_roi_format(boxes)
+            levels = self.map_levels(boxes).to(torch.int32) if n_lv > 1 else torch.zeros(
+                (rois.shape[0],), dtype=torch.int32, device=rois.device)
         return fused.RoiAlignFpnFn.apply(rois, levels, self.output_size[0], self.scales, self.sampling_ratio,
                                          *list(x)[:n_lv])

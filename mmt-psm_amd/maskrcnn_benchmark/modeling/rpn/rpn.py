@@ -100,8 +100,8 @@ class RPNPostProcessor(nn.Module):
         return torch.cat([o, r], 1).contiguous(memory_format=torch.channels_last)
 
     def compute_candidates(self, anchors, objectness, box_regression, pre_n):
-        """rpn/inference.py:86-135 for every (image, level): top-k of the objectness (a library top-k per level, on the
-        logits -- ordered like their sigmoid), then ONE launch for gather + sigmoid + decode + clip of all levels
+        """rpn/inference.py:86-135 for every (image, level): top-k of the objectness (`mmt_rpn_topk`: all levels and images in
+        five launches, on the logits -- ordered like their sigmoid), then ONE launch for gather + sigmoid + decode + clip of all levels
         (`mmt_rpn_gather_decode`) and one `mmt_nms_batched` launch pair over all segments"""
         N, L = len(anchors), len(objectness)
         dev = objectness[0].device
@@ -111,11 +111,12 @@ class RPNPostProcessor(nn.Module):
         heads, topks, ks = [], [], []
         for lvl in range(L):
             head = self._fused_head(objectness[lvl].detach(), box_regression[lvl].detach())
-            flat = head[:, :A].permute(0, 2, 3, 1).reshape(N, -1)
-            k = min(pre_n, flat.shape[1])
-            topks.append(flat.topk(k, dim=1, sorted=True)[1])
             heads.append(head)
-            ks.append(k)
+            ks.append(min(pre_n, head.shape[2] * head.shape[3] * A))
+        if max(ks) <= 2048 and heads[0].dtype == torch.float32:
+            topks = H.rpn_topk(heads, ks, A)   # every (image, level) in five launches
+        else:                                  # PRE_NMS_TOP_N beyond the kernel's candidate list: the library top-k per level
+            topks = [h[:, :A].permute(0, 2, 3, 1).reshape(N, -1).topk(k, dim=1, sorted=True)[1] for h, k in zip(heads, ks)]
         kmax = max(ks)
         boxes, scores, idx, reg, offs = H.rpn_gather_decode(heads, [anchors[0][lvl].bbox for lvl in range(L)], topks, A,
                                                             self.box_coder.bbox_xform_clip, lim)

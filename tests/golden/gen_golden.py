@@ -472,6 +472,66 @@ def gen_checkpoint():
           {k: sum(v is not None for v in c["mapping"].values()) for k, c in out.items()})
 
 
+def gen_proposals():
+    """VERDICT r2 (next 6a): the REFERENCE's RPNPostProcessor (training selector with GT boxes, TEST-config selector,
+    TRAIN-config selector of a teacher in eval mode) and PostProcessor on the head outputs of tests/proposal_inputs.py at
+    2 x 1024^2 -- pre-NMS top-2000 on three levels, batch-wide top-2000, per-image top-1000 / 2000, > 400 detections per image
+    before the kthvalue cut to 200: the sizes where every cap binds, which the 160^2 model fixtures never reach."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import proposal_inputs as pi
+    from maskrcnn_benchmark.modeling.rpn.rpn import RPNModule
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.inference import make_roi_box_post_processor
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.image_list import ImageList
+    cfg = make_cfg()
+    out = {}
+    il = ImageList(torch.zeros(pi.N_IMG, 3, pi.PAD, pi.PAD), [(pi.SIZE, pi.SIZE)] * pi.N_IMG)
+    feats = [torch.zeros(pi.N_IMG, 1, s, s) for s in pi.GRIDS]
+
+    def dump(tag, lists, fields, int_fields=()):
+        out[tag + "_count"] = torch.tensor([len(b) for b in lists])
+        for i, b in enumerate(lists):
+            out["%s_%d_bbox" % (tag, i)] = b.bbox
+            for f in fields:
+                out["%s_%d_%s" % (tag, i, f)] = b.get_field(f).float()
+            for f in int_fields:
+                out["%s_%d_%s" % (tag, i, f)] = b.get_field(f).to(torch.int32)
+
+    with torch.no_grad():
+        # (1) training selector of a student RPN: pre-NMS 2000 / level, NMS 0.7, batch-wide top-2000, + GT boxes
+        m = RPNModule(cfg, is_teacher=False)
+        anchors = m.anchor_generator(il, feats)
+        obj, reg = pi.head_outputs(3)
+        tg = [BoxList(b, (pi.SIZE, pi.SIZE), mode="xyxy") for b in pi.gt_boxes(5)]
+        for t in tg:
+            t.add_field("labels", torch.ones(12, dtype=torch.int64))
+        m.train()
+        dump("train", m.box_selector_train(anchors, obj, reg, tg), ("objectness",))
+        # (2) the two selectors a teacher runs on pyramid 0 (generalized_rcnn.py:126,146), eval mode
+        t = RPNModule(cfg, is_teacher=True)
+        t.eval()
+        obj, reg = pi.head_outputs(4)
+        dump("test", t.box_selector_test(anchors, obj, reg), ("objectness",))
+        dump("teach", t.box_selector_train(anchors, obj, reg, None), ("objectness", "box_reg"), ("rpn_topk", "rpn_ancher_level"))
+        # (3) detection post-processor: 1000 proposals per image, kthvalue cut to 200 -- and uncut
+        boxes, objs, logits, deltas = pi.box_head_inputs(8, 1000)
+        for tag, dets in (("det", 200), ("det_uncut", 10 ** 6)):
+            c2 = make_cfg()
+            c2.MODEL.ROI_HEADS.DETECTIONS_PER_IMG = dets
+            pp = make_roi_box_post_processor(c2)
+            props = []
+            for b, o in zip(boxes, objs):
+                p = BoxList(b.clone(), (pi.SIZE, pi.SIZE), mode="xyxy")
+                p.add_field("objectness", o)
+                props.append(p)
+            dump(tag, pp((logits, deltas), props), ("scores",), ("labels",))
+    for k in list(out):
+        if k.endswith("_bbox") or k.endswith("_box_reg"):
+            out[k] = out[k].float()
+    save("proposals1024", **out)
+    print({k: out[k].tolist() for k in out if k.endswith("_count")})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["nms", "roi", "small", "mt", "masks", "model"]
     if "nms" in which:
@@ -492,3 +552,5 @@ if __name__ == "__main__":
         gen_checkpoint()
     if "transforms" in which:
         gen_transforms()
+    if "proposals" in which:
+        gen_proposals()

@@ -94,3 +94,15 @@ def sample_fg_bg(labels, keys, batch, max_pos):
         return out
 
     return take(pos, num_pos), take(neg, num_neg)
+
+
+def roi_format_levels(boxes, k_min, k_max, s0=224, lvl0=4, eps=1e-6):
+    """Pooler.convert_to_roi_format + LevelMapper (modeling/poolers.py:11-32, 91-104) as the tensor calls mmt_roi_format_levels
+    replaced: boxes = per-image (n_i, 4) xyxy tensors -> rois (K, 5), levels (K,) int32"""
+    bb = torch.cat(boxes, 0)
+    ids = torch.cat([torch.full((len(b), 1), i, dtype=bb.dtype, device=bb.device) for i, b in enumerate(boxes)], 0)
+    area = torch.cat([(b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1) for b in boxes])
+    s = torch.sqrt(area)
+    lv = torch.floor(lvl0 + torch.log2(s / s0 + eps))
+    lv = torch.clamp(lv, min=k_min, max=k_max).to(torch.int64) - k_min
+    return torch.cat([ids, bb], 1), lv.to(torch.int32)

@@ -19,31 +19,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-N_IMG, SIZE, PAD = 2, 1000, 1024
-GRIDS = [PAD // s for s in (4, 8, 16, 32, 64)]
-A = 3
-
-
-def _head_outputs(seed):
-    """distinct objectness probabilities per image over all levels; box deltas N(0, 0.5^2) (clip at log(1000/16) active
-    for some), NCHW on the host"""
-    g = torch.Generator().manual_seed(seed)
-    per_img = sum(A * s * s for s in GRIDS)
-    grid = 1 << 18
-    assert per_img < grid
-    obj = [[] for _ in GRIDS]
-    for _ in range(N_IMG):
-        p = (torch.randperm(grid - 1, generator=g)[:per_img].double() + 1) / grid
-        lg = torch.log(p / (1 - p)).float()
-        o = 0
-        for l, s in enumerate(GRIDS):
-            n = A * s * s
-            obj[l].append(lg[o:o + n].view(A, s, s))
-            o += n
-    objectness = [torch.stack(o) for o in obj]
-    regression = [torch.randn(N_IMG, 4 * A, s, s, generator=g) * 0.5 for s in GRIDS]
-    regression[0][:, 2::4] += 3.0  # widths beyond the clip on level 0
-    return objectness, regression
+from proposal_inputs import N_IMG, SIZE, PAD, GRIDS, A, head_outputs as _head_outputs, gt_boxes, box_head_inputs
 
 
 def _cl(t):
@@ -51,13 +27,9 @@ def _cl(t):
 
 
 def _gt_targets(om, seed):
-    g = torch.Generator().manual_seed(seed)
     out_o, out_p = [], []
     from maskrcnn_benchmark.structures.bounding_box import BoxList
-    for _ in range(N_IMG):
-        xy = torch.rand(12, 2, generator=g) * 800 + 50
-        wh = torch.rand(12, 2, generator=g) * 100 + 10
-        b = torch.cat([xy, xy + wh], 1)
+    for b in gt_boxes(seed):
         out_o.append(om.Boxes(b, (SIZE, SIZE), {"labels": torch.ones(12, dtype=torch.int64)}))
         out_p.append(BoxList(b.cuda(), (SIZE, SIZE), "xyxy"))
     return out_o, out_p
@@ -172,19 +144,13 @@ def test_box_postprocessor_more_than_200_detections():
     from maskrcnn_benchmark.structures.bounding_box import BoxList
     _hip.lib()
     ocfg = om.default_cfg()
-    g = torch.Generator().manual_seed(8)
-    R = 1000
+    boxes, objs, logits, deltas = box_head_inputs(8, 1000)
     props_o, props_p = [], []
-    for _ in range(N_IMG):
-        xy = torch.rand(R, 2, generator=g) * 900
-        wh = torch.rand(R, 2, generator=g) * 60 + 6
-        b = torch.cat([xy, (xy + wh).clamp(max=SIZE - 1)], 1)
-        props_o.append(om.Boxes(b, (SIZE, SIZE), {"objectness": torch.rand(R, generator=g)}))
+    for b, o in zip(boxes, objs):
+        props_o.append(om.Boxes(b, (SIZE, SIZE), {"objectness": o}))
         p = BoxList(b.cuda(), (SIZE, SIZE), "xyxy")
-        p.add_field("objectness", props_o[-1].fields["objectness"].cuda())
+        p.add_field("objectness", o.cuda())
         props_p.append(p)
-    logits = torch.randn(N_IMG * R, 3, generator=g) * 1.5
-    deltas = torch.randn(N_IMG * R, 12, generator=g) * 0.5
     ref = om.box_postprocess(ocfg, logits, deltas, props_o)
     pp = make_roi_box_post_processor(make_default_cfg()).cuda()
     with torch.no_grad():

@@ -123,3 +123,62 @@ def test_sample_fg_bg_any_key_distribution(hip):
         pm, nm, cnt = hip.sample_fg_bg(lab.cuda(), keys.cuda(), off, 256, 128)
         rp, rn = tf.sample_fg_bg(lab.cuda(), keys.cuda(), 256, 128)
         assert torch.equal(pm, rp) and torch.equal(nm, rn)
+
+
+def test_roi_format_levels_kernel(hip):
+    """mmt_roi_format_levels == convert_to_roi_format + LevelMapper, bit for bit, on boxes that straddle every level boundary
+    (sizes swept densely around 112 / 224 / 448 px), degenerate boxes, an empty image, fixed-capacity views"""
+    H = hip
+    g = torch.Generator().manual_seed(5)
+    boxes = []
+    for n in (3000, 0, 1777, 1, 4096):
+        side = torch.cat([torch.rand(n // 2, generator=g) * 900 + 1,
+                          torch.tensor([112.0, 224.0, 448.0])[torch.randint(0, 3, (n - n // 2,), generator=g)]
+                          * (1 + (torch.rand(n - n // 2, generator=g) - 0.5) * 1e-3)])
+        asp = torch.exp((torch.rand(n, generator=g) - 0.5) * 1.5)
+        w, h = side * asp.sqrt(), side / asp.sqrt()
+        xy = torch.rand(n, 2, generator=g) * 500
+        b = torch.stack([xy[:, 0], xy[:, 1], xy[:, 0] + w - 1, xy[:, 1] + h - 1], 1)
+        if n > 10:
+            b[3] = torch.tensor([5.0, 5.0, 5.0, 5.0])      # 1 x 1 px
+            b[4] = torch.tensor([7.0, 9.0, 6.0, 8.0])      # x2 = x1 - 1: area 0
+        cap = torch.zeros((n + 5, 4))
+        cap[:n] = b
+        boxes.append(cap.cuda()[:n])                       # a prefix view of a fixed-capacity tensor, as the RPN hands them over
+    rois, lv = H.roi_format_levels(boxes, 224, 4, 1e-6, 2, 5)
+    ref_rois, ref_lv = tf.roi_format_levels(boxes, 2, 5)
+    assert torch.equal(rois, ref_rois)
+    assert torch.equal(lv, ref_lv)
+    assert set(lv.unique().tolist()) == {0, 1, 2, 3}
+
+
+def test_rpn_topk_kernel(hip):
+    """mmt_rpn_topk == torch.topk(sorted=True) per (image, level) on tie-free logits at the full sizes (k = 2000 on four levels,
+    all 768 anchors of the coarsest), for k = 1000 as well; equal logits come out lower index first, and a segment of
+    thousands of equal logits AT the threshold (a blank image) takes the exact 64-bit path"""
+    H = hip
+    heads = _heads(17)
+    for pre in (2000, 1000):
+        ks = [min(pre, h.shape[2] * h.shape[3] * A) for h in heads]
+        got = H.rpn_topk(heads, ks, A)
+        for h, k, t in zip(heads, ks, got):
+            ref = h[:, :A].permute(0, 2, 3, 1).reshape(N, -1).topk(k, dim=1, sorted=True)[1]
+            assert torch.equal(t, ref), (pre, k)
+    # ties: quantised logits (every value ~50 times) and one image that is constant
+    g = torch.Generator().manual_seed(3)
+    th = []
+    for s in (128, 32):
+        lg = torch.randint(0, 1000, (N, s, s, A), generator=g).float() * 0.01 - 5.0
+        lg[1] = 0.25
+        h = torch.cat([lg, torch.zeros(N, s, s, 4 * A)], 3).permute(0, 3, 1, 2).cuda()
+        th.append(h)
+    ks = [2000, 2000]
+    got = H.rpn_topk(th, ks, A)
+    for h, k, t in zip(th, ks, got):
+        flat = h[:, :A].permute(0, 2, 3, 1).reshape(N, -1)
+        n = flat.shape[1]
+        # reference with the kernel's tie rule: sort by (value descending, index ascending)
+        key = flat.double() * 1e7 - torch.arange(n, device="cuda").double() * 1e-3
+        ref = key.argsort(dim=1, descending=True)[:, :k]
+        assert torch.equal(t, ref)
+        assert torch.equal(t[1], torch.arange(k, device="cuda"))   # the constant image: the first k indices
