@@ -472,6 +472,11 @@ def main():
             out["roofline"]["single_stream"] = single
         if ref_fp32 is not None:
             out["fp32_mfma_mode"] = ref_fp32
+        if use_dist and getattr(trainer._bucketed, "last_trace", None) is not None:
+            # MMT_DIST_TRACE=1: when each piece of the flat gradient went out and arrived, on the device clock of the last step
+            out["dist_trace"] = dict(trainer._bucketed.last_trace, backend=dist.get_backend(), world=world,
+                                     teacher_stream_priority=trainer.t_stream.priority if trainer.t_stream is not None else None,
+                                     grad_mbytes=round(trainer.flat_s.grad.numel() * 4 / 1e6, 1))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -129,14 +129,25 @@ class BucketedAllReduce(object):
 
     def reset(self):
         self.registered, self.fired, self.sent, self.works = {}, {}, set(), []
+        self._marks = []
 
     def install(self):
         self.reset()
         self.body.grad_ready = self._event
+        # MMT_DIST_TRACE=1: per-piece issue / completion times on the device clock (events on the step stream), so that the
+        # first multi-GPU run shows at once whether the exchange hides behind the backward pass (`last_trace`)
+        self.tracing = os.environ.get("MMT_DIST_TRACE") == "1" and self.flat.grad.is_cuda
+        if self.tracing:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record()
 
     def _send(self, lo, hi):
         from maskrcnn_benchmark.layers.fused import join_wgrads
         join_wgrads()   # weight gradients run on a side stream (layers/fused.py): the piece is final when they are done
+        if getattr(self, "tracing", False):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._marks.append([lo, hi, e, None, time.perf_counter()])
         self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def _event(self, stage, what):
@@ -163,14 +174,29 @@ class BucketedAllReduce(object):
             if s_ in self.pieces and s_ not in self.sent:
                 self._send(*self.pieces[s_])
                 self.sent.add(s_)
+        tracing = getattr(self, "tracing", False)
+        if tracing:
+            bw_end = torch.cuda.Event(enable_timing=True)
+            bw_end.record()
+            n_early = len(self._marks)
         for lo, hi in self.rest:
             self._send(lo, hi)
-        for w in self.works:
+        for i, w in enumerate(self.works):
             if w is not None:
                 w.wait()
+            if tracing:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()       # the step stream gets here when piece i has arrived
+                self._marks[i][3] = e
         ws = get_world_size()
         if ws > 1:
             self.flat.grad.mul_(1.0 / ws)
+        if tracing:
+            torch.cuda.synchronize()
+            self.last_trace = {
+                "backward_end_ms": round(self._t0.elapsed_time(bw_end), 3), "pieces_sent_before_backward_end": n_early,
+                "pieces": [{"range": [lo, hi], "mbytes": round((hi - lo) * 4 / 1e6, 2), "issued_ms": round(self._t0.elapsed_time(a), 3),
+                            "arrived_ms": round(self._t0.elapsed_time(b), 3)} for lo, hi, a, b, _ in self._marks]}
         self.reset()
 
 

@@ -65,6 +65,32 @@ class GeneralizedRCNN(nn.Module):
 
     def _tap(self, name, value):
         rp = getattr(self, "_replay", None)
+        if rp is not None and rp.substitute_lists == "where_different" and rp.has(name):
+            # reduced-precision runs against the fp32 oracle: the product's own list is kept wherever its discrete decisions
+            # agree with the record (same count, same boxes to 1 px after the near-tie alignment) and replaced -- and
+            # reported in taps[name + "_substituted"] -- only where they do not (the recorded sampler positions would then
+            # refer to other boxes)
+            aligned, moved = rp.align(name, value, tol=1.0)
+            rec = rp.d[name]
+            same = len(rec) == len(aligned) and all(
+                len(b) == r[0].shape[0] and (len(b) == 0 or float((b.bbox - r[0].to(b.bbox.device)).abs().max()) <= 1.0)
+                for b, r in zip(aligned, rec))
+            if self.taps is not None:
+                self.taps[name + "_substituted"] = not same
+                # how far apart the two lists are as SETS: share of the recorded boxes that the product also produced (1 px)
+                found = total = 0
+                for b, r in zip(value, rec):
+                    rb = r[0].to(b.bbox.device)
+                    total += rb.shape[0]
+                    if rb.shape[0] and len(b):
+                        found += int(((rb[:, None, :] - b.bbox[None, :, :]).abs().amax(2) <= 1.0).any(1).sum())
+                self.taps[name + "_agreement"] = found / max(total, 1)
+            if same:
+                value = aligned
+                if self.taps is not None:
+                    self.taps[name + "_moved"] = moved
+                    self.taps[name] = value
+                return value
         if rp is not None and rp.substitute_lists and rp.has(name):
             from maskrcnn_benchmark.structures.bounding_box import BoxList
             rec, new = rp.take_all(name), []
