@@ -1558,15 +1558,25 @@ struct PackDesc { long src_off, dst_off; int Cout, K, unit0, pad; };
 //   * the pre-split weight planes of panel nt+1 are DMA-copied into the other LDS buffer while panel nt is multiplied;
 //   * per panel: KT x 6 x TN MFMAs from registers / LDS fragments, then the shared epilogue.
 // Arithmetic and summation order are those of conv_fwd_glds_kernel (bit-identical results).
-template <int KT, int BN, int NS>
+// F16 (round 3): the two-term fp16 split of the default arithmetic -- A scaled by the power of two of its recorded maximum
+// (p.f16_sx -> max |x|) and split ONCE into (h, l) fragments that stay in registers for every panel; weight planes are the
+// fp16 pair of the packed weight (scale *p.f16_sw); 3 products per multiply; the epilogue divides by both scales.  With that,
+// K = 256 fits too (KT = 16: 128 fragment registers per wave), i.e. the expanding 1x1 layers of layer3 (256 -> 1024), the
+// FPN lateral of C2, the hint adaptors and the data gradients of every 1x1 layer with 256 output channels.  In the tiled
+// kernel those re-read the raw fp32 rows once per 64-column tile through the L2 -> LDS path (256 -> 1024 at 8 x 64 x 64:
+// 786 MB for 17 GFLOP, 170 us); here a row is read once per column group.  blockIdx.y = column group (`ppb` panels each):
+// the few-tile student shapes (N = 2: 64 row blocks) still fill the chip.  The (x > 0) mask of a data gradient is applied
+// in the epilogue like the residual (requested before the panel's MFMAs).
+template <int KT, int BN, int NS, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, const unsigned short* __restrict__ wpl,
-                                                              const long wpl_stride) {
+                                                              const long wpl_stride, const int ppb) {
   float amx = 0.f, asum = 0.f, acnt = 0.f;   // max |y| / sum |y| / count over what this thread stores (p.amax_out)
   constexpr int TN = BN / 32;
   constexpr int PIECES = KT * NS * TN;       // 1 KiB DMA pieces per panel: [kt][plane][32-column block]
   constexpr int BBUF = PIECES * 1024;
   constexpr int CT_BYTES = 128 * BN * 4;     // epilogue staging
   static_assert(PIECES % 4 == 0, "pieces per wave");
+  static_assert(!F16 || NS == 2, "fp16 split: two terms");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* const bring = (char*)lds + CT_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1582,6 +1592,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
   const int K = 16 * KT;
   const int nb32 = (p.Cout + 31) >> 5;
   const int npanel = (p.Cout + BN - 1) / BN;
+  const int nt_lo = blockIdx.y * ppb, nt_hi = min(npanel, nt_lo + ppb);
   auto issue_b = [&](int nt, int buf) {
 #pragma unroll
     for (int i = 0; i < PIECES / 4; i++) {
@@ -1592,61 +1603,73 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
       dma16(wpl + q * wpl_stride + ((long)kt * nb32 + nb) * 512 + lane * 8, bring + buf * BBUF + piece * 1024);
     }
   };
-  issue_b(0, 0);
+  issue_b(nt_lo, 0);
   // ---- A: rows m0 + 32 wave + lr, k = 16 kt + 8 kh2 .. + 7 per step; rows past M read zeros (buffer bounds)
-  bf16x8 fa[KT][NS];
+  uint4 fa[KT][NS];   // bf16x8 / f16x8 fragments as raw words
+  const float sx = F16 ? f16_scale_of_fwd(*p.f16_sx) : 1.f;
   {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long)p.M * K * 4), 0x00020000);
     const int m = m0 + wave * 32 + lr;
     const unsigned base = m < p.M ? ((unsigned)m * (unsigned)K + 8u * kh2) * 4u : 0x80000000u;
-    f32x4 ra[KT][2];
+    constexpr int CH = KT < 8 ? KT : 8;   // raw rows in flight: 8 k-steps (64 registers) at a time, then split
 #pragma unroll
-    for (int kt = 0; kt < KT; kt++)
+    for (int k0 = 0; k0 < KT; k0 += CH) {
+      f32x4 ra[CH][2];
 #pragma unroll
-      for (int h = 0; h < 2; h++)
-        ra[kt][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + kt * 64 + h * 16), 0, 0));
+      for (int kt = 0; kt < CH; kt++)
 #pragma unroll
-    for (int kt = 0; kt < KT; kt++) {
-      uint2 o0[NS], o1[NS];
-      split4<NS>(ra[kt][0], o0);
-      split4<NS>(ra[kt][1], o1);
+        for (int h = 0; h < 2; h++)
+          ra[kt][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + (k0 + kt) * 64 + h * 16), 0, 0));
 #pragma unroll
-      for (int q = 0; q < NS; q++) {
-        const uint4 u = {o0[q].x, o0[q].y, o1[q].x, o1[q].y};
-        fa[kt][q] = __builtin_bit_cast(bf16x8, u);
+      for (int kt = 0; kt < CH; kt++) {
+        uint2 o0[NS], o1[NS];
+        if constexpr (F16) {
+          split4h(ra[kt][0], sx, o0);
+          split4h(ra[kt][1], sx, o1);
+        } else {
+          split4<NS>(ra[kt][0], o0);
+          split4<NS>(ra[kt][1], o1);
+        }
+#pragma unroll
+        for (int q = 0; q < NS; q++) fa[k0 + kt][q] = uint4{o0[q].x, o0[q].y, o1[q].x, o1[q].y};
       }
+      if (KT > CH) __builtin_amdgcn_sched_barrier(0);
     }
   }
   const int boff = lr * 32 + (((kh2 ^ (lr >> 3)) & 1) << 4);
-  // Epilogue (plain / residual-add output, Cout % 4 == 0 -- the launcher checks) inlined: the residual rows of a panel are
-  // requested BEFORE its MFMAs, so their latency hides behind the matrix phase instead of sitting in the epilogue
-  // (with two to four blocks per CU nothing else would cover it).  Same expressions as conv_epilogue.
+  // Epilogue (plain / residual-add / masked output, Cout % 4 == 0 -- the launcher checks) inlined: the residual and mask rows
+  // of a panel are requested BEFORE its MFMAs, so their latency hides behind the matrix phase instead of sitting in the
+  // epilogue (with two to four blocks per CU nothing else would cover it).  Same expressions as conv_epilogue.
   constexpr int C4 = BN / 4, RPP = 256 / C4, ROWS = 128 / RPP;
-  constexpr bool fast_epi = true;  // the launcher sends everything else to the tiled kernel
   const int cc = tid % C4, r0 = tid / C4;
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.res_mode == 1 ? p.res : p.x), 0, p.res_mode == 1 ? (int)((long)p.M * p.Cout * 4) : 0, 0x00020000);
-  for (int nt = 0; nt < npanel; nt++) {
-    const int buf = nt & 1;
-    // own DMA pieces of this panel landed (for nt > 0 they were waited for before the previous epilogue already)
+  const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.mask ? p.mask : p.x), 0, p.mask ? (int)((long)p.M * p.Cout * 4) : 0, 0x00020000);
+  const float finv = F16 ? 1.f / (sx * *p.f16_sw) : 1.f;
+  for (int nt = nt_lo; nt < nt_hi; nt++) {
+    const int buf = (nt - nt_lo) & 1;
+    // own DMA pieces of this panel landed (for later panels they were waited for before the previous epilogue already)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // panel nt readable by everybody; everybody is done with the other buffer and with the staging area
-    if (nt + 1 < npanel) issue_b(nt + 1, buf ^ 1);
+    if (nt + 1 < nt_hi) issue_b(nt + 1, buf ^ 1);
     const int c = nt * BN + cc * 4;
-    f32x4 ur[ROWS], sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-    if (fast_epi) {
+    f32x4 ur[ROWS], um[ROWS], sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    {
       const bool cok = c < p.Cout;
 #pragma unroll
       for (int g = 0; g < ROWS; g++) {
         const int m = m0 + r0 + g * RPP;
         const unsigned off = (cok && m < p.M) ? ((unsigned)m * (unsigned)p.Cout + (unsigned)c) * 4u : 0x80000000u;
         ur[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));
+        if (p.mask) um[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmask, (int)off, 0, 0));
       }
       if (cok) {
         if (p.scale) sc4 = ldg4(p.scale + c);
         if (p.shift) sh4 = ldg4(p.shift + c);
       }
+      if (F16) sc4 *= finv;   // operands were scaled by powers of two: exact rescale of the accumulated sum
     }
     f32x16 acc[1][TN];
 #pragma unroll
@@ -1655,12 +1678,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
       for (int r = 0; r < 16; r++) acc[0][b][r] = 0.f;
     const char* bb = bring + buf * BBUF + boff;
     // B fragments one k-step ahead, fenced: left alone the compiler hoists the fragment reads of ALL k-steps (and spills)
-    bf16x8 fb[2][NS][TN];
-    auto read_b = [&](int kt, bf16x8 (&f)[NS][TN]) {
+    uint4 fb[2][NS][TN];
+    auto read_b = [&](int kt, uint4 (&f)[NS][TN]) {
 #pragma unroll
       for (int q = 0; q < NS; q++)
 #pragma unroll
-        for (int b = 0; b < TN; b++) f[q][b] = *(const bf16x8*)(bb + ((kt * NS + q) * TN + b) * 1024);
+        for (int b = 0; b < TN; b++) f[q][b] = *(const uint4*)(bb + ((kt * NS + q) * TN + b) * 1024);
     };
     read_b(0, fb[0]);
 #pragma unroll
@@ -1671,9 +1694,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
 #pragma unroll
         for (int qa = 0; qa <= sum; qa++) {
           const int qb = sum - qa;
+          if (F16 && qa + qb > 1) continue;   // (never: NS = 2)
 #pragma unroll
-          for (int b = 0; b < TN; b++)
-            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kt][qa], fb[kt & 1][qb][b], acc[0][b], 0, 0, 0);
+          for (int b = 0; b < TN; b++) {
+            if constexpr (F16)
+              acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[kt][qa]),
+                                                                 __builtin_bit_cast(f16x8, fb[kt & 1][qb][b]), acc[0][b], 0, 0, 0);
+            else
+              acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kt][qa]),
+                                                                  __builtin_bit_cast(bf16x8, fb[kt & 1][qb][b]), acc[0][b], 0, 0, 0);
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1706,6 +1736,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
         }
+        if (p.mask) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = um[g][e] > 0.f ? v[e] * p.mask_scale : 0.f;
+        }
         if (p.amax_out) {
           amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
           asum += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
@@ -1721,11 +1755,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
     const unsigned bits = __builtin_bit_cast(unsigned, amx);
     if ((threadIdx.x & 63) == 0 && amx > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       atomicMax(p.amax_out, bits);
-    if (p.amax_stats && (blockIdx.x & 63) == 0) {   // a sample of the row blocks, as in conv_epilogue_finish
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.amax_stats && (lin & 63) == 0) {   // a sample of the blocks, as in conv_epilogue_finish
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { asum += __shfl_xor(asum, o, 64); acnt += __shfl_xor(acnt, o, 64); }
       if ((threadIdx.x & 63) == 0 && acnt > 0.f) {
-        const int k = (blockIdx.x >> 6) & 15;
+        const int k = (lin >> 6) & 15;
         atomicAdd((float*)p.amax_out + 1 + k, asum);
         atomicAdd((float*)p.amax_out + 17 + k, acnt);
       }
@@ -3006,10 +3041,20 @@ int launch_strip(const ConvP& p, hipStream_t s) {
   return 0;
 }
 
-template <int KT, int BN, int NS>
+// panels per block of the row-resident 1x1 kernel: all of them when the row blocks alone fill the chip (>= 512 resident
+// slots), else column groups so that about 512 blocks exist
+static int rows_ppb(const ConvP& p, int BN) {
+  const int tiles_m = mmt_cdiv(p.M, 128), npanel = mmt_cdiv(p.Cout, BN);
+  if (tiles_m >= 512) return npanel;
+  int groups = mmt_cdiv(512, tiles_m);
+  if (groups > npanel) groups = npanel;
+  return mmt_cdiv(npanel, groups);
+}
+
+template <int KT, int BN, int NS, bool F16 = false>
 int launch_rows(const ConvP& p, hipStream_t s) {
   const size_t lds = (size_t)128 * BN * 4 + 2 * (size_t)KT * NS * (BN / 32) * 1024;
-  auto kern = conv1x1_rows_kernel<KT, BN, NS>;
+  auto kern = conv1x1_rows_kernel<KT, BN, NS, F16>;
   if (lds > 65536) {
     static bool done = false;  // per instantiation
     if (!done) {
@@ -3018,20 +3063,29 @@ int launch_rows(const ConvP& p, hipStream_t s) {
       done = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(mmt_cdiv(p.M, 128)), dim3(256), lds, s, p, p.wpl, p.wpl_stride);
+  const int ppb = rows_ppb(p, BN);
+  hipLaunchKernelGGL(kern, dim3(mmt_cdiv(p.M, 128), mmt_cdiv(mmt_cdiv(p.Cout, BN), ppb)), dim3(256), lds, s, p, p.wpl, p.wpl_stride, ppb);
   MMT_LAUNCH_CHECK();
   return 0;
+}
+
+// is this call one for the row-resident 1x1 kernel?  (K = 64 / 128 in every split mode; K = 256 on the fp16 split only)
+static bool rows_shape(const ConvP& p, bool f16) {
+  const char* rows_env = getenv("MMT_ROWS");  // read per call: the parity tests switch it
+  const int rows = rows_env ? atoi(rows_env) : 1;
+  static const int rows_min = getenv("MMT_ROWS_MIN") ? atoi(getenv("MMT_ROWS_MIN")) : 256;  // blocks of 128 rows (bf16 split)
+  static const int rows_min16 = getenv("MMT_ROWS_MIN16") ? atoi(getenv("MMT_ROWS_MIN16")) : 16;
+  if (!rows || p.io || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.Cout < 64 || (p.Cout & 3) || p.res_mode > 1 || p.mul ||
+      p.out_stride != 1 || (long)p.M * p.Cin * 4 >= (1L << 31) || (long)p.M * p.Cout * 4 >= (1L << 31))
+    return false;
+  if (f16) return (p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && p.M >= 128 * rows_min16;
+  return !p.mask && (p.Cin == 64 || p.Cin == 128) && p.M >= 128 * rows_min;
 }
 
 template <int NS>
 int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
   // 1x1 / stride 1 layers with K = 64 or 128 and many rows: one block per 128 rows, all Cout panels (see the kernel)
-  const char* rows_env = getenv("MMT_ROWS");  // read per call: the parity tests switch it
-  const int rows = rows_env ? atoi(rows_env) : 1;
-  static const int rows_min = getenv("MMT_ROWS_MIN") ? atoi(getenv("MMT_ROWS_MIN")) : 256;  // blocks of 128 rows
-  if (rows && !p.io && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.Cout >= 64 && p.M >= 128 * rows_min &&
-      (p.Cout & 3) == 0 && p.res_mode <= 1 && !p.mask && !p.mul && p.out_stride == 1 &&
-      (long)p.M * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31)) {
+  if (rows_shape(p, false)) {
     static const int bn64 = getenv("MMT_ROWS_BN") ? atoi(getenv("MMT_ROWS_BN")) : 32;
     if (p.Cin == 64) return bn64 == 64 ? launch_rows<4, 64, NS>(p, s) : launch_rows<4, 32, NS>(p, s);
     if (p.Cin == 128) return launch_rows<8, 32, NS>(p, s);
@@ -3287,6 +3341,11 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
   if (variant == 0) return MMT_EINVAL;
   p.f16_sx = x_amax; p.f16_sw = s_w; p.f16_ax = 1;
   hipStream_t s = (hipStream_t)stream;
+  if (rows_shape(p, true)) {   // 1x1 layers with K = 64 / 128 / 256: rows resident in registers as fp16 fragments
+    if (p.Cin == 64) return launch_rows<4, 32, 2, true>(p, s);
+    if (p.Cin == 128) return launch_rows<8, 32, 2, true>(p, s);
+    return launch_rows<16, 32, 2, true>(p, s);
+  }
   const int ksplit = pick_ksplit(p);
   auto go = [&](auto kern, int BM, int BN, int ks) -> int {
     const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN) * ks;

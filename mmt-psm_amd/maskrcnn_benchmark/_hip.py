@@ -827,9 +827,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if F16X2 and not io and get_conv_precision() == 3:
         # consumers on the fp16 split scale y themselves: no bf16 planes from this epilogue, max |y| recorded on the way
         want_amax, want_planes = True, False
-        rows_shape = (a.KH == 1 and stride == 1 and Cin in (64, 128) and N * Ho * Wo >= 128 * 256 and res_mode <= 1
-                      and mask is None and mul is None and out_stride == 1)   # the row-resident 1x1 kernel keeps these
-        if (f16 is None and F16X2_TILED and a.w_planes and Cout > 32 and Cin % 16 == 0 and y_out is None and not rows_shape):
+        if (f16 is None and F16X2_TILED and a.w_planes and Cout > 32 and Cin % 16 == 0 and y_out is None):
             if w is not None:
                 f16t = (w, False, None)
             elif f16_src is not None:

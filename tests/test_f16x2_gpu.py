@@ -151,6 +151,60 @@ def test_wgrad_f16x2(hip, shape):
     assert eh < 2e-5 and eh <= 2.0 * e3 + 1e-7, (shape, eh, e3)
 
 
+ROWS_CASES = [  # N, Cin, H, W, Cout, epilogue: the row-resident 1x1 kernel on the fp16 split (K = 64 / 128 / 256)
+    (8, 256, 64, 64, 1024, "res"), (2, 256, 64, 64, 1024, "res"), (2, 256, 64, 64, 1024, "mask"), (1, 256, 47, 45, 200, "relu"),
+    (4, 64, 128, 128, 256, "res"), (1, 64, 257, 259, 96, ""), (2, 128, 128, 128, 512, "maskres"), (8, 256, 256, 256, 128, ""),
+    (2, 256, 32, 32, 2048, "mask"),
+]
+
+
+@pytest.mark.parametrize("case", ROWS_CASES)
+def test_rows_kernel_f16x2(hip, case):
+    """conv1x1_rows_kernel<KT, 32, 2, true>: 1x1 layers with K = 64 / 128 / 256 keep their rows in registers as (h, l) fp16
+    fragments and walk the output panels (column groups when the row blocks alone would not fill the chip): against fp64
+    within the default mode's bound, no worse than the 3-term bf16 split, and equal to fp32 rounding to the tiled kernel on
+    the same arithmetic (MMT_ROWS=0); residual, ReLU, the (x > 0) mask of a data gradient, ragged M, Cout % 32 != 0"""
+    H = hip
+    N, C, Hh, W, Co, opts = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = _inputs("act" if "mask" not in opts else "grad", (N, C, Hh, W), g)
+    w = _cl((torch.randn(Co, C, 1, 1, generator=g) * (2.0 / C) ** 0.5).cuda())
+    mag = x.abs().max().item() * 0.3
+    sc, sh = (torch.rand(Co, generator=g) + 0.5).cuda(), (torch.randn(Co, generator=g) * 0.1 * mag).cuda()
+    res = _cl((torch.randn(N, Co, Hh, W, generator=g) * mag).cuda()) if "res" in opts else None
+    mask = _cl(torch.randn(N, Co, Hh, W, generator=g).cuda()) if "mask" in opts else None
+    kw = dict(relu=opts in ("res", "relu"), res=res, res_mode=1 if res is not None else 0, mask=mask, mask_scale=2.0)
+    H.set_f16x2(False)
+    y3 = H.conv_forward(x, w, sc, sh, 1, 0, **kw)
+    H.set_f16x2(True)
+    n0 = H.F16_STATS["tiled"]
+    yh = H.conv_forward(x, w, sc, sh, 1, 0, **kw)
+    assert H.F16_STATS["tiled"] == n0 + 1
+    old = os.environ.get("MMT_ROWS")
+    os.environ["MMT_ROWS"] = "0"
+    try:
+        yt = H.conv_forward(x, w, sc, sh, 1, 0, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("MMT_ROWS", None)
+        else:
+            os.environ["MMT_ROWS"] = old
+    H.set_f16x2(False)
+    ref = F.conv2d(x.double(), w.double()) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if res is not None:
+        ref = ref + res.double()
+    if kw["relu"]:
+        ref = F.relu(ref)
+    if mask is not None:
+        ref = torch.where(mask > 0, ref * 2.0, torch.zeros_like(ref))
+    scale = ref.abs().max().item()
+    e3 = (y3.double() - ref).abs().max().item() / scale
+    eh = (yh.double() - ref).abs().max().item() / scale
+    assert eh < 1e-5 and eh <= 2.0 * e3 + 2e-7, (case, eh, e3)
+    assert not torch.equal(yh, y3)
+    assert (yh - yt).abs().max().item() <= 4e-6 * scale, case      # same products, another summation order at most
+
+
 def test_f16_weight_cache_is_per_tensor_object(hip):
     """two different weights that the allocator places at the same address must not share packed planes"""
     H = hip
