@@ -1527,12 +1527,21 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p, 
     f32x4 v[U];
 #pragma unroll
     for (int u = 0; u < U; u++) v[u] = base[i0 + u * 256];
-    for (int j = 1; j < ksplit; j++) {
-      f32x4 t[U];
+    // slabs four at a time: all 16 loads of a group are in flight before the first add (slab by slab this kernel was a chain
+    // of ksplit memory latencies: 23-35 us per call on the few-tile layers); the order of the additions is unchanged
+    for (int j = 1; j < ksplit; j += 4) {
+      f32x4 t[4][U];
 #pragma unroll
-      for (int u = 0; u < U; u++) t[u] = base[(long)j * TILE4 + i0 + u * 256];
+      for (int jj = 0; jj < 4; jj++)
 #pragma unroll
-      for (int u = 0; u < U; u++) v[u] += t[u];
+        for (int u = 0; u < U; u++)
+          t[jj][u] = j + jj < ksplit ? base[(long)(j + jj) * TILE4 + i0 + u * 256] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+        if (j + jj < ksplit) {
+#pragma unroll
+          for (int u = 0; u < U; u++) v[u] += t[jj][u];
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) ((f32x4*)lds)[i0 + u * 256] = v[u];
@@ -1643,8 +1652,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
   // epilogue (with two to four blocks per CU nothing else would cover it).  Same expressions as conv_epilogue.
   constexpr int C4 = BN / 4, RPP = 256 / C4, ROWS = 128 / RPP;
   const int cc = tid % C4, r0 = tid / C4;
+  // residual rows of this thread, the same for every panel: same pixel (mode 1) or the nearest-x2 upsampled coarser map
+  // (mode 2: the FPN top-down add, backbone/fpn.py:57-62)
+  const int res_rows = p.res_mode == 2 ? p.N * (p.Ho >> 1) * (p.Wo >> 1) : p.M;
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res_mode == 1 ? p.res : p.x), 0, p.res_mode == 1 ? (int)((long)p.M * p.Cout * 4) : 0, 0x00020000);
+      (void*)(p.res_mode ? p.res : p.x), 0, p.res_mode ? (int)((long)res_rows * p.Cout * 4) : 0, 0x00020000);
+  unsigned rrow[ROWS];
+#pragma unroll
+  for (int g = 0; g < ROWS; g++) {
+    const int m = m0 + r0 + g * RPP;
+    rrow[g] = (unsigned)m;
+    if (p.res_mode == 2 && m < p.M) {
+      const int HoWo = p.Ho * p.Wo;
+      const int img = m / HoWo, rem = m - img * HoWo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      rrow[g] = (unsigned)((img * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+    }
+  }
   const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.mask ? p.mask : p.x), 0, p.mask ? (int)((long)p.M * p.Cout * 4) : 0, 0x00020000);
   const float finv = F16 ? 1.f / (sx * *p.f16_sw) : 1.f;
@@ -1662,7 +1686,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
       for (int g = 0; g < ROWS; g++) {
         const int m = m0 + r0 + g * RPP;
         const unsigned off = (cok && m < p.M) ? ((unsigned)m * (unsigned)p.Cout + (unsigned)c) * 4u : 0x80000000u;
-        ur[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));
+        const unsigned roff = (cok && m < p.M) ? (rrow[g] * (unsigned)p.Cout + (unsigned)c) * 4u : 0x80000000u;
+        ur[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)roff, 0, 0));
         if (p.mask) um[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmask, (int)off, 0, 0));
       }
       if (cok) {
@@ -1728,7 +1753,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
         if (m >= p.M) break;
         const f32x4 t = *(const f32x4*)(ct + row * BN + cc * 4);
         float v[4] = {t[0] * sc4[0] + sh4[0], t[1] * sc4[1] + sh4[1], t[2] * sc4[2] + sh4[2], t[3] * sc4[3] + sh4[3]};
-        if (p.res_mode == 1) {
+        if (p.res_mode) {
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] += ur[g][e];
         }
@@ -3075,11 +3100,11 @@ static bool rows_shape(const ConvP& p, bool f16) {
   const int rows = rows_env ? atoi(rows_env) : 1;
   static const int rows_min = getenv("MMT_ROWS_MIN") ? atoi(getenv("MMT_ROWS_MIN")) : 256;  // blocks of 128 rows (bf16 split)
   static const int rows_min16 = getenv("MMT_ROWS_MIN16") ? atoi(getenv("MMT_ROWS_MIN16")) : 16;
-  if (!rows || p.io || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.Cout < 64 || (p.Cout & 3) || p.res_mode > 1 || p.mul ||
+  if (!rows || p.io || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.Cout < 64 || (p.Cout & 3) || p.res_mode > 2 || p.mul ||
       p.out_stride != 1 || (long)p.M * p.Cin * 4 >= (1L << 31) || (long)p.M * p.Cout * 4 >= (1L << 31))
     return false;
   if (f16) return (p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && p.M >= 128 * rows_min16;
-  return !p.mask && (p.Cin == 64 || p.Cin == 128) && p.M >= 128 * rows_min;
+  return !p.mask && p.res_mode <= 1 && (p.Cin == 64 || p.Cin == 128) && p.M >= 128 * rows_min;
 }
 
 template <int NS>

@@ -154,7 +154,7 @@ def test_wgrad_f16x2(hip, shape):
 ROWS_CASES = [  # N, Cin, H, W, Cout, epilogue: the row-resident 1x1 kernel on the fp16 split (K = 64 / 128 / 256)
     (8, 256, 64, 64, 1024, "res"), (2, 256, 64, 64, 1024, "res"), (2, 256, 64, 64, 1024, "mask"), (1, 256, 47, 45, 200, "relu"),
     (4, 64, 128, 128, 256, "res"), (1, 64, 257, 259, 96, ""), (2, 128, 128, 128, 512, "maskres"), (8, 256, 256, 256, 128, ""),
-    (2, 256, 32, 32, 2048, "mask"),
+    (2, 256, 32, 32, 2048, "mask"), (8, 256, 64, 96, 256, "up2"), (2, 256, 256, 256, 256, "up2"),
 ]
 
 
@@ -174,6 +174,10 @@ def test_rows_kernel_f16x2(hip, case):
     res = _cl((torch.randn(N, Co, Hh, W, generator=g) * mag).cuda()) if "res" in opts else None
     mask = _cl(torch.randn(N, Co, Hh, W, generator=g).cuda()) if "mask" in opts else None
     kw = dict(relu=opts in ("res", "relu"), res=res, res_mode=1 if res is not None else 0, mask=mask, mask_scale=2.0)
+    if opts == "up2":   # the FPN lateral: + the coarser level, nearest-x2 upsampled (res_mode 2)
+        top = _cl((torch.randn(N, Co, Hh // 2, W // 2, generator=g) * mag).cuda())
+        kw.update(res=top, res_mode=2)
+        res = F.interpolate(top, scale_factor=2, mode="nearest")
     H.set_f16x2(False)
     y3 = H.conv_forward(x, w, sc, sh, 1, 0, **kw)
     H.set_f16x2(True)
