@@ -2,9 +2,10 @@
 moved to the host and keyed by image id, gathered over ranks, optionally saved as predictions.pth and handed to an
 evaluator.
 
-The reference's PAP metrics (data/datasets/evaluation/pap/pap_eval.py: AJI / F1 / DSC / mAP on a private dataset that ships
-with an empty image list) are out of scope: `inference` calls `dataset.evaluate(predictions, ...)` when the
-dataset provides one (or the `evaluator` argument) and otherwise returns the predictions.  Differences from the reference,
+The reference's PAP metrics (data/datasets/evaluation/pap/pap_eval.py: AJI / F1 / DSC / mAP with `iouIntUni`) are built in
+`data/datasets/evaluation/pap/` (round 3; pinned to the reference's own evaluator, tests/test_pap_eval.py): `inference` calls
+the `evaluator` argument, else `dataset.evaluate`, else `data.datasets.evaluation.evaluate` when the dataset offers what the
+PAP evaluator reads, and otherwise returns the predictions (the dataset classes are private data).  Differences,
 on purpose: a failing batch raises instead of being skipped by a bare `except: continue` (:39-40), and predictions of
 other ranks travel through `torch.distributed.all_gather_object` instead of a temporary directory (utils/comm.py:81-147)."""
 import datetime
@@ -78,6 +79,10 @@ def inference(model, data_loader, dataset_name, iou_types=("bbox",), box_only=Fa
     if output_folder:
         torch.save(predictions, os.path.join(output_folder, "predictions.pth"))
     evaluate = evaluator if evaluator is not None else getattr(dataset, "evaluate", None)
+    if evaluate is None and dataset is not None:
+        from maskrcnn_benchmark.data.datasets import evaluation as _ev
+        if all(hasattr(dataset, a) for a in ("id_to_img_map", "get_ground_truth", "contiguous_category_id_to_json_id", "maxWS")):
+            return _ev.evaluate(dataset, predictions, output_folder, box_only=box_only, iou_types=iou_types, visual_num=visual_num)
     if evaluate is None:
         return predictions
     return evaluate(predictions=predictions, output_folder=output_folder, box_only=box_only, iou_types=iou_types,

@@ -532,6 +532,60 @@ def gen_proposals():
     print({k: out[k].tolist() for k in out if k.endswith("_count")})
 
 
+def gen_pap_eval():
+    """SURVEY 8f-4 / VERDICT r2 (next 9): the REFERENCE's PAP evaluator (data/datasets/evaluation/pap/pap_eval.py: Papeval
+    evaluate / accumulate / summarize) with the reference's own pycocotools (pycoco/, built by oracle/refharness) on the
+    synthetic windows of tests/pap_inputs.py: RLE strings, the iouIntUni triples of one window and the final statistics."""
+    import re
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pap_inputs
+    from pycocotools import mask as mu
+    # the evaluator module is loaded by path (the package's __init__ pulls in the data loaders: torch._six); its visualisation
+    # import is a private module of the authors; numpy 2 refuses the float `num` of two np.linspace calls
+    v = types.ModuleType("maskrcnn_benchmark.utils.visual")
+    v.display_instance = None
+    sys.modules["maskrcnn_benchmark.utils.visual"] = v
+    path = os.path.join(os.path.dirname(mb.__file__), "data", "datasets", "evaluation", "pap", "pap_eval.py")
+    src = open(path).read()
+    src = re.sub(r"np\.round\(\(0\.95 - \.5\) / \.05\) \+ 1", "int(np.round((0.95 - .5) / .05)) + 1", src)
+    src = re.sub(r"np\.round\(\(1\.00 - \.0\) / \.01\) \+ 1", "int(np.round((1.00 - .0) / .01)) + 1", src)
+    pe = types.ModuleType("ref_pap_eval")
+    exec(compile(src, path, "exec"), pe.__dict__)
+    gts, dts = pap_inputs.make(7)
+    rles = []
+    for lst in (gts, dts):
+        for x in lst:
+            r = mu.encode(np.asfortranarray(x["mask"]))
+            x["segmentation"] = {"size": r["size"], "counts": r["counts"].decode("ascii")}
+            rles.append(x["segmentation"]["counts"])
+    ev = pe.Papeval([{k: v_ for k, v_ in g.items() if k != "mask"} for g in gts],
+                    [{k: v_ for k, v_ in d.items() if k != "mask"} for d in dts], "segm")
+    ev.evaluate()
+    ev.accumulate()
+    ev.summarize()
+    out = {"stats": {m: {str(k): (float(np.asarray(v_).reshape(-1)[0]) if not isinstance(v_, (int, float)) else float(v_))
+                         for k, v_ in d.items()} for m, d in ev.stats.items()},
+           "rle_counts": rles, "areas": [int(mu.area(x["segmentation"])) for x in gts + dts]}
+    # one window's raw iouIntUni triple (detections in score order x ground truths), cells the C code writes
+    key = sorted(k for k in ev.ious if len(ev.ious[k]) == 5 and len(ev.ious[k][0]))[0]
+    g_ = ev._gts[key]
+    d_ = sorted(ev._dts[key], key=lambda q: -q["score"])
+    iou, inter, uni = mu.iouIntUni([q["segmentation"] for q in d_], [q["segmentation"] for q in g_], [0] * len(g_))
+    out["window"] = {"key": [key[0], key[1]], "iou": iou.tolist(), "inter": np.where(iou > 0, inter, 0).tolist(),
+                     "union": np.where(iou > 0, uni, 0).tolist()}
+    out["per_window"] = [None if e is None else {"image_id": e["image_id"], "category_id": e["category_id"], "AJI": float(e["AJI"][0, 0]),
+                                                  "F1": float(e["F1"]), "FNRo": float(e["FNRo"]), "FDR": float(e["FDR"]),
+                                                  "DSC": [float(x) for x in e["DSC"]], "TPRp": [float(x) for x in e["TPRp"]]}
+                         for e in ev.evalImgs]
+    out["precision_shape"] = list(ev.eval["precision"].shape)
+    out["precision_sum"] = float(ev.eval["precision"].sum())
+    out["recall"] = ev.eval["recall"].tolist()
+    with open(os.path.join(HERE, "pap_eval.json"), "w") as f:
+        json.dump(out, f, default=lambda o: o.item() if hasattr(o, "item") else str(o))
+    print("wrote pap_eval.json", {m: d for m, d in out["stats"].items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["nms", "roi", "small", "mt", "masks", "model"]
     if "nms" in which:
@@ -554,3 +608,5 @@ if __name__ == "__main__":
         gen_transforms()
     if "proposals" in which:
         gen_proposals()
+    if "pap" in which:
+        gen_pap_eval()
