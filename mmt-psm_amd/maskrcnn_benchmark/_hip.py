@@ -422,8 +422,15 @@ def _check(code, what):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+import threading as _threading
+_TLS = _threading.local()   # .stream: raw handle that replaces the current stream for the launches of this thread (side-stream weight gradients)
+
+
 def _stream():
     """raw hipStream_t of torch's current stream on the current device (per thread: the teacher thread has its own)"""
+    ov = getattr(_TLS, "stream", None)
+    if ov is not None:
+        return ov
     if _raw_stream is not None:  # one C call instead of building a torch.cuda.Stream object (~9 us, ~230 calls per step)
         return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
@@ -1040,8 +1047,20 @@ def wgrad_prepare(x, dy):
         _amax_of(nhwc(dy))
 
 
-def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
-    """accumulates into dw (same memory layout as the weight) and dbias"""
+def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=None):
+    """accumulates into dw (same memory layout as the weight) and dbias.  `side`: a torch stream to launch on instead of the
+    current one (the caller orders it against the producers of x / dy and joins it later; the split-K workspace is handed
+    to it with record_stream) -- cheaper than entering a stream context per call"""
+    if side is not None:
+        _TLS.stream = side.cuda_stream
+        try:
+            return conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale, dbias)
+        finally:
+            _TLS.stream = None
+            ws = getattr(_TLS, "last_ws", None)
+            if ws is not None:
+                ws.record_stream(side)
+                _TLS.last_ws = None
     x = nhwc(x)
     dy = nhwc(dy)
     Cout, Cin, KH, KW = w_shape
@@ -1066,6 +1085,7 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None):
             F16_STATS["wgrad"] += 1
     splits = lib().mmt_conv_wgrad_splits(ctypes.byref(a))
     ws = torch.empty((splits * Cout * KH * KW * Cin,), dtype=torch.float32, device=x.device) if splits > 1 else None
+    _TLS.last_ws = ws
     if PROFILE is not None and PROFILE_ALL:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -81,7 +81,8 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
     db = None
     if with_bias:
         db = dst_b if dst_b is not None else torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
-    if _WG_ON and dst_w is not None and (dst_b is not None or not with_bias) and not (H.PROFILE is not None and H.PROFILE_ALL):
+    if (_WG_ON and dst_w is not None and (dst_b is not None or not with_bias) and not (H.PROFILE is not None and H.PROFILE_ALL)
+            and H.get_conv_precision() == 3):   # (the bf16 configuration is bound by its host threads: 28.5 vs 33.6 ms with it)
         ent = _wg_stream(x.device)
         side, cur = ent[0], torch.cuda.current_stream(x.device)
         H.wgrad_prepare(x, g)            # reduction passes for operands nobody recorded a maximum of: on THIS stream
@@ -89,10 +90,9 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
             ent[2] = True
             torch.autograd.Variable._execution_engine.queue_callback(join_wgrads)
         side.wait_stream(cur)            # operands (x, g) and everything before them on this stream
-        with torch.cuda.stream(side):
-            H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
-        x.record_stream(side)
-        g.record_stream(side)
+        H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db, side=side)
+        x.record_stream(side)            # autograd frees the saved activation when this node returns: not before the side
+        g.record_stream(side)            # stream is done with it
         ent[1] += 1
     else:
         H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)

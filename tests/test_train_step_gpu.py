@@ -250,7 +250,9 @@ def _schedule_equivalence(trainer, batch):
         assert bench_l[k] == pytest.approx(same_l[k], rel=1e-6), k
     _close(bench_g, same_g, 1e-4, "gradient, overlapped vs serial")
     _close(bench_s - snap["s"], same_s - snap["s"], 1e-4, "student update")
-    _close(bench_t - snap["t"], same_t - snap["t"], 1e-4, "teacher update")
+    # (the teacher moves by 1 % of the student's step: the difference of two nearly equal fp32 weights, where one ulp of a
+    # weight already is ~1e-4 of the largest update -- measured 0.2e-4 .. 1.7e-4 between runs)
+    _close(bench_t - snap["t"], same_t - snap["t"], 5e-4, "teacher update")
     # (2) two passes + early supervised backward + graph of two backward calls vs one batched pass + one backward
     for k in b2_l:
         assert b2_l[k] == pytest.approx(ser_l[k], rel=2e-5), k
