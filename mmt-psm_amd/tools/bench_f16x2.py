@@ -26,6 +26,8 @@ def f16x2(x, w, scale, shift, relu, pre=None):
     a.x_planes, a.x_plane_stride, a.w_planes, a.w_plane_stride = xp.data_ptr(), xp.stride(0), wp.data_ptr(), wp.stride(0)
     H._check(L.mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), H._stream()), "strip f16x2")
     return y, ((xp, sx), (wp, sw))
+H.lib()
+H.set_f16x2(False)   # tool: the arms below switch the arithmetic explicitly
 g = torch.Generator().manual_seed(0)
 def act(shape): return cl(torch.randn(shape, generator=g).relu_().cuda())                       # post-ReLU activations
 def grad(shape): return cl((torch.randn(shape, generator=g) * torch.exp(torch.randn(shape, generator=g) * 2.0) * 1e-5).cuda())  # 6 decades

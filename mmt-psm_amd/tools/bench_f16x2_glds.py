@@ -24,6 +24,8 @@ def f16(x, w, sc, sh, stride, pad, relu, res, amax, wp, sw):
     a.w_planes, a.w_plane_stride = wp.data_ptr(), wp.stride(0)
     H._check(L.mmt_conv_forward_f16x2(ctypes.byref(a), amax.data_ptr(), sw.data_ptr(), H._stream()), "conv f16x2")
     return y
+H.lib()
+H.set_f16x2(False)   # tool: the arms below switch the arithmetic explicitly
 g = torch.Generator().manual_seed(0)
 cases = [("1x1 256->1024 @64^2 N8 +res+relu", 8, 256, 64, 1024, 1, 1, True), ("1x1 1024->256 @64^2 N8 relu", 8, 1024, 64, 256, 1, 1, False),
          ("1x1 256->1024 @64^2 N2 +res+relu", 2, 256, 64, 1024, 1, 1, True), ("1x1 1024->256 @64^2 N2 relu", 2, 1024, 64, 256, 1, 1, False),
