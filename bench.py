@@ -435,7 +435,7 @@ def main():
             ck["peak_at_median_sclk"] = round(out["roofline"]["peak"] * ck["sclk_mhz_median"] / NOMINAL_SCLK_MHZ, 1)
             ck["frac_of_peak_at_median_sclk"] = round(out["roofline"]["achieved"] / ck["peak_at_median_sclk"], 4)
             ck["note"] = ("sysfs hwmon of this GPU, 10 ms samples over the bracketed leg; `peak` above is quoted at %d MHz, under "
-                          "bf16 MFMA load the part sits at its board power limit below that (profiles/r02_clock_under_load.txt)"
+                          "bf16 / fp16 MFMA load the part sits at its board power limit below that (profiles/r03_clock_under_load.txt)"
                           % NOMINAL_SCLK_MHZ)
         if ck is not None:
             out["roofline"]["clock"] = ck
@@ -444,7 +444,10 @@ def main():
             odom = "fwd4" if dom == "fwd1" else "fwd1"
             opeak = PEAK_FP32_MFMA_TFLOPS if mode == 0 else PEAK_BF16_MFMA_TFLOPS / products_of(mode, odom)
             out["roofline"]["other_large_tile_kernel"] = {
-                "kernel": KERNEL_NAMES[odom](mode) + (" [two-term fp16 split: 3 products, peak %.0f]" % opeak if products_of(mode, odom) == 3 else ""),
+                "kernel": (("conv_fwd_glds_kernel<128,128,4,1,2,3,true> (raw fp32 rows split into two fp16 terms in registers, "
+                            "v_mfma_f32_32x32x16_f16 x 3 products)" if odom == "fwd1" else
+                            "conv3x3_strip_kernel<TW,2,0,true> (two fp16 planes per operand, v_mfma_f32_32x32x16_f16 x 3 products)")
+                           if products_of(mode, odom) == 3 else KERNEL_NAMES[odom](mode)),
                 "launches_per_step": len(other) // npf,
                 "achieved": round(fo / (mo * 1e-3) / 1e12, 2), "frac": round(fo / (mo * 1e-3) / 1e12 / opeak, 4),
                 "avg_launch_ms": round(mo / len(other), 4), "share_of_step_time": round(mo / (dtp * 1e3), 4)}

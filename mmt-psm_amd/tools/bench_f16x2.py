@@ -79,4 +79,4 @@ for name, N, Cin, Hh, W, Cout, mk in cases:
     print("%s\n   fp32-input MFMA %7.3f ms %6.1f TF  err max/max %.2e rms %.2e per-output max|d|/sum|a||b| %.2e\n   bf16 x3 (6 prod) %7.3f ms %6.1f TF  err max/max %.2e rms %.2e per-output %.2e\n"
           "   fp16 x2 (3 prod) %7.3f ms %6.1f TF  err max/max %.2e rms %.2e per-output %.2e   [+ amax / split passes of the input %.3f ms; scales 2^%d, 2^%d]" % (
               name, t0, fl / t0 / 1e9, e0[0], e0[1], e0[2], t3, fl / t3 / 1e9, e3[0], e3[1], e3[2], th, fl / th / 1e9, eh[0], eh[1], eh[2], tp,
-              round(math.log2(pre[0][1][0].item())), round(math.log2(pre[1][1][1].item()))))
+              round(math.log2(pre[0][1][0].item())), round(math.log2(pre[1][1][0].item()))))

@@ -1,5 +1,6 @@
 """Every convolution call of one train_step by shape: count, time, algorithmic TFLOP/s, and the time a perfect kernel would
-need (max of 6-product MFMA time at 2500/6 TFLOP/s and fp32 HBM bytes at 5 TB/s).  Single stream (MMT_OVERLAP_TEACHER=0)
+need (max of the MFMA time at 2500 / products-per-multiply TFLOP/s -- 3 products on the default fp16 split, 6 on the bf16 split --
+and fp32 HBM bytes at 5 TB/s).  Single stream (MMT_OVERLAP_TEACHER=0)
 so the event brackets hold one kernel's own time.  Sorted by the time above that bound -- the list of what is left."""
 import os, sys, collections, torch
 os.environ.setdefault("MMT_OVERLAP_TEACHER", "0")
@@ -22,6 +23,7 @@ for r in rec:
     fl, e0, e1, key = r[0], r[1], r[2], r[3]
     a = agg[key]
     a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] = fl
+NPROD = 3 if (H.F16X2 and H.get_conv_precision() == 3) else bench.PRODUCTS[H.get_conv_precision()]   # matrix products per multiply
 rows = []
 for key, (c, ms, fl) in agg.items():
     kind, N, Hh, W, Cin, Cout, KH, stride, ostride = key
@@ -30,12 +32,12 @@ for key, (c, ms, fl) in agg.items():
         byts = 4.0 * N * (Hh * W * Cin + Ho * Wo * Cout) + 4.0 * Cin * Cout * KH * KH
     else:
         byts = 4.0 * N * (Hh * W * Cin + Ho * Wo * Cout * (ostride if ostride else 1)) + 6.0 * Cin * Cout * KH * KH
-    t_m, t_h = fl / (2500e12 / 6) * 1e3, byts / 5e12 * 1e3
+    t_m, t_h = fl / (2500e12 / NPROD) * 1e3, byts / 5e12 * 1e3
     per = ms / c
     rows.append((c / STEPS * (per - max(t_m, t_h)), key, c / STEPS, per, fl / per / 1e9, t_m, t_h))
 rows.sort(key=lambda r: -r[0])
 tot = sum(r[2] * r[3] for r in rows)
-print("total conv time per step %.2f ms; bound %.2f ms" % (tot, sum(r[2] * max(r[5], r[6]) for r in rows)))
+print("total conv time per step %.2f ms; bound %.2f ms (%d matrix products per multiply)" % (tot, sum(r[2] * max(r[5], r[6]) for r in rows), NPROD))
 print("%-46s %6s %8s %8s %8s %8s %8s" % ("shape (kind,N,H,W,Cin,Cout,K,s,os)", "n/step", "ms each", "TFLOP/s", "t_mfma", "t_hbm", "excess"))
 cat = collections.defaultdict(lambda: [0.0, 0.0, 0.0])
 for ex, key, c, per, tf, t_m, t_h in rows:
