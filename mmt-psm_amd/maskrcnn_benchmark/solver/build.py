@@ -37,6 +37,9 @@ class FlatSGD(object):
 
     def load_state_dict(self, sd):
         f = self.flat
+        if "momentum_buffers" not in sd:
+            raise ValueError("FlatSGD.load_state_dict: not a FlatSGD state (torch.optim.SGD's state / param_groups format of a "
+                             "reference checkpoint is not convertible by name; only the `model` entry is interchangeable)")
         for n, v in sd["momentum_buffers"].items():
             if n in f.index and f.index[n][0] < f.n_trainable:
                 o, k = f.index[n]

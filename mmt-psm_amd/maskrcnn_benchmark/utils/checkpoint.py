@@ -1,9 +1,11 @@
 """Checkpoint I/O (reference: utils/checkpoint.py:13-205).
 
 Same file format as the reference -- `torch.save({"model": state_dict, "optimizer": ..., "scheduler": ..., **extra})`
-plus a `last_checkpoint` tag file in the save directory -- and the same state-dict KEYS, so checkpoints
-move between the reference and this build in both directions (the one layout difference inside this build, fc6's column
-order, is converted at the state-dict boundary: modeling/roi_heads/box_head/box_head.py).
+plus a `last_checkpoint` tag file in the save directory -- and the same state-dict KEYS, so the `model` entry
+of a checkpoint moves between the reference and this build in both directions (the one layout difference inside this build,
+fc6's column order, is converted at the state-dict boundary: modeling/roi_heads/box_head/box_head.py).  The `optimizer` entry is
+this build's own (FlatSGD: momentum by parameter name), not torch.optim.SGD's state/param_groups: the fork never restores it
+anyway (below), and `FlatSGD.load_state_dict` says so when handed the other format.
 
 Loading follows the FORK's `Checkpointer.load` (utils/checkpoint.py:69-117), which differs from upstream maskrcnn-benchmark:
   * `load(f, test=True)` -- what tools/train_mean_teacher.py:42-43 calls for both models: plain suffix-matched load;
