@@ -63,7 +63,8 @@ def build(device, rank, irnet=False, crop=None, n_inst=None, base_lr=None):
         # RELATION_NMS.LOSS 0.01 (shipped: 1.0): the synthetic fc7 features have |x|^2 ~ 1e3, so an MSE head on top of
         # them is unstable at BASE_LR 0.005 with weight 1 (lr * |x|^2 > 2) and the run turns NaN within 4 steps;
         # the loss weight only scales the gradient -- the launches per step are the same
-        cfg.merge_from_list(["MODEL.RELATION_NMS.USE_RELATION_NMS", True, "MODEL.RELATION_MASK.USE_RELATION", True,
+        parts = os.environ.get("MMT_IRNET_PARTS", "nms,mask")   # tools: one of the two relation modules alone
+        cfg.merge_from_list(["MODEL.RELATION_NMS.USE_RELATION_NMS", "nms" in parts, "MODEL.RELATION_MASK.USE_RELATION", "mask" in parts,
                              "MODEL.RELATION_NMS.LOSS", 0.01])
     if base_lr is not None:
         cfg.merge_from_list(["SOLVER.BASE_LR", base_lr])
@@ -72,7 +73,7 @@ def build(device, rank, irnet=False, crop=None, n_inst=None, base_lr=None):
     teacher = build_detection_model(cfg, is_teacher=True)
     shapes = {k: tuple(v.shape) for k, v in student.state_dict().items()}
     sd = synthetic.make_weights(shapes, seed=0)  # identical on every rank (DP replicas start equal)
-    if irnet:
+    if irnet and student.relation_nms is not None:
         # the relation-NMS IoU regressor keeps its own (seeded) training initialisation: with the O(1) synthetic
         # weights its MSE loss starts at ~20 and diverges to NaN within three SGD steps at BASE_LR.  Its output bias
         # is set to 0.5 (a regressor that predicts IoU 0.5 +- small for every ranked box) so that the teacher's

@@ -159,6 +159,12 @@ int mmt_box_decode(const float* codes, const float* boxes, int R, int ncls, floa
  * code's fp32 expression order (replaces ~40 elementwise / cat launches per pooler call) */
 int mmt_roi_format_levels(const float* const* boxes /*[host]*/, const int32_t* counts /*[host]*/, int n_img, float s0, float lvl0,
                           float eps, int k_min, int k_max, float* rois, int32_t* levels /*or NULL*/, void* stream);
+/* IR-Net relation NMS: the IoU-regression labels of the n ranked boxes per foreground class of one image against its ground
+ * truth (reference modeling/relation/relation_module.py:323-391, numpy on the host): boxes [n][fg][4], score [n][fg], gt [G][4],
+ * gt_labels [G] (class c + 1 belongs to class column c), thresholds [T <= 4] (host) -> out [n][fg][T]; numpy's first-index
+ * tie rules; n * G <= 8192, G <= 256. */
+int mmt_relation_reg_labels(const float* boxes, const float* score, const float* gt, const int64_t* gt_labels, int n, int fg, int G,
+                            const float* thresholds /*[host]*/, int T, float* out, void* stream);
 int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
                       const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total, int shared_cand,
                       float high, float low, int allow_low_quality, float wx, float wy, float ww, float wh, uint32_t* top_ws,

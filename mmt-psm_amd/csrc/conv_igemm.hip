@@ -3136,9 +3136,11 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
     return MMT_EINVAL;
   }
   // activations pre-split into planes by the caller: the all-planes kernel (128 x 128 tiles, 2 x 2 waves)
-  static const int use_pp = getenv("MMT_PP") ? atoi(getenv("MMT_PP")) : 0;  // measured: no faster than the kernel below
+#ifdef MMT_PP_EXPERIMENTS   // the all-planes 128 x 128 kernel on the split arithmetics: measured no faster; not in the shipping build
+  static const int use_pp = getenv("MMT_PP") ? atoi(getenv("MMT_PP")) : 0;
   if (use_pp && p.xpl && NS == 3 && (ksplit > 1 || variant == 1) && !((size_t)p.xpl & 15) && !(p.xpl_stride & 7))
     return launch_pp<128, 128, 2, 2, NS, 3>(p, s, ksplit);
+#endif
   if (ksplit > 1) return launch_glds<128, 128, 4, 1, NS, 3>(p, s, ksplit);
   switch (variant) {
     case 1: return launch_glds<128, 128, 4, 1, NS, 3>(p, s);

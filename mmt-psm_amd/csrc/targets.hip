@@ -167,6 +167,72 @@ __global__ __launch_bounds__(256) void roi_format_kernel(const RoiFmtArgs a) {
     a.levels[r] = (int)(long)lv - (int)a.k_min;
   }
 }
+
+// IR-Net relation NMS, regression labels of the ranked boxes of ONE image (reference relation_module.py:323-391: a D2H copy
+// and numpy loops per class; the device tensor formulation of modeling/relation/relation_module.py::prepare_reg_label was
+// ~100 launches per image).  One block per foreground class: IoU of the n ranked boxes of the class with every gt box,
+// each box's best gt of the class (first maximal index), per threshold every gt's best-scoring box among the boxes that
+// overlap it above the threshold and have it as their best gt (first maximal index), and for every box the IoU recorded by
+// the FIRST gt that chose it -- numpy's tie rules, fp32 expressions in the tensor code's order.
+constexpr int REL_MAX = 8192;   // n * G cells of the IoU matrix in LDS
+__global__ __launch_bounds__(128) void relation_labels_kernel(const float* __restrict__ boxes /*[n][fg][4]*/,
+                                                              const float* __restrict__ score /*[n][fg]*/,
+                                                              const float* __restrict__ gt /*[G][4]*/, const long* __restrict__ gl /*[G]*/,
+                                                              int n, int fg, int G, int T, float t0, float t1, float t2, float t3,
+                                                              float* __restrict__ out /*[n][fg][T]*/) {
+  __shared__ float iou[REL_MAX];
+  __shared__ int best[128], msi[256];
+  __shared__ float moi[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float thr[4] = {t0, t1, t2, t3};
+  for (int b = tid; b < n; b += 128) {
+    const float* bx = boxes + ((long)b * fg + c) * 4;
+    const float a1 = (bx[2] - bx[0] + 1.f) * (bx[3] - bx[1] + 1.f);
+    float bv = 0.f;
+    int bi = -1;
+    for (int g = 0; g < G; g++) {
+      const float* t = gt + (long)g * 4;
+      const float a2 = (t[2] - t[0] + 1.f) * (t[3] - t[1] + 1.f);
+      const float w = fmaxf(fminf(bx[2], t[2]) - fmaxf(bx[0], t[0]) + 1.f, 0.f);
+      const float h = fmaxf(fminf(bx[3], t[3]) - fmaxf(bx[1], t[1]) + 1.f, 0.f);
+      const float inter = w * h;
+      const float v = inter / (a1 + a2 - inter);
+      iou[b * G + g] = v;
+      const float vc = gl[g] == (long)(c + 1) ? v : -1.f;
+      if (bi < 0 || vc > bv) { bv = vc; bi = g; }   // first maximal index
+    }
+    best[b] = bi;
+  }
+  __syncthreads();
+  for (int k = 0; k < T; k++) {
+    for (int g = tid; g < G; g += 128) {
+      const bool cm = gl[g] == (long)(c + 1);
+      float ms = 0.f;
+      int mb = 0;
+      bool any = false;
+      for (int b = 0; b < n; b++) {
+        const float v = iou[b * G + g];
+        const float osc = (cm && v > thr[k] && best[b] == g) ? score[(long)b * fg + c] : 0.f;
+        if (!any || osc > ms) { ms = osc; mb = b; any = true; }
+      }
+      msi[g] = mb;
+      const float v = iou[mb * G + g];
+      moi[g] = (cm && v > thr[k] && best[mb] == g) ? v : 0.f;
+    }
+    __syncthreads();
+    for (int b = tid; b < n; b += 128) {
+      bool valid = false;
+      int first = G;
+      for (int g = 0; g < G; g++) {
+        if (gl[g] != (long)(c + 1)) continue;
+        if (iou[b * G + g] > thr[k]) valid = true;
+        if (msi[g] == b && first == G) first = g;
+      }
+      out[((long)b * fg + c) * T + k] = (valid && first < G) ? moi[first] : 0.f;
+    }
+    __syncthreads();
+  }
+}
 }  // namespace
 
 extern "C" int mmt_box_decode(const float* codes, const float* boxes, int R, int ncls, float wx, float wy, float ww, float wh,
@@ -218,6 +284,19 @@ extern "C" int mmt_roi_format_levels(const float* const* boxes, const int32_t* c
   const int total = a.off[n_img];
   if (total == 0) return 0;
   hipLaunchKernelGGL(roi_format_kernel, dim3(mmt_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_relation_reg_labels(const float* boxes, const float* score, const float* gt, const int64_t* gt_labels, int n, int fg,
+                                       int G, const float* thresholds, int T, float* out, void* stream) {
+  if (!boxes || !score || !out || n < 1 || fg < 1 || T < 1 || T > 4 || G < 0 || G > 256 || (long)n * G > REL_MAX || (G && (!gt || !gt_labels)))
+    return MMT_EINVAL;
+  if (G == 0) return hipMemsetAsync(out, 0, (size_t)n * fg * T * sizeof(float), (hipStream_t)stream) == hipSuccess ? 0 : MMT_EINVAL;
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < T; i++) t[i] = thresholds[i];
+  hipLaunchKernelGGL(relation_labels_kernel, dim3(fg), dim3(128), 0, (hipStream_t)stream, boxes, score, gt, (const long*)gt_labels, n, fg, G, T,
+                     t[0], t[1], t[2], t[3], out);
   MMT_LAUNCH_CHECK();
   return 0;
 }

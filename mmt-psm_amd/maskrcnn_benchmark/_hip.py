@@ -77,6 +77,7 @@ _SIGS = {
     "mmt_aug_erase": [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float),
                       c_void_p],
     "mmt_roi_format_levels": [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mmt_relation_reg_labels": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_float), c_int, c_void_p, c_void_p],
     "mmt_match_targets": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                           c_float, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p],
@@ -638,6 +639,23 @@ def rpn_topk(heads, ks, A):
         ws = _TOPK_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
     _check(lib().mmt_rpn_topk(ctypes.addressof(lv), L, N, A, ws.data_ptr(), _stream()), "mmt_rpn_topk")
     return outs
+
+
+def relation_reg_labels(sorted_boxes, sorted_score, gt, gt_labels, thresholds):
+    """IR-Net relation NMS label preparation of one image in one launch (include/mmtpsm.h: mmt_relation_reg_labels) or None
+    when the shapes are beyond the kernel's LDS matrix (the caller keeps its tensor formulation)"""
+    n, fg = sorted_score.shape
+    G, T = gt.shape[0], len(thresholds)
+    if T > 4 or G > 256 or n * max(G, 1) > 8192:
+        return None
+    b = _dev(sorted_boxes, "boxes").float().contiguous()
+    sc = sorted_score.float().contiguous()
+    out = torch.empty((n, fg, T), dtype=torch.float32, device=b.device)
+    th = (c_float * T)(*[float(t) for t in thresholds])
+    g, gl = gt.float().contiguous(), gt_labels.to(torch.int64).contiguous()
+    _check(lib().mmt_relation_reg_labels(_p(b), _p(sc), _p(g) if G else None, _p(gl) if G else None, n, fg, G, th, T, _p(out), _stream()),
+           "mmt_relation_reg_labels")
+    return out
 
 
 def rpn_gather_decode(heads, anchors, topks, A, clip, lim):

@@ -23,6 +23,10 @@ class BoxCoder(object):
                             wh * torch.log(gh / ph)), dim=1)
 
     def decode(self, rel_codes, boxes):
+        if (rel_codes.is_cuda and rel_codes.dtype == torch.float32 and not rel_codes.requires_grad and rel_codes.dim() == 2
+                and rel_codes.shape[1] % 4 == 0 and rel_codes.shape[0] > 0):
+            from maskrcnn_benchmark import _hip as H   # one launch (mmt_box_decode) instead of ~30 elementwise ones
+            return H.box_decode(rel_codes, boxes, self.weights, self.bbox_xform_clip)
         boxes = boxes.to(rel_codes.dtype)
         w = (boxes[:, 2] - boxes[:, 0] + 1)[:, None]
         h = (boxes[:, 3] - boxes[:, 1] + 1)[:, None]

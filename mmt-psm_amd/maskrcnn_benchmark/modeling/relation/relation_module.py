@@ -25,7 +25,19 @@ from maskrcnn_benchmark.structures.bounding_box import BoxList
 from maskrcnn_benchmark.structures.boxlist_ops import cat_boxlist
 
 
+_RANK_EMB = {}
+
+
 def extract_rank_embedding(rank_dim, feat_dim, wave_length=1000, device="cpu"):
+    """sin / cos embedding of the ranks 0..rank_dim-1: a constant of (rank_dim, feat_dim, device), computed once"""
+    key = (int(rank_dim), int(feat_dim), wave_length, str(device))
+    hit = _RANK_EMB.get(key)
+    if hit is None:
+        hit = _RANK_EMB[key] = _rank_embedding(rank_dim, feat_dim, wave_length, device)
+    return hit
+
+
+def _rank_embedding(rank_dim, feat_dim, wave_length, device):
     rank_range = torch.arange(0, rank_dim, device=device).float()
     feat_range = torch.arange(feat_dim / 2, device=device)
     dim_mat = 1. / (torch.pow(wave_length, feat_range / (feat_dim / 2)))
@@ -153,6 +165,11 @@ class DuplicationRemovalNetwork(nn.Module):
         dev = sorted_boxes.device
         if G == 0:
             return torch.zeros((n, self.fg_class, len(self.target_thresh)), device=dev)
+        if sorted_boxes.is_cuda and not getattr(self, "tensor_labels", False):
+            from maskrcnn_benchmark import _hip as H
+            out = H.relation_reg_labels(sorted_boxes, sorted_score, tb, labels, self.target_thresh)   # one launch per image
+            if out is not None:
+                return out
         a2 = (tb[:, 2] - tb[:, 0] + 1) * (tb[:, 3] - tb[:, 1] + 1)
         ar_g = torch.arange(G, device=dev)
         per_cls = []

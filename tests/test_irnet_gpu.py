@@ -151,3 +151,42 @@ def test_irnet_bf16_products_mode(setup, synth):
     for k, v in dev.items():
         assert v < (0.25 if k == "nms_loss" else 5e-2), dev
     assert max(v for k, v in dev.items() if k != "nms_loss") > 1e-6  # it really ran the bf16 kernels
+
+
+def test_relation_label_kernel_matches_tensor_formulation(setup):
+    """mmt_relation_reg_labels (one launch per image) == the device tensor formulation of prepare_reg_label it replaces (itself
+    checked against the oracle's numpy restatement), bit for bit: random ranked boxes around the ground truth, duplicated boxes
+    and scores (first-index tie rules), gts of a class that choose the same box, a class without ground truth, no gt at all"""
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    cfg, student, _, _ = setup
+    net = student.relation_nms
+    g = torch.Generator().manual_seed(21)
+    for case, (n, G) in enumerate(((90, 12), (90, 31), (37, 5), (90, 7), (90, 0))):
+        gtb = torch.rand(max(G, 1), 2, generator=g) * 120 + 10
+        gt = torch.cat([gtb, gtb + torch.rand(max(G, 1), 2, generator=g) * 40 + 8], 1)[:G]
+        lab = torch.randint(1, 3, (G,), generator=g)
+        if case == 3:
+            lab[:] = 1                                            # class 2 has no ground truth
+        if G:
+            src = gt[torch.randint(0, G, (n, 2), generator=g)]    # [n, fg, 4]: jittered copies of gt boxes
+            boxes = src + torch.randn(n, 2, 4, generator=g) * 4.0
+        else:
+            boxes = torch.rand(n, 2, 4, generator=g) * 100
+        boxes[..., 2:] = torch.maximum(boxes[..., 2:], boxes[..., :2] + 1)
+        score = torch.sort(torch.rand(n, 2, generator=g), 0, descending=True)[0]
+        if n > 20:
+            boxes[5] = boxes[4]                                   # duplicated boxes and scores
+            score[5] = score[4]
+            boxes[11, 0] = boxes[10, 0]
+            if G > 2:
+                gt[1] = gt[0]                                     # two identical gts: both pick the same box, the first wins
+                lab[1] = lab[0]
+        t = BoxList(gt.cuda(), (160, 160), "xyxy")
+        t.add_field("labels", lab.cuda())
+        net.tensor_labels = True
+        ref = net.prepare_reg_label(boxes.cuda(), score.cuda(), t)
+        net.tensor_labels = False
+        own = net.prepare_reg_label(boxes.cuda(), score.cuda(), t)
+        assert own.shape == ref.shape and torch.equal(own, ref), case
+        if G:
+            assert (ref > 0).any()
