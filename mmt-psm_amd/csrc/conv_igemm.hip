@@ -3025,7 +3025,8 @@ static int strip_tw(const ConvP& p, bool need_planes = true) {
   int tw = 0;
   if (p.Wo % 128 == 0 && p.Ho % 2 == 0) tw = 128;
   else if (p.Wo % 64 == 0 && p.Ho % 4 == 0) tw = 64;
-  if (!tw || p.Cin < 128) return 0;  // K = 576 (the 64-channel layer1 convs): 12 super-steps do not amortise the fill
+  static const int minc = getenv("MMT_STRIP_MINC") ? atoi(getenv("MMT_STRIP_MINC")) : 128;
+  if (!tw || p.Cin < minc) return 0;  // K = 576 (the 64-channel layer1 convs): 12 super-steps do not amortise the fill
   return strip_ksplit(p, tw) ? tw : 0;
 }
 

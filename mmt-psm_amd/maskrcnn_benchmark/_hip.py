@@ -821,6 +821,10 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         a.stride, a.pad, a.Ho, a.Wo = stride, pad, Ho, Wo
         a.out_stride, a.mask_scale = 1, 1.0
         a.w_planes, a.w_plane_stride = planes.data_ptr(), planes.stride(0)
+        _TLS.bf16_owner = None
+        if f16_src is not None:   # data-gradient planes of a flat model's weight: deferred like the forward planes
+            ent = PLANES.get(f16_src[0].data_ptr())
+            _TLS.bf16_owner = ent[0]() if ent is not None else None
     else:
         w = nhwc(w)
         Cout, _, KH, KW = w.shape
@@ -945,6 +949,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
                 split_planes(x, x_planes)
                 pre[1].record()
             e0.record()
+            _ensure_bf16()
             _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
             e1.record()
             PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1,
@@ -957,6 +962,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             return y
     if auto_split:
         split_planes(x, x_planes)
+    _ensure_bf16()
     _check(lib().mmt_conv_forward(ctypes.byref(a), _stream()), "mmt_conv_forward")
     if y_planes is not None:
         y._mmt_planes = (y_planes, y._version)
@@ -1027,8 +1033,15 @@ def pack_weights(base, planes, descs, unit_desc, n_units):
                                   unit_desc.data_ptr(), n_units, _stream()), "mmt_pack_weights")
 
 
+def _ensure_bf16():
+    o = getattr(_TLS, "bf16_owner", None)
+    if o is not None:
+        o.ensure_bf16()
+
+
 def _weight_planes(w, a):
     """fill a.w_planes / a.w_plane_stride for a dense weight tensor when a split-bf16 mode is on"""
+    _TLS.bf16_owner = None
     if get_conv_precision() == 0 or (w.shape[1] & 15) or w.shape[0] <= 32:
         return None
     ptr = w.data_ptr()
@@ -1039,6 +1052,7 @@ def _weight_planes(w, a):
             del PLANES[ptr]
         elif ent[2] == w.numel() and flat.plane_versions.get(ptr) == w._version and flat.plane_epoch >= PLANES_EPOCH:
             a.w_planes, a.w_plane_stride = flat.planes.data_ptr() + 2 * ent[1], flat.planes.stride(0)
+            _TLS.bf16_owner = flat   # (packed lazily on the fp16 split: conv_forward calls ensure_bf16 before a launch that reads them)
             return flat.planes
     pl = pack_weight(w)
     a.w_planes, a.w_plane_stride = pl.data_ptr(), pl.stride(0)

@@ -58,6 +58,8 @@ class FlatParams(object):
         self.planes = None
         self.planes16 = self.stat16 = None   # fp16 two-term planes of the same matrices + (max, scale) per matrix
         self.f16_gen = -1
+        self.bf16_gen = -1                   # generation the bf16 planes (forward + data-gradient form) were packed for
+        self._lazy_bf16 = False
         self.views16 = {}                    # weight address -> (its slice of planes16, its scale in stat16)
         self.plane_versions = {}
         self.plane_epoch = -1
@@ -97,7 +99,12 @@ class FlatParams(object):
             self._n_descs = len(descs)
             self.planes16 = self.stat16 = None
             self.views16 = {}
-        H.pack_weights(self.data, self.planes, self._pack_descs, self._pack_units, self._n_units)
+        # on the fp16 split (the default) next to nothing reads the bf16 planes -- only a site that fell back, or a shape the
+        # fp16 kernels do not take: they are packed on first use of a generation (`ensure_bf16`) instead of after every step
+        self._lazy_bf16 = bool(H.F16X2 and H.get_conv_precision() == 3 and self._n_descs)
+        if not self._lazy_bf16:
+            H.pack_weights(self.data, self.planes, self._pack_descs, self._pack_units, self._n_units)
+            self.bf16_gen = self.plane_gen
         if H.F16X2 and H.get_conv_precision() == 3 and self._n_descs:
             # the default arithmetic's form of the same matrices: two fp16 planes of w * s, s per matrix from its maximum
             # (reduction launch + packing launch over the same tables); stat16[d] = (max |w_d|, s_d)
@@ -182,9 +189,22 @@ class FlatParams(object):
             self._flip_table = (torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev),
                                 torch.tensor(unit_desc, dtype=torch.int32, device=dev), unit0)
         d, u, n = self._flip_table
-        H._check(H.lib().mmt_pack_weights_flipped(d.data_ptr(), u.data_ptr(), n, H._stream()), "mmt_pack_weights_flipped")
+        if not self._lazy_bf16:
+            H._check(H.lib().mmt_pack_weights_flipped(d.data_ptr(), u.data_ptr(), n, H._stream()), "mmt_pack_weights_flipped")
         for w, scale, planes, _ in ent.values():
             H.FLIPPED[w.data_ptr()] = ((id(self), self.plane_gen, H._p(scale), None if scale is None else scale._version), planes)
+
+    def ensure_bf16(self):
+        """the bf16 planes of this parameter generation, packed now if they were deferred (called right before a launch that
+        reads them, on that launch's stream: all consumers of a model's planes sit on one stream)"""
+        if self.bf16_gen == self.plane_gen or self.planes is None:
+            return
+        from .. import _hip as H
+        H.pack_weights(self.data, self.planes, self._pack_descs, self._pack_units, self._n_units)
+        t = self.__dict__.get("_flip_table")
+        if t is not None and self.__dict__.get("_flip_entries"):
+            H._check(H.lib().mmt_pack_weights_flipped(t[0].data_ptr(), t[1].data_ptr(), t[2], H._stream()), "mmt_pack_weights_flipped")
+        self.bf16_gen = self.plane_gen
 
     def active_ranges(self, names, lo, hi):
         """merged [a, b) element ranges inside [lo, hi) of the flat buffer covered by the parameters in `names`
