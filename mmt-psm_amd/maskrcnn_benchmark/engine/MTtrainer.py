@@ -292,18 +292,22 @@ class MTtrainer(object):
         if bucketed is not None:
             bucketed.install()  # the stage hooks are registered by the forward passes below
         feats_s = feats_u = None
-        early, cut = False, None
+        early, cut, merged = False, None, None
         job = None
         if use_mt and self.overlap_teacher and os.environ.get("MMT_TEACHER_FIRST") == "1":   # schedule experiment (tools)
             job = self._start_teacher(data_u_list)
         if use_mt and self.student_bs == 1:
             xs = data_s.tensors.to(self.device)
             xu = data_u_list[-1].tensors.to(self.device)
-            if self.student_passes == "pair" and xs.shape == xu.shape and not self.use_graphs:
+            if self.student_passes in ("pair", "pairm") and xs.shape == xu.shape and not self.use_graphs:
                 # one set of forward launches for both passes (N = 4), two autograd graphs (modeling/backbone/backbone.py:
-                # forward_pair): the schedule below is that of "split"
+                # forward_pair): the schedule below is that of "split".  "pairm": the two graphs end at C2..C5 and the ResNet
+                # body is back-propagated ONCE for both (N = 4) after the consistency branch's backward
                 from maskrcnn_benchmark.modeling.backbone.backbone import forward_pair
-                feats_s, fu = forward_pair(self.student.backbone, xs, xu)
+                if self.student_passes == "pairm":
+                    feats_s, fu, merged = forward_pair(self.student.backbone, xs, xu, merged_body=True)
+                else:
+                    feats_s, fu = forward_pair(self.student.backbone, xs, xu)
                 feats_u = [fu]
                 early = True
             elif self.student_passes in ("split", "pair"):
@@ -355,6 +359,8 @@ class MTtrainer(object):
                 if cut is not None:
                     pairs = [(r, l.grad) for r, l in zip(*cut) if l.grad is not None]
                     torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
+                if merged is not None:
+                    merged.finish()
             else:
                 if use_mt:
                     unl = self.forward_unlabel(data_u_list, feats_u, job)
