@@ -1510,25 +1510,25 @@ __global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __re
   if (amax_next) block_amax_commit(m, amax_next);   // the maximum of THIS tensor, for the scale of the next one in this role
 }
 
-// one block per QUARTER tile (BM / 4 rows): four times the blocks of the main launch's tile count, or this small kernel is a
-// latency chain on a few dozen blocks
-template <int BM, int BN>
+// one block per 1/PARTS of a tile (BM / PARTS rows), PARTS = 4 (quarter tiles: four times the blocks of the main launch's tile
+// count).  The kernel is a pure memory pass of ksplit x tile reads: 21 us for 40 MB on the student's 64-tile 3x3 layers at
+// N = 2.  More, smaller blocks do NOT help (MMT_FINISH_PARTS=16: 33.6 us -- 8 KB instead of 32 KB runs per slab)
+template <int BM, int BN, int PARTS>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p, const int ksplit, const float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int QM = BM / 4;
+  constexpr int QM = BM / PARTS;
   const int tid = threadIdx.x;
   const int tiles_n = (p.Cout + BN - 1) / BN;
-  const int bid = blockIdx.x >> 2, part = blockIdx.x & 3;
+  const int bid = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-  constexpr int TILE4 = BM * BN / 4, PART4 = QM * BN / 4, U = 4;
-  static_assert(PART4 % (256 * U) == 0, "tile size");
+  constexpr int TILE4 = BM * BN / 4, PART4 = QM * BN / 4, U = PART4 / 256 < 4 ? PART4 / 256 : 4;
+  static_assert(PART4 % (256 * U) == 0 && U >= 1, "tile size");
   const f32x4* base = (const f32x4*)ws + (long)bid * ksplit * TILE4 + part * PART4;
   for (int i0 = tid; i0 < PART4; i0 += 256 * U) {
     f32x4 v[U];
 #pragma unroll
     for (int u = 0; u < U; u++) v[u] = base[i0 + u * 256];
-    // slabs four at a time: all 16 loads of a group are in flight before the first add (slab by slab this kernel was a chain
-    // of ksplit memory latencies: 23-35 us per call on the few-tile layers); the order of the additions is unchanged
+    // slabs four at a time: all loads of a group are in flight before the first add; the order of the additions is unchanged
     for (int j = 1; j < ksplit; j += 4) {
       f32x4 t[4][U];
 #pragma unroll
@@ -1548,6 +1548,15 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p, 
   }
   __syncthreads();
   conv_epilogue_finish<QM, BN>(p, lds, tile_m * BM + part * QM, tile_n * BN, tid, p.Ho * p.Wo);
+}
+
+template <int BM, int BN>
+static void launch_finish(const ConvP& p, int tiles, int ksplit, const float* ws, hipStream_t s) {
+  static const int parts = getenv("MMT_FINISH_PARTS") ? atoi(getenv("MMT_FINISH_PARTS")) : 4;
+  if (parts == 16)
+    hipLaunchKernelGGL((conv_splitk_finish_kernel<BM, BN, 16>), dim3(tiles * 16), dim3(256), (size_t)(BM / 16) * BN * 4, s, p, ksplit, ws);
+  else
+    hipLaunchKernelGGL((conv_splitk_finish_kernel<BM, BN, 4>), dim3(tiles * 4), dim3(256), (size_t)(BM / 4) * BN * 4, s, p, ksplit, ws);
 }
 
 // Weight packing for the DMA-fed kernels.  For a weight matrix [Cout][K] (K % 16 == 0) plane q of the packed form is
@@ -2948,7 +2957,7 @@ int launch_glds(const ConvP& p, hipStream_t s, int ksplit = 1) {
   MMT_LAUNCH_CHECK();
   if (ksplit > 1) {
     if constexpr (BM == 128 && BN == 128)
-      hipLaunchKernelGGL((conv_splitk_finish_kernel<BM, BN>), dim3(tiles / ksplit * 4), dim3(256), epi / 4, s, p, ksplit, w.ws);
+      launch_finish<BM, BN>(p, tiles / ksplit, ksplit, w.ws, s);
     else
       return MMT_EINVAL;
     MMT_LAUNCH_CHECK();
@@ -2990,7 +2999,7 @@ int launch_pp(const ConvP& p, hipStream_t s, int ksplit = 1) {
   MMT_LAUNCH_CHECK();
   if (ksplit > 1) {
     if constexpr (BM == 128 && BN == 128)
-      hipLaunchKernelGGL((conv_splitk_finish_kernel<BM, BN>), dim3(tiles / ksplit * 4), dim3(256), epi / 4, s, p, ksplit, w.ws);
+      launch_finish<BM, BN>(p, tiles / ksplit, ksplit, w.ws, s);
     else
       return MMT_EINVAL;
     MMT_LAUNCH_CHECK();
@@ -3061,7 +3070,7 @@ int launch_strip(const ConvP& p, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit, w.ws);
   MMT_LAUNCH_CHECK();
   if (ksplit > 1) {  // Wo == TW: tile t covers the 256 consecutive pixels [256 t', 256 t' + 256) of its channel block
-    hipLaunchKernelGGL((conv_splitk_finish_kernel<256, 128>), dim3(tiles * 4), dim3(256), (size_t)64 * 128 * 4, s, p, ksplit, w.ws);
+    launch_finish<256, 128>(p, tiles, ksplit, w.ws, s);
     MMT_LAUNCH_CHECK();
   }
   return 0;
@@ -3350,7 +3359,7 @@ extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x,
   if (e) return e;
   MMT_LAUNCH_CHECK();
   if (ksplit > 1) {
-    hipLaunchKernelGGL((conv_splitk_finish_kernel<256, 128>), dim3(tiles * 4), dim3(256), (size_t)64 * 128 * 4, s, p, ksplit, w.ws);
+    launch_finish<256, 128>(p, tiles, ksplit, w.ws, s);
     MMT_LAUNCH_CHECK();
   }
   return 0;
@@ -3390,7 +3399,7 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, p, p.wpl, p.wpl_stride, ks, w.ws);
     if (ks > 1)
-      hipLaunchKernelGGL((conv_splitk_finish_kernel<128, 128>), dim3(tiles / ks * 4), dim3(256), epi / 4, s, p, ks, w.ws);
+      launch_finish<128, 128>(p, tiles / ks, ks, w.ws, s);
     return 0;
   };
   if (ksplit > 1) e = go(conv_fwd_glds_kernel<128, 128, 4, 1, 2, 3, true>, 128, 128, ksplit);
