@@ -88,10 +88,43 @@ __device__ __forceinline__ void conv_epilogue_stage(f32x16 (&acc)[BM / (32 * WM)
 }
 
 // second half of the epilogue: the [BM][BN] tile in LDS (complete, synchronised) -> scale/shift, residual, ReLU, ... -> y
+struct AmaxAcc { float amx = 0.f, asum = 0.f, acnt = 0.f; };   // max |y| / sum |y| / count over what a thread stores (p.amax_out)
+
+// the block's contribution to the statistics slot of its output: ONE conditional atomic per block (wave reduce, LDS reduce
+// over the waves, then the test against what is already there).  One per wave was measured at 3 - 8 us of a 36 us launch
+// when a single round of tiles finishes together (1024 same-address atomics at 11 - 13 ns each).  Every thread of the
+// block calls this (it holds a barrier).
+__device__ __forceinline__ void conv_amax_commit(const ConvP& p, AmaxAcc a, const int lin) {
+  __shared__ float red[3][8];
+  const int t = threadIdx.x, w = t >> 6, nw = (blockDim.x + 63) >> 6;
+  const bool stats = p.amax_stats && (lin & 63) == 0;   // mean |y| from a SAMPLE of the blocks: atomics on the two cache
+                                                         // lines of a slot serialise at the L2
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a.amx = fmaxf(a.amx, __shfl_xor(a.amx, o, 64));
+  if (stats) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a.asum += __shfl_xor(a.asum, o, 64); a.acnt += __shfl_xor(a.acnt, o, 64); }
+  }
+  if ((t & 63) == 0) { red[0][w] = a.amx; red[1][w] = a.asum; red[2][w] = a.acnt; }
+  __syncthreads();
+  if (t == 0) {
+    float m = red[0][0], sm = red[1][0], cn = red[2][0];
+    for (int i = 1; i < nw; i++) { m = fmaxf(m, red[0][i]); sm += red[1][i]; cn += red[2][i]; }
+    const unsigned bits = __builtin_bit_cast(unsigned, m);
+    if (m > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, bits);
+    if (stats && cn > 0.f) {
+      const int k = (lin >> 6) & 15;
+      atomicAdd((float*)p.amax_out + 1 + k, sm);
+      atomicAdd((float*)p.amax_out + 17 + k, cn);
+    }
+  }
+}
+
+// acc: the caller runs this more than once per block and commits the statistics itself (conv_amax_commit); null: committed here
 template <int BM, int BN>
 __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds, const int m0, const int n0, const int tid,
-                                                     const int HoWo) {
-  float amx = 0.f, asum = 0.f, acnt = 0.f;   // max |y| / sum |y| / count over what this thread stores (p.amax_out)
+                                                     const int HoWo, AmaxAcc* acc = nullptr) {
+  float amx = 0.f, asum = 0.f, acnt = 0.f;
   {
     float* ct = lds;  // [BM][BN]
     constexpr int C4 = BN / 4, RPP = 256 / C4;
@@ -210,23 +243,9 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
       }
     }
   }
-  if (p.amax_out) {   // one atomic per wave, and only when it beats the value already there (see block_amax_commit)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
-    const unsigned bits = __builtin_bit_cast(unsigned, amx);
-    if ((tid & 63) == 0 && amx > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      atomicMax(p.amax_out, bits);
-    // mean |y| from a SAMPLE of the tiles (every 64th block; atomics on the two cache lines of a slot serialise at the L2:
-    // one per wave of EVERY block doubled the time of the large launches)
-    if (p.amax_stats && (blockIdx.x & 63) == 0) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { asum += __shfl_xor(asum, o, 64); acnt += __shfl_xor(acnt, o, 64); }
-      if ((tid & 63) == 0 && acnt > 0.f) {
-        const int k = (blockIdx.x >> 6) & 15;
-        atomicAdd((float*)p.amax_out + 1 + k, asum);
-        atomicAdd((float*)p.amax_out + 17 + k, acnt);
-      }
-    }
+  if (p.amax_out) {
+    if (acc) { acc->amx = fmaxf(acc->amx, amx); acc->asum += asum; acc->acnt += acnt; }
+    else conv_amax_commit(p, AmaxAcc{amx, asum, acnt}, blockIdx.x);
   }
 }
 
@@ -1411,12 +1430,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   {
     const int half = tid >> 8, t2 = tid & 255;
     constexpr int RUN = TW < 128 ? TW : 128;
+    AmaxAcc st;
 #pragma unroll
     for (int run = 0; run < 128 / RUN; run++) {
       const int mrow = half * 128 + run * RUN;
       const int m_lin = (img * p.Ho + ho0 + mrow / TW) * p.Wo + wo0 + mrow % TW;
-      conv_epilogue_finish<RUN, BN>(p, lds + mrow * BN, m_lin, n0, t2, p.Ho * p.Wo);
+      conv_epilogue_finish<RUN, BN>(p, lds + mrow * BN, m_lin, n0, t2, p.Ho * p.Wo, &st);
     }
+    if (p.amax_out) conv_amax_commit(p, st, blockIdx.x);
   }
 }
 
@@ -1783,23 +1804,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
       }
     }
   }
-  if (p.amax_out) {   // as in conv_epilogue_finish: one conditional atomic per wave
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
-    const unsigned bits = __builtin_bit_cast(unsigned, amx);
-    if ((threadIdx.x & 63) == 0 && amx > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      atomicMax(p.amax_out, bits);
-    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if (p.amax_stats && (lin & 63) == 0) {   // a sample of the blocks, as in conv_epilogue_finish
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { asum += __shfl_xor(asum, o, 64); acnt += __shfl_xor(acnt, o, 64); }
-      if ((threadIdx.x & 63) == 0 && acnt > 0.f) {
-        const int k = (lin >> 6) & 15;
-        atomicAdd((float*)p.amax_out + 1 + k, asum);
-        atomicAdd((float*)p.amax_out + 17 + k, acnt);
-      }
-    }
-  }
+  if (p.amax_out) conv_amax_commit(p, AmaxAcc{amx, asum, acnt}, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 
@@ -3384,6 +3389,8 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
     return launch_rows<16, 32, 2, true>(p, s);
   }
   const int ksplit = pick_ksplit(p);
+  static const int stages_env = [] { const char* v = getenv("MMT_GLDS_S"); const int n = v ? atoi(v) : 3; return n >= 3 && n <= 5 ? n : 3; }();
+  const int S = stages_env;
   auto go = [&](auto kern, int BM, int BN, int ks) -> int {
     const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN) * ks;
     SplitWs w{nullptr};
@@ -3391,7 +3398,7 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
       w = split_workspace(s);
       if (!w.ws || tiles > 1024) return MMT_EINVAL;
     }
-    const size_t ring = (size_t)3 * (BM * 64 + 2 * BN * 32), epi = (size_t)BM * BN * sizeof(float);
+    const size_t ring = (size_t)S * (BM * 64 + 2 * BN * 32), epi = (size_t)BM * BN * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
     if (lds > 65536) {
       const hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -3402,10 +3409,17 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
       launch_finish<128, 128>(p, tiles / ks, ks, w.ws, s);
     return 0;
   };
-  if (ksplit > 1) e = go(conv_fwd_glds_kernel<128, 128, 4, 1, 2, 3, true>, 128, 128, ksplit);
-  else if (variant == 1) e = go(conv_fwd_glds_kernel<128, 128, 4, 1, 2, 3, true>, 128, 128, 1);
-  else if (variant == 3) e = go(conv_fwd_glds_kernel<128, 64, 4, 1, 2, 3, true>, 128, 64, 1);
-  else e = go(conv_fwd_glds_kernel<64, 64, 2, 2, 2, 3, true>, 64, 64, 1);
+#define MMT_GLDS_GO(SS)                                                                                      \
+  do {                                                                                                       \
+    if (ksplit > 1) e = go(conv_fwd_glds_kernel<128, 128, 4, 1, 2, SS, true>, 128, 128, ksplit);            \
+    else if (variant == 1) e = go(conv_fwd_glds_kernel<128, 128, 4, 1, 2, SS, true>, 128, 128, 1);          \
+    else if (variant == 3) e = go(conv_fwd_glds_kernel<128, 64, 4, 1, 2, SS, true>, 128, 64, 1);            \
+    else e = go(conv_fwd_glds_kernel<64, 64, 2, 2, 2, SS, true>, 64, 64, 1);                                \
+  } while (0)
+  if (S == 5) MMT_GLDS_GO(5);
+  else if (S == 4) MMT_GLDS_GO(4);
+  else MMT_GLDS_GO(3);
+#undef MMT_GLDS_GO
   if (e) return e;
   MMT_LAUNCH_CHECK();
   return 0;
