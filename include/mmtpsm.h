@@ -263,6 +263,13 @@ int mmt_amax(const float* x, long n, const float* rowscale, long inner, int rows
  * sample of the tensor, slot[17..32] += the sample's element counts
  * (what mmt_conv_args.y_amax_stats makes a producing convolution record about its output) */
 int mmt_amax_stats(const float* x, long n, float* slot /*device, zeroed*/, void* stream);
+/* y = a + b (+ c) (+ d), elementwise in that order (n % 4 == 0, 16-byte aligned, c / d NULL when absent, y may be an input),
+ * and the statistics of y into `slot` exactly as mmt_amax_stats records them.  The gradient of a tensor with several
+ * consumers (a pyramid level read by the RPN head and two poolers; a ResNet stage output read by the next stage and the
+ * FPN lateral; reference: autograd's own accumulation in engine/MTtrainer.py:101-104 `losses.backward()`) in one pass
+ * instead of n - 1 additions plus a reduction pass. */
+int mmt_sum_stats(const float* a, const float* b, const float* c, const float* d, float* y, long n,
+                  float* slot /*device, zeroed*/, void* stream);
 int mmt_split_planes_f16(const float* x, void* planes, long plane_stride, long n, float scale, const float* amax /*device or NULL*/,
                          float* scale_out /*device or NULL*/, float* amax_next /*device or NULL: max |x| of THIS tensor is
                          accumulated here, for the scale of the next tensor in the same role (delayed scaling)*/,

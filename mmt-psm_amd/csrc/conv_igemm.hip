@@ -1505,6 +1505,33 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   }
 }
 
+// out = a + b (+ c (+ d)) in that order, and the statistics of the sum into a 33-float slot as amax_kernel<true> records them: the
+// gradient of a tensor with several consumers in ONE pass (instead of n - 1 library additions and a reduction pass)
+__global__ __launch_bounds__(256) void sum_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ c, const float* __restrict__ d,
+                                                        float* __restrict__ y, const long n4, unsigned* __restrict__ out) {
+  float m = 0.f, sum = 0.f, cnt = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
+    if (c) v += ((const f32x4*)c)[i];
+    if (d) v += ((const f32x4*)d)[i];
+    ((f32x4*)y)[i] = v;
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    sum += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
+    cnt += 4.f;
+  }
+  block_amax_commit(m, out);
+  if ((blockIdx.x & 15) == 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+    if ((threadIdx.x & 63) == 0 && cnt > 0.f) {
+      const int k = (blockIdx.x >> 4) & 15;
+      atomicAdd((float*)out + 1 + k, sum);
+      atomicAdd((float*)out + 17 + k, cnt);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __restrict__ x, unsigned short* __restrict__ pl,
                                                                const long plane_stride, const long n8, const float s_host,
                                                                const float* __restrict__ amax, float* __restrict__ s_out,
@@ -3291,6 +3318,20 @@ extern "C" int mmt_amax_stats(const float* x, long n, float* slot, void* stream)
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(amax_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n / 4, (const float*)nullptr, 1L, 1,
                      (unsigned*)slot);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+// y = a + b (+ c) (+ d) elementwise (n % 4 == 0, 16-byte aligned; y may be one of the inputs) and the statistics of y into `slot`
+// (33 floats, zeroed by the caller) as mmt_amax_stats records them
+extern "C" int mmt_sum_stats(const float* a, const float* b, const float* c, const float* d, float* y, long n, float* slot,
+                             void* stream) {
+  if (!a || !b || !y || !slot || n < 0 || (n & 3) || (((size_t)a | (size_t)b | (size_t)c | (size_t)d | (size_t)y) & 15)) return MMT_EINVAL;
+  if (!c && d) return MMT_EINVAL;
+  if (n == 0) return 0;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sum_stats_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, d, y, n / 4, (unsigned*)slot);
   MMT_LAUNCH_CHECK();
   return 0;
 }

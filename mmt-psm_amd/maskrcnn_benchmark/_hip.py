@@ -107,6 +107,7 @@ _SIGS = {
     "mmt_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_amax": [c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p],
     "mmt_amax_stats": [c_void_p, ctypes.c_long, c_void_p, c_void_p],
+    "mmt_sum_stats": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_flipped_f16": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
@@ -294,6 +295,29 @@ def _amax_of(x):
         _check(lib().mmt_amax_stats(x.data_ptr(), x.numel(), slot.ptr, _stream()), "mmt_amax_stats")
         am = x._mmt_amax = (slot, x._version)
     return am
+
+
+def sum_stats(ts):
+    """sum of 2..4 equally shaped dense fp32 tensors (same memory order) in one launch; the statistics of the sum are recorded
+    (the consumers of the result then need no reduction pass: fp16-split scale, crest-factor test)"""
+    a = ts[0]
+    if not (2 <= len(ts) <= 4) or any(t.shape != a.shape or t.stride() != a.stride() or t.dtype != torch.float32 for t in ts):
+        raise RuntimeError("sum_stats: 2..4 fp32 tensors of one shape and memory order")
+    _dev(a)
+    n = a.numel()
+    if n == 0 or (n & 3):
+        y = ts[0] + ts[1]
+        for t in ts[2:]:
+            y = y + t
+        return y
+    y = torch.empty_like(a)
+    if y.stride() != a.stride():
+        raise RuntimeError("sum_stats: dense tensors only")
+    slot = _amax_slot(a.device)
+    p = [t.data_ptr() for t in ts] + [None] * (4 - len(ts))
+    _check(lib().mmt_sum_stats(p[0], p[1], p[2], p[3], y.data_ptr(), n, slot.ptr, _stream()), "mmt_sum_stats")
+    y._mmt_amax = (slot, y._version)
+    return y
 
 
 _F16SITE = {}   # role of a tensor (consumer weight address, flipped) -> [device state (scale, a0, a1, a2), calls so far]

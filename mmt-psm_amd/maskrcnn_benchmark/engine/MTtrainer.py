@@ -15,6 +15,7 @@ import torch.distributed as dist
 
 from maskrcnn_benchmark import _hip as H
 from maskrcnn_benchmark.engine.flat import flatten_model
+from maskrcnn_benchmark.layers import fused
 from maskrcnn_benchmark.utils.miscellaneous import sigmoid_rampdown, sigmoid_rampup
 
 
@@ -483,8 +484,16 @@ class MTtrainer(object):
         """MTtrainer.py:247-275 (N_STEP_UNLABEL = 1)"""
         student = [s.to(self.device) for s in data_u_list[-self.student_bs:]]
         emb = None
+        if features is not None and len(features) == 1 and self.cfg.MT.FG_HINT and self.cfg.MT.CLS_LOSS and torch.is_grad_enabled():
+            # two consumers of every pyramid level (hint adaptor, box pooler): their gradients are summed in one launch
+            f_emb, f_box = fused.fork_levels(features[0], 2)
+            if job is None:
+                emb = self.student.get_emb_feature([f_emb])
+            features, f_emb = [f_box], [f_emb]
+        else:
+            f_emb = features
         if job is not None and features is not None and self.cfg.MT.FG_HINT:
-            emb = self.student.get_emb_feature(features)  # independent of the teacher: queued before the wait
+            emb = self.student.get_emb_feature(f_emb)  # independent of the teacher: queued before the wait
         try:
             if job is not None:
                 job["thread"].join()

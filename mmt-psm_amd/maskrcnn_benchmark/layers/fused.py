@@ -478,3 +478,53 @@ class SplitBatchFn(torch.autograd.Function):
 
 def split_batch(x, n):
     return SplitBatchFn.apply(x, n)
+
+
+_FORK_ON = _os.environ.get("MMT_FORK_SUM", "1") != "0"
+
+
+class ForkFn(torch.autograd.Function):
+    """x -> n aliases of x, one per consumer.  Autograd would add the consumers' gradients pairwise with library launches
+    (n - 1 of them) and the first fp16-split consumer of the sum would then take a reduction pass for its scale; here the
+    backward is ONE `mmt_sum_stats` launch that adds them and records max / mean |.| of the sum on the way."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        if gs[0].dim() == 4:
+            gs = [H.nhwc(g) for g in gs]
+        else:
+            gs = [g.contiguous() for g in gs]
+        while len(gs) > 4:
+            gs = [H.sum_stats(gs[:4])] + gs[4:]
+        return H.sum_stats(gs), None
+
+
+def fork(x, n):
+    """n handles of x for n consumers whose gradients are summed in one launch (the fp16-split arithmetic on fp32 tensors only:
+    elsewhere autograd's own accumulation stays)"""
+    if n < 2:
+        return (x,) * n
+    if not (_FORK_ON and x.requires_grad and x.is_cuda and x.dtype == torch.float32 and H.F16X2 and H.get_conv_precision() == 3):
+        return (x,) * n
+    outs = ForkFn.apply(x, n)
+    for a in ("_mmt_planes", "_mmt_amax"):   # planes / statistics of the tensor go along with its aliases
+        v = getattr(x, a, None)
+        if v is not None and v[1] == x._version:
+            for o in outs:
+                setattr(o, a, (v[0], o._version))
+    return outs
+
+
+def fork_levels(levels, n):
+    """fork() of every tensor of a pyramid -> n pyramids"""
+    cols = [fork(t, n) for t in levels]
+    return [tuple(c[i] for c in cols) for i in range(n)]

@@ -134,7 +134,11 @@ class ResNet(nn.Module):
             else:
                 x = getattr(self, name)(x)
                 _stage_hook(self, name, x)
-            outs.append(x)
+            if i >= self.freeze_at and i < len(self.stages):
+                o, x = fused.fork(x, 2)   # the FPN lateral and the next stage: their gradients are summed in one launch
+                outs.append(o)
+            else:
+                outs.append(x)
         return outs
 
 
@@ -237,6 +241,10 @@ def forward_pair(backbone, xa, xb, merged_body=False):
                 for bi, blk in enumerate(getattr(body, name)):
                     x = blk(x, pre=tuple(fused.batch_slice(t, lo, hi) for t in raw[(name, bi)]))
                 _stage_hook(body, name, x)
+                if i < len(body.stages):
+                    o, x = fused.fork(x, 2)   # FPN lateral / next stage
+                    outs.append(o)
+                    continue
             outs.append(x)
         args = list(outs)
         for nm in fpn.inner_blocks:

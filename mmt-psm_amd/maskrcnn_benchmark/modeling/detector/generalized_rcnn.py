@@ -127,15 +127,19 @@ class GeneralizedRCNN(nn.Module):
         images = to_image_list(images)
         if features is None:
             features = self.backbone(images.tensors)
-        proposals, proposal_losses = self.rpn(images, features, targets)
+        f_rpn = f_box = f_mask = features
+        if self.training and torch.is_grad_enabled():
+            # three consumers of every pyramid level: one launch sums their gradients (layers/fused.py::ForkFn)
+            f_rpn, f_box, f_mask = fused.fork_levels(features, 3)
+        proposals, proposal_losses = self.rpn(images, f_rpn, targets)
         proposals = self._tap("rpn_proposals" if self.training else "infer_proposals", proposals)
-        x, result, losses, class_logits, box_regression = self.box_heads(features, proposals, targets)
+        x, result, losses, class_logits, box_regression = self.box_heads(f_box, proposals, targets)
         nms_loss = None
         if self.relation_nms is not None:
             result, nms_loss = self._relation_nms(x, result, class_logits, box_regression, targets)
         if not self.training:
             result = self._tap("detections", result)
-        result, detector_losses = self.mask_heads(losses, features, result, targets, images)
+        result, detector_losses = self.mask_heads(losses, f_mask, result, targets, images)
         if self.training:
             out = {}
             out.update(detector_losses)

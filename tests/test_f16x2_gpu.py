@@ -270,6 +270,49 @@ def test_fallback_to_bf16x3_when_the_dynamic_range_defeats_fp16(hip, shape):
     assert (y3[:1].double() - ref3).abs().max().item() < 1e-5 * ref3.abs().max().item()
 
 
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_sum_stats_and_fork(hip, n):
+    """mmt_sum_stats: the sum of n gradients in the order given (bit-equal to the chained library additions), its statistics in
+    the slot (max exact; mean from the sample within 2 %); ForkFn: the gradient of a tensor with n consumers is that sum, it
+    carries the statistics (no reduction pass at its fp16-split consumer), and with one live consumer it is handed through."""
+    H = hip
+    from maskrcnn_benchmark.layers import fused
+    H.set_f16x2(True)
+    g = torch.Generator().manual_seed(5 + n)
+    ts = [_inputs("grad", (2, 256, 64, 64), g) for _ in range(n)]
+    y = H.sum_stats(ts)
+    ref = ts[0] + ts[1]
+    for t in ts[2:]:
+        ref = ref + t
+    assert torch.equal(y, ref)
+    slot = y._mmt_amax[0]
+    H.f16_flush_stats()
+    row = slot.pool.host[slot.idx]
+    assert float(row[0]) == ref.abs().max().item()
+    mean = float(row[1:17].sum()) / float(row[17:33].sum())
+    assert abs(mean - ref.abs().mean().item()) < 0.02 * ref.abs().mean().item()
+    # the autograd node
+    x = _inputs("act", (2, 256, 64, 64), g).requires_grad_(True)
+    mid = x * 1.0                                   # a non-leaf: its gradient passes through a hook
+    seen = []
+    mid.register_hook(lambda gr: seen.append(gr))
+    outs = fused.fork(mid, n)
+    assert len(outs) == n and all(o.data_ptr() == mid.data_ptr() for o in outs)
+    sum(((o * t).sum() for o, t in zip(outs, ts)), torch.zeros((), device="cuda")).backward()
+    assert torch.equal(x.grad, ref)
+    assert getattr(seen[0], "_mmt_amax", None) is not None and seen[0]._mmt_amax[1] == seen[0]._version
+    a0 = H.F16_STATS["amax_pass"]
+    w = _cl((torch.randn(256, 256, 3, 3, generator=g) * 0.05).cuda())
+    H.conv_forward(seen[0], w, None, None, 1, 1)
+    assert H.F16_STATS["amax_pass"] == a0
+    # one live consumer: no launch, the gradient itself comes back
+    x.grad = None
+    mid = x * 1.0
+    outs = fused.fork(mid, n)
+    (outs[1] * ts[1]).sum().backward()
+    assert torch.equal(x.grad, ts[1])
+
+
 def test_detector_f16x2_vs_oracle(hip):
     """supervised forward + backward of the detector with the strip convolutions on the fp16 split: losses against the fp32
     CPU oracle at 1e-4, parameter gradients against the default arithmetic's run"""
