@@ -2500,9 +2500,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int co0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  // XCD-aware block order.  The hardware deals workgroups to the 8 XCDs round-robin in launch order (x fastest); the
+  // tx * ty blocks of one pixel range (same z) read the same slices of x and dy, so they are made neighbours on ONE XCD
+  // (consecutive remapped ids) and the slices cross the fabric once instead of once per XCD
+  int bx, by, bz;
+  {
+    const int tx = gridDim.x, ty = gridDim.y, nwg = tx * ty * (int)gridDim.z;
+    const int lin = blockIdx.x + tx * (blockIdx.y + ty * blockIdx.z);
+    const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = id % tx;
+    const int t = id / tx;
+    by = t % ty;
+    bz = t / ty;
+  }
+  const int co0 = by * 128, n0 = bx * 128;
   const int NP = p.KH * p.KW * p.Cin;
-  const int ms = blockIdx.z * m_per_split;
+  const int ms = bz * m_per_split;
   const int me = min(p.M, ms + m_per_split);
   if (ms >= me) return;
   const int HoWo = p.Ho * p.Wo;
@@ -2530,7 +2544,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
     r_wo[j] = rem - r_ho[j] * p.Wo;
   }
   const int step_q = 16 / p.Wo, step_r = 16 - step_q * p.Wo;
-  const bool do_bias = dbias != nullptr && blockIdx.x == 0 && !roleB;
+  const bool do_bias = dbias != nullptr && bx == 0 && !roleB;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   f32x16 acc[2][2];
 #pragma unroll
@@ -2717,8 +2731,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
       __syncthreads();
     };
 
-    f32x4 rgP[4], rgQ[4];
-    {  // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers
+    // three register sets: the loads of pixel step t + 3 go out during step t (two steps ahead of the split that consumes
+    // them: one step -- about a microsecond -- did not cover the L2 / fabric latency under load)
+    f32x4 rgP[4], rgQ[4], rgR[4];
+    {  // prologue: tile 0 -> LDS buffer 0, tiles 1 and 2 -> registers
 #pragma unroll
       for (int j = 0; j < 4; j++) load_px(j, rgP);
       char* base = ring + woff;
@@ -2729,11 +2745,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
         for (int e = 0; e < 4; e++) { if (lvl & 1) split_sub(e); else split_cvt(e, lvl >> 1, base); }
 #pragma unroll
       for (int j = 0; j < 4; j++) load_px(j, rgP);
+#pragma unroll
+      for (int j = 0; j < 4; j++) load_px(j, rgQ);
       __syncthreads();
     }
-    for (int t = 0; t < ntile; t += 2) {
-      step(0, rgQ, rgP);
+    for (int t = 0; t < ntile; t += 6) {
+      step(0, rgR, rgP);
       if (t + 1 < ntile) step(1, rgP, rgQ);
+      if (t + 2 < ntile) step(0, rgQ, rgR);
+      if (t + 3 < ntile) step(1, rgR, rgP);
+      if (t + 4 < ntile) step(0, rgP, rgQ);
+      if (t + 5 < ntile) step(1, rgQ, rgR);
     }
   };
   if (roleB) run(std::true_type{}); else run(std::false_type{});
@@ -2763,7 +2785,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
     const int n = n0 + cc * 4;
     if (n < NP) {
       const bool direct = ws == nullptr;
-      float* dst = direct ? dw : ws + (long)blockIdx.z * p.Cout * NP;
+      float* dst = direct ? dw : ws + (long)bz * p.Cout * NP;
       for (int row = r0; row < 128; row += 8) {
         const int co = co0 + row;
         if (co >= p.Cout) break;
