@@ -2655,12 +2655,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
 #pragma unroll
       for (int e = 0; e < 4; e++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) sv[e][j] = F16 ? rg[j][e] * f16_role : rg[j][e];
+        for (int j = 0; j < 4; j++) sv[e][j] = rg[j][e];   // (F16: the scale rides in the conversions below)
     };
     auto split_cvt = [&](int e, int q, char* base) {
       if constexpr (F16) {
-        su[e][0] = __builtin_bit_cast(unsigned, f16x2{(_Float16)sv[e][0], (_Float16)sv[e][1]});
-        su[e][1] = __builtin_bit_cast(unsigned, f16x2{(_Float16)sv[e][2], (_Float16)sv[e][3]});
+        // h = rn16(s x), l = rn16(s x - h) with the mixed-precision FMA: the scale (a power of two: s x is exact) and the
+        // conversion in ONE instruction per value and term, results packed in place -- 32 vector instructions per 16
+        // values where multiply / convert / pack / widen / subtract / convert / pack was 56 (the kernel's time is the SUM
+        // of its vector-ALU and matrix time: the two hardly co-issue on this part)
+        if (q == 0) {
+          asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(su[e][0]) : "v"(f16_role), "v"(sv[e][0]));
+          asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(su[e][0]) : "v"(f16_role), "v"(sv[e][1]));
+          asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(su[e][1]) : "v"(f16_role), "v"(sv[e][2]));
+          asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(su[e][1]) : "v"(f16_role), "v"(sv[e][3]));
+        } else {
+          unsigned l0, l1;
+          asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(f16_role), "v"(sv[e][0]), "v"(su[e][0]));
+          asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(f16_role), "v"(sv[e][1]), "v"(su[e][0]));
+          asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(f16_role), "v"(sv[e][2]), "v"(su[e][1]));
+          asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(f16_role), "v"(sv[e][3]), "v"(su[e][1]));
+          su[e][0] = l0; su[e][1] = l1;
+        }
       } else {
         su[e][0] = pk_bf16(sv[e][0], sv[e][1]);
         su[e][1] = pk_bf16(sv[e][2], sv[e][3]);
@@ -2671,8 +2686,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
     auto fsub = [](float a, unsigned b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
     auto split_sub = [&](int e) {
       if constexpr (F16) {
-        const f16x2 h0 = __builtin_bit_cast(f16x2, su[e][0]), h1 = __builtin_bit_cast(f16x2, su[e][1]);
-        sv[e][0] -= (float)h0[0]; sv[e][1] -= (float)h0[1]; sv[e][2] -= (float)h1[0]; sv[e][3] -= (float)h1[1];
+        (void)e;   // the subtraction is inside the second conversion
       } else {
         sv[e][0] = fsub(sv[e][0], su[e][0] << 16);
         sv[e][1] = fsub(sv[e][1], su[e][0] & 0xffff0000u);
@@ -2691,22 +2705,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
       const int lvl = idx >> 2, e = idx & 3;
       if (lvl & 1) split_sub(e); else split_cvt(e, lvl >> 1, base);
     };
-    // one step: fragments of `buf`, MFMAs with the staging of step t+1 (from rg_w, into buf^1) and the loads of
-    // step t+2 (into rg_g) behind them
-    auto step = [&](int buf, f32x4 (&rg_g)[4], const f32x4 (&rg_w)[4]) {
-      const char* A = ring + buf * STAGE + froff + (wm * 2) * 512;
-      const char* B = ring + buf * STAGE + NS * PL + froff + (wn * 2) * 512;
-      char* base = ring + (buf ^ 1) * STAGE + woff;
-      bf16x8 fa[NS][2], fb[NS][2];
-      // in the order the MFMAs want them (smallest terms first: fa[0], fb[NS-1] lead)
-#pragma unroll
-      for (int q = 0; q < NS; q++)
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-          fa[q][a] = *(const bf16x8*)(A + q * PL + a * 512);
-          fb[NS - 1 - q][a] = *(const bf16x8*)(B + (NS - 1 - q) * PL + a * 512);
-        }
+    // one step: MFMAs on the fragments already in registers (fa, fb: tile t); behind them the fragment reads of tile t+1
+    // (complete in LDS stage s_next since the barrier that ended the previous step) into (fan, fbn), the split + LDS stores of
+    // tile t+2 (from rg_w, into stage s_store, whose last reader finished before that same barrier) and the global loads of
+    // tile t+4 (into rg_g).  Three LDS stages: no wave waits for a fragment at the top of a step.
+    constexpr int NFR = 4 * NS;
+    auto step = [&](int s_next, int s_store, const bf16x8 (&fa)[NS][2], const bf16x8 (&fb)[NS][2], bf16x8 (&fan)[NS][2],
+                    bf16x8 (&fbn)[NS][2], f32x4 (&rg_g)[4], const f32x4 (&rg_w)[4]) {
+      const char* A = ring + s_next * STAGE + froff + (wm * 2) * 512;
+      const char* B = ring + s_next * STAGE + NS * PL + froff + (wn * 2) * 512;
+      char* base = ring + s_store * STAGE + woff;
+      auto fread = [&](int r) {   // in the order the MFMAs want them (smallest terms first: fa[0], fb[NS-1] lead)
+        const int q = r >> 2, a = (r >> 1) & 1;
+        if (r & 1) fbn[NS - 1 - q][a] = *(const bf16x8*)(B + (NS - 1 - q) * PL + a * 512);
+        else fan[q][a] = *(const bf16x8*)(A + q * PL + a * 512);
+      };
       constexpr int NM = 4 * (NS * (NS + 1) / 2);
+      constexpr int NMI = NMICRO + NFR;
       int j = 0, mi = 0;
 #pragma unroll
       for (int sum = NS - 1; sum >= 0; sum--)
@@ -2723,39 +2738,60 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
               j++;
 #pragma unroll
-              for (int r = 0; r < (NMICRO + NM - 1) / NM; r++)
-                if (mi < (j * NMICRO + NM - 1) / NM) { micro(mi, base, rg_g, rg_w); mi++; }
+              for (int r = 0; r < (NMI + NM - 1) / NM; r++)
+                if (mi < (j * NMI + NM - 1) / NM) {
+                  // the staging pieces and the fragment reads alternate (a read is one instruction)
+                  const int k = mi;
+                  const int nf = k < 2 * NFR ? (k + 1) / 2 : NFR;          // fragment reads among the first k pieces
+                  if (k < 2 * NFR && (k & 1) == 0) fread(k >> 1); else micro(k - nf, base, rg_g, rg_w);
+                  mi++;
+                }
               __builtin_amdgcn_sched_barrier(0);
             }
         }
       __syncthreads();
     };
 
-    // three register sets: the loads of pixel step t + 3 go out during step t (two steps ahead of the split that consumes
+    // three register sets: the loads of pixel step t + 4 go out during step t (two steps ahead of the split that consumes
     // them: one step -- about a microsecond -- did not cover the L2 / fabric latency under load)
     f32x4 rgP[4], rgQ[4], rgR[4];
-    {  // prologue: tile 0 -> LDS buffer 0, tiles 1 and 2 -> registers
+    bf16x8 fa0[NS][2], fb0[NS][2], fa1[NS][2], fb1[NS][2];
+    {  // prologue: tiles 0, 1 -> LDS stages 0, 1; tiles 2, 3 -> registers; fragments of tile 0
 #pragma unroll
       for (int j = 0; j < 4; j++) load_px(j, rgP);
-      char* base = ring + woff;
-      split_begin(rgP);
 #pragma unroll
-      for (int lvl = 0; lvl < SPL; lvl++)
+      for (int j = 0; j < 4; j++) load_px(j, rgQ);
 #pragma unroll
-        for (int e = 0; e < 4; e++) { if (lvl & 1) split_sub(e); else split_cvt(e, lvl >> 1, base); }
+      for (int t = 0; t < 2; t++) {
+        char* base = ring + t * STAGE + woff;
+        split_begin(t ? rgQ : rgP);
+#pragma unroll
+        for (int lvl = 0; lvl < SPL; lvl++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) { if (lvl & 1) split_sub(e); else split_cvt(e, lvl >> 1, base); }
+      }
 #pragma unroll
       for (int j = 0; j < 4; j++) load_px(j, rgP);
 #pragma unroll
       for (int j = 0; j < 4; j++) load_px(j, rgQ);
       __syncthreads();
+      const char* A = ring + froff + (wm * 2) * 512;
+      const char* B = ring + NS * PL + froff + (wn * 2) * 512;
+#pragma unroll
+      for (int q = 0; q < NS; q++)
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+          fa0[q][a] = *(const bf16x8*)(A + q * PL + a * 512);
+          fb0[q][a] = *(const bf16x8*)(B + q * PL + a * 512);
+        }
     }
     for (int t = 0; t < ntile; t += 6) {
-      step(0, rgR, rgP);
-      if (t + 1 < ntile) step(1, rgP, rgQ);
-      if (t + 2 < ntile) step(0, rgQ, rgR);
-      if (t + 3 < ntile) step(1, rgR, rgP);
-      if (t + 4 < ntile) step(0, rgP, rgQ);
-      if (t + 5 < ntile) step(1, rgQ, rgR);
+      step(1, 2, fa0, fb0, fa1, fb1, rgR, rgP);
+      if (t + 1 < ntile) step(2, 0, fa1, fb1, fa0, fb0, rgP, rgQ);
+      if (t + 2 < ntile) step(0, 1, fa0, fb0, fa1, fb1, rgQ, rgR);
+      if (t + 3 < ntile) step(1, 2, fa1, fb1, fa0, fb0, rgR, rgP);
+      if (t + 4 < ntile) step(2, 0, fa0, fb0, fa1, fb1, rgP, rgQ);
+      if (t + 5 < ntile) step(0, 1, fa1, fb1, fa0, fb0, rgQ, rgR);
     }
   };
   if (roleB) run(std::true_type{}); else run(std::false_type{});
@@ -3626,7 +3662,7 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
     p.f16_sw = (const float*)a->f16_dy_amax;
     const dim3 grid(tx, ty, split);
     const int mode = !(p.Wo >= 8 && p.Ho >= 8) ? 0 : ((p.Wo & 3) == 0 ? 2 : 1);
-#define WGF(MODE) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<2, MODE, true, 0, true>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)
+#define WGF(MODE) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<2, MODE, true, 0, true>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)   /* 3 stages of 16 KB <= the 64 KB epilogue tile */
     if (mode == 2) WGF(2); else if (mode == 1) WGF(1); else WGF(0);
 #undef WGF
     MMT_LAUNCH_CHECK();
@@ -3651,7 +3687,9 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
     const bool small = (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31);
     const int mode = !(p.Wo >= 8 && p.Ho >= 8) ? 0 : ((p.Wo & 3) == 0 ? 2 : 1);
     const bool vec4 = (p.Cout & 3) == 0;
-#define WGPL(K) hipLaunchKernelGGL(K, grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)
+    // LDS: the 64 KB epilogue tile, or the three operand stages of the 3-term split (3 x 24 KB)
+    const size_t wg_lds = prec >= 3 ? 73728 : 65536;
+#define WGPL(K) do { if (wg_lds > 65536) { const hipError_t er = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_lds); if (er != hipSuccess) return (int)er; } hipLaunchKernelGGL(K, grid, dim3(256), wg_lds, s, p, dy, rowscale, dw, mps, ws, dbias); } while (0)
 #define WGP(NS, MODE) do { if (bf && NS == 1) { if (bf == 1) WGPL((conv_wgrad_pipe_kernel<1, MODE, true, 1>)); else if (bf == 2) WGPL((conv_wgrad_pipe_kernel<1, MODE, true, 2>)); else WGPL((conv_wgrad_pipe_kernel<1, MODE, true, 3>)); } else if (vec4) WGPL((conv_wgrad_pipe_kernel<NS, MODE, true>)); else WGPL((conv_wgrad_pipe_kernel<NS, MODE, false>)); } while (0)
 #define WGP3(NS) do { if (mode == 2) WGP(NS, 2); else if (mode == 1) WGP(NS, 1); else WGP(NS, 0); } while (0)
 #define WGS(NS, INC) do { if ((pipe && small) || bf) WGP3(NS); else hipLaunchKernelGGL((conv_wgrad_split_kernel<NS, INC>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias); } while (0)
