@@ -121,6 +121,17 @@ int mmt_rpn_gather_decode(const mmt_rpn_select_args* a /*[host]*/, void* stream)
 typedef struct { const float* head; int64_t* topk; int HW; int k; } mmt_rpn_topk_level;
 long mmt_rpn_topk_workspace_bytes(int N, int L, long anchors_per_image);
 int mmt_rpn_topk(const mmt_rpn_topk_level* levels /*[host][L]*/, int L, int N, int A, void* workspace, void* stream);
+/* mmt_det_postprocess: PostProcessor.filter_results (box_head/inference.py:91-160) for the N images of a batch without a
+ *   host round trip: per (image, foreground class j) the rows with prob[:, j] > score_thresh in stable descending score order,
+ *   NMS (mmt_nms_batched semantics), survivors in ascending original row order, classes concatenated, and when more than
+ *   detections_per_img (> 0) remain the cut `score >= kthvalue(scores, n - D + 1)` (ties kept).  prob [rows][nc], boxes
+ *   [rows][nc * 4] (decoded, clipped), row_off [N + 1] on the device and on the host; images of at most 2048 rows, nc <= 64.
+ *   Outputs: [N][capo]-shaped with capo = (largest image's rows) * (nc - 1), out_cnt [N] detections per image.
+ *   workspace: mmt_det_workspace_bytes(rows, N, nc) bytes, 16-byte aligned. */
+long mmt_det_workspace_bytes(int rows, int N, int nc);
+int mmt_det_postprocess(const float* prob, const float* boxes, const int32_t* row_off, const int32_t* row_off_host /*[host]*/,
+                        int N, int nc, float score_thresh, float nms_thresh, int detections_per_img, void* workspace,
+                        float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_cnt, void* stream);
 /* mmt_rpn_post_select: after mmt_nms_batched over the N*L segments (keep [N*L,kmax], keep_cnt [N*L]): a kept candidate
  *   survives when its rank in its segment is < post_n and its position < own_pre[level] (rpn/inference.py:130-135); of the
  *   survivors the best fpn_post_n of the WHOLE BATCH (training: rpn/inference.py:223-234, written per image in (level,

@@ -543,6 +543,131 @@ __global__ __launch_bounds__(NT) void sample_kernel(const LT* __restrict__ label
   if (tid == 0) { counts[2 * img] = num_pos; counts[2 * img + 1] = num_neg; }
 }
 
+// ------------------------------------------------------------------------------------------------ detections
+// PostProcessor.filter_results (box_head/inference.py:91-160) for a batch without a host round trip in the middle: per
+// (image, foreground class) the candidates with score > thresh in stable descending score order (det_sort_kernel: one
+// sorting block per segment, segments laid out back to back -- every block counts the candidates of the segments before
+// it itself, B is a handful), mmt_nms_batched over the segments, then per image (det_finish_kernel) the survivors of
+// every class in ascending ORIGINAL row order (`_C.nms` returns ascending indices, cpu/nms_cpu.cpp:64), classes
+// concatenated, and the DETECTIONS_PER_IMG cut `score >= kthvalue(scores, n - D + 1)` (ties kept, list order kept).
+struct DetArgs {
+  const float* prob;      // [rows][nc] class probabilities
+  const float* boxes;     // [rows][nc * 4] decoded boxes
+  const int* row_off;     // [N + 1] rows of image n
+  int N, nc, max_n, D, capo;
+  float thresh;
+  float* sboxes; float* sscores; int* srow; int* seg_off;   // sorted candidates [<= rows * (nc - 1)], seg_off [B + 1]
+  const int* keep; const int* keep_cnt;                      // NMS result [B][max_n], [B]
+  int* cand;                                                 // [N][capo] scratch
+  float* out_boxes; float* out_scores; long* out_labels; int* out_cnt;   // [N][capo] ..., [N]
+};
+
+__global__ __launch_bounds__(NT) void det_sort_kernel(const DetArgs a) {
+  __shared__ unsigned long long list[2048];
+  __shared__ int n_before, n_valid;
+  const int tid = threadIdx.x, seg = blockIdx.x, F = a.nc - 1;
+  const int img = seg / F, j = seg % F + 1;
+  if (tid == 0) { n_before = 0; n_valid = 0; }
+  __syncthreads();
+  {  // candidates of the segments before this one
+    int c = 0;
+    for (int s2 = 0; s2 < seg; s2++) {
+      const int im = s2 / F, jj = s2 % F + 1, r0 = a.row_off[im], R = a.row_off[im + 1] - r0;
+      for (int t = tid; t < R; t += NT) c += a.prob[(long)(r0 + t) * a.nc + jj] > a.thresh;
+    }
+    if (c) atomicAdd(&n_before, c);
+  }
+  const int r0 = a.row_off[img], R = a.row_off[img + 1] - r0;
+  int P = 2;
+  while (P < R) P <<= 1;
+  int c = 0;
+  for (int t = tid; t < P; t += NT) {
+    float sc = -1.f;
+    if (t < R) sc = a.prob[(long)(r0 + t) * a.nc + j];
+    const bool ok = t < R && sc > a.thresh;
+    list[t] = ok ? (((unsigned long long)f2ord(sc) << 32) | (unsigned)(0xffffffffu - (unsigned)t)) : 0ull;
+    c += ok;
+  }
+  if (c) atomicAdd(&n_valid, c);
+  block_sort_desc(list, P);    // (starts and ends with a barrier) equal scores: lower row first, as the stable sort
+  const int off = n_before, nv = n_valid;
+  for (int pos = tid; pos < nv; pos += NT) {
+    const int row = (int)(0xffffffffu - (unsigned)list[pos]);
+    *(f32x4*)(a.sboxes + (long)(off + pos) * 4) = *(const f32x4*)(a.boxes + ((long)(r0 + row) * a.nc + j) * 4);
+    a.sscores[off + pos] = a.prob[(long)(r0 + row) * a.nc + j];
+    a.srow[off + pos] = row;
+  }
+  if (tid == 0) {
+    a.seg_off[seg] = off;
+    if (seg == gridDim.x - 1) a.seg_off[seg + 1] = off + nv;
+  }
+}
+
+__global__ __launch_bounds__(NT) void det_finish_kernel(const DetArgs a) {
+  __shared__ SelShared sh;
+  __shared__ unsigned long long list[2048];
+  __shared__ int wsum[NT / 64];
+  __shared__ int cum[65], total_sel;
+  const int tid = threadIdx.x, img = blockIdx.x, F = a.nc - 1;
+  int* const cand = a.cand + (long)img * a.capo;
+  int total = 0;
+  for (int j = 1; j <= F; j++) {
+    const int seg = img * F + j - 1, c = min(a.keep_cnt[seg], 2048), s0 = a.seg_off[seg];
+    int P = 2;
+    while (P < c) P <<= 1;
+    __syncthreads();
+    for (int t = tid; t < P; t += NT) {
+      unsigned long long k = 0ull;
+      if (t < c) {
+        const int pos = a.keep[(long)seg * a.max_n + t];
+        k = ((unsigned long long)(0xffffffffu - (unsigned)a.srow[s0 + pos]) << 32) | (unsigned)pos;
+      }
+      list[t] = k;
+    }
+    block_sort_desc(list, P);   // descending in ~row = ascending original row
+    for (int t = tid; t < c; t += NT) cand[total + t] = s0 + (int)(unsigned)list[t];
+    if (tid == 0) cum[j] = total + c;
+    total += c;
+  }
+  if (tid == 0) cum[0] = 0;
+  __syncthreads();   // cand (global, written by this block) and cum are visible to every thread of the block
+  const int n = total;
+  unsigned thr = 0u;
+  if (a.D > 0 && n > a.D) {
+    auto key = [&](int e) -> unsigned long long {
+      return ((unsigned long long)f2ord(a.sscores[cand[e]]) << 32) | (unsigned)(0xffffffffu - (unsigned)e);
+    };
+    thr = (unsigned)(block_select(key, n, a.D, sh) >> 32);   // score of the D-th largest: everything >= it stays (ties too)
+  }
+  // ordered compaction: each thread owns a contiguous run of the list
+  const int chunk = (n + NT - 1) / NT, lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+  int c = 0;
+  for (int e = lo; e < hi; e++) c += f2ord(a.sscores[cand[e]]) >= thr;
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += v; }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < (tid >> 6); w++) wbase += wsum[w];
+  int slot = wbase + incl - c;
+  if (tid == NT - 1) total_sel = wbase + incl;
+  for (int e = lo; e < hi; e++) {
+    const int src = cand[e];
+    const float sc = a.sscores[src];
+    if (f2ord(sc) < thr) continue;
+    int j = 1;
+    while (e >= cum[j]) j++;
+    const long dst = (long)img * a.capo + slot++;
+    *(f32x4*)(a.out_boxes + dst * 4) = *(const f32x4*)(a.sboxes + (long)src * 4);
+    a.out_scores[dst] = sc;
+    a.out_labels[dst] = j;
+  }
+  __syncthreads();
+  if (tid == 0) a.out_cnt[img] = total_sel;
+}
+
+
 }  // namespace
 
 extern "C" int mmt_rpn_gather_decode(const mmt_rpn_select_args* a, void* stream) {
@@ -621,6 +746,60 @@ extern "C" int mmt_rpn_topk(const mmt_rpn_topk_level* levels, int L, int N, int 
   hipLaunchKernelGGL(topk_pass_kernel<2>, grid, dim3(256), 0, s, a);
   hipLaunchKernelGGL(topk_pass_kernel<3>, grid, dim3(256), 0, s, a);
   hipLaunchKernelGGL(topk_final_kernel, dim3((int)segs), dim3(NT), 0, s, a);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" long mmt_det_workspace_bytes(int rows, int N, int nc) {
+  if (rows < 0 || N < 1 || nc < 2) return -1;
+  const long F = nc - 1, cap = (long)rows * F;
+  // sboxes, sscores, srow | seg_off [N F + 1], keep_cnt [N F] | keep [N F][max_n <= rows] | NMS mask words | cand [N][capo]
+  long b = cap * 16 + cap * 4 + cap * 4 + (N * F + 1) * 4 + N * F * 4 + N * F * (long)rows * 4 +
+           N * F * (long)rows * ((rows + 63) / 64) * 8 + (long)N * cap * 4;
+  return b + 256;
+}
+
+// prob [rows][nc] / boxes [rows][nc * 4] of N images (row_off [N + 1], host copy row_off_host for the bounds) ->
+// out_boxes [N][capo][4], out_scores [N][capo], out_labels int64 [N][capo], out_cnt [N] with capo = max rows per image x (nc - 1).
+// Three kernels + the two of mmt_nms_batched, nothing read back.  Images of at most 2048 rows, nc <= 64.
+extern "C" int mmt_det_postprocess(const float* prob, const float* boxes, const int32_t* row_off, const int32_t* row_off_host,
+                                   int N, int nc, float score_thresh, float nms_thresh, int detections_per_img, void* workspace,
+                                   float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_cnt, void* stream) {
+  if (!prob || !boxes || !row_off || !row_off_host || !workspace || !out_boxes || !out_scores || !out_labels || !out_cnt ||
+      N < 1 || nc < 2 || nc > 64 || ((size_t)boxes & 15) || ((size_t)workspace & 15) || ((size_t)out_boxes & 15))
+    return MMT_EINVAL;
+  int rmax = 0;
+  for (int n = 0; n < N; n++) {
+    const int R = row_off_host[n + 1] - row_off_host[n];
+    if (R < 0 || R > 2048) return MMT_EINVAL;
+    rmax = R > rmax ? R : rmax;
+  }
+  const int rows = row_off_host[N] - row_off_host[0], F = nc - 1, B = N * F;
+  hipStream_t s = (hipStream_t)stream;
+  if (rmax == 0) return hipMemsetAsync(out_cnt, 0, (size_t)N * 4, s) == hipSuccess ? 0 : MMT_EINVAL;
+  const long cap = (long)rows * F;
+  char* w = (char*)workspace;
+  DetArgs a;
+  memset(&a, 0, sizeof(a));
+  a.prob = prob; a.boxes = boxes; a.row_off = row_off;
+  a.N = N; a.nc = nc; a.max_n = rmax; a.D = detections_per_img; a.capo = rmax * F; a.thresh = score_thresh;
+  a.sboxes = (float*)w; w += cap * 16;
+  a.sscores = (float*)w; w += cap * 4;
+  a.srow = (int*)w; w += cap * 4;
+  a.seg_off = (int*)w; w += (long)(B + 1) * 4;
+  int* keep_cnt = (int*)w; w += (long)B * 4;
+  int* keep = (int*)w; w += (long)B * rmax * 4;
+  w = (char*)(((size_t)w + 15) & ~(size_t)15);
+  unsigned long long* mask = (unsigned long long*)w; w += (long)B * rmax * ((rmax + 63) / 64) * 8;
+  a.cand = (int*)w;
+  a.keep = keep; a.keep_cnt = keep_cnt;
+  a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_labels = (long*)out_labels; a.out_cnt = out_cnt;
+  hipLaunchKernelGGL(det_sort_kernel, dim3(B), dim3(NT), 0, s, a);
+  MMT_LAUNCH_CHECK();
+  if (hipMemsetAsync(keep_cnt, 0, (size_t)B * 4, s) != hipSuccess) return MMT_EINVAL;
+  const int e = mmt_nms_batched(a.sboxes, a.seg_off, B, rmax, nms_thresh, (uint64_t*)mask, keep, keep_cnt, stream);
+  if (e) return e;
+  hipLaunchKernelGGL(det_finish_kernel, dim3(N), dim3(NT), 0, s, a);
   MMT_LAUNCH_CHECK();
   return 0;
 }

@@ -107,6 +107,9 @@ _SIGS = {
     "mmt_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_amax": [c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p],
     "mmt_amax_stats": [c_void_p, ctypes.c_long, c_void_p, c_void_p],
+    "mmt_det_workspace_bytes": [c_int, c_int, c_int],
+    "mmt_det_postprocess": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_sum_stats": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
@@ -552,6 +555,36 @@ def nms_batched(boxes, seg_off, max_n, thr):
         _check(lib().mmt_nms_batched(_p(boxes), _p(seg_off), B, max_n, float(thr), _p(ws), _p(keep), _p(cnt), _stream()),
                "mmt_nms_batched")
     return keep, cnt
+
+
+def det_postprocess(prob, dec, per, score_thresh, nms_thresh, detections_per_img):
+    """PostProcessor.filter_results for a batch (prob (R, nc), dec (R, nc * 4), per = rows per image) on the device:
+    -> boxes (N, cap, 4), scores (N, cap), labels int64 (N, cap), counts int32 (N,) -- or None when an image has more than
+    2048 rows / nc > 64 (the caller's tensor formulation takes those)"""
+    N, nc = len(per), prob.shape[1]
+    if N == 0 or nc < 2 or nc > 64 or max(per) > 2048 or prob.dtype != torch.float32:
+        return None
+    prob = _dev(prob).contiguous()
+    dec = _dev(dec).float().contiguous()
+    offs = [0]
+    for n_ in per:
+        offs.append(offs[-1] + int(n_))
+    host = (ctypes.c_int32 * (N + 1))(*offs)
+    dev = prob.device
+    row_off = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    cap = max(max(per) * (nc - 1), 1)
+    nb = lib().mmt_det_workspace_bytes(offs[-1], N, nc)
+    if nb < 0:
+        return None
+    ws = torch.empty((nb // 16 + 1, 4), dtype=torch.float32, device=dev)
+    ob = torch.empty((N, cap, 4), dtype=torch.float32, device=dev)
+    os_ = torch.empty((N, cap), dtype=torch.float32, device=dev)
+    ol = torch.empty((N, cap), dtype=torch.int64, device=dev)
+    oc = torch.empty((N,), dtype=torch.int32, device=dev)
+    _check(lib().mmt_det_postprocess(_p(prob), _p(dec), _p(row_off), ctypes.cast(host, c_void_p), N, nc, float(score_thresh),
+                                     float(nms_thresh), int(detections_per_img), _p(ws), _p(ob), _p(os_), _p(ol), _p(oc),
+                                     _stream()), "mmt_det_postprocess")
+    return ob, os_, ol, oc
 
 
 # ------------------------------------------------------------------------------------------ input augmentation

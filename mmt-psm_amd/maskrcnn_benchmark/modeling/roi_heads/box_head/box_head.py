@@ -4,6 +4,8 @@ hint adaptor) and the same three entry points: forward / forward_teacher / forwa
 
 Execution: 4-level ROIAlign in one launch -> fc6/fc7 on the fp32 MFMA GEMM with bias+ReLU(+dropout) in the
 epilogue -> cls_score and bbox_pred as ONE 15-wide GEMM; PSM loss as two small kernels."""
+import os
+
 import torch
 
 from maskrcnn_benchmark.utils.miscellaneous import dev_const
@@ -224,6 +226,7 @@ class PostProcessor(nn.Module):
     def __init__(self, score_thresh=0.05, nms=0.5, detections_per_img=100, box_coder=None, cfg=None):
         super().__init__()
         self.score_thresh, self.nms, self.detections_per_img = score_thresh, nms, detections_per_img
+        self.tensor_path = os.environ.get("MMT_DET_TENSOR", "0") == "1"   # the tensor formulation (tests, A/B runs)
         self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(10., 10., 5., 5.))
 
     def forward(self, x, boxes):
@@ -240,6 +243,20 @@ class PostProcessor(nn.Module):
                            dev_const(offs_rows, torch.int32, dev),
                            dev_const([[b.size[0] - 1, b.size[1] - 1] for b in boxes], torch.float32, dev))
         nc = prob.shape[1]
+        if prob.is_cuda and not getattr(self, "tensor_path", False):
+            # threshold / stable sort / NMS / ascending-row order / DETECTIONS_PER_IMG cut of every (image, class) on the
+            # device (mmt_det_postprocess: five launches), ONE read-back (the detection counts) for the BoxList sizes
+            out = H.det_postprocess(prob, dec, per, self.score_thresh, self.nms, self.detections_per_img)
+            if out is not None:
+                ob, os_, ol, oc = out
+                results = []
+                for i, (b, n) in enumerate(zip(boxes, oc.tolist())):
+                    r = BoxList(ob[i, :n], b.size, "xyxy")
+                    r.add_field("scores", os_[i, :n])
+                    r.add_field("objectness", os_[i, :n])
+                    r.add_field("labels", ol[i, :n])
+                    results.append(r)
+                return results
         segs, metas = [], []
         for pr, bx, b in zip(prob.split(per, 0), dec.split(per, 0), boxes):
             for j in range(1, nc):

@@ -182,3 +182,42 @@ def test_rpn_topk_kernel(hip):
         ref = key.argsort(dim=1, descending=True)[:, :k]
         assert torch.equal(t, ref)
         assert torch.equal(t[1], torch.arange(k, device="cuda"))   # the constant image: the first k indices
+
+
+@pytest.mark.parametrize("case", [(3, [1000, 1000], 200, 0.05, False), (3, [1000, 700], 200, 0.05, True),
+                                  (5, [300, 2048, 17], 50, 0.3, True), (2, [64, 0], 100, 0.05, False),
+                                  (3, [500, 500], 0, 0.05, True), (3, [40, 30], 200, 0.99, False)])
+def test_det_postprocess_kernel(hip, case):
+    """mmt_det_postprocess (PostProcessor.filter_results on the device: threshold, stable descending sort, NMS, ascending-row
+    order, DETECTIONS_PER_IMG cut with ties kept) against the tensor formulation it replaces -- same boxes, scores and
+    labels in the same order.  Cases: the bench shape, ragged images, ties in the scores (quantised), an empty image, no
+    cut (D = 0), nothing above the threshold."""
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.box_head import PostProcessor
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    nc, per, D, thr, ties = case
+    g = torch.Generator().manual_seed(1000 + nc + sum(per))
+    R = sum(per)
+    logits = torch.randn(R, nc, generator=g) * 2.0
+    if ties:
+        logits = (logits * 2).round() / 2            # many equal probabilities
+    ctr = torch.rand(R, 2, generator=g) * 400 + 50
+    wh = torch.rand(R, 2, generator=g) * 120 + 8
+    props = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    reg = torch.randn(R, nc * 4, generator=g) * 0.5
+    boxes, lo = [], 0
+    for n in per:
+        boxes.append(BoxList(props[lo:lo + n].cuda(), (512, 512), "xyxy"))
+        lo += n
+    pp = PostProcessor(thr, 0.5, D).cuda()
+    x = (logits.cuda(), reg.cuda())
+    got = pp(x, boxes)
+    pp.tensor_path = True
+    want = pp(x, boxes)
+    assert len(got) == len(want) == len(per)
+    for a, b in zip(got, want):
+        assert a.bbox.shape == b.bbox.shape
+        assert torch.equal(a.bbox, b.bbox)
+        assert torch.equal(a.get_field("scores"), b.get_field("scores"))
+        assert torch.equal(a.get_field("labels"), b.get_field("labels"))
+    if D > 0 and not ties:
+        assert all(len(a) <= D for a in got)
