@@ -107,7 +107,6 @@ _SIGS = {
     "mmt_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_amax": [c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p],
     "mmt_amax_stats": [c_void_p, ctypes.c_long, c_void_p, c_void_p],
-    "mmt_det_workspace_bytes": [c_int, c_int, c_int],
     "mmt_det_postprocess": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_sum_stats": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p],
@@ -573,7 +572,9 @@ def det_postprocess(prob, dec, per, score_thresh, nms_thresh, detections_per_img
     dev = prob.device
     row_off = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
     cap = max(max(per) * (nc - 1), 1)
-    nb = lib().mmt_det_workspace_bytes(offs[-1], N, nc)
+    fn = lib().mmt_det_workspace_bytes
+    fn.restype, fn.argtypes = ctypes.c_long, [c_int, c_int, c_int]
+    nb = fn(offs[-1], N, nc)
     if nb < 0:
         return None
     ws = torch.empty((nb // 16 + 1, 4), dtype=torch.float32, device=dev)
