@@ -221,7 +221,7 @@ class _Slot(object):
 
 def _amax_slot(device):
     """-> a zeroed statistics slot of the current pool of this (device, stream)"""
-    key = (str(device), _stream())
+    key = (device.index, _stream())   # (the device's ordinal: str(device) costs a microsecond per launch)
     ent = _AMAX_POOL.get(key)
     if ent is None:
         ent = _AMAX_POOL[key] = [[_StatPool(device)], 0]
@@ -480,6 +480,8 @@ def nhwc(x):
         raise RuntimeError("expected a 4-D activation")
     if x.dtype != torch.float32 and x.dtype != torch.bfloat16:
         raise RuntimeError("fp32 (or, with bf16 storage, bf16) activations only")
+    if x.is_contiguous(memory_format=torch.channels_last):   # (one call; size-1 dimensions are ignored by both tests)
+        return x
     if not x.permute(0, 2, 3, 1).is_contiguous():
         x = x.contiguous(memory_format=torch.channels_last)
         if not x.permute(0, 2, 3, 1).is_contiguous():  # C==1 / H==W==1 corner cases of torch's format logic
@@ -488,8 +490,9 @@ def nhwc(x):
 
 
 def empty_nhwc(n, c, h, w, device, zero=False, dtype=torch.float32):
-    f = torch.zeros if zero else torch.empty
-    return f((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
+    if zero:
+        return torch.zeros((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)   # one call
 
 
 # ------------------------------------------------------------------------------------------ ROIAlign
@@ -902,16 +905,18 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         y = y_out if y_out is not None else empty_nhwc(N, Cout, Ho, Wo, x.device, dtype=out_dtype)
     a.y = y.data_ptr() + esz * int(y_offset)
     y_planes = None
+    prec = get_conv_precision()
+    # would this shape run on the tap-strip kernel?  (asked once: the answer depends on the shape only)
+    strip = bool(a.KH == 3 and a.w_planes and not io and lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1)
     f16 = None   # (weight source, flipped?, row scale): this call runs on the two-term fp16 split (experiment)
-    if (F16X2 and not io and a.KH == 3 and a.w_planes and out_stride == 1 and y_out is None and mul is None
-            and get_conv_precision() == 3 and lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1):
+    if F16X2 and strip and out_stride == 1 and y_out is None and mul is None and prec == 3:
         if w is not None:
             f16 = (w, False, None)
         elif f16_src is not None:
             f16 = (nhwc(f16_src[0]), True, f16_src[1])
     f16t = None   # the same arithmetic on the tiled DMA kernel (1x1 layers, 3x3 on small maps, fc): x split in registers
     want_amax = False
-    if F16X2 and not io and get_conv_precision() == 3:
+    if F16X2 and not io and prec == 3:
         # consumers on the fp16 split scale y themselves: no bf16 planes from this epilogue, max |y| recorded on the way
         want_amax, want_planes = True, False
         if (f16 is None and F16X2_TILED and a.w_planes and Cout > 32 and Cin % 16 == 0 and y_out is None):
@@ -927,8 +932,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0 and not io:
         y_planes = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=x.device)
         a.y_planes, a.y_plane_stride = y_planes.data_ptr(), y_planes.stride(0)
-    auto_split = (x_planes is None and AUTO_PLANES and a.KH == 3 and a.w_planes and not io and f16 is None
-                  and lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1)
+    auto_split = x_planes is None and AUTO_PLANES and strip and f16 is None
     if auto_split:
         # one pass over x; the 3x3 kernel then reads bf16 planes (9 taps x Cout/128 re-reads).  Allocated here, filled
         # below INSIDE the profiling bracket: the pass is part of this convolution's cost
@@ -1117,15 +1121,22 @@ def _weight_planes(w, a):
     return pl
 
 
+_PREC = None   # the library's mode, mirrored here (asked several times per launch)
+
+
 def set_conv_precision(mode):
     """0 fp32 MFMA | 1 bf16 | 2 bf16x2 split | 3 bf16x3 split (include/mmtpsm.h: mmt_set_conv_precision)"""
-    global PLANES_EPOCH
+    global PLANES_EPOCH, _PREC
     _check(lib().mmt_set_conv_precision(int(mode)), "mmt_set_conv_precision")
+    _PREC = lib().mmt_get_conv_precision()
     PLANES_EPOCH += 1
 
 
 def get_conv_precision():
-    return lib().mmt_get_conv_precision()
+    global _PREC
+    if _PREC is None:
+        _PREC = lib().mmt_get_conv_precision()
+    return _PREC
 
 
 def wgrad_prepare(x, dy):

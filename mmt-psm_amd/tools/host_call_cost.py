@@ -35,3 +35,11 @@ t("BottleneckFn forward (4 convs)", blk, 500)
 def blk_fb():
     o = blk(); o.backward(o.detach())
 t("BottleneckFn forward + backward (13 launches)", blk_fb, 300)
+if os.environ.get("MMT_HOST_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(300): blk_fb()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)

@@ -7,6 +7,8 @@ cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, len(sys.argv) > 1 
 for i in range(3):
     il, tg, ul = batch(); trainer.train_step(1400 + i, il, tg, ul)
 torch.cuda.synchronize()
+if os.environ.get('MMT_BW_INLINE'):
+    torch.autograd.set_multithreading_enabled(False)   # backward on the calling thread: visible to cProfile
 pr = cProfile.Profile()
 il, tg, ul = batch()
 pr.enable()
