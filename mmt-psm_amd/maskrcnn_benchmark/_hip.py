@@ -1148,10 +1148,11 @@ def wgrad_prepare(x, dy):
         _amax_of(nhwc(dy))
 
 
-def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=None):
+def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=None, keep=None):
     """accumulates into dw (same memory layout as the weight) and dbias.  `side`: a torch stream to launch on instead of the
-    current one (the caller orders it against the producers of x / dy and joins it later; the split-K workspace is handed
-    to it with record_stream) -- cheaper than entering a stream context per call"""
+    current one (the caller orders it against the producers of x / dy and joins it later) -- cheaper than entering a stream
+    context per call; the split-K workspace is handed to it with record_stream, or -- `keep`, a list -- simply kept alive by
+    the caller until it has joined the side stream"""
     if side is not None:
         _TLS.stream = side.cuda_stream
         try:
@@ -1160,7 +1161,10 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
             _TLS.stream = None
             ws = getattr(_TLS, "last_ws", None)
             if ws is not None:
-                ws.record_stream(side)
+                if keep is not None:
+                    keep.append(ws)
+                else:
+                    ws.record_stream(side)
                 _TLS.last_ws = None
     x = nhwc(x)
     dy = nhwc(dy)

@@ -48,29 +48,52 @@ def _touch(*slots):
 # Weight gradients on a SIDE stream (MMT_WGRAD_STREAM=1, default): a backward pass is a chain of data gradients with one
 # weight gradient hanging off every link -- nothing downstream reads it before the optimiser.  The student's layer3 / layer4
 # calls are few-tile launches that leave most of the 256 CUs idle (profiles/r02_conv_table.txt: 40-65 us each against a
-# 10 us bound), so the weight gradients run beside the chain instead of inside it: every one waits for the event that marks
-# its operands ready, and whoever reads the flat gradient buffer (SGD, the all-reduce pieces) joins first (`join_wgrads`).
-# Only gradients that land in the flat buffer go there (dst_w given); their operands are kept alive by record_stream.
+# 10 us bound), so the weight gradients run beside the chain instead of inside it, and whoever reads the flat gradient buffer
+# (SGD, the all-reduce pieces) joins first (`join_wgrads`).  Only gradients that land in the flat buffer go there (dst_w
+# given).  The step is bound by the interpreter time of its launch-issuing threads, so the bookkeeping is batched: jobs are
+# collected and handed to the side stream a few at a time behind ONE stream wait (an event record + wait per weight gradient
+# cost ~10 us each, 120 times per step), and their operands / split-K workspaces are simply kept alive until the join instead
+# of three record_stream calls per job.
 import os as _os
 _WG_ON = _os.environ.get("MMT_WGRAD_STREAM", "1") != "0"
-_WG = {}   # device -> [side stream, launches since the last join, end-of-backward callback queued]
+_WG_BATCH = int(_os.environ.get("MMT_WGRAD_BATCH", "8"))   # measured 1 / 4 / 8 / 16: 36.8 / 36.6 / 36.4 / 36.4 ms per step
+_WG = {}   # device -> [side stream, launches since the last join, end-of-backward callback queued, pending jobs, kept-alive tensors]
 
 
 def _wg_stream(dev):
     ent = _WG.get(dev)
     if ent is None:
-        ent = _WG[dev] = [torch.cuda.Stream(device=dev, priority=int(_os.environ.get("MMT_WGRAD_PRIORITY", "0"))), 0, False]
+        ent = _WG[dev] = [torch.cuda.Stream(device=dev, priority=int(_os.environ.get("MMT_WGRAD_PRIORITY", "0"))), 0, False, [], []]
     return ent
+
+
+def flush_wgrads(ent, dev):
+    """hand the collected weight-gradient jobs to the side stream: it waits for everything issued so far on the current
+    stream (their operands among it), then takes the launches"""
+    jobs = ent[3]
+    if not jobs:
+        return
+    side, keep = ent[0], ent[4]
+    side.wait_stream(torch.cuda.current_stream(dev))
+    for x, g, shape, stride, pad, dw, rowscale, db in jobs:
+        H.conv_wgrad(x, g, shape, stride, pad, dw, rowscale, db, side=side, keep=keep)
+        keep.append(x)    # autograd frees the saved activation / the gradient when the node returns: not before the side
+        keep.append(g)    # stream has been joined
+    ent[1] += len(jobs)
+    jobs.clear()
 
 
 def join_wgrads(device=None):
     """the current stream waits for every weight gradient issued on the side stream so far (queued as an end-of-backward
-    callback by the first side-stream launch of a pass, so `.backward()` returns with the gradients ordered on its stream)"""
+    callback by the first side-stream job of a pass, so `.backward()` returns with the gradients ordered on its stream)"""
     for dev, ent in _WG.items():
         ent[2] = False
-        if ent[1] and (device is None or dev == device):
-            torch.cuda.current_stream(dev).wait_stream(ent[0])
-            ent[1] = 0
+        if device is None or dev == device:
+            flush_wgrads(ent, dev)
+            if ent[1]:
+                torch.cuda.current_stream(dev).wait_stream(ent[0])
+                ent[1] = 0
+            ent[4].clear()   # (memory handed back after the wait is re-used behind it in stream order)
 
 
 def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst_b=None):
@@ -84,16 +107,13 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
     if (_WG_ON and dst_w is not None and (dst_b is not None or not with_bias) and not (H.PROFILE is not None and H.PROFILE_ALL)
             and H.get_conv_precision() == 3):   # (the bf16 configuration is bound by its host threads: 28.5 vs 33.6 ms with it)
         ent = _wg_stream(x.device)
-        side, cur = ent[0], torch.cuda.current_stream(x.device)
         H.wgrad_prepare(x, g)            # reduction passes for operands nobody recorded a maximum of: on THIS stream
         if not ent[2]:
             ent[2] = True
             torch.autograd.Variable._execution_engine.queue_callback(join_wgrads)
-        side.wait_stream(cur)            # operands (x, g) and everything before them on this stream
-        H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db, side=side)
-        x.record_stream(side)            # autograd frees the saved activation when this node returns: not before the side
-        g.record_stream(side)            # stream is done with it
-        ent[1] += 1
+        ent[3].append((x, g, tuple(w.shape), stride, pad, dw, rowscale, db))
+        if len(ent[3]) >= _WG_BATCH:
+            flush_wgrads(ent, x.device)
     else:
         H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
     _touch(dst_w, dst_b if with_bias else None)
