@@ -19,5 +19,5 @@ s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(35)
 print(s.getvalue()[:6000])
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
-print(s.getvalue()[:7000])
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(70)
+print(s.getvalue()[:14000])
