@@ -25,13 +25,16 @@ class FrozenBatchNorm2d(nn.Module):
         self._folded = None
 
     def folded(self):
-        key = tuple(b._version for b in (self.weight, self.bias, self.running_mean, self.running_var)) + (
-            self.weight.data_ptr(), str(self.weight.device))
-        if self._folded is None or self._folded[0] != key:
-            scale = self.weight * self.running_var.rsqrt()
-            shift = self.bias - self.running_mean * scale
-            self._folded = (key, scale.contiguous(), shift.contiguous())
-        return self._folded[1], self._folded[2]
+        # (asked once per convolution launch: the buffers are read from the module's dict, not through nn.Module.__getattr__)
+        bf = self._buffers
+        w, b, m, v = bf["weight"], bf["bias"], bf["running_mean"], bf["running_var"]
+        key = (w._version, b._version, m._version, v._version, w.data_ptr(), w.device)
+        f = self._folded
+        if f is None or f[0] != key:
+            scale = w * v.rsqrt()
+            shift = b - m * scale
+            f = self._folded = (key, scale.contiguous(), shift.contiguous())
+        return f[1], f[2]
 
     def forward(self, x):
         scale, shift = self.folded()
@@ -57,7 +60,8 @@ class Conv2d(nn.Module):
             h = (x.shape[2] + 2 * self.padding[0] - self.kernel_size[0]) // self.stride[0] + 1
             w = (x.shape[3] + 2 * self.padding[1] - self.kernel_size[1]) // self.stride[1] + 1
             return x.new_empty((x.shape[0], self.out_channels, h, w))
-        return fused.conv(x, self.weight, self.bias, self.stride[0], self.padding[0], relu, input_relu)
+        pr = self._parameters   # (not through nn.Module.__getattr__: once per launch on the issuing thread)
+        return fused.conv(x, pr["weight"], pr.get("bias"), self.stride[0], self.padding[0], relu, input_relu)
 
     def extra_repr(self):
         return "{}, {}, kernel_size={}, stride={}, padding={}".format(
@@ -80,7 +84,8 @@ class ConvTranspose2d(nn.Module):
     def forward(self, x, relu=False, input_relu=False):
         if x.numel() == 0:
             return x.new_empty((x.shape[0], self.out_channels, 2 * x.shape[2], 2 * x.shape[3]))
-        return fused.DeconvFn.apply(x, self.weight, self.bias, relu, input_relu)
+        pr = self._parameters
+        return fused.DeconvFn.apply(x, pr["weight"], pr.get("bias"), relu, input_relu)
 
 
 class Linear(nn.Module):
@@ -95,7 +100,8 @@ class Linear(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_features))
 
     def forward(self, x, relu=False, input_relu=False, in_mask_scale=1.0, mul=None):
-        return fused.linear(x, self.weight, self.bias, relu, input_relu, in_mask_scale, mul)
+        pr = self._parameters
+        return fused.linear(x, pr["weight"], pr.get("bias"), relu, input_relu, in_mask_scale, mul)
 
 
 class _ROIAlign(torch.autograd.Function):

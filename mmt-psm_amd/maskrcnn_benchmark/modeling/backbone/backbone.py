@@ -76,14 +76,18 @@ class BottleneckWithFixedBatchNorm(nn.Module):
         self.stride = stride
 
     def _args(self):
-        s1, b1 = self.bn1.folded()
-        s2, b2 = self.bn2.folded()
-        s3, b3 = self.bn3.folded()
+        # (once per block and pass, on the launch-issuing thread: sub-modules and parameters straight from the module dicts)
+        m = self._modules
+        s1, b1 = m["bn1"].folded()
+        s2, b2 = m["bn2"].folded()
+        s3, b3 = m["bn3"].folded()
         wd = sd = bd = None
-        if self.downsample is not None:
-            wd = self.downsample[0].weight
-            sd, bd = self.downsample[1].folded()
-        return self.conv1.weight, self.conv2.weight, self.conv3.weight, wd, (s1, b1, s2, b2, s3, b3, sd, bd), self.stride
+        ds = m["downsample"] if "downsample" in m else self.downsample
+        if ds is not None:
+            wd = ds[0]._parameters["weight"]
+            sd, bd = ds[1].folded()
+        return (m["conv1"]._parameters["weight"], m["conv2"]._parameters["weight"], m["conv3"]._parameters["weight"], wd,
+                (s1, b1, s2, b2, s3, b3, sd, bd), self.stride)
 
     def forward(self, x, pre=None):
         return fused.BottleneckFn.apply(x, *self._args(), pre)
