@@ -447,6 +447,7 @@ def _check(code, what):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device   # (the C call, without torch.cuda's lazy-init wrapper: ~700 calls per step)
 
 
 import threading as _threading
@@ -459,7 +460,7 @@ def _stream():
     if ov is not None:
         return ov
     if _raw_stream is not None:  # one C call instead of building a torch.cuda.Stream object (~9 us, ~230 calls per step)
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_cur_dev())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -833,8 +834,8 @@ def split_planes(x, out=None):
 def planes_wanted_3x3(N, C, H, W, Cout):
     """would a 3x3 / stride 1 / pad 1 convolution (C -> Cout) over an (N, C, H, W) tensor run on the all-planes kernel?
     (asked by the PRODUCER of that tensor, which then writes the planes from its epilogue: conv_forward(want_planes=True))"""
-    if not AUTO_PLANES or get_conv_precision() != 3:
-        return False
+    if not AUTO_PLANES or get_conv_precision() != 3 or F16X2:   # (on the fp16 split no epilogue writes bf16 planes: consumers scale
+        return False                                              # the tensor themselves, conv_forward ignores the request)
     a = ConvArgs()
     a.x, a.w_planes = 16, 16  # placeholders: only the shape is looked at
     a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, C, Cout, 3, 3
