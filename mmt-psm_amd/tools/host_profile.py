@@ -11,6 +11,23 @@ if os.environ.get('MMT_BW_INLINE'):
     torch.autograd.set_multithreading_enabled(False)   # backward on the calling thread: visible to cProfile
 pr = cProfile.Profile()
 il, tg, ul = batch()
+if os.environ.get('MMT_PROFILE_TEACHER'):   # the profile of the TEACHER thread instead (cProfile is per thread)
+    tp = cProfile.Profile()
+    orig = trainer.teacher.forward_teacher
+    def wrapped(*a, **k):
+        tp.enable()
+        try:
+            return orig(*a, **k)
+        finally:
+            tp.disable()
+    trainer.teacher.forward_teacher = wrapped
+    trainer.train_step(1403, il, tg, ul)
+    torch.cuda.synchronize()
+    for key in ("tottime", "cumulative"):
+        s = io.StringIO()
+        pstats.Stats(tp, stream=s).sort_stats(key).print_stats(45)
+        print(s.getvalue()[:9000])
+    sys.exit(0)
 pr.enable()
 trainer.train_step(1403, il, tg, ul)
 pr.disable()
