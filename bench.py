@@ -452,6 +452,13 @@ def main():
                 "launches_per_step": len(other) // npf,
                 "achieved": round(fo / (mo * 1e-3) / 1e12, 2), "frac": round(fo / (mo * 1e-3) / 1e12 / opeak, 4),
                 "avg_launch_ms": round(mo / len(other), 4), "share_of_step_time": round(mo / (dtp * 1e3), 4)}
+            if mode != 0:   # the 6-product line of rounds 1-2, as for the dominant kernel
+                out["roofline"]["other_large_tile_kernel"]["six_product_frac"] = round(
+                    fo / (mo * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6), 4)
+        out["roofline"]["step_bound"] = (
+            "interpreter time of the two launch-issuing threads (main / autograd and teacher, one GIL): kernel time removed from "
+            "any stream did not move the step in round 3, host work removed did (DESIGN.md section 5, profiles/r03_history.md); "
+            "the kernels' in-step durations are read while up to three streams share the GPU")
         # the launches of that kernel with an un-split K (the large FPN / layer1-2 shapes); the others are the few-tile,
         # long-K layers, whose bracketed duration also contains their small finish launch
         uns = [q for q in prof if len(q) < 5 or q[4] <= 1]
