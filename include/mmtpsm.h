@@ -176,6 +176,10 @@ int mmt_roi_format_levels(const float* const* boxes /*[host]*/, const int32_t* c
  * tie rules; n * G <= 8192, G <= 256. */
 int mmt_relation_reg_labels(const float* boxes, const float* score, const float* gt, const int64_t* gt_labels, int n, int fg, int G,
                             const float* thresholds /*[host]*/, int T, float* out, void* stream);
+/* mmt_position_embedding: IR-Net's geometric position embedding of every ordered box pair of a class
+ * (relation/relation_module.py:93-135 extract_multi_position_matrix): boxes [n][C][4] xyxy, freq [dim_g / 8] device =
+ * wave_len^(-m / (dim_g / 8)), out [C][n][n][dim_g] = (sin(100 d_k f_m) for the four log-ratios d_k, then the cosines). */
+int mmt_position_embedding(const float* boxes, int n, int C, int dim_g, const float* freq, float* out, void* stream);
 int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
                       const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total, int shared_cand,
                       float high, float low, int allow_low_quality, float wx, float wy, float ww, float wh, uint32_t* top_ws,

@@ -300,3 +300,53 @@ extern "C" int mmt_relation_reg_labels(const float* boxes, const float* score, c
   MMT_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------- IR-Net geometric position embedding
+// extract_multi_position_matrix (relation/relation_module.py:93-135): for every class c and ordered box pair (i, j)
+//   d = (log max(|cx_i - cx_j| / w_i, 1e-3), log max(|cy_i - cy_j| / h_i, 1e-3), log(w_i / w_j), log(h_i / h_j)),
+//   out[c][i][j] = (sin(100 d_k f_m), k = 0..3, m = 0..F-1; then cos of the same) with f_m = wave_len^(-m / F), F = dim_g / 8
+// -- thirty-odd elementwise launches of the tensor formulation in one; fp32 expressions in the tensor code's order (this file is
+// built without FMA contraction).  One lane per output value: a wave covers the 8 F values of one pair.
+__global__ __launch_bounds__(256) void position_embedding_kernel(const float* __restrict__ boxes /*[n][C][4]*/, int n, int C, int F,
+                                                                 const float* __restrict__ freq /*[F]*/,
+                                                                 float* __restrict__ out /*[C][n][n][8 F]*/) {
+  const int D = 8 * F;
+  const long total = (long)C * n * n * D;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int d = (int)(e % D);
+    long t = e / D;
+    const int j = (int)(t % n); t /= n;
+    const int i = (int)(t % n);
+    const int c = (int)(t / n);
+    const float* bi = boxes + ((long)i * C + c) * 4;
+    const float* bj = boxes + ((long)j * C + c) * 4;
+    const int half = d / (4 * F), k = (d % (4 * F)) / F, m = d % F;
+    float v;
+    if (k == 0) {
+      const float cxi = (bi[0] + bi[2]) * 0.5f, cxj = (bj[0] + bj[2]) * 0.5f, wi = (bi[2] - bi[0]) + 1.f;
+      v = logf(fmaxf(fabsf((cxi - cxj) / wi), 1e-3f));
+    } else if (k == 1) {
+      const float cyi = (bi[1] + bi[3]) * 0.5f, cyj = (bj[1] + bj[3]) * 0.5f, hi = (bi[3] - bi[1]) + 1.f;
+      v = logf(fmaxf(fabsf((cyi - cyj) / hi), 1e-3f));
+    } else if (k == 2) {
+      const float wi = (bi[2] - bi[0]) + 1.f, wj = (bj[2] - bj[0]) + 1.f;
+      v = logf(wi / wj);
+    } else {
+      const float hi = (bi[3] - bi[1]) + 1.f, hj = (bj[3] - bj[1]) + 1.f;
+      v = logf(hi / hj);
+    }
+    const float a = (100.f * v) * freq[m];
+    out[e] = half ? cosf(a) : sinf(a);
+  }
+}
+
+extern "C" int mmt_position_embedding(const float* boxes, int n, int C, int dim_g, const float* freq, float* out, void* stream) {
+  if (!boxes || !freq || !out || n < 0 || C < 1 || dim_g < 8 || (dim_g & 7)) return MMT_EINVAL;
+  if (n == 0) return 0;
+  const long total = (long)C * n * n * dim_g;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(position_embedding_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, boxes, n, C, dim_g / 8, freq, out);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}

@@ -109,6 +109,7 @@ _SIGS = {
     "mmt_amax_stats": [c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_det_postprocess": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_position_embedding": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mmt_sum_stats": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
@@ -717,6 +718,16 @@ def relation_reg_labels(sorted_boxes, sorted_score, gt, gt_labels, thresholds):
     g, gl = gt.float().contiguous(), gt_labels.to(torch.int64).contiguous()
     _check(lib().mmt_relation_reg_labels(_p(b), _p(sc), _p(g) if G else None, _p(gl) if G else None, n, fg, G, th, T, _p(out), _stream()),
            "mmt_relation_reg_labels")
+    return out
+
+
+def position_embedding(boxes, dim_g, freq):
+    """IR-Net geometric embedding of all ordered box pairs per class: boxes (n, C, 4) -> (C, n, n, dim_g), one launch
+    (include/mmtpsm.h: mmt_position_embedding); freq = the dim_g / 8 wave-length factors (device)"""
+    b = _dev(boxes, "boxes").float().contiguous()
+    n, C = b.shape[0], b.shape[1]
+    out = torch.empty((C, n, n, dim_g), dtype=torch.float32, device=b.device)
+    _check(lib().mmt_position_embedding(_p(b), n, C, int(dim_g), _p(freq), _p(out), _stream()), "mmt_position_embedding")
     return out
 
 

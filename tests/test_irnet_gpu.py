@@ -190,3 +190,25 @@ def test_relation_label_kernel_matches_tensor_formulation(setup):
         assert own.shape == ref.shape and torch.equal(own, ref), case
         if G:
             assert (ref > 0).any()
+
+
+@pytest.mark.parametrize("shape", [(90, 2), (90, 4), (37, 1), (1, 2)])
+def test_position_embedding_kernel_matches_tensor_formulation(shape):
+    """mmt_position_embedding (one launch) == extract_multi_position_matrix's tensor formulation: same fp32 expressions, so the
+    arguments of sin / cos are equal and the values agree to the last place of the device math library (<= 1e-6 absolute on
+    [-1, 1]); identical boxes (|d| clamped at 1e-3), touching and far-apart boxes included"""
+    from maskrcnn_benchmark.modeling.relation.relation_module import extract_multi_position_matrix
+    n, C = shape
+    g = torch.Generator().manual_seed(5 * n + C)
+    xy = torch.rand(n, C, 2, generator=g) * 900
+    wh = torch.rand(n, C, 2, generator=g) * 300 + 1
+    boxes = torch.cat([xy, xy + wh], 2)
+    if n > 8:
+        boxes[3] = boxes[2]                     # identical boxes: zero centre distance
+        boxes[7] = torch.cat([boxes[6, :, :2], boxes[6, :, :2] + wh[7]], 1)   # same corner, different size
+    b = boxes.cuda()
+    ref = extract_multi_position_matrix(b, None, 64, 1000, tensor_path=True)
+    own = extract_multi_position_matrix(b, None, 64, 1000)
+    assert own.shape == ref.shape == (C, n, n, 64)
+    assert (own - ref).abs().max().item() <= 1e-6
+    assert (own == ref).float().mean().item() > 0.99
