@@ -160,6 +160,8 @@ def set_f16x2(on):
     """True / False; None restores the process default (MMT_F16X2, on unless set to 0)"""
     global F16X2
     F16X2 = F16X2_DEFAULT if on is None else bool(on)
+    _PLAN_EPOCH[0] += 1
+    _PLAN.clear()
     _F16W.clear()
     _F16SITE.clear()
     _SITES.clear()
@@ -251,7 +253,7 @@ def f16_flush_stats():
     torch.cuda.synchronize()
 
 
-def _site_ok(site, x):
+def _site_ok(site, x, count=True):
     """may the consumer `site` take `x` on the two-term fp16 split?  (lagged crest-factor test, see above)"""
     ent = _SITES.get(site)
     if ent is None:
@@ -276,7 +278,7 @@ def _site_ok(site, x):
         am = getattr(x, "_mmt_amax", None)
         if am is not None and am[1] == x._version and type(am[0]) is _Slot:
             ent[1] = am[0]
-    if not ent[0]:
+    if not ent[0] and count:
         F16_STATS["fallback"] = F16_STATS.get("fallback", 0) + 1
     return ent[0]
 
@@ -862,6 +864,80 @@ def planes_of(x):
     return None
 
 
+# ---- launch plans of the default arithmetic.  The step is bound by the interpreter time of its launch-issuing threads
+# (DESIGN.md section 5), and most of conv_forward's is spent re-deriving what never changes for a call site: shapes, the kernel
+# family, the static half of mmt_conv_args.  The first call of a (weight, input shape, epilogue form) on the fp16 split leaves
+# a PLAN -- the filled argument block and the path taken; later calls copy the block, patch the pointers and launch.  Anything
+# unusual (profiling, bf16 storage, explicit planes / outputs, a site that fell back to the 3-term bf16 split) takes the
+# general path below; a plan is tied to the weight OBJECT (addresses are re-used) and to the mode epoch.
+_PLAN = {}
+_PLAN_EPOCH = [0]
+FAST_PLANS = os.environ.get("MMT_FAST_PLANS", "1") != "0"
+
+
+def _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask):
+    src = w if w is not None else (f16_src[0] if f16_src is not None else None)
+    if src is None:
+        return None, None
+    return (src.data_ptr(), w is None, x.shape, stride, pad, relu, res_mode, res is not None, mask is not None, _PLAN_EPOCH[0]), src
+
+
+def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_scale, f16_src):
+    key, src = _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask)
+    plan = _PLAN.get(key) if key is not None else None
+    if plan is None:
+        return None
+    tmpl, kind, Cout, Ho, Wo, wref = plan
+    if wref() is not src or x.dtype != torch.float32 or (res is not None and res.dtype != torch.float32) or (
+            mask is not None and mask.dtype != torch.float32):
+        return None
+    x = nhwc(x)
+    flipped = w is None
+    wsrc = nhwc(src)
+    if not _site_ok((wsrc.data_ptr(), flipped), x, count=False):
+        return None   # (the general path asks again, counts the fall-back and runs the 3-term bf16 split for this site)
+    a = ConvArgs.from_buffer_copy(tmpl)
+    y = torch.empty((x.shape[0], Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    a.x, a.y = x.data_ptr(), y.data_ptr()
+    a.scale, a.shift = _p(scale), _p(shift)
+    if res is not None:
+        a.res = nhwc(res).data_ptr()
+    if mask is not None:
+        a.mask, a.mask_scale = nhwc(mask).data_ptr(), float(mask_scale)
+    slot = _amax_slot(x.device)
+    a.y_amax = slot.ptr
+    wp16, sw = f16_weight_planes(wsrc, f16_src[1] if flipped else None, flipped)
+    a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
+    if a.KH == 3 and (lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1) != (kind == 1):
+        return None   # the library's choice between the strip and the tiled kernel can be switched per call (MMT_STRIP): re-plan
+    if kind == 0:     # tiled / row-resident kernels: x is split in registers, its recorded maximum gives the scale
+        am = _amax_of(x)
+        F16_STATS["tiled"] += 1
+        _check(lib().mmt_conv_forward_f16x2(ctypes.byref(a), am[0].data_ptr(), sw.data_ptr(), _stream()), "mmt_conv_forward_f16x2")
+    else:             # tap-strip kernel: one split pass over x, then the launch
+        F16_STATS["conv"] += 1
+        xp16, sx = f16_split(x, (wsrc.data_ptr(), flipped) if F16X2_DELAYED else None)
+        a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+        _check(lib().mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), _stream()), "mmt_conv3x3_strip_f16x2")
+    y._mmt_amax = (slot, y._version)
+    return y
+
+
+def _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, kind, Cout, Ho, Wo):
+    key, src = _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask)
+    if key is None:
+        return
+    t = ConvArgs.from_buffer_copy(a)
+    # everything a call patches is cleared in the template (a stale pointer must never survive into a launch)
+    t.x = t.y = t.scale = t.shift = t.res = t.mask = t.mul = t.w = None
+    t.w_planes = t.x_planes = t.y_planes = t.y_amax = t.f16_x_amax = t.f16_dy_amax = None
+    t.w_plane_stride = t.x_plane_stride = t.y_plane_stride = 0
+    t.mask_scale, t.io_bf16, t.y_amax_stats = 1.0, 0, 1
+    if len(_PLAN) > 4096:
+        _PLAN.clear()
+    _PLAN[key] = (bytes(t), kind, Cout, Ho, Wo, weakref.ref(src))
+
+
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
                  mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0,
                  w_shape=None, planes=None, out_size=None, x_planes=None, want_planes=False, out_dtype=None, f16_src=None):
@@ -871,6 +947,12 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     out_size=(Ho, Wo): fewer output rows / columns than `pad` on both sides would give, i.e. a smaller pad at the
     bottom / right (taps that fall outside the input read zeros either way).
     bf16 storage (mode 1): a bf16 `x`, `res`, `mask` is taken as it is; out_dtype=torch.bfloat16 makes y a bf16 tensor."""
+    fast_ok = (FAST_PLANS and F16X2 and PROFILE is None and y_out is None and mul is None and out_stride == 1 and x_planes is None
+               and out_size is None and out_dtype is None and _PREC == 3)
+    if fast_ok:
+        y = _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_scale, f16_src)
+        if y is not None:
+            return y
     if x_planes is None:
         x_planes = planes_of(x)
     x = nhwc(x)
@@ -977,6 +1059,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
         a.x_planes = None
         F16_STATS["tiled"] += 1
+        if fast_ok and not io:
+            _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, 0, Cout, Ho, Wo)
         rec = PROFILE is not None and (PROFILE_ALL or lib().mmt_conv_variant(ctypes.byref(a)) == 1)
         if rec:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -996,6 +1080,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
         F16_STATS["conv"] += 1
+        if fast_ok and not io:
+            _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, 1, Cout, Ho, Wo)
         xp16, sx = f16_split(x, (f16[0].data_ptr(), f16[1]) if F16X2_DELAYED else None)
         wp16, sw = f16_weight_planes(f16[0], f16[2], f16[1])
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
@@ -1142,6 +1228,8 @@ def set_conv_precision(mode):
     _check(lib().mmt_set_conv_precision(int(mode)), "mmt_set_conv_precision")
     _PREC = lib().mmt_get_conv_precision()
     PLANES_EPOCH += 1
+    _PLAN_EPOCH[0] += 1
+    _PLAN.clear()
 
 
 def get_conv_precision():

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_irnet_gpu.py tests/test_config4_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
