@@ -871,6 +871,7 @@ def planes_of(x):
 # unusual (profiling, bf16 storage, explicit planes / outputs, a site that fell back to the 3-term bf16 split) takes the
 # general path below; a plan is tied to the weight OBJECT (addresses are re-used) and to the mode epoch.
 _PLAN = {}
+_WPLAN = {}   # weight gradient: (shapes, stride, pad, dtypes) -> (shape half of mmt_conv_args, split count)
 _PLAN_EPOCH = [0]
 FAST_PLANS = os.environ.get("MMT_FAST_PLANS", "1") != "0"
 
@@ -1269,13 +1270,25 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
     x = nhwc(x)
     dy = nhwc(dy)
     Cout, Cin, KH, KW = w_shape
-    a = ConvArgs()
     N, _, H, W = x.shape
+    # the shape half of the argument block and the split count depend on the shapes only: kept after the first call
+    key = (x.shape, dy.shape, w_shape, stride, pad, x.dtype, dy.dtype)
+    plan = _WPLAN.get(key)
+    if plan is None:
+        a = ConvArgs()
+        a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
+        a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
+        a.out_stride = 1
+        a.io_bf16 = (IO_X if x.dtype == torch.bfloat16 else 0) | (IO_DY if dy.dtype == torch.bfloat16 else 0)
+        a.x = x.data_ptr()
+        splits = lib().mmt_conv_wgrad_splits(ctypes.byref(a))
+        a.x = None
+        if len(_WPLAN) > 4096:
+            _WPLAN.clear()
+        _WPLAN[key] = (bytes(a), splits)
+    else:
+        a, splits = ConvArgs.from_buffer_copy(plan[0]), plan[1]
     a.x = x.data_ptr()
-    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
-    a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
-    a.out_stride = 1
-    a.io_bf16 = (IO_X if x.dtype == torch.bfloat16 else 0) | (IO_DY if dy.dtype == torch.bfloat16 else 0)
     if F16X2 and not a.io_bf16 and Cout % 4 == 0 and get_conv_precision() == 3:
         ax, ad = getattr(x, "_mmt_amax", None), getattr(dy, "_mmt_amax", None)
         big = N * H * W * Cin >= WGRAD_F16_MIN_ELEMS   # where 3 products instead of 6 pay for a reduction pass over an operand
@@ -1288,7 +1301,6 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
             # both operands carry their recorded maximum: two-term fp16 split (3 products instead of 6)
             a.f16_x_amax, a.f16_dy_amax = ax[0].data_ptr(), ad[0].data_ptr()
             F16_STATS["wgrad"] += 1
-    splits = lib().mmt_conv_wgrad_splits(ctypes.byref(a))
     ws = torch.empty((splits * Cout * KH * KW * Cin,), dtype=torch.float32, device=x.device) if splits > 1 else None
     _TLS.last_ws = ws
     if PROFILE is not None and PROFILE_ALL:
