@@ -949,7 +949,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     bottom / right (taps that fall outside the input read zeros either way).
     bf16 storage (mode 1): a bf16 `x`, `res`, `mask` is taken as it is; out_dtype=torch.bfloat16 makes y a bf16 tensor."""
     fast_ok = (FAST_PLANS and F16X2 and PROFILE is None and y_out is None and mul is None and out_stride == 1 and x_planes is None
-               and out_size is None and out_dtype is None and _PREC == 3)
+               and out_size is None and (out_dtype is None or out_dtype is torch.float32) and _PREC == 3)
     if fast_ok:
         y = _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_scale, f16_src)
         if y is not None:
