@@ -47,7 +47,7 @@ class StemWithFixedBatchNorm(nn.Module):
             z[..., :3] = x.view(n, c, h // 2, 2, w // 2, 2).permute(0, 2, 4, 3, 5, 1)
             y = H.conv_forward(z.view(n, h // 2, w // 2, 16).permute(0, 3, 1, 2), self._s2d_weight(), s, b, 1, 2,
                                relu=True, out_size=(h // 2, w // 2), out_dtype=torch.bfloat16 if H.bf16_storage() else None)
-            return H.maxpool3x3s2(y)
+            return _pool_keep_stats(y)
         # odd sizes: pad RGB -> 4 channels (zero weight on the 4th), fp32-input kernel
         x4 = x.new_zeros((n, h, w, 4))
         x4[..., :3] = x.permute(0, 2, 3, 1)
@@ -55,7 +55,19 @@ class StemWithFixedBatchNorm(nn.Module):
         w4[..., :3] = self.conv1.weight.detach().permute(0, 2, 3, 1)
         y = H.conv_forward(x4.permute(0, 3, 1, 2), w4.permute(0, 3, 1, 2), s, b, 2, 3, relu=True,
                            out_dtype=torch.bfloat16 if H.bf16_storage() else None)
-        return H.maxpool3x3s2(y)
+        return _pool_keep_stats(y)
+
+
+def _pool_keep_stats(y):
+    """3x3 / stride-2 / pad-1 max pooling of a ReLU output.  Every element of y lies in some window and y >= 0, so
+    max |pool(y)| == max |y| exactly: the statistics slot the stem convolution recorded for y serves the pooled tensor too
+    (its sampled mean is y's, i.e. lower than the pooled tensor's: the crest-factor test errs on the careful side) and
+    layer1's first convolutions need no reduction pass over the 134 MB tensor."""
+    p = H.maxpool3x3s2(y)
+    am = getattr(y, "_mmt_amax", None)
+    if am is not None and am[1] == y._version:
+        p._mmt_amax = (am[0], p._version)
+    return p
 
 
 class BottleneckWithFixedBatchNorm(nn.Module):
