@@ -879,17 +879,19 @@ FAST_PLANS = os.environ.get("MMT_FAST_PLANS", "1") != "0"
 def _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask):
     src = w if w is not None else (f16_src[0] if f16_src is not None else None)
     if src is None:
-        return None, None
-    return (src.data_ptr(), w is None, x.shape, stride, pad, relu, res_mode, res is not None, mask is not None, _PLAN_EPOCH[0]), src
+        return None, None, None
+    base = src._base   # a reshaped view of a parameter (Linear: a fresh (O, K, 1, 1) view per call) stands for the parameter
+    return ((src.data_ptr(), w is None, x.shape, stride, pad, relu, res_mode, res is not None, mask is not None, src.shape,
+             _PLAN_EPOCH[0]), src, src if base is None else base)
 
 
 def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_scale, f16_src):
-    key, src = _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask)
+    key, src, owner = _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask)
     plan = _PLAN.get(key) if key is not None else None
     if plan is None:
         return None
     tmpl, kind, Cout, Ho, Wo, wref = plan
-    if wref() is not src or x.dtype != torch.float32 or (res is not None and res.dtype != torch.float32) or (
+    if wref() is not owner or x.dtype != torch.float32 or (res is not None and res.dtype != torch.float32) or (
             mask is not None and mask.dtype != torch.float32):
         return None
     x = nhwc(x)
@@ -925,7 +927,7 @@ def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_
 
 
 def _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, kind, Cout, Ho, Wo):
-    key, src = _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask)
+    key, src, owner = _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask)
     if key is None:
         return
     t = ConvArgs.from_buffer_copy(a)
@@ -936,7 +938,7 @@ def _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, kind,
     t.mask_scale, t.io_bf16, t.y_amax_stats = 1.0, 0, 1
     if len(_PLAN) > 4096:
         _PLAN.clear()
-    _PLAN[key] = (bytes(t), kind, Cout, Ho, Wo, weakref.ref(src))
+    _PLAN[key] = (bytes(t), kind, Cout, Ho, Wo, weakref.ref(owner))
 
 
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,

@@ -168,6 +168,14 @@ def conv(x, w, b=None, stride=1, pad=0, relu=False, input_relu=False):
     return ConvFn.apply(x, w, b, stride, pad, relu, input_relu)
 
 
+def _carry_stats(src, view):
+    """a reshaped view of a tensor keeps the statistics slot its producer recorded (same values, shared version counter)"""
+    if view is not src:
+        am = getattr(src, "_mmt_amax", None)
+        if am is not None and am[1] == src._version:
+            view._mmt_amax = (am[0], view._version)
+
+
 class LinearFn(torch.autograd.Function):
     """y = relu?(x @ w.T + b) * mul  -- a 1x1 'conv' over R rows; `mul` carries the scaled dropout mask"""
 
@@ -176,13 +184,16 @@ class LinearFn(torch.autograd.Function):
         R, K = x.shape
         O = w.shape[0]
         x4 = x.contiguous().view(R, K, 1, 1)
-        w4 = w.view(O, K, 1, 1)
+        _carry_stats(x, x4)
+        w4 = w.view(O, K, 1, 1)   # (a fresh view per call: _hip's launch plans are tied to the view's BASE object)
         y = H.conv_forward(x4, w4, None, b, relu=relu, mul=None if mul is None else mul.view(R, O, 1, 1))
         ctx.save_for_backward(x4, w4)
         ctx.cfgv = (input_relu, in_mask_scale, b is not None)
         dw_ = _dst(w)
         ctx.dst = (dw_.view(O, K, 1, 1) if dw_ is not None else None, _dst(b))
-        return y.view(R, O)
+        out = y.view(R, O)
+        _carry_stats(y, out)   # the next Linear reads its input's recorded maximum from the 2-D view
+        return out
 
     @staticmethod
     def backward(ctx, g):
