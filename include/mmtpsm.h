@@ -180,6 +180,34 @@ int mmt_relation_reg_labels(const float* boxes, const float* score, const float*
  * (relation/relation_module.py:93-135 extract_multi_position_matrix): boxes [n][C][4] xyxy, freq [dim_g / 8] device =
  * wave_len^(-m / (dim_g / 8)), out [C][n][n][dim_g] = (sin(100 d_k f_m) for the four log-ratios d_k, then the cosines). */
 int mmt_position_embedding(const float* boxes, int n, int C, int dim_g, const float* freq, float* out, void* stream);
+/* mmt_relation_attention_{fwd,bwd}: the multi-head geometric relation attention of IR-Net's duplicate-removal network
+ * (reference modeling/relation/relation_module.py:33-90, RelationModule.forward: two torch.bmm, log / clamp / add, topk,
+ * softmax, scatter, permutes and the 16-group 1x1 conv1) in ONE launch each way.  C = classes (x images), N <= 120 ranked
+ * boxes per class, G heads, DQ <= 128 query / key dims per head, DV <= 16 value dims per head.
+ *   q, k [C*N][G*DQ] (rows in (class, box) order: the WQ / WK Linear outputs as they are), wg [C][N][N][G] (ReLU(WG(position
+ *   embedding)), v [C*N][G*DV] = features x conv1.weight^T (the grouped 1x1 conv applied BEFORE the mix: the same bilinear
+ *   form), bias [G*DV] (conv1.bias)
+ *   S = scale q k^T + log(max(wg, 1e-6)); P = softmax over the top-k entries of every row of S (lower index wins a tie), zero
+ *   elsewhere -> P [C][G][N][N] (kept for the backward); out [N][C][G*DV] = P v + bias.
+ * bwd: dout [N][C][G*DV] -> dq, dk (like q), dwg (like wg; the clamp passes the gradient where wg >= 1e-6), dv (like v); every
+ * element is written by exactly one workgroup (no atomics, nothing to zero). */
+int mmt_relation_attention_fwd(const float* q, const float* k, const float* wg, const float* v, const float* bias, int C, int N,
+                               int G, int DQ, int DV, int topk, float scale, float* P, float* out, void* stream);
+int mmt_relation_attention_bwd(const float* q, const float* k, const float* wg, const float* v, const float* P, const float* dout,
+                               int C, int N, int G, int DQ, int DV, float scale, float* dq, float* dk, float* dwg, float* dv,
+                               void* stream);
+/* mmt_ciam_{fwd,bwd}: IR-Net's cross-instance attention of the mask refinement (reference
+ * modeling/relation/mask_relation_module.py:199-242, CIAM_Module.forward: bmm, max, mean, softmax, mm), all (image, class)
+ * groups of the batch in one launch.  x [n][C <= 16][HW] fp32, group [n] int64 ids with equal ids CONTIGUOUS (the attention
+ * stays inside a group), max_group >= the largest group (<= 512; n is always a valid bound), gamma [1] device.
+ *   E[c][i][j] = <x[i,c,:], x[j,c,:]>; M[i][j] = mean_c (max_j' E[c][i][j'] - E[c][i][j]); A = softmax_j M over the group;
+ *   out = gamma A x + x.   Kept for the backward: A [n][n] (zero outside the group), J [C][n] = the arg-max column of E[c][i][:]
+ *   (first index on a tie).
+ * bwd: dout -> dx [n][C][HW], dgamma [1] (zeroed here, then one atomic per instance); T [n][n], R [n] = workspace. */
+int mmt_ciam_fwd(const float* x, const int64_t* group, int n, int C, int HW, int max_group, const float* gamma, float* A, int* J,
+                 float* out, void* stream);
+int mmt_ciam_bwd(const float* x, const int64_t* group, int n, int C, int HW, int max_group, const float* gamma, const float* A,
+                 const int* J, const float* dout, float* T, float* R, float* dx, float* dgamma, void* stream);
 int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
                       const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total, int shared_cand,
                       float high, float low, int allow_low_quality, float wx, float wy, float ww, float wh, uint32_t* top_ws,

@@ -110,6 +110,13 @@ _SIGS = {
     "mmt_det_postprocess": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_position_embedding": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mmt_relation_attention_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                   c_void_p, c_void_p, c_void_p],
+    "mmt_relation_attention_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_ciam_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_ciam_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                     c_void_p, c_void_p, c_void_p],
     "mmt_sum_stats": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
@@ -731,6 +738,57 @@ def position_embedding(boxes, dim_g, freq):
     out = torch.empty((C, n, n, dim_g), dtype=torch.float32, device=b.device)
     _check(lib().mmt_position_embedding(_p(b), n, C, int(dim_g), _p(freq), _p(out), _stream()), "mmt_position_embedding")
     return out
+
+
+RELATION_ATTENTION_MAX_N = 120   # csrc/relation.hip: RA_MAXN
+CIAM_MAX_N = 512                 # csrc/relation.hip: CI_MAXG (the whole batch is used as the bound of a group's size)
+
+
+def relation_attention_fits(N, G, DQ, DV):
+    return 1 <= N <= RELATION_ATTENTION_MAX_N and DQ <= 128 and DV <= 16 and 4 * (N * (N + 1) + 2 * N * DV) <= 65536 \
+        and 4 * (N * (DQ + 1) + N * DV + 4 * DQ + 512) <= 65536
+
+
+def relation_attention_fwd(q, k, wg, v, bias, C, N, G, topk, scale):
+    """include/mmtpsm.h: mmt_relation_attention_fwd.  q, k (C*N, G*DQ), wg (C*N*N, G), v (C*N, G*DV), bias (G*DV)
+    -> out (N, C, G*DV), P (C, G, N, N)"""
+    DQ, DV = q.shape[1] // G, v.shape[1] // G
+    out = torch.empty((N, C, G * DV), dtype=torch.float32, device=q.device)
+    P = torch.empty((C, G, N, N), dtype=torch.float32, device=q.device)
+    _check(lib().mmt_relation_attention_fwd(_p(q), _p(k), _p(wg), _p(v), _p(bias), C, N, G, DQ, DV, int(topk), float(scale), _p(P),
+                                            _p(out), _stream()), "mmt_relation_attention_fwd")
+    return out, P
+
+
+def relation_attention_bwd(q, k, wg, v, P, dout, C, N, G, scale):
+    DQ, DV = q.shape[1] // G, v.shape[1] // G
+    dq, dk, dwg, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(wg), torch.empty_like(v)
+    _check(lib().mmt_relation_attention_bwd(_p(q), _p(k), _p(wg), _p(v), _p(P), _p(dout), C, N, G, DQ, DV, float(scale), _p(dq), _p(dk),
+                                            _p(dwg), _p(dv), _stream()), "mmt_relation_attention_bwd")
+    return dq, dk, dwg, dv
+
+
+def ciam_fwd(x, group, gamma):
+    """include/mmtpsm.h: mmt_ciam_fwd.  x (n, C, H, W) NCHW-dense fp32, group (n,) int64 with equal ids contiguous, gamma (1,)
+    -> out like x, A (n, n), J (C, n) int32"""
+    n, C = x.shape[0], x.shape[1]
+    HW = x.shape[2] * x.shape[3]
+    out = torch.empty((n, C, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+    A = torch.empty((n, n), dtype=torch.float32, device=x.device)
+    J = torch.empty((C, n), dtype=torch.int32, device=x.device)
+    _check(lib().mmt_ciam_fwd(_p(x), _p(group), n, C, HW, n, _p(gamma), _p(A), _p(J), _p(out), _stream()), "mmt_ciam_fwd")
+    return out, A, J
+
+
+def ciam_bwd(x, group, gamma, A, J, dout):
+    n, C = x.shape[0], x.shape[1]
+    HW = x.shape[2] * x.shape[3]
+    dx = torch.empty((n, C, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+    ws = torch.empty((n * n + n,), dtype=torch.float32, device=x.device)
+    dgamma = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _check(lib().mmt_ciam_bwd(_p(x), _p(group), n, C, HW, n, _p(gamma), _p(A), _p(J), _p(dout), _p(ws), ws.data_ptr() + 4 * n * n, _p(dx),
+                              _p(dgamma), _stream()), "mmt_ciam_bwd")
+    return dx, dgamma
 
 
 def rpn_gather_decode(heads, anchors, topks, A, clip, lim):

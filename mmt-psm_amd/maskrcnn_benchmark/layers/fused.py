@@ -559,3 +559,50 @@ def fork_levels(levels, n):
     """fork() of every tensor of a pyramid -> n pyramids"""
     cols = [fork(t, n) for t in levels]
     return [tuple(c[i] for c in cols) for i in range(n)]
+
+
+class RelationAttentionFn(torch.autograd.Function):
+    """IR-Net's multi-head geometric relation attention (reference relation/relation_module.py:33-90) as one launch each way
+    (csrc/relation.hip): q, k (C*N, G*DQ), wg (C*N*N, G) = the fused-ReLU output of WG, v (C*N, G*DV), bias (G*DV)
+    -> (N, C, G*DV).  The gradient w.r.t. wg comes out masked by the clamp (wg >= 1e-6), i.e. already in the convention of a
+    fused-ReLU output (see the top of this file)."""
+
+    @staticmethod
+    def forward(ctx, q, k, wg, v, bias, C, N, G, topk, scale):
+        ctx.types = tuple(t.dtype for t in (q, k, wg, v))
+        q, k, wg, v = (t.float().contiguous() for t in (q, k, wg, v))   # (fp32 in every shipped configuration: no copies)
+        out, P = H.relation_attention_fwd(q, k, wg, v, bias.float(), C, N, G, topk, scale)
+        ctx.save_for_backward(q, k, wg, v, P)
+        ctx.cfgv = (C, N, G, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, wg, v, P = ctx.saved_tensors
+        C, N, G, scale = ctx.cfgv
+        g = g.contiguous()
+        g = g.float().contiguous()
+        grads = H.relation_attention_bwd(q, k, wg, v, P, g, C, N, G, scale)
+        dq, dk, dwg, dv = (t if t.dtype == d else t.to(d) for t, d in zip(grads, ctx.types))
+        db = g.sum((0, 1)) if ctx.needs_input_grad[4] else None
+        return dq, dk, dwg, dv, db, None, None, None, None, None
+
+
+class CIAMFn(torch.autograd.Function):
+    """IR-Net's cross-instance attention (reference relation/mask_relation_module.py:199-242) over all (image, class) groups
+    of the batch: one forward launch, two backward launches (csrc/relation.hip): x (n, C, H, W), group (n,) int64 with
+    equal ids contiguous, gamma (1,) -> gamma * attention(x) + x"""
+
+    @staticmethod
+    def forward(ctx, x, group, gamma):
+        ctx.xtype = x.dtype
+        x = x.float().contiguous()          # NCHW-dense rows [C][H W] per instance
+        out, A, J = H.ciam_fwd(x, group.contiguous(), gamma)
+        ctx.save_for_backward(x, group, gamma, A, J)
+        return out if out.dtype == ctx.xtype else out.to(ctx.xtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, group, gamma, A, J = ctx.saved_tensors
+        dx, dgamma = H.ciam_bwd(x, group.contiguous(), gamma, A, J, g.float().contiguous())
+        return (dx if dx.dtype == ctx.xtype else dx.to(ctx.xtype)), None, dgamma

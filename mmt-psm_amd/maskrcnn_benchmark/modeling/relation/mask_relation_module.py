@@ -6,13 +6,17 @@ max-pooled 14x14) is concatenated to the 256-channel ROI feature, pushed through
 mixed across instances by the cross-instance channel attention CIAM, then deconv(16) + 1x1(3) give the second
 mask logits.  Parameter names as in the reference (mask_heads.mask.mask_relation_module.*).  The convolutions run
 on the MFMA implicit GEMM (the 257-channel input is carried as 272 channels, weights zero-padded on the fly);
-CIAM is two batched library GEMMs over <= 128 instances."""
+CIAM is one launch forward, two backward (csrc/relation.hip: mmt_ciam_fwd / mmt_ciam_bwd); its tensor formulation (two
+batched library GEMMs) stays as the checker of tests/test_relation_kernels_gpu.py and for CPU tensors."""
 import torch
 from torch import nn
 import torch.nn.functional as F
 
-from maskrcnn_benchmark.layers import Conv2d, ConvTranspose2d
+from maskrcnn_benchmark import _hip as _H
+from maskrcnn_benchmark.layers import Conv2d, ConvTranspose2d, fused
 from maskrcnn_benchmark.structures.boxlist_ops import cat_boxlist
+
+_TENSOR_PATH = __import__("os").environ.get("MMT_IRNET_TENSOR", "0") == "1"   # A/B switch: library-GEMM attention
 
 
 class RoiAlignMaskFeatureExtractor(nn.Module):
@@ -56,6 +60,10 @@ class CIAM_Module(nn.Module):
         with the cross-group entries masked out (exp(-inf) = 0 exactly: the same softmax over the same values), so that no
         group size ever has to reach the host."""
         n, C, Hh, Ww = x.size()
+        if x.is_cuda and group is not None and not getattr(self, "tensor_path", _TENSOR_PATH) and 0 < n <= _H.CIAM_MAX_N and C <= 16:
+            # one forward launch, two backward launches for all groups of the batch (csrc/relation.hip); `group` is sorted by
+            # the caller (forward_batch orders the instances by (image, class)): equal ids are contiguous
+            return fused.CIAMFn.apply(x, group, self.gamma)
         cw = x.permute(1, 0, 2, 3).reshape(C, n, -1)
         energy = torch.bmm(cw, cw.permute(0, 2, 1))
         if group is not None:

@@ -19,13 +19,15 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
-from maskrcnn_benchmark.layers import Linear, nms as _box_nms
+from maskrcnn_benchmark import _hip as _H
+from maskrcnn_benchmark.layers import Linear, fused as _fused, nms as _box_nms
 from maskrcnn_benchmark.modeling.box_coder import BoxCoder
 from maskrcnn_benchmark.structures.bounding_box import BoxList
 from maskrcnn_benchmark.structures.boxlist_ops import cat_boxlist
 
 
 _RANK_EMB = {}
+_TENSOR_PATH = __import__("os").environ.get("MMT_IRNET_TENSOR", "0") == "1"   # A/B switch: library-GEMM attention
 
 
 def extract_rank_embedding(rank_dim, feat_dim, wave_length=1000, device="cpu"):
@@ -112,6 +114,16 @@ class RelationModule(nn.Module):
         g = self.group
         f_a = f_a.permute(1, 0, 2)
         fr = f_a.contiguous().view(N * ncls, feat_dim)
+        dv = self.dim[2] // g
+        if (f_a.is_cuda and not getattr(self, "tensor_path", _TENSOR_PATH) and self.dim[2] == feat_dim and self.dim[0] == self.dim[1]
+                and _H.relation_attention_fits(N, g, self.dim_group[0], dv)):
+            # one launch each way (csrc/relation.hip).  conv1 (16 groups of feat_dim -> dim[2] / 16) is applied to the
+            # features BEFORE the attention mixes them -- sum_m w[n, m] (W_g f[m]) instead of W_g (sum_m w[n, m] f[m]): the
+            # same bilinear form -- so it is one plain Linear over the (class, box) rows and the head outputs are dv wide
+            w_g = self.WG(position_embedding.reshape(-1, self.fc_dim[0]).contiguous(), relu=True)     # (C N N, 16), (c, n, m) rows
+            v = _fused.linear(fr, self.conv1.weight.view(self.dim[2], feat_dim))
+            return _fused.RelationAttentionFn.apply(self.WQ(fr), self.WK(fr), w_g, v, self.conv1.bias, ncls, N, g,
+                                                    min(N, self.topk), 1.0 / math.sqrt(float(self.dim_group[1])))
         w_g = F.relu(self.WG(position_embedding.reshape(-1, self.fc_dim[0]).contiguous()))
         w_k = self.WK(fr).view(-1, N, g, self.dim_group[1]).permute(0, 2, 3, 1).contiguous().view(-1, self.dim_group[1], N)
         w_q = self.WQ(fr).view(-1, N, g, self.dim_group[0]).transpose(1, 2).contiguous().view(-1, N, self.dim_group[0])
