@@ -208,6 +208,18 @@ int mmt_ciam_fwd(const float* x, const int64_t* group, int n, int C, int HW, int
                  float* out, void* stream);
 int mmt_ciam_bwd(const float* x, const int64_t* group, int n, int C, int HW, int max_group, const float* gamma, const float* A,
                  const int* J, const float* dout, float* T, float* R, float* dx, float* dgamma, void* stream);
+/* mmt_rpn_loss: the RPN's two losses over all anchors of the batch (reference modeling/rpn/loss.py:183-194, with the sampler's
+ * masks instead of index gathers): obj [R] logits, reg / regt [R][4] (16-byte aligned), labels [R] float (-1 / 0 / 1), pos / neg
+ * [R] bool bytes.  n = max(#(pos | neg), 1); out[0] = sum_{pos | neg} BCEWithLogits(obj, max(label, 0)) / n; out[1] =
+ * sum_{pos} smooth_l1(reg - regt, beta, sum) / n; dobj [R], dreg [R][4] = the gradients of out[0] w.r.t. obj and of out[1]
+ * w.r.t. reg (zero outside the samples).  sums [3] = workspace (zeroed here).  Two launches. */
+int mmt_rpn_loss(const float* obj, const float* reg, const float* labels, const float* regt, const uint8_t* pos, const uint8_t* neg,
+                 long R, float beta, float* sums, float* out, float* dobj, float* dreg, void* stream);
+/* mmt_box_loss: the box head's two losses (reference modeling/roi_heads/box_head/loss.py:118-162): logits [R][NC], breg
+ * [R][4 NC], labels [R] int64 in [0, NC), regt [R][4].  out[0] = mean_i CE(logits_i, label_i); out[1] = sum_{label > 0}
+ * smooth_l1(breg[i][4 label ..] - regt_i, beta = 1, sum) / R; dlogits, dbreg = their gradients.  out is zeroed here.  One launch. */
+int mmt_box_loss(const float* logits, const float* breg, const int64_t* labels, const float* regt, int R, int NC, float* out,
+                 float* dlogits, float* dbreg, void* stream);
 int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
                       const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total, int shared_cand,
                       float high, float low, int allow_low_quality, float wx, float wy, float ww, float wh, uint32_t* top_ws,

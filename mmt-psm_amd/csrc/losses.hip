@@ -270,3 +270,150 @@ extern "C" int mmt_psm_variance(const float* teacher, int Kaug, int R, int NC, i
   MMT_LAUNCH_CHECK();
   return 0;
 }
+
+// ----------------------------------------------------------------------------- RPN loss
+// rpn/loss.py:183-194 over all anchors of the batch with the sampler's masks instead of gathers:
+//   n = max(#(pos | neg), 1);  objectness = sum_{pos | neg} BCEWithLogits(obj, max(label, 0)) / n;
+//   box = sum_{pos} smooth_l1(reg - regt, beta, sum) / n
+// two streaming passes (the gradients need n): sums, then losses + unit gradients -- instead of ~22 elementwise / reduction
+// launches forward and ~25 backward.
+__global__ __launch_bounds__(256) void rpn_loss_sums_kernel(const float* __restrict__ obj, const float4* __restrict__ reg,
+                                                            const float* __restrict__ labels, const float4* __restrict__ regt,
+                                                            const uint8_t* __restrict__ pos, const uint8_t* __restrict__ neg,
+                                                            long R, float beta, float* __restrict__ sums) {
+  float cnt = 0.f, bce = 0.f, box = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < R; i += (long)gridDim.x * 256) {
+    const bool p = pos[i] != 0, s = p || neg[i] != 0;
+    if (s) {
+      const float x = obj[i], t = fmaxf(labels[i], 0.f);
+      cnt += 1.f;
+      bce += (1.f - t) * x + fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));
+    }
+    if (p) {
+      const float4 a = reg[i], b = regt[i];
+      const float d[4] = {fabsf(a.x - b.x), fabsf(a.y - b.y), fabsf(a.z - b.z), fabsf(a.w - b.w)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) box += d[j] < beta ? 0.5f * d[j] * d[j] / beta : d[j] - 0.5f * beta;
+    }
+  }
+  cnt = wave_sum(cnt);
+  bce = wave_sum(bce);
+  box = wave_sum(box);
+  __shared__ float red[4][3];
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6][0] = cnt;
+    red[threadIdx.x >> 6][1] = bce;
+    red[threadIdx.x >> 6][2] = box;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (v != 0.f) atomicAdd(sums + threadIdx.x, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void rpn_loss_grad_kernel(const float* __restrict__ obj, const float4* __restrict__ reg,
+                                                            const float* __restrict__ labels, const float4* __restrict__ regt,
+                                                            const uint8_t* __restrict__ pos, const uint8_t* __restrict__ neg,
+                                                            long R, float beta, const float* __restrict__ sums,
+                                                            float* __restrict__ out, float* __restrict__ dobj,
+                                                            float4* __restrict__ dreg) {
+  const float inv = 1.f / fmaxf(sums[0], 1.f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = sums[1] * inv;
+    out[1] = sums[2] * inv;
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < R; i += (long)gridDim.x * 256) {
+    const bool p = pos[i] != 0, s = p || neg[i] != 0;
+    float g = 0.f;
+    if (s) {
+      const float x = obj[i], t = fmaxf(labels[i], 0.f);
+      g = (1.f / (1.f + expf(-x)) - t) * inv;
+    }
+    dobj[i] = g;
+    float4 o = {0.f, 0.f, 0.f, 0.f};
+    if (p) {
+      const float4 a = reg[i], b = regt[i];
+      const float e[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w};
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = fabsf(e[j]);
+        r[j] = (d < beta ? e[j] / beta : (e[j] > 0.f ? 1.f : (e[j] < 0.f ? -1.f : 0.f))) * inv;
+      }
+      o = {r[0], r[1], r[2], r[3]};
+    }
+    dreg[i] = o;
+  }
+}
+
+extern "C" int mmt_rpn_loss(const float* obj, const float* reg, const float* labels, const float* regt, const uint8_t* pos,
+                            const uint8_t* neg, long R, float beta, float* sums, float* out, float* dobj, float* dreg,
+                            void* stream) {
+  if (!obj || !reg || !labels || !regt || !pos || !neg || !sums || !out || !dobj || !dreg || R < 1 || !(beta > 0.f) ||
+      (((size_t)reg | (size_t)regt | (size_t)dreg) & 15))
+    return MMT_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, 3 * sizeof(float), s) != hipSuccess) return MMT_EINVAL;
+  int blocks = (int)((R + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(rpn_loss_sums_kernel, dim3(blocks), dim3(256), 0, s, obj, (const float4*)reg, labels, (const float4*)regt, pos,
+                     neg, R, beta, sums);
+  MMT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3(blocks), dim3(256), 0, s, obj, (const float4*)reg, labels, (const float4*)regt, pos,
+                     neg, R, beta, sums, out, dobj, (float4*)dreg);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+// ----------------------------------------------------------------------------- box-head loss
+// box_head/loss.py:118-162: classification = mean_i CE(logits_i, label_i); box = sum_{label > 0} smooth_l1(breg[i, 4 label ..] -
+// regt_i, beta = 1, sum) / R.  One launch: both values (out[2], zeroed here) and the unit gradients of both inputs.
+__global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__ logits, const float* __restrict__ breg,
+                                                       const int64_t* __restrict__ labels, const float* __restrict__ regt, int R,
+                                                       int NC, float* __restrict__ out, float* __restrict__ dlogits,
+                                                       float* __restrict__ dbreg) {
+  const float inv = 1.f / (float)R;
+  float ce = 0.f, box = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += gridDim.x * 256) {
+    const float* l = logits + (long)i * NC;
+    const int lab = (int)labels[i];
+    float mx = l[0];
+    for (int c = 1; c < NC; ++c) mx = fmaxf(mx, l[c]);
+    float se = 0.f;
+    for (int c = 0; c < NC; ++c) se += expf(l[c] - mx);
+    const float lse = mx + logf(se);
+    ce += lse - l[lab];
+    for (int c = 0; c < NC; ++c) dlogits[(long)i * NC + c] = (expf(l[c] - lse) - (c == lab ? 1.f : 0.f)) * inv;
+    float* db = dbreg + (long)i * 4 * NC;
+    for (int c = 0; c < 4 * NC; ++c) db[c] = 0.f;
+    if (lab > 0) {
+      for (int j = 0; j < 4; ++j) {
+        const float e = breg[(long)i * 4 * NC + 4 * lab + j] - regt[(long)i * 4 + j], d = fabsf(e);
+        box += d < 1.f ? 0.5f * d * d : d - 0.5f;
+        db[4 * lab + j] = (d < 1.f ? e : (e > 0.f ? 1.f : -1.f)) * inv;
+      }
+    }
+  }
+  ce = wave_sum(ce);
+  box = wave_sum(box);
+  __shared__ float red[4][2];
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6][0] = ce;
+    red[threadIdx.x >> 6][1] = box;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) atomicAdd(out + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * inv);
+}
+
+extern "C" int mmt_box_loss(const float* logits, const float* breg, const int64_t* labels, const float* regt, int R, int NC,
+                            float* out, float* dlogits, float* dbreg, void* stream) {
+  if (!logits || !breg || !labels || !regt || !out || !dlogits || !dbreg || R < 1 || NC < 2) return MMT_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, 2 * sizeof(float), s) != hipSuccess) return MMT_EINVAL;
+  int blocks = (R + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(box_loss_kernel, dim3(blocks), dim3(256), 0, s, logits, breg, labels, regt, R, NC, out, dlogits, dbreg);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}

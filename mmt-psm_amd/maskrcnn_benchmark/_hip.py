@@ -110,6 +110,9 @@ _SIGS = {
     "mmt_det_postprocess": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_position_embedding": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mmt_rpn_loss": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p,
+                     c_void_p, c_void_p],
+    "mmt_box_loss": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_relation_attention_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p, c_void_p, c_void_p],
     "mmt_relation_attention_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
@@ -1403,6 +1406,34 @@ def maxpool3x3s2(x):
 
 
 # ------------------------------------------------------------------------------------------ losses
+def rpn_loss(obj, reg, labels, regt, pos, neg, beta):
+    """include/mmtpsm.h: mmt_rpn_loss.  obj (R,), reg / regt (R, 4), labels (R,) float, pos / neg (R,) bool
+    -> out (2,) = (objectness loss, box loss), d out[0] / d obj (R,), d out[1] / d reg (R, 4)"""
+    obj, reg = _dev(obj, "obj").float().contiguous(), _dev(reg, "reg").float().contiguous()
+    labels, regt = labels.float().contiguous(), regt.float().contiguous()
+    pos, neg = pos.contiguous(), neg.contiguous()
+    if pos.dtype != torch.bool or neg.dtype != torch.bool:
+        raise RuntimeError("rpn_loss: the sampler masks are bool tensors")
+    R = obj.numel()
+    ws = torch.empty((8,), dtype=torch.float32, device=obj.device)      # sums [0:3], out [4:6]
+    dobj, dreg = torch.empty_like(obj), torch.empty_like(reg)
+    _check(lib().mmt_rpn_loss(_p(obj), _p(reg), _p(labels), _p(regt), _p(pos), _p(neg), R, float(beta), _p(ws), ws.data_ptr() + 16,
+                              _p(dobj), _p(dreg), _stream()), "mmt_rpn_loss")
+    return ws[4:6], dobj, dreg
+
+
+def box_loss(logits, breg, labels, regt):
+    """include/mmtpsm.h: mmt_box_loss.  logits (R, NC), breg (R, 4 NC), labels (R,) int64, regt (R, 4)
+    -> out (2,) = (classification loss, box loss), d out[0] / d logits, d out[1] / d breg"""
+    logits, breg = _dev(logits, "logits").float().contiguous(), _dev(breg, "breg").float().contiguous()
+    labels, regt = labels.to(torch.int64).contiguous(), regt.float().contiguous()
+    R, NC = logits.shape
+    out = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    dl, db = torch.empty_like(logits), torch.empty_like(breg)
+    _check(lib().mmt_box_loss(_p(logits), _p(breg), _p(labels), _p(regt), R, NC, _p(out), _p(dl), _p(db), _stream()), "mmt_box_loss")
+    return out, dl, db
+
+
 def mask_bce(logits, labels, targets, grad_scale=1.0):
     """logits (P,NC,M,M) NHWC-dense, labels (P,) int, targets (P,M,M) -> (loss scalar tensor, grad like logits)"""
     logits = nhwc(logits)

@@ -419,6 +419,38 @@ class MaskBCEFn(torch.autograd.Function):
         return grad * g, None, None
 
 
+class RPNLossFn(torch.autograd.Function):
+    """(objectness loss, box loss) of rpn/loss.py:183-194 in two launches, gradients kept from the forward pass"""
+
+    @staticmethod
+    def forward(ctx, obj, reg, labels, regt, pos, neg, beta):
+        out, dobj, dreg = H.rpn_loss(obj, reg, labels, regt, pos, neg, beta)
+        ctx.save_for_backward(dobj, dreg)
+        ctx.shapes = (obj.shape, reg.shape)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        dobj, dreg = ctx.saved_tensors
+        so, sr = ctx.shapes
+        return (dobj * g0).view(so), (dreg * g1).view(sr), None, None, None, None, None
+
+
+class BoxLossFn(torch.autograd.Function):
+    """(classification loss, box loss) of box_head/loss.py:118-162 in one launch, gradients kept from the forward pass"""
+
+    @staticmethod
+    def forward(ctx, logits, breg, labels, regt):
+        out, dl, db = H.box_loss(logits, breg, labels, regt)
+        ctx.save_for_backward(dl, db)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        dl, db = ctx.saved_tensors
+        return dl * g0, db * g1, None, None
+
+
 class PSMLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, student, teacher, roww, norm, temp, sharpen, kind):

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from maskrcnn_benchmark.utils.miscellaneous import dev_const
+from maskrcnn_benchmark.utils.miscellaneous import dev_const, dev_ints
 from torch import nn
 import torch.nn.functional as F
 
@@ -132,9 +132,8 @@ class FastRCNNLossComputation(object):
         gt = torch.cat([t.bbox.to(dev) for t in targets], 0) if N > 1 else targets[0].bbox.to(dev)
         gl = torch.cat([t.get_field("labels").to(dev) for t in targets], 0) if N > 1 else targets[0].get_field("labels").to(dev)
         m = self.proposal_matcher
-        # data-dependent offsets (proposal counts): plain H2D tensors, the counts came from a host sync anyway
-        _, lab, reg = H.match_targets(cand, torch.tensor(coff, dtype=torch.int32, device=dev), gt,
-                                      torch.tensor(goff, dtype=torch.int32, device=dev), N, m.high_threshold,
+        # data-dependent offsets (proposal counts): through the pinned ring -- a pageable copy would drain the stream first
+        _, lab, reg = H.match_targets(cand, dev_ints(coff, dev), gt, dev_ints(goff, dev), N, m.high_threshold,
                                       m.low_threshold, m.allow_low_quality_matches, gt_labels=gl, box_labels=True,
                                       weights=self.box_coder.weights)
         return list(lab.split(A, 0)), list(reg.split(A, 0))
@@ -164,6 +163,8 @@ class FastRCNNLossComputation(object):
         props = self._proposals
         labels = torch.cat([p.get_field("labels") for p in props], 0)
         regt = torch.cat([p.get_field("regression_targets") for p in props], 0)
+        if class_logits.is_cuda and not getattr(self, "tensor_loss", False):
+            return fused.BoxLossFn.apply(class_logits, box_regression, labels, regt)   # one launch (csrc/losses.hip: mmt_box_loss)
         cls = F.cross_entropy(class_logits, labels)
         posf = (labels > 0).to(torch.float32)
         idx = (4 * labels.clamp(min=0))[:, None] + torch.arange(4, device=labels.device)[None, :]

@@ -15,6 +15,7 @@ from maskrcnn_benchmark.modeling.matcher import Matcher
 from maskrcnn_benchmark.modeling.poolers import Pooler
 from maskrcnn_benchmark.structures.bounding_box import BoxList
 from maskrcnn_benchmark.structures.boxlist_ops import boxlist_iou
+from maskrcnn_benchmark.utils.miscellaneous import dev_ints
 from maskrcnn_benchmark.modeling.relation.mask_relation_module import MaskRelationRefineNet
 
 
@@ -76,16 +77,40 @@ class MaskRCNNLossComputation(object):
     def prepare_targets(self, proposals, targets):
         """-> labels (cat over images), mask targets (P, M, M) float -- mask_head/loss.py:119-149"""
         labels, mts = [], []
-        for p, t in zip(proposals, targets):
-            m = self.proposal_matcher(boxlist_iou(t, p))
-            mi = m.clamp(min=0)
-            lab = t.get_field("labels")[mi].to(torch.int64)
-            lab = torch.where(m == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(lab), lab)
+        pm = self.proposal_matcher
+        dev = proposals[0].bbox.device
+        fused_match = (dev.type == "cuda" and pm.high_threshold == pm.low_threshold and not pm.allow_low_quality_matches
+                       and all(len(p) > 0 and len(t) > 0 for p, t in zip(proposals, targets)))
+        if fused_match:
+            # IoU + Matcher + label lookup of ALL images in one launch (`mmt_match_targets`, the box head's call): with equal
+            # thresholds there is no BETWEEN_THRESHOLDS class, so its box-head labels (0 below the threshold, else the matched
+            # ground truth's label) are exactly the labels of mask_head/loss.py:119-138
+            N = len(proposals)
+            A = [len(p) for p in proposals]
+            coff, goff = [0], [0]
+            for a, t in zip(A, targets):
+                coff.append(coff[-1] + a)
+                goff.append(goff[-1] + len(t))
+            cand = torch.cat([p.bbox for p in proposals], 0) if N > 1 else proposals[0].bbox
+            gt = torch.cat([t.bbox.to(dev) for t in targets], 0) if N > 1 else targets[0].bbox.to(dev)
+            gl = torch.cat([t.get_field("labels").to(dev) for t in targets], 0) if N > 1 else targets[0].get_field("labels").to(dev)
+            mt_all, lab_all, _ = H.match_targets(cand, dev_ints(coff, dev), gt, dev_ints(goff, dev), N,
+                                                 pm.high_threshold, pm.low_threshold, False, gt_labels=gl, box_labels=True)
+            mi_all = mt_all.clamp(min=0).long()
+            pos_all = (lab_all > 0).to(torch.int32)[:, None]
+        for i, (p, t) in enumerate(zip(proposals, targets)):
+            if fused_match:
+                mi, lab = mi_all[coff[i]:coff[i + 1]], lab_all[coff[i]:coff[i + 1]]
+            else:
+                m = pm(boxlist_iou(t, p))
+                mi = m.clamp(min=0)
+                lab = t.get_field("labels")[mi].to(torch.int64)
+                lab = torch.where(m == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(lab), lab)
             labels.append(lab)
             # every box handed to the mask head is already a positive of the same matcher (mask_head.py:74-78),
             # so `positive_inds` is all of them; non-positives (never produced) would get an all-zero range
             xy, poly_off, inst_rng = t.get_field("masks").packed(p.bbox.device)
-            rng = inst_rng[mi] * (lab > 0).to(torch.int32)[:, None]
+            rng = inst_rng[mi] * (pos_all[coff[i]:coff[i + 1]] if fused_match else (lab > 0).to(torch.int32)[:, None])
             mt, ovf = H.polygon_targets(xy, poly_off, rng, p.bbox, self.discretization_size)
             mts.append(mt)
         return torch.cat(labels, 0), torch.cat(mts, 0)

@@ -19,7 +19,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from maskrcnn_benchmark import _hip as H
-from maskrcnn_benchmark.layers import Conv2d, smooth_l1_loss
+from maskrcnn_benchmark.layers import Conv2d, fused, smooth_l1_loss
 from maskrcnn_benchmark.modeling.box_coder import BoxCoder
 from maskrcnn_benchmark.modeling.matcher import Matcher
 from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
@@ -272,6 +272,9 @@ class RPNLossComputation(object):
         obj = torch.cat(of, 1).reshape(-1)
         reg = torch.cat(rf, 1).reshape(-1, 4)
         labels, regt = torch.cat(labels, 0), torch.cat(regt, 0)
+        if obj.is_cuda and not getattr(self, "tensor_loss", False):
+            obj_loss, box_loss = fused.RPNLossFn.apply(obj, reg, labels, regt, pos, neg, 1.0 / 9)   # two launches (csrc/losses.hip)
+            return obj_loss, box_loss
         samp = pos | neg
         n_samp = samp.sum().clamp(min=1).to(torch.float32)
         posf = pos.to(torch.float32)

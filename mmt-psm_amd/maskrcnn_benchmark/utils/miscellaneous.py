@@ -1,4 +1,6 @@
 """The helpers of utils/miscellaneous.py that sit on the path: :37-58 (flips) and :233-247 (ramps)."""
+import threading
+
 import numpy as np
 import torch
 
@@ -54,3 +56,25 @@ def dev_const(values, dtype, device):
         t = torch.tensor(values, dtype=dtype, device=device)
         _DEV_CONST[key] = t
     return t
+
+
+_INT_RING = {}
+
+
+def dev_ints(values, device):
+    """a short int32 vector whose content changes from step to step (per-image proposal counts and their prefix sums) on the
+    device WITHOUT draining the stream: the values are written into a slot of a pinned ring and copied asynchronously on the
+    current stream (a `torch.tensor(list, device=cuda)` is a pageable copy that blocks the host, see `dev_const`, and caching by
+    content does not help when the content is new every step).  A slot is re-used after 256 calls, i.e. tens of steps later."""
+    n = len(values)
+    if n > 64:
+        return torch.tensor(values, dtype=torch.int32).to(device, non_blocking=True)
+    ent = _INT_RING.get(device)
+    if ent is None:
+        ent = _INT_RING[device] = [torch.zeros((256, 64), dtype=torch.int32).pin_memory(), 0, threading.Lock()]
+    with ent[2]:   # (the teacher thread shares the ring)
+        i = ent[1]
+        ent[1] = (i + 1) & 255
+    slot = ent[0][i, :n]
+    slot.copy_(torch.tensor(values, dtype=torch.int32))
+    return slot.to(device, non_blocking=True)

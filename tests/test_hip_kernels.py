@@ -653,3 +653,88 @@ def test_box_decode_kernel(hip):
     for nm, w in (("10", (10., 10., 5., 5.)), ("1", (1., 1., 1., 1.))):             # the reference's own outputs
         own = hip.box_decode(T(g["codes" + nm]).cuda(), T(g["props"]).cuda(), w, BoxCoder(w).bbox_xform_clip)
         np.testing.assert_allclose(own.cpu().numpy(), g["dec" + nm], rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,frac", [(300000, 0.002), (5000, 0.2), (1000, 0.0)])
+def test_rpn_loss_kernel_vs_tensor_formulation(R, frac):
+    """mmt_rpn_loss (two launches) against the tensor formulation of rpn/loss.py:183-194 it replaces: values and both gradients"""
+    from maskrcnn_benchmark.layers import fused
+    torch.manual_seed(R)
+    dev = "cuda"
+    obj = (torch.randn(R, device=dev) * 3).requires_grad_(True)
+    reg = (torch.randn(R, 4, device=dev) * 0.3).requires_grad_(True)
+    regt = torch.randn(R, 4, device=dev) * 0.3
+    u = torch.rand(R, device=dev)
+    pos, neg = u < frac, (u >= frac) & (u < 3 * frac)
+    labels = torch.where(pos, torch.ones_like(u), torch.where(neg, torch.zeros_like(u), -torch.ones_like(u)))
+    lo, lb = fused.RPNLossFn.apply(obj, reg, labels, regt, pos, neg, 1.0 / 9)
+    (2.0 * lo + 3.0 * lb).backward()
+    o2, r2 = obj.detach().clone().requires_grad_(True), reg.detach().clone().requires_grad_(True)
+    samp = pos | neg
+    n = samp.sum().clamp(min=1).float()
+    d = torch.abs(r2 - regt)
+    beta = 1.0 / 9
+    sl1 = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
+    wb = (sl1 * pos.float()[:, None]).sum() / n
+    wo = (torch.nn.functional.binary_cross_entropy_with_logits(o2, labels.clamp(min=0), reduction="none") * samp.float()).sum() / n
+    (2.0 * wo + 3.0 * wb).backward()
+    assert lo.item() == pytest.approx(wo.item(), rel=2e-6, abs=1e-9)
+    assert lb.item() == pytest.approx(wb.item(), rel=2e-6, abs=1e-9)
+    assert torch.allclose(obj.grad, o2.grad, rtol=1e-5, atol=1e-9)
+    assert torch.allclose(reg.grad, r2.grad, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,NC", [(1024, 3), (7, 3), (2000, 81)])
+def test_box_loss_kernel_vs_tensor_formulation(R, NC):
+    """mmt_box_loss (one launch) against the tensor formulation of box_head/loss.py:118-162 it replaces"""
+    from maskrcnn_benchmark.layers import fused
+    torch.manual_seed(R + NC)
+    dev = "cuda"
+    logits = (torch.randn(R, NC, device=dev) * 2).requires_grad_(True)
+    breg = (torch.randn(R, 4 * NC, device=dev) * 0.8).requires_grad_(True)
+    labels = torch.randint(0, NC, (R,), device=dev) * (torch.rand(R, device=dev) < 0.4)
+    regt = torch.randn(R, 4, device=dev) * 0.8
+    lc, lb = fused.BoxLossFn.apply(logits, breg, labels, regt)
+    (2.0 * lc + 3.0 * lb).backward()
+    l2, b2 = logits.detach().clone().requires_grad_(True), breg.detach().clone().requires_grad_(True)
+    wc = torch.nn.functional.cross_entropy(l2, labels)
+    idx = (4 * labels.clamp(min=0))[:, None] + torch.arange(4, device=dev)[None, :]
+    d = torch.abs(torch.gather(b2, 1, idx) - regt)
+    wb = (torch.where(d < 1.0, 0.5 * d * d, d - 0.5) * (labels > 0).float()[:, None]).sum() / R
+    (2.0 * wc + 3.0 * wb).backward()
+    assert lc.item() == pytest.approx(wc.item(), rel=2e-6)
+    assert lb.item() == pytest.approx(wb.item(), rel=2e-6, abs=1e-9)
+    assert torch.allclose(logits.grad, l2.grad, rtol=1e-5, atol=1e-9)
+    assert torch.allclose(breg.grad, b2.grad, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_mask_head_targets_one_launch_matching_vs_tensor_formulation(synth):
+    """MaskRCNNLossComputation.prepare_targets: IoU + Matcher + label lookup of all images through `mmt_match_targets` (one
+    launch) against the per-image tensor formulation of mask_head/loss.py:119-149 (boxlist_iou, Matcher, gathers): labels and
+    mask targets bit-equal, with proposals that are ground truth (IoU 1), jittered boxes, and boxes below the threshold"""
+    from test_model_gpu import _targets_product
+    from maskrcnn_benchmark.config import make_default_cfg
+    from maskrcnn_benchmark.modeling.matcher import Matcher
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head.mask_head import MaskRCNNLossComputation
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    dev = torch.device("cuda")
+    _, tgs = synth.make_labeled(2, 320, 6, seed=77)
+    targets = _targets_product(tgs, dev)
+    torch.manual_seed(5)
+    props = []
+    for t in targets:
+        g = t.bbox
+        jit = g.repeat(4, 1) + torch.randn(4 * len(g), 4, device=dev) * 6.0
+        far = torch.rand(10, 4, device=dev) * 40
+        far[:, 2:] += far[:, :2] + 5
+        props.append(BoxList(torch.cat([g, jit, far]), t.size, "xyxy"))
+    ev = MaskRCNNLossComputation(Matcher(0.5, 0.5, allow_low_quality_matches=False), 28, make_default_cfg())
+    lab, mt = ev.prepare_targets(props, targets)
+    ev.proposal_matcher = Matcher(0.5, 0.5 - 1e-9, allow_low_quality_matches=False)   # unequal thresholds: the tensor formulation
+    lab_t, mt_t = ev.prepare_targets(props, targets)
+    assert (lab > 0).any() and (lab == 0).any()
+    assert torch.equal(lab, lab_t)
+    assert torch.equal(mt, mt_t)
