@@ -23,6 +23,9 @@ from maskrcnn_benchmark.structures.boxlist_ops import boxlist_iou
 from maskrcnn_benchmark.utils.miscellaneous import batch_boxlist_hflip
 
 
+_TENSOR_GLUE = __import__("os").environ.get("MMT_TENSOR_GLUE", "0") == "1"   # A/B switch: the tensor formulations of the losses / matching
+
+
 class MaskRCNNFPNAdaptor(nn.Module):
     """MGD hint adaptors: 5 independent 1x1 convs (roi_box_feature_extractors.py:45-75)"""
 
@@ -163,7 +166,7 @@ class FastRCNNLossComputation(object):
         props = self._proposals
         labels = torch.cat([p.get_field("labels") for p in props], 0)
         regt = torch.cat([p.get_field("regression_targets") for p in props], 0)
-        if class_logits.is_cuda and not getattr(self, "tensor_loss", False):
+        if class_logits.is_cuda and not getattr(self, "tensor_loss", _TENSOR_GLUE):
             return fused.BoxLossFn.apply(class_logits, box_regression, labels, regt)   # one launch (csrc/losses.hip: mmt_box_loss)
         cls = F.cross_entropy(class_logits, labels)
         posf = (labels > 0).to(torch.float32)

@@ -28,6 +28,9 @@ from maskrcnn_benchmark.structures.boxlist_ops import box_iou_tensor
 from .anchor_generator import make_anchor_generator
 
 
+_TENSOR_GLUE = __import__("os").environ.get("MMT_TENSOR_GLUE", "0") == "1"   # A/B switch: the tensor formulations of the losses / matching
+
+
 class RPNHead(nn.Module):
     def __init__(self, cfg, in_channels, num_anchors):
         super().__init__()
@@ -272,7 +275,7 @@ class RPNLossComputation(object):
         obj = torch.cat(of, 1).reshape(-1)
         reg = torch.cat(rf, 1).reshape(-1, 4)
         labels, regt = torch.cat(labels, 0), torch.cat(regt, 0)
-        if obj.is_cuda and not getattr(self, "tensor_loss", False):
+        if obj.is_cuda and not getattr(self, "tensor_loss", _TENSOR_GLUE):
             obj_loss, box_loss = fused.RPNLossFn.apply(obj, reg, labels, regt, pos, neg, 1.0 / 9)   # two launches (csrc/losses.hip)
             return obj_loss, box_loss
         samp = pos | neg
