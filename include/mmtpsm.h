@@ -182,20 +182,21 @@ int mmt_relation_reg_labels(const float* boxes, const float* score, const float*
 int mmt_position_embedding(const float* boxes, int n, int C, int dim_g, const float* freq, float* out, void* stream);
 /* mmt_relation_attention_{fwd,bwd}: the multi-head geometric relation attention of IR-Net's duplicate-removal network
  * (reference modeling/relation/relation_module.py:33-90, RelationModule.forward: two torch.bmm, log / clamp / add, topk,
- * softmax, scatter, permutes and the 16-group 1x1 conv1) in ONE launch each way.  C = classes (x images), N <= 120 ranked
+ * softmax, scatter, permutes and the 16-group 1x1 conv1) in one launch forward, two backward.  C = classes (x images), N <= 128 ranked
  * boxes per class, G heads, DQ <= 128 query / key dims per head, DV <= 16 value dims per head.
  *   q, k [C*N][G*DQ] (rows in (class, box) order: the WQ / WK Linear outputs as they are), wg [C][N][N][G] (ReLU(WG(position
  *   embedding)), v [C*N][G*DV] = features x conv1.weight^T (the grouped 1x1 conv applied BEFORE the mix: the same bilinear
  *   form), bias [G*DV] (conv1.bias)
  *   S = scale q k^T + log(max(wg, 1e-6)); P = softmax over the top-k entries of every row of S (lower index wins a tie), zero
  *   elsewhere -> P [C][G][N][N] (kept for the backward); out [N][C][G*DV] = P v + bias.
- * bwd: dout [N][C][G*DV] -> dq, dk (like q), dwg (like wg; the clamp passes the gradient where wg >= 1e-6), dv (like v); every
- * element is written by exactly one workgroup (no atomics, nothing to zero). */
+ * bwd: dout [N][C][G*DV] -> dq, dk (like q), dwg (like wg; the clamp passes the gradient where wg >= 1e-6), dv (like v); a row
+ * pass (softmax backward, dwg, dq; writes dS) and a column pass (dk, dv): every element is written by exactly one workgroup
+ * (no atomics, nothing to zero). */
 int mmt_relation_attention_fwd(const float* q, const float* k, const float* wg, const float* v, const float* bias, int C, int N,
                                int G, int DQ, int DV, int topk, float scale, float* P, float* out, void* stream);
 int mmt_relation_attention_bwd(const float* q, const float* k, const float* wg, const float* v, const float* P, const float* dout,
-                               int C, int N, int G, int DQ, int DV, float scale, float* dq, float* dk, float* dwg, float* dv,
-                               void* stream);
+                               int C, int N, int G, int DQ, int DV, float scale, float* dS /* workspace [C][G][N][N] */, float* dq,
+                               float* dk, float* dwg, float* dv, void* stream);
 /* mmt_ciam_{fwd,bwd}: IR-Net's cross-instance attention of the mask refinement (reference
  * modeling/relation/mask_relation_module.py:199-242, CIAM_Module.forward: bmm, max, mean, softmax, mm), all (image, class)
  * groups of the batch in one launch.  x [n][C <= 16][HW] fp32, group [n] int64 ids with equal ids CONTIGUOUS (the attention

@@ -1,7 +1,7 @@
 // IR-Net attention kernels of libmmtpsm.so (include/mmtpsm.h): the multi-head geometric relation attention of the
 // relation NMS (reference modeling/relation/relation_module.py:33-90, RelationModule.forward) and the cross-instance
 // attention of the mask refinement (reference modeling/relation/mask_relation_module.py:199-242, CIAM_Module.forward),
-// each as ONE forward and ONE backward launch instead of ~15 + ~30 library launches (batched GEMMs, top-k, softmax,
+// each as one forward and two backward launches instead of ~15 + ~30 library launches (batched GEMMs, top-k, softmax,
 // scatter, permutes).  The problems are tiny (<= 128 boxes x 16 heads x 64 dims; <= a few hundred instances x 16
 // channels x 196 pixels): they are latency-bound, not matrix-bound -- fp32 FMAs on the vector ALU, operands staged in LDS,
 // one workgroup per (class, head) / per row block; nothing here is shaped for the MFMA units on purpose.
@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int RA_MAXN = 120;    // boxes per class (FIRST_N = 90 in the shipped recipe); LDS of the backward: N (N + 1) floats
+constexpr int RA_MAXN = 128;    // boxes per class (FIRST_N = 90 in the shipped recipe): two columns per lane of a wave
 constexpr int RA_MAXDV = 16;
 
 // lanes of ONE wave exchange values through LDS: LDS operations of a wave complete in order, the fences keep the compiler from
@@ -34,19 +34,26 @@ __device__ __forceinline__ float wave_max(float v) {
 //   out[n][c][g*DV + o] = bias[g*DV + o] + sum_m P[n][m] V[c,m,g,o]
 // V = (appearance features) x (conv1 weight of head g)^T is a plain Linear done by the caller: the reference's
 // `conv1(bmm(w, f_a))` (grouped 1x1 over the 16 x feat_dim stacked head outputs) is the same bilinear form, summed in the
-// other order.  grid (G, C), 256 threads: a wave owns the rows n = wave, wave + 4, ...; its lanes own the columns m = lane, lane + 64.
+// other order.  The problem is a chain of latencies, not of arithmetic: grid (G, C, row chunks of RA_RB rows) -- ~770
+// workgroups for the shipped shape -- and every global operand of a workgroup (key slice, value slice, its query rows, its
+// strided w_g rows) is requested in ONE round up front into LDS; a wave then owns RA_RB / 4 rows, its lanes the columns
+// m = lane, lane + 64.
+constexpr int RA_RB = 8;
+
 __global__ __launch_bounds__(256) void relation_attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                      const float* __restrict__ wg, const float* __restrict__ v,
                                                                      const float* __restrict__ bias, int C, int N, int G, int DQ,
                                                                      int DV, int topk, float scale, float* __restrict__ P,
                                                                      float* __restrict__ out) {
   extern __shared__ float lds[];
-  const int g = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = blockIdx.x, c = blockIdx.y, n0 = blockIdx.z * RA_RB, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nr = min(RA_RB, N - n0);
   const int KP = DQ + 1;                       // padded key rows: lanes walk m, the inner loop walks d
   float* Ks = lds;                             // [N][DQ + 1]
   float* Vs = Ks + N * KP;                     // [N][DV]
-  float* Qr = Vs + N * DV;                     // [4][DQ]   the wave's query row
-  float* Sr = Qr + 4 * DQ;                     // [4][128]  the wave's score / probability row
+  float* Qs = Vs + N * DV;                     // [RA_RB][DQ]
+  float* Ws = Qs + RA_RB * DQ;                 // [RA_RB][N]     log(max(w_g, 1e-6)) of the chunk's rows
+  float* Sr = Ws + RA_RB * N;                  // [4][128]       the wave's score row
   const long ldq = (long)G * DQ, ldv = (long)G * DV;
   for (int e = tid; e < N * DQ; e += 256) {
     const int m = e / DQ, d = e - m * DQ;
@@ -56,24 +63,28 @@ __global__ __launch_bounds__(256) void relation_attention_fwd_kernel(const float
     const int m = e / DV, o = e - m * DV;
     Vs[e] = v[((long)c * N + m) * ldv + (long)g * DV + o];
   }
+  for (int e = tid; e < nr * DQ; e += 256) {
+    const int r = e / DQ, d = e - r * DQ;
+    Qs[e] = q[((long)c * N + n0 + r) * ldq + (long)g * DQ + d];
+  }
+  for (int e = tid; e < nr * N; e += 256) Ws[e] = logf(fmaxf(wg[(((long)c * N + n0) * N + e) * G + g], 1e-6f));
   __syncthreads();
-  float* qr = Qr + wave * DQ;
   float* sr = Sr + wave * 128;
   const int m0 = lane, m1 = lane + 64;
-  for (int n = wave; n < N; n += 4) {
-    for (int d = lane; d < DQ; d += 64) qr[d] = q[((long)c * N + n) * ldq + (long)g * DQ + d];
-    WAVE_SYNC();
+  for (int r = wave; r < nr; r += 4) {
+    const int n = n0 + r;
+    const float* qr = Qs + r * DQ;
     float s0 = 0.f, s1 = 0.f;
     if (m0 < N) {
       const float* kr = Ks + m0 * KP;
       for (int d = 0; d < DQ; ++d) s0 = fmaf(qr[d], kr[d], s0);
-      s0 = s0 * scale + logf(fmaxf(wg[(((long)c * N + n) * N + m0) * G + g], 1e-6f));
+      s0 = s0 * scale + Ws[r * N + m0];
       sr[m0] = s0;
     }
     if (m1 < N) {
       const float* kr = Ks + m1 * KP;
       for (int d = 0; d < DQ; ++d) s1 = fmaf(qr[d], kr[d], s1);
-      s1 = s1 * scale + logf(fmaxf(wg[(((long)c * N + n) * N + m1) * G + g], 1e-6f));
+      s1 = s1 * scale + Ws[r * N + m1];
       sr[m1] = s1;
     }
     WAVE_SYNC();
@@ -107,70 +118,117 @@ __global__ __launch_bounds__(256) void relation_attention_fwd_kernel(const float
 //   dP[n][m] = <dOut[n,c,g,:], V[c,m,g,:]>;  dS = P (dP - sum_m P dP)  (zero outside the top-k: P is zero there)
 //   dQ[c,n,g,:] = scale sum_m dS[n][m] K[c,m,g,:];   dK[c,m,g,:] = scale sum_n dS[n][m] Q[c,n,g,:]
 //   dV[c,m,g,:] = sum_n P[n][m] dOut[n,c,g,:];       dWG[c,n,m,g] = dS[n][m] / WG[c,n,m,g] where WG >= 1e-6 (clamp), else 0
-// every output element belongs to exactly one (c, g) workgroup: no atomics.
-__global__ __launch_bounds__(256) void relation_attention_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                     const float* __restrict__ wg, const float* __restrict__ v,
-                                                                     const float* __restrict__ P, const float* __restrict__ dout,
-                                                                     int C, int N, int G, int DQ, int DV, float scale,
-                                                                     float* __restrict__ dq, float* __restrict__ dk,
-                                                                     float* __restrict__ dwg, float* __restrict__ dv) {
+// Two launches, both over (G, C, chunks of RA_RB) like the forward pass: the ROW pass owns rows of dS (softmax backward, dWG,
+// dQ; dS is also written out), the COLUMN pass owns columns (dK, dV: sums over all rows).  Every output element belongs to
+// exactly one workgroup: no atomics.
+__global__ __launch_bounds__(256) void relation_attention_bwd_rows_kernel(const float* __restrict__ k, const float* __restrict__ wg,
+                                                                          const float* __restrict__ v, const float* __restrict__ P,
+                                                                          const float* __restrict__ dout, int C, int N, int G,
+                                                                          int DQ, int DV, float scale, float* __restrict__ dS,
+                                                                          float* __restrict__ dq, float* __restrict__ dwg) {
   extern __shared__ float lds[];
-  const int g = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int SP = N + 1;
-  float* dS = lds;                 // [N][N + 1]
-  float* Vs = dS + N * SP;         // [N][DV]
-  float* Gs = Vs + N * DV;         // [N][DV]   dOut[n, c, g, :]
+  const int g = blockIdx.x, c = blockIdx.y, n0 = blockIdx.z * RA_RB, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nr = min(RA_RB, N - n0);
+  const int KP = DQ + 1;
+  float* Ks = lds;                 // [N][DQ + 1]
+  float* Vs = Ks + N * KP;         // [N][DV]
+  float* Gs = Vs + N * DV;         // [RA_RB][DV]   dOut[n, c, g, :]
+  float* Ps = Gs + RA_RB * DV;     // [RA_RB][N]    P rows, then dS rows
+  float* Wr = Ps + RA_RB * N;      // [RA_RB][N]    w_g rows
   const long ldq = (long)G * DQ, ldv = (long)G * DV;
+  const float* Pcg = P + ((long)c * G + g) * N * N;
+  float* dScg = dS + ((long)c * G + g) * N * N;
+  for (int e = tid; e < N * DQ; e += 256) {
+    const int m = e / DQ, d = e - m * DQ;
+    Ks[m * KP + d] = k[((long)c * N + m) * ldq + (long)g * DQ + d];
+  }
   for (int e = tid; e < N * DV; e += 256) {
     const int m = e / DV, o = e - m * DV;
     Vs[e] = v[((long)c * N + m) * ldv + (long)g * DV + o];
-    Gs[e] = dout[((long)m * C + c) * ldv + (long)g * DV + o];
+  }
+  for (int e = tid; e < nr * DV; e += 256) {
+    const int r = e / DV, o = e - r * DV;
+    Gs[e] = dout[((long)(n0 + r) * C + c) * ldv + (long)g * DV + o];
+  }
+  for (int e = tid; e < nr * N; e += 256) {
+    Ps[e] = Pcg[(long)n0 * N + e];
+    Wr[e] = wg[(((long)c * N + n0) * N + e) * G + g];
   }
   __syncthreads();
-  const float* Pcg = P + ((long)c * G + g) * N * N;
   const int m0 = lane, m1 = lane + 64;
-  for (int n = wave; n < N; n += 4) {
-    const float p0 = m0 < N ? Pcg[(long)n * N + m0] : 0.f, p1 = m1 < N ? Pcg[(long)n * N + m1] : 0.f;
+  for (int r = wave; r < nr; r += 4) {
+    const float p0 = m0 < N ? Ps[r * N + m0] : 0.f, p1 = m1 < N ? Ps[r * N + m1] : 0.f;
     float d0 = 0.f, d1 = 0.f;
     for (int o = 0; o < DV; ++o) {
-      const float go = Gs[n * DV + o];
+      const float go = Gs[r * DV + o];
       if (m0 < N) d0 = fmaf(go, Vs[m0 * DV + o], d0);
       if (m1 < N) d1 = fmaf(go, Vs[m1 * DV + o], d1);
     }
     const float rs = wave_sum(p0 * d0 + p1 * d1);
     const float t0 = p0 * (d0 - rs), t1 = p1 * (d1 - rs);
+    WAVE_SYNC();                   // every lane has read its P entries of the row before the row is overwritten with dS
     if (m0 < N) {
-      dS[n * SP + m0] = t0;
-      const long iw = (((long)c * N + n) * N + m0) * G + g;
-      const float w = wg[iw];
-      dwg[iw] = w >= 1e-6f ? t0 / w : 0.f;
+      Ps[r * N + m0] = t0;
+      dScg[(long)(n0 + r) * N + m0] = t0;
+      const float w = Wr[r * N + m0];
+      dwg[(((long)c * N + n0 + r) * N + m0) * G + g] = w >= 1e-6f ? t0 / w : 0.f;
     }
     if (m1 < N) {
-      dS[n * SP + m1] = t1;
-      const long iw = (((long)c * N + n) * N + m1) * G + g;
-      const float w = wg[iw];
-      dwg[iw] = w >= 1e-6f ? t1 / w : 0.f;
+      Ps[r * N + m1] = t1;
+      dScg[(long)(n0 + r) * N + m1] = t1;
+      const float w = Wr[r * N + m1];
+      dwg[(((long)c * N + n0 + r) * N + m1) * G + g] = w >= 1e-6f ? t1 / w : 0.f;
     }
   }
   __syncthreads();
-  // dQ, dK: one thread per (row, d), lanes along d (coalesced rows of K / Q, dS broadcast or strided by a padded row)
+  for (int e = tid; e < nr * DQ; e += 256) {   // dQ: lanes along d (Ks rows conflict-free, the dS entry is a broadcast)
+    const int r = e / DQ, d = e - r * DQ;
+    float a = 0.f;
+    for (int m = 0; m < N; ++m) a = fmaf(Ps[r * N + m], Ks[m * KP + d], a);
+    dq[((long)c * N + n0 + r) * ldq + (long)g * DQ + d] = a * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void relation_attention_bwd_cols_kernel(const float* __restrict__ q, const float* __restrict__ P,
+                                                                          const float* __restrict__ dS, const float* __restrict__ dout,
+                                                                          int C, int N, int G, int DQ, int DV, float scale,
+                                                                          float* __restrict__ dk, float* __restrict__ dv) {
+  extern __shared__ float lds[];
+  const int g = blockIdx.x, c = blockIdx.y, m0 = blockIdx.z * RA_RB, tid = threadIdx.x;
+  const int nc = min(RA_RB, N - m0);
+  float* Qs = lds;                 // [N][DQ]
+  float* Gs = Qs + N * DQ;         // [N][DV]      dOut[n, c, g, :]
+  float* Dc = Gs + N * DV;         // [N][RA_RB]   dS columns of the chunk
+  float* Pc = Dc + N * RA_RB;      // [N][RA_RB]   P columns of the chunk
+  const long ldq = (long)G * DQ, ldv = (long)G * DV;
+  const float* Pcg = P + ((long)c * G + g) * N * N;
+  const float* dScg = dS + ((long)c * G + g) * N * N;
   for (int e = tid; e < N * DQ; e += 256) {
     const int n = e / DQ, d = e - n * DQ;
-    float aq = 0.f, ak = 0.f;
-    for (int m = 0; m < N; ++m) {
-      aq = fmaf(dS[n * SP + m], k[((long)c * N + m) * ldq + (long)g * DQ + d], aq);
-      ak = fmaf(dS[m * SP + n], q[((long)c * N + m) * ldq + (long)g * DQ + d], ak);
-    }
-    const long io = ((long)c * N + n) * ldq + (long)g * DQ + d;
-    dq[io] = aq * scale;
-    dk[io] = ak * scale;
+    Qs[e] = q[((long)c * N + n) * ldq + (long)g * DQ + d];
   }
-  // dV: one thread per (m, o)
   for (int e = tid; e < N * DV; e += 256) {
-    const int m = e / DV, o = e - m * DV;
+    const int n = e / DV, o = e - n * DV;
+    Gs[e] = dout[((long)n * C + c) * ldv + (long)g * DV + o];
+  }
+  for (int e = tid; e < N * RA_RB; e += 256) {
+    const int n = e / RA_RB, j = e - n * RA_RB;
+    const bool ok = j < nc;
+    Dc[e] = ok ? dScg[(long)n * N + m0 + j] : 0.f;
+    Pc[e] = ok ? Pcg[(long)n * N + m0 + j] : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < nc * DQ; e += 256) {   // dK: lanes along d
+    const int j = e / DQ, d = e - j * DQ;
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a = fmaf(Pcg[(long)n * N + m], Gs[n * DV + o], a);
-    dv[((long)c * N + m) * ldv + (long)g * DV + o] = a;
+    for (int n = 0; n < N; ++n) a = fmaf(Dc[n * RA_RB + j], Qs[n * DQ + d], a);
+    dk[((long)c * N + m0 + j) * ldq + (long)g * DQ + d] = a * scale;
+  }
+  for (int e = tid; e < nc * DV; e += 256) {
+    const int j = e / DV, o = e - j * DV;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a = fmaf(Pc[n * RA_RB + j], Gs[n * DV + o], a);
+    dv[((long)c * N + m0 + j) * ldv + (long)g * DV + o] = a;
   }
 }
 
@@ -182,6 +240,27 @@ __global__ __launch_bounds__(256) void relation_attention_bwd_kernel(const float
 // One workgroup per instance i: the row of E for every channel lives in LDS ([C][nj] with nj = the group's size), x[i] in
 // LDS; the group's x[j] stream through L2 twice (energies, then the mix).  Saved for the backward: A (dense n x n, zero
 // outside the group) and the per-channel arg-max J[c][i].
+// the contiguous run of instances with instance i's group id: every thread looks at a strided share of the ids (one round of
+// loads; a scan outwards from i would be a chain of up to n dependent global loads), [lo, hi) by LDS atomics.  Ends with a
+// barrier.
+__device__ __forceinline__ void group_bounds(const int64_t* __restrict__ grp, int n, int i, int* s_lo, int* s_hi) {
+  if (threadIdx.x == 0) {
+    *s_lo = i;
+    *s_hi = i + 1;
+  }
+  __syncthreads();
+  const int64_t gi = grp[i];
+  int lo = i, hi = i + 1;
+  for (int j = threadIdx.x; j < n; j += 256)
+    if (grp[j] == gi) {
+      lo = min(lo, j);
+      hi = max(hi, j + 1);
+    }
+  if (lo < i) atomicMin(s_lo, lo);
+  if (hi > i + 1) atomicMax(s_hi, hi);
+  __syncthreads();
+}
+
 constexpr int CI_MAXG = 512;     // instances of one (image, class) group
 constexpr int CI_MAXC = 16;
 
@@ -191,14 +270,7 @@ __global__ __launch_bounds__(256) void ciam_fwd_kernel(const float* __restrict__
   extern __shared__ float lds[];
   const int i = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   __shared__ int s_lo, s_hi;
-  if (tid == 0) {
-    const int64_t gi = grp[i];
-    int lo = i, hi = i + 1;
-    while (lo > 0 && grp[lo - 1] == gi) --lo;
-    while (hi < n && grp[hi] == gi) ++hi;
-    s_lo = lo;
-    s_hi = hi;
-  }
+  group_bounds(grp, n, i, &s_lo, &s_hi);
   float* xi = lds;                      // [C][HW]
   const int CH = C * HW;
   for (int e = tid; e < CH; e += 256) xi[e] = x[(long)i * CH + e];
@@ -206,14 +278,25 @@ __global__ __launch_bounds__(256) void ciam_fwd_kernel(const float* __restrict__
   const int lo = s_lo, nj = s_hi - s_lo;
   float* E = xi + CH;                   // [C][nj]
   float* Mr = E + C * nj;               // [nj]
-  // energies: a wave per (c, j) pair, lanes along the pixels
-  for (int t = wave; t < C * nj; t += 4) {
+  // energies: one thread per (c, j) pair walks the HW pixels (consecutive lanes = consecutive j of one channel: x[i, c, h] is an
+  // LDS broadcast, every lane streams its own 4 HW-byte run of x[j, c, :]; no cross-lane reduction per pair)
+  for (int t = tid; t < C * nj; t += 256) {
     const int c = t / nj, j = t - c * nj;
     const float* xj = x + (long)(lo + j) * CH + (long)c * HW;
-    float a = 0.f;
-    for (int h = lane; h < HW; h += 64) a = fmaf(xi[c * HW + h], xj[h], a);
-    a = wave_sum(a);
-    if (lane == 0) E[c * nj + j] = a;
+    const float* xc = xi + c * HW;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int h = 0;
+    if ((HW & 3) == 0) {
+      for (; h < HW; h += 4) {
+        const float4 u = *(const float4*)(xj + h);
+        a0 = fmaf(xc[h], u.x, a0);
+        a1 = fmaf(xc[h + 1], u.y, a1);
+        a2 = fmaf(xc[h + 2], u.z, a2);
+        a3 = fmaf(xc[h + 3], u.w, a3);
+      }
+    }
+    for (; h < HW; ++h) a0 = fmaf(xc[h], xj[h], a0);
+    E[c * nj + j] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
   // per channel: max over j and its FIRST index (what torch.max's gradient follows on the device is one index; see the backward)
@@ -291,14 +374,7 @@ __global__ __launch_bounds__(256) void ciam_bwd_rows_kernel(const float* __restr
   const int i = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   __shared__ int s_lo, s_hi;
   __shared__ float s_red[4];
-  if (tid == 0) {
-    const int64_t gi = grp[i];
-    int lo = i, hi = i + 1;
-    while (lo > 0 && grp[lo - 1] == gi) --lo;
-    while (hi < n && grp[hi] == gi) ++hi;
-    s_lo = lo;
-    s_hi = hi;
-  }
+  group_bounds(grp, n, i, &s_lo, &s_hi);
   const int CH = C * HW;
   float* gi_ = lds;                      // [CH] dOut[i]
   for (int e = tid; e < CH; e += 256) gi_[e] = dout[(long)i * CH + e];
@@ -345,14 +421,7 @@ __global__ __launch_bounds__(256) void ciam_bwd_dx_kernel(const float* __restric
   extern __shared__ float lds[];
   const int i = blockIdx.x, tid = threadIdx.x;
   __shared__ int s_lo, s_hi;
-  if (tid == 0) {
-    const int64_t gi = grp[i];
-    int lo = i, hi = i + 1;
-    while (lo > 0 && grp[lo - 1] == gi) --lo;
-    while (hi < n && grp[hi] == gi) ++hi;
-    s_lo = lo;
-    s_hi = hi;
-  }
+  group_bounds(grp, n, i, &s_lo, &s_hi);
   __syncthreads();
   const int lo = s_lo, nj = s_hi - s_lo;
   const int CH = C * HW;
@@ -382,29 +451,44 @@ __global__ __launch_bounds__(256) void ciam_bwd_dx_kernel(const float* __restric
 
 }  // namespace
 
+static int ra_set_lds(const void* kern, size_t lds) {
+  if (lds > 160 * 1024) return MMT_EINVAL;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
 extern "C" int mmt_relation_attention_fwd(const float* q, const float* k, const float* wg, const float* v, const float* bias, int C,
                                           int N, int G, int DQ, int DV, int topk, float scale, float* P, float* out, void* stream) {
   if (!q || !k || !wg || !v || !bias || !P || !out || C < 1 || N < 1 || N > RA_MAXN || G < 1 || DQ < 1 || DQ > 128 || DV < 1 ||
       DV > RA_MAXDV || topk < 1)
     return MMT_EINVAL;
-  const size_t lds = sizeof(float) * ((size_t)N * (DQ + 1) + (size_t)N * DV + 4 * DQ + 4 * 128);
-  if (lds > 64 * 1024) return MMT_EINVAL;
-  hipLaunchKernelGGL(relation_attention_fwd_kernel, dim3(G, C), dim3(256), lds, (hipStream_t)stream, q, k, wg, v, bias, C, N, G, DQ,
-                     DV, topk < N ? topk : N, scale, P, out);
+  const size_t lds = sizeof(float) * ((size_t)N * (DQ + 1) + (size_t)N * DV + RA_RB * DQ + RA_RB * (size_t)N + 4 * 128);
+  if (int e = ra_set_lds((const void*)relation_attention_fwd_kernel, lds)) return e;
+  hipLaunchKernelGGL(relation_attention_fwd_kernel, dim3(G, C, (N + RA_RB - 1) / RA_RB), dim3(256), lds, (hipStream_t)stream, q, k, wg,
+                     v, bias, C, N, G, DQ, DV, topk < N ? topk : N, scale, P, out);
   MMT_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int mmt_relation_attention_bwd(const float* q, const float* k, const float* wg, const float* v, const float* P,
-                                          const float* dout, int C, int N, int G, int DQ, int DV, float scale, float* dq, float* dk,
-                                          float* dwg, float* dv, void* stream) {
-  if (!q || !k || !wg || !v || !P || !dout || !dq || !dk || !dwg || !dv || C < 1 || N < 1 || N > RA_MAXN || G < 1 || DQ < 1 ||
+                                          const float* dout, int C, int N, int G, int DQ, int DV, float scale, float* dS, float* dq,
+                                          float* dk, float* dwg, float* dv, void* stream) {
+  if (!q || !k || !wg || !v || !P || !dout || !dS || !dq || !dk || !dwg || !dv || C < 1 || N < 1 || N > RA_MAXN || G < 1 || DQ < 1 ||
       DQ > 128 || DV < 1 || DV > RA_MAXDV)
     return MMT_EINVAL;
-  const size_t lds = sizeof(float) * ((size_t)N * (N + 1) + 2 * (size_t)N * DV);
-  if (lds > 64 * 1024) return MMT_EINVAL;
-  hipLaunchKernelGGL(relation_attention_bwd_kernel, dim3(G, C), dim3(256), lds, (hipStream_t)stream, q, k, wg, v, P, dout, C, N, G, DQ,
-                     DV, scale, dq, dk, dwg, dv);
+  const dim3 grid(G, C, (N + RA_RB - 1) / RA_RB);
+  const size_t lds1 = sizeof(float) * ((size_t)N * (DQ + 1) + (size_t)N * DV + RA_RB * DV + 2 * RA_RB * (size_t)N);
+  const size_t lds2 = sizeof(float) * ((size_t)N * DQ + (size_t)N * DV + 2 * RA_RB * (size_t)N);
+  if (int e = ra_set_lds((const void*)relation_attention_bwd_rows_kernel, lds1)) return e;
+  if (int e = ra_set_lds((const void*)relation_attention_bwd_cols_kernel, lds2)) return e;
+  hipLaunchKernelGGL(relation_attention_bwd_rows_kernel, grid, dim3(256), lds1, (hipStream_t)stream, k, wg, v, P, dout, C, N, G, DQ, DV,
+                     scale, dS, dq, dwg);
+  MMT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(relation_attention_bwd_cols_kernel, grid, dim3(256), lds2, (hipStream_t)stream, q, P, dS, dout, C, N, G, DQ, DV,
+                     scale, dk, dv);
   MMT_LAUNCH_CHECK();
   return 0;
 }

@@ -116,7 +116,7 @@ _SIGS = {
     "mmt_relation_attention_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p, c_void_p, c_void_p],
     "mmt_relation_attention_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_ciam_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_ciam_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_void_p, c_void_p, c_void_p],
@@ -743,13 +743,12 @@ def position_embedding(boxes, dim_g, freq):
     return out
 
 
-RELATION_ATTENTION_MAX_N = 120   # csrc/relation.hip: RA_MAXN
+RELATION_ATTENTION_MAX_N = 128   # csrc/relation.hip: RA_MAXN
 CIAM_MAX_N = 512                 # csrc/relation.hip: CI_MAXG (the whole batch is used as the bound of a group's size)
 
 
 def relation_attention_fits(N, G, DQ, DV):
-    return 1 <= N <= RELATION_ATTENTION_MAX_N and DQ <= 128 and DV <= 16 and 4 * (N * (N + 1) + 2 * N * DV) <= 65536 \
-        and 4 * (N * (DQ + 1) + N * DV + 4 * DQ + 512) <= 65536
+    return 1 <= N <= RELATION_ATTENTION_MAX_N and DQ <= 128 and DV <= 16
 
 
 def relation_attention_fwd(q, k, wg, v, bias, C, N, G, topk, scale):
@@ -766,8 +765,9 @@ def relation_attention_fwd(q, k, wg, v, bias, C, N, G, topk, scale):
 def relation_attention_bwd(q, k, wg, v, P, dout, C, N, G, scale):
     DQ, DV = q.shape[1] // G, v.shape[1] // G
     dq, dk, dwg, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(wg), torch.empty_like(v)
-    _check(lib().mmt_relation_attention_bwd(_p(q), _p(k), _p(wg), _p(v), _p(P), _p(dout), C, N, G, DQ, DV, float(scale), _p(dq), _p(dk),
-                                            _p(dwg), _p(dv), _stream()), "mmt_relation_attention_bwd")
+    dS = torch.empty_like(P)
+    _check(lib().mmt_relation_attention_bwd(_p(q), _p(k), _p(wg), _p(v), _p(P), _p(dout), C, N, G, DQ, DV, float(scale), _p(dS), _p(dq),
+                                            _p(dk), _p(dwg), _p(dv), _stream()), "mmt_relation_attention_bwd")
     return dq, dk, dwg, dv
 
 

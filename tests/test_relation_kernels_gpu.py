@@ -33,7 +33,7 @@ def _relation(N, C, topk, seed):
     return mod, f_a, pos
 
 
-@pytest.mark.parametrize("N,C,topk", [(90, 4, 40), (20, 2, 40), (100, 3, 40), (64, 1, 10), (1, 2, 40)])
+@pytest.mark.parametrize("N,C,topk", [(90, 4, 40), (20, 2, 40), (100, 3, 40), (64, 1, 10), (1, 2, 40), (128, 1, 40), (9, 2, 4)])
 def test_relation_attention_vs_oracle(N, C, topk):
     from oracle import irnet as oi
     mod, f_a, pos = _relation(N, C, topk, seed=N)
