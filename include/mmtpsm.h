@@ -173,7 +173,7 @@ int mmt_roi_format_levels(const float* const* boxes /*[host]*/, const int32_t* c
 /* IR-Net relation NMS: the IoU-regression labels of the n ranked boxes per foreground class of one image against its ground
  * truth (reference modeling/relation/relation_module.py:323-391, numpy on the host): boxes [n][fg][4], score [n][fg], gt [G][4],
  * gt_labels [G] (class c + 1 belongs to class column c), thresholds [T <= 4] (host) -> out [n][fg][T]; numpy's first-index
- * tie rules; n * G <= 8192, G <= 256. */
+ * tie rules; n <= 128, n * G <= 8192, G <= 256. */
 int mmt_relation_reg_labels(const float* boxes, const float* score, const float* gt, const int64_t* gt_labels, int n, int fg, int G,
                             const float* thresholds /*[host]*/, int T, float* out, void* stream);
 /* mmt_position_embedding: IR-Net's geometric position embedding of every ordered box pair of a class

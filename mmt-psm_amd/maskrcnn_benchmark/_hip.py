@@ -721,7 +721,7 @@ def relation_reg_labels(sorted_boxes, sorted_score, gt, gt_labels, thresholds):
     when the shapes are beyond the kernel's LDS matrix (the caller keeps its tensor formulation)"""
     n, fg = sorted_score.shape
     G, T = gt.shape[0], len(thresholds)
-    if T > 4 or G > 256 or n * max(G, 1) > 8192:
+    if T > 4 or G > 256 or n > 128 or n * max(G, 1) > 8192:   # (n <= 128: the per-box LDS arrays of the kernel)
         return None
     b = _dev(sorted_boxes, "boxes").float().contiguous()
     sc = sorted_score.float().contiguous()
