@@ -103,10 +103,17 @@ class BoxList(object):
 
     def clip_to_image(self, remove_empty=True):
         w, h = self.size
-        self.bbox[:, 0].clamp_(min=0, max=w - _TO_REMOVE)
-        self.bbox[:, 1].clamp_(min=0, max=h - _TO_REMOVE)
-        self.bbox[:, 2].clamp_(min=0, max=w - _TO_REMOVE)
-        self.bbox[:, 3].clamp_(min=0, max=h - _TO_REMOVE)
+        if self.bbox.is_cuda and self.bbox.dtype == torch.float32 and self.bbox.dim() == 2:
+            # one launch instead of four column clamps: the same comparisons against per-column bounds
+            from maskrcnn_benchmark.utils.miscellaneous import dev_const
+            lo = dev_const([0.0, 0.0, 0.0, 0.0], torch.float32, self.bbox.device)
+            hi = dev_const([w - _TO_REMOVE, h - _TO_REMOVE, w - _TO_REMOVE, h - _TO_REMOVE], torch.float32, self.bbox.device)
+            torch.clamp(self.bbox, min=lo, max=hi, out=self.bbox)
+        else:
+            self.bbox[:, 0].clamp_(min=0, max=w - _TO_REMOVE)
+            self.bbox[:, 1].clamp_(min=0, max=h - _TO_REMOVE)
+            self.bbox[:, 2].clamp_(min=0, max=w - _TO_REMOVE)
+            self.bbox[:, 3].clamp_(min=0, max=h - _TO_REMOVE)
         if remove_empty:
             b = self.bbox
             return self[(b[:, 3] > b[:, 1]) & (b[:, 2] > b[:, 0])]
