@@ -156,6 +156,14 @@ int mmt_rpn_post_select(const mmt_rpn_post_args* a /*[host]*/, void* stream);
  *   the smallest keys (equal keys: lower index first); counts [n_images][2].  One block per image. */
 int mmt_sample_fg_bg(const void* labels, int labels_are_float, const float* keys, const int32_t* off, int n_images,
                      int batch_size_per_image, int max_pos, uint8_t* pos_mask, uint8_t* neg_mask, int32_t* counts, void* stream);
+/* mmt_sample_fg_bg_wide: the same sampler, same results bit for bit, for long label vectors (the RPN's 262 k anchors per image):
+ * the streaming passes run SW_CHUNK = 16384 labels per block instead of one block per image (count, collect the members below
+ * tau of both classes into global lists, exact select per image, masks: four launches).  max_n >= every off[i+1] - off[i];
+ * workspace: mmt_sample_fg_bg_workspace_bytes(n_images) bytes, 8-byte aligned; n_images <= 64. */
+long mmt_sample_fg_bg_workspace_bytes(int n_images);
+int mmt_sample_fg_bg_wide(const void* labels, int labels_are_float, const float* keys, const int32_t* off, int n_images, int max_n,
+                          int batch_size_per_image, int max_pos, uint8_t* pos_mask, uint8_t* neg_mask, int32_t* counts,
+                          void* workspace, void* stream);
 
 /* BoxCoder.decode (modeling/box_coder.py:52-95) of codes [R, ncls*4] against boxes [R,4] with weights (wx,wy,ww,wh) and the
  * dw/dh clip, optionally followed by clip_to_image (structures/bounding_box.py:229-238): row r belongs to image i with

@@ -543,6 +543,169 @@ __global__ __launch_bounds__(NT) void sample_kernel(const LT* __restrict__ label
   if (tid == 0) { counts[2 * img] = num_pos; counts[2 * img + 1] = num_neg; }
 }
 
+// The same sampler for LONG label vectors (the RPN's 262 k anchors per image): the single-block kernel above walks the vector
+// four times with one block per image -- 4 x 64 rounds of memory latency, 0.15 - 0.46 ms per call on the main stream's chain.
+// Here the three streaming passes are many blocks wide (SW_CHUNK labels per block) and only the exact select on the short list
+// stays a one-block-per-image step: count -> collect both classes' members below their tau into global lists -> thresholds
+// (same `block_select`, same fall-backs: a list that overflowed or came up short selects over the whole vector) -> masks.
+// The order in which the lists fill is arbitrary, the keys are unique: the result is the single-block kernel's, bit for bit.
+constexpr int SW_CAP = 4096;
+constexpr int SW_CHUNK = 16384;
+struct SampleWs {                 // per image
+  int npos, nneg, nl[2];
+  unsigned long long thr[2];
+  unsigned long long list[2][SW_CAP];
+};
+
+template <typename LT>
+__global__ __launch_bounds__(NT) void sample_count_kernel(const LT* __restrict__ labels, const int* __restrict__ off,
+                                                          SampleWs* __restrict__ ws) {
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const int o0 = off[img], n = off[img + 1] - o0;
+  const int c0 = blockIdx.x * SW_CHUNK, c1 = min(n, c0 + SW_CHUNK);
+  if (c0 >= n) return;
+  const LT* lab = labels + o0;
+  int cp = 0, cn = 0;
+  for (int i = c0 + tid; i < c1; i += 4 * NT) {
+    LT l[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) l[u] = i + u * NT < c1 ? lab[i + u * NT] : (LT)-1;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { cp += l[u] >= (LT)1; cn += l[u] == (LT)0; }
+  }
+  __shared__ int sp, sn;
+  if (tid == 0) { sp = 0; sn = 0; }
+  __syncthreads();
+  if (cp) atomicAdd(&sp, cp);
+  if (cn) atomicAdd(&sn, cn);
+  __syncthreads();
+  if (tid == 0) {
+    if (sp) atomicAdd(&ws[img].npos, sp);
+    if (sn) atomicAdd(&ws[img].nneg, sn);
+  }
+}
+
+template <typename LT>
+__global__ __launch_bounds__(NT) void sample_collect_kernel(const LT* __restrict__ labels, const float* __restrict__ keys,
+                                                            const int* __restrict__ off, const int batch, const int max_pos,
+                                                            SampleWs* __restrict__ ws) {
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const int o0 = off[img], n = off[img + 1] - o0;
+  const int c0 = blockIdx.x * SW_CHUNK, c1 = min(n, c0 + SW_CHUNK);
+  if (c0 >= n) return;
+  const LT* lab = labels + o0;
+  const float* ky = keys + o0;
+  SampleWs& w = ws[img];
+  const int npos = w.npos, nneg = w.nneg;
+  const int num_pos = min(npos, max_pos), num_neg = min(nneg, batch - num_pos);
+  // a class needs a list only when it is actually cut (threshold(): 0 < num < members)
+  const bool need_p = num_pos > 0 && npos > num_pos, need_n = num_neg > 0 && nneg > num_neg;
+  if (!need_p && !need_n) return;
+  const float tau_p = need_p ? fminf(1.0f, 8.0f * (float)num_pos / (float)npos) : -1.f;
+  const float tau_n = need_n ? fminf(1.0f, 8.0f * (float)num_neg / (float)nneg) : -1.f;
+  for (int i = c0 + tid; i < c1; i += 4 * NT) {
+    LT l[4];
+    float kf[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool in = i + u * NT < c1;
+      l[u] = in ? lab[i + u * NT] : (LT)-1;
+      kf[u] = in ? ky[i + u * NT] : 2.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool isp = l[u] >= (LT)1, isn = l[u] == (LT)0;
+      if ((isp && kf[u] < tau_p) || (isn && kf[u] < tau_n)) {
+        const int cls = isp ? 0 : 1;
+        const int p = atomicAdd(&w.nl[cls], 1);
+        if (p < SW_CAP) w.list[cls][p] = ((unsigned long long)(~f2ord(kf[u])) << 32) | (unsigned)(0xffffffffu - (unsigned)(i + u * NT));
+      }
+    }
+  }
+}
+
+template <typename LT>
+__global__ __launch_bounds__(NT) void sample_threshold_kernel(const LT* __restrict__ labels, const float* __restrict__ keys,
+                                                              const int* __restrict__ off, const int batch, const int max_pos,
+                                                              SampleWs* __restrict__ ws, int* __restrict__ counts) {
+  __shared__ SelShared sh;
+  __shared__ unsigned long long list[SW_CAP];
+  __shared__ unsigned long long lmin_s;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int o0 = off[img], n = off[img + 1] - o0;
+  const LT* lab = labels + o0;
+  const float* ky = keys + o0;
+  SampleWs& w = ws[img];
+  const int npos = w.npos, nneg = w.nneg;
+  const int num_pos = min(npos, max_pos), num_neg = min(nneg, batch - num_pos);
+  auto k64 = [&](int i) -> unsigned long long {
+    return ((unsigned long long)(~f2ord(ky[i])) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+  };
+  auto threshold = [&](const int cls, const int members, const int num) -> unsigned long long {
+    if (num <= 0) return ~0ull;          // nothing
+    if (members <= num) return 1ull;     // everything
+    const int nl = w.nl[cls];
+    __syncthreads();
+    if (nl >= num && nl <= SW_CAP)
+      for (int j = tid; j < nl; j += NT) list[j] = w.list[cls][j];
+    __syncthreads();
+    if (nl > num && nl <= SW_CAP) {
+      auto lk = [&](int j) -> unsigned long long { return list[j]; };
+      return block_select(lk, nl, num, sh);
+    }
+    if (nl == num && nl <= SW_CAP) {     // exactly `num` members below tau: they are the sample
+      if (tid == 0) lmin_s = ~0ull;
+      __syncthreads();
+      unsigned long long m = ~0ull;
+      for (int j = tid; j < nl; j += NT) m = list[j] < m ? list[j] : m;
+      if (m != ~0ull) atomicMin(&lmin_s, m);
+      __syncthreads();
+      return lmin_s;
+    }
+    auto gk = [&](int i) -> unsigned long long { return (cls == 0 ? lab[i] >= (LT)1 : lab[i] == (LT)0) ? k64(i) : 0ull; };
+    return block_select(gk, n, num, sh);
+  };
+  const unsigned long long Tp = threshold(0, npos, num_pos);
+  const unsigned long long Tn = threshold(1, nneg, num_neg);
+  if (tid == 0) {
+    w.thr[0] = Tp;
+    w.thr[1] = Tn;
+    counts[2 * img] = num_pos;
+    counts[2 * img + 1] = num_neg;
+  }
+}
+
+template <typename LT>
+__global__ __launch_bounds__(NT) void sample_mask_kernel(const LT* __restrict__ labels, const float* __restrict__ keys,
+                                                         const int* __restrict__ off, const SampleWs* __restrict__ ws,
+                                                         unsigned char* __restrict__ pos_mask, unsigned char* __restrict__ neg_mask) {
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const int o0 = off[img], n = off[img + 1] - o0;
+  const int c0 = blockIdx.x * SW_CHUNK, c1 = min(n, c0 + SW_CHUNK);
+  if (c0 >= n) return;
+  const LT* lab = labels + o0;
+  const float* ky = keys + o0;
+  const unsigned long long Tp = ws[img].thr[0], Tn = ws[img].thr[1];
+  for (int i = c0 + tid; i < c1; i += 4 * NT) {
+    LT l[4];
+    float kf[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool in = i + u * NT < c1;
+      l[u] = in ? lab[i + u * NT] : (LT)-1;
+      kf[u] = in ? ky[i + u * NT] : 2.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = i + u * NT;
+      if (j >= c1) break;
+      const unsigned long long k = ((unsigned long long)(~f2ord(kf[u])) << 32) | (unsigned)(0xffffffffu - (unsigned)j);
+      pos_mask[o0 + j] = (l[u] >= (LT)1 && k >= Tp) ? 1 : 0;
+      neg_mask[o0 + j] = (l[u] == (LT)0 && k >= Tn) ? 1 : 0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ detections
 // PostProcessor.filter_results (box_head/inference.py:91-160) for a batch without a host round trip in the middle: per
 // (image, foreground class) the candidates with score > thresh in stable descending score order (det_sort_kernel: one
@@ -711,6 +874,39 @@ extern "C" int mmt_sample_fg_bg(const void* labels, int labels_are_float, const 
                        batch_size_per_image, max_pos, pos_mask, neg_mask, counts);
   MMT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" long mmt_sample_fg_bg_workspace_bytes(int n_images) { return n_images < 1 ? -1 : (long)n_images * (long)sizeof(SampleWs); }
+
+template <typename LT>
+static int sample_wide(const LT* labels, const float* keys, const int32_t* off, int n_images, int max_n, int batch, int max_pos,
+                       uint8_t* pos_mask, uint8_t* neg_mask, int32_t* counts, SampleWs* ws, hipStream_t s) {
+  // only the counters need zeroing (the head of every per-image record); the lists are read up to their counters
+  for (int i = 0; i < n_images; i++)
+    if (hipMemsetAsync(&ws[i], 0, 4 * sizeof(int), s) != hipSuccess) return MMT_EINVAL;
+  const dim3 wide(mmt_cdiv(max_n, SW_CHUNK), n_images);
+  hipLaunchKernelGGL(sample_count_kernel<LT>, wide, dim3(NT), 0, s, labels, off, ws);
+  MMT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sample_collect_kernel<LT>, wide, dim3(NT), 0, s, labels, keys, off, batch, max_pos, ws);
+  MMT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sample_threshold_kernel<LT>, dim3(n_images), dim3(NT), 0, s, labels, keys, off, batch, max_pos, ws, counts);
+  MMT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sample_mask_kernel<LT>, wide, dim3(NT), 0, s, labels, keys, off, (const SampleWs*)ws, pos_mask, neg_mask);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_sample_fg_bg_wide(const void* labels, int labels_are_float, const float* keys, const int32_t* off, int n_images,
+                                     int max_n, int batch_size_per_image, int max_pos, uint8_t* pos_mask, uint8_t* neg_mask,
+                                     int32_t* counts, void* workspace, void* stream) {
+  if (!labels || !keys || !off || !pos_mask || !neg_mask || !counts || !workspace || ((size_t)workspace & 7) || n_images < 1 ||
+      n_images > 64 || max_n < 1)
+    return MMT_EINVAL;
+  if (labels_are_float)
+    return sample_wide((const float*)labels, keys, off, n_images, max_n, batch_size_per_image, max_pos, pos_mask, neg_mask, counts,
+                       (SampleWs*)workspace, (hipStream_t)stream);
+  return sample_wide((const long*)labels, keys, off, n_images, max_n, batch_size_per_image, max_pos, pos_mask, neg_mask, counts,
+                     (SampleWs*)workspace, (hipStream_t)stream);
 }
 
 extern "C" long mmt_rpn_topk_workspace_bytes(int N, int L, long anchors_per_image) {

@@ -85,8 +85,18 @@ def test_rpn_gather_decode_and_post_select(hip):
             assert sum(x.numel() for x in ref) == min(fpn, sum(x.numel() for x in ref))
 
 
+@pytest.fixture(params=[True, False], ids=["wide", "one-block"])
+def sampler_form(request, hip):
+    """both forms of the sampler on every case: the many-blocks-wide one (mmt_sample_fg_bg_wide, the RPN's long vectors) and
+    the one-block-per-image kernel (mmt_sample_fg_bg) -- the same masks bit for bit"""
+    old = (hip.SAMPLE_WIDE, hip.SAMPLE_WIDE_MIN)
+    hip.SAMPLE_WIDE, hip.SAMPLE_WIDE_MIN = request.param, 1
+    yield request.param
+    hip.SAMPLE_WIDE, hip.SAMPLE_WIDE_MIN = old
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.int64])
-def test_sample_fg_bg_kernel(hip, dtype):
+def test_sample_fg_bg_kernel(hip, dtype, sampler_form):
     g = torch.Generator().manual_seed(11)
     lens = [261888, 261888, 2012, 37, 1500]
     labs, keys = [], []
@@ -111,7 +121,7 @@ def test_sample_fg_bg_kernel(hip, dtype):
     assert cnt[3].tolist() == [0, 37] and cnt[4].tolist() == [128, 128]
 
 
-def test_sample_fg_bg_any_key_distribution(hip):
+def test_sample_fg_bg_any_key_distribution(hip, sampler_form):
     """keys that are NOT uniform (most below the kernel's pre-filter, or none): the exact select over the whole vector
     takes over -- same result as the tensor formulation"""
     g = torch.Generator().manual_seed(12)
