@@ -456,9 +456,13 @@ def main():
                 out["roofline"]["other_large_tile_kernel"]["six_product_frac"] = round(
                     fo / (mo * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6), 4)
         out["roofline"]["step_bound"] = (
-            "interpreter time of the two launch-issuing threads (main / autograd and teacher, one GIL): kernel time removed from "
-            "any stream did not move the step in round 3, host work removed did (DESIGN.md section 5, profiles/r03_history.md); "
-            "the kernels' in-step durations are read while up to three streams share the GPU")
+            "no single resource: the main stream's device chain (the student's N = 2 / N = 4 launches queue behind the teacher's "
+            "chip-filling N = 8 kernels; ~40 ms of kernel time per step at ~1.1-1.2 x overlap) and the interpreter time of the two "
+            "launch-issuing threads (main / autograd and teacher, one GIL) end within ~2 ms of each other: ~1 ms removed from either "
+            "alone (140 library launches of the main thread; the RPN sampler's place in the student's chain) did not move the step "
+            "at the +-0.4 ms resolution of same-box A/B runs, host work removed from the TEACHER's chain earlier in the round did "
+            "(DESIGN.md sections 5 and 7, profiles/r03_history.md); the kernels' in-step durations are read while up to three "
+            "streams share the GPU")
         # the launches of that kernel with an un-split K (the large FPN / layer1-2 shapes); the others are the few-tile,
         # long-K layers, whose bracketed duration also contains their small finish launch
         uns = [q for q in prof if len(q) < 5 or q[4] <= 1]
