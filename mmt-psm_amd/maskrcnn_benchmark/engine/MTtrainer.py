@@ -19,6 +19,9 @@ from maskrcnn_benchmark.layers import fused
 from maskrcnn_benchmark.utils.miscellaneous import sigmoid_rampdown, sigmoid_rampup
 
 
+_WGRAD_DEFER = os.environ.get("MMT_WGRAD_DEFER", "1") != "0"   # supervised weight gradients in one batch after the supervised backward (0: interleaved, the A/B alternative)
+
+
 def get_world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -350,7 +353,16 @@ class MTtrainer(object):
             loss_dict = self.forward_source(data_s, target_s, feats_s)
             if early:
                 losses_dict = self.weight_sum_loss(loss_dict, iteration)
-                sum(v for v in losses_dict.values()).backward()
+                defer = _WGRAD_DEFER and use_mt and job is not None
+                if defer:
+                    from maskrcnn_benchmark.layers import fused as _fused
+                    _fused.defer_wgrads(True)
+                try:
+                    sum(v for v in losses_dict.values()).backward()
+                finally:
+                    if defer:
+                        _fused.defer_wgrads(False)
+                        _fused.flush_deferred_wgrads()   # one batch, behind the supervised backward, beside the consistency branch
                 unl = self.weight_sum_loss(self.forward_unlabel(data_u_list, feats_u, job), iteration)
                 job = None
                 if unl:

@@ -83,6 +83,30 @@ def flush_wgrads(ent, dev):
     jobs.clear()
 
 
+# Deferral (MMT_WGRAD_DEFER=1, engine/MTtrainer.py): while it is on, jobs are collected but not handed over, and the end-of-backward
+# join does nothing -- the supervised pass's weight gradients then go to the side stream in one batch when the trainer says so
+# (before it waits for the teacher), behind the whole supervised backward, and run beside the consistency branch, where the GPU
+# has room, instead of beside the teacher's backbone, where it has none.
+_WG_DEFER = [False]
+
+
+def defer_wgrads(on):
+    _WG_DEFER[0] = bool(on)
+
+
+def flush_deferred_wgrads():
+    for dev, ent in _WG.items():
+        flush_wgrads(ent, dev)
+
+
+def _join_wgrads_cb():
+    if _WG_DEFER[0]:
+        for ent in _WG.values():
+            ent[2] = False          # the next backward pass queues its own callback
+        return
+    join_wgrads()
+
+
 def join_wgrads(device=None):
     """the current stream waits for every weight gradient issued on the side stream so far (queued as an end-of-backward
     callback by the first side-stream job of a pass, so `.backward()` returns with the gradients ordered on its stream)"""
@@ -110,9 +134,9 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
         H.wgrad_prepare(x, g)            # reduction passes for operands nobody recorded a maximum of: on THIS stream
         if not ent[2]:
             ent[2] = True
-            torch.autograd.Variable._execution_engine.queue_callback(join_wgrads)
+            torch.autograd.Variable._execution_engine.queue_callback(_join_wgrads_cb)
         ent[3].append((x, g, tuple(w.shape), stride, pad, dw, rowscale, db))
-        if len(ent[3]) >= _WG_BATCH:
+        if len(ent[3]) >= _WG_BATCH and not _WG_DEFER[0]:
             flush_wgrads(ent, x.device)
     else:
         H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
