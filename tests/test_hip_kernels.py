@@ -682,8 +682,9 @@ def test_rpn_loss_kernel_vs_tensor_formulation(R, frac):
     wb = (sl1 * pos.float()[:, None]).sum() / n
     wo = (torch.nn.functional.binary_cross_entropy_with_logits(o2, labels.clamp(min=0), reduction="none") * samp.float()).sum() / n
     (2.0 * wo + 3.0 * wb).backward()
-    assert lo.item() == pytest.approx(wo.item(), rel=2e-6, abs=1e-9)
-    assert lb.item() == pytest.approx(wb.item(), rel=2e-6, abs=1e-9)
+    # (block partials meet in fp32 atomics: the order changes from run to run)
+    assert lo.item() == pytest.approx(wo.item(), rel=1e-5, abs=1e-9)
+    assert lb.item() == pytest.approx(wb.item(), rel=1e-5, abs=1e-9)
     assert torch.allclose(obj.grad, o2.grad, rtol=1e-5, atol=1e-9)
     assert torch.allclose(reg.grad, r2.grad, rtol=1e-5, atol=1e-9)
 
@@ -707,8 +708,8 @@ def test_box_loss_kernel_vs_tensor_formulation(R, NC):
     d = torch.abs(torch.gather(b2, 1, idx) - regt)
     wb = (torch.where(d < 1.0, 0.5 * d * d, d - 0.5) * (labels > 0).float()[:, None]).sum() / R
     (2.0 * wc + 3.0 * wb).backward()
-    assert lc.item() == pytest.approx(wc.item(), rel=2e-6)
-    assert lb.item() == pytest.approx(wb.item(), rel=2e-6, abs=1e-9)
+    assert lc.item() == pytest.approx(wc.item(), rel=1e-5)
+    assert lb.item() == pytest.approx(wb.item(), rel=1e-5, abs=1e-9)
     assert torch.allclose(logits.grad, l2.grad, rtol=1e-5, atol=1e-9)
     assert torch.allclose(breg.grad, b2.grad, rtol=1e-5, atol=1e-9)
 
