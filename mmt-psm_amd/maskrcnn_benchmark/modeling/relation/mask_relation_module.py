@@ -60,7 +60,8 @@ class CIAM_Module(nn.Module):
         with the cross-group entries masked out (exp(-inf) = 0 exactly: the same softmax over the same values), so that no
         group size ever has to reach the host."""
         n, C, Hh, Ww = x.size()
-        if x.is_cuda and group is not None and not getattr(self, "tensor_path", _TENSOR_PATH) and 0 < n <= _H.CIAM_MAX_N and C <= 16:
+        if (x.is_cuda and group is not None and not getattr(self, "tensor_path", _TENSOR_PATH) and 0 < n <= _H.CIAM_MAX_N and C <= 16
+                and 4 * (C * Hh * Ww + (C + 1) * n) <= 65536):   # (the kernel's LDS: the instance's feature + its energy rows)
             # one forward launch, two backward launches for all groups of the batch (csrc/relation.hip); `group` is sorted by
             # the caller (forward_batch orders the instances by (image, class)): equal ids are contiguous
             return fused.CIAMFn.apply(x, group, self.gamma)
