@@ -3,7 +3,6 @@
 mask_relation_module.py:199-242, pinned to the reference by tests/golden/model160_irnet.npz), forward and every gradient, and
 against the product's own tensor formulation (the library-GEMM path that the kernels replace, kept for CPU tensors).
 Tolerances: fp32 sums in another order -- 2e-5 of the tensor's largest magnitude forward, 2e-4 for gradients."""
-import math
 import types
 
 import pytest
