@@ -56,6 +56,7 @@ def _touch(*slots):
 # of three record_stream calls per job.
 import os as _os
 _WG_ON = _os.environ.get("MMT_WGRAD_STREAM", "1") != "0"
+_WG_BF16 = _os.environ.get("MMT_WGRAD_BF16", "1") != "0"   # bf16 configuration: the DEFERRED (supervised-pass) jobs go to the side stream (0: inline)
 _WG_BATCH = int(_os.environ.get("MMT_WGRAD_BATCH", "8"))   # measured 1 / 4 / 8 / 16: 36.8 / 36.6 / 36.4 / 36.4 ms per step
 _WG = {}   # device -> [side stream, launches since the last join, end-of-backward callback queued, pending jobs, kept-alive tensors]
 
@@ -129,7 +130,8 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
     if with_bias:
         db = dst_b if dst_b is not None else torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
     if (_WG_ON and dst_w is not None and (dst_b is not None or not with_bias) and not (H.PROFILE is not None and H.PROFILE_ALL)
-            and H.get_conv_precision() == 3):   # (the bf16 configuration is bound by its host threads: 28.5 vs 33.6 ms with it)
+            and (H.get_conv_precision() == 3 or (_WG_BF16 and _WG_DEFER[0]))):   # (the bf16 configuration is bound by its host threads:
+            # 28.5 vs 33.6 ms with the side stream for every job; MMT_WGRAD_BF16=1: only the DEFERRED jobs, handed over while the main thread waits for the teacher)
         ent = _wg_stream(x.device)
         H.wgrad_prepare(x, g)            # reduction passes for operands nobody recorded a maximum of: on THIS stream
         if not ent[2]:
