@@ -8,10 +8,11 @@ ground truth (REG_IOU); at inference those scores replace greedy NMS.  Same para
 Shipped configuration only (configs/pap/e2e_mask_rcnn_R_50_FPN_1x.yaml + scripts/train_mt.sh): REG_IOU True,
 USE_IOU False, CLASS_AGNOSTIC False, CLS_WISE_RELATION False, MERGE_METHOD 0.
 
-Execution: the Linear layers run on the fp32 MFMA GEMM (layers.Linear); the attention itself is <= 90 boxes
-(batched 90x64x90 products, top-40 softmax, a 16-group 1x1 conv = 16 tiny GEMMs) and is expressed with batched
-library GEMMs (torch.bmm) plus device elementwise ops; the numpy label preparation of the reference
-(relation_module.py:323-391, a D2H copy + host loops per class) is tensor arithmetic on the device here.
+Execution: the Linear layers run on the MFMA GEMM (layers.Linear); the attention itself (<= 128 boxes per class: scores,
+top-40 softmax, mix, with the 16-group 1x1 conv folded into the value projection) is one launch forward and two backward
+(csrc/relation.hip, layers/fused.py::RelationAttentionFn); its formulation with batched library GEMMs (torch.bmm) stays
+for CPU tensors and as the A/B alternative MMT_IRNET_TENSOR=1; the numpy label preparation of the reference
+(relation_module.py:323-391, a D2H copy + host loops per class) is one launch per image (mmt_relation_reg_labels).
 """
 import math
 
