@@ -48,7 +48,7 @@ N_LAB, N_UNLAB, N_INST = 2, 2, 12
 BENCH_BASE_LR = 1e-7
 
 
-def build(device, rank, irnet=False, crop=None, n_inst=None, base_lr=None):
+def build(device, rank, irnet=False, crop=None, n_inst=None, base_lr=None, n_lab=None, n_unlab=None):
     import synthetic
     from maskrcnn_benchmark.config import make_default_cfg
     from maskrcnn_benchmark.modeling.detector import build_detection_model
@@ -94,8 +94,10 @@ def build(device, rank, irnet=False, crop=None, n_inst=None, base_lr=None):
 
     crop = CROP if crop is None else crop      # tests build the same trainer on small crops
     n_inst = N_INST if n_inst is None else n_inst
-    imgs, tgs = synthetic.make_labeled(N_LAB, crop, n_inst, seed=1234 + rank)
-    unl = synthetic.make_unlabeled(N_UNLAB, crop, cfg.MT.AUG_K + cfg.MT.AUG_S, seed=4321 + rank)
+    n_lab = N_LAB if n_lab is None else n_lab           # tests: the cpu_baseline sample (1 + 1 crop) at full size
+    n_unlab = N_UNLAB if n_unlab is None else n_unlab
+    imgs, tgs = synthetic.make_labeled(n_lab, crop, n_inst, seed=1234 + rank)
+    unl = synthetic.make_unlabeled(n_unlab, crop, cfg.MT.AUG_K + cfg.MT.AUG_S, seed=4321 + rank)
     targets = []
     for t in tgs:
         b = BoxList(t["boxes"].to(device), t["size"], "xyxy")
@@ -259,6 +261,28 @@ def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, nsteps, dom="fw
     return r
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: re-execute this command line under torch.distributed.run with
+    N ranks on this node (127.0.0.1 rendezvous on a free port).  Fails -- non-zero, before anything is timed -- when the node
+    has fewer than N GPUs: a multi-GPU line must never be produced by fewer ranks than it names."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible on this node; one process per GPU, no "
+                         "oversubscription -- not running" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit("bench.py: the %d-rank run failed (torch.distributed.run exit code %d)" % (n, rc))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,11 +299,23 @@ def main():
                     "activation storage in the backbone + FPN (MMT_CONV_PRECISION=1 MMT_BF16_STORAGE=1); not the headline line")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` outside a launcher: start the N ranks here (one process per GPU, RCCL over xGMI) --
+        # the line this process would otherwise print is a one-rank number labelled with a flag nobody read
+        return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks -- refusing to print a line whose "
+                         "n_gpus does not match the request" % (args.gpus, world))
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no GPU of its own: %d device(s) visible, one process per GPU "
+                         "is the only supported layout" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("MMT_FORCE_DIST") == "1"  # the latter: exercise RCCL on a 1-GPU box
@@ -412,6 +448,8 @@ def main():
                                     round(sorted(per_step)[(len(per_step) * 9) // 10 - (1 if len(per_step) >= 10 else 0)], 3)],
             "imgs_per_sec_at_median": round(imgs_per_step / (med * 1e-3), 4),
             "higher_is_better": True, "scaling": "weak",
+            "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "backend": (dist.get_backend() + " (RCCL)") if use_dist else "none (single process, no process group)",
             "vs_baseline": None, "dtype": "bf16" if mode == 1 else "f32", "data": "synthetic",
             "config": {"workload": "MMT-PSM mean-teacher step (BASELINE configs[2]; configs[3] when n_gpus>1): per GPU 2 "
                                    "labeled + 2 unlabeled 1000x1000x3 crops, AUG_K=2 + flip, AUG_S=1, MT.LAMBDA 5, "

@@ -19,6 +19,7 @@ from maskrcnn_benchmark.layers import fused
 from maskrcnn_benchmark.utils.miscellaneous import sigmoid_rampdown, sigmoid_rampup
 
 
+_TEACHER_EARLY = os.environ.get("MMT_TEACHER_EARLY", "1") != "0"   # the teacher's stream starts behind the step's FIRST launch, not behind the student's forward
 _WGRAD_DEFER = os.environ.get("MMT_WGRAD_DEFER", "1") != "0"   # supervised weight gradients in one batch after the supervised backward (0: interleaved, the A/B alternative)
 
 
@@ -80,11 +81,23 @@ def sync_touched(flat):
     THIS rank's backward nodes.  A rank whose teacher found no boxes skipped the consistency branch and never touched the
     hint adaptors while the others did; updating them on some ranks only would let the students -- and with them the EMA
     teachers -- drift apart for good.  The update set is therefore the UNION over ranks: one MAX all-reduce of
-    a per-parameter flag vector (a few hundred bytes) and one read-back, only when there is somebody to differ from."""
+    a per-parameter flag vector (a few hundred bytes) and one read-back.  The trainer calls it only on steps whose set CAN
+    differ between ranks (the mean-teacher branch is active); the name list and the pinned staging buffer are built once
+    (no pageable copy, no per-step sort)."""
     if get_world_size() < 2:
         return
-    names = [n for n, (o, _) in sorted(flat.index.items(), key=lambda kv: kv[1][0]) if o < flat.n_trainable]
-    flags = torch.tensor([1 if n in flat.touched else 0 for n in names], dtype=torch.int32, device=flat.grad.device)
+    ent = flat.__dict__.get("_touch_sync")
+    if ent is None:
+        names = [n for n, (o, _) in sorted(flat.index.items(), key=lambda kv: kv[1][0]) if o < flat.n_trainable]
+        host = torch.zeros((len(names),), dtype=torch.int32)
+        if flat.grad.is_cuda:
+            host = host.pin_memory()
+        ent = flat._touch_sync = (names, host)
+    names, host = ent
+    touched = flat.touched
+    for i, n in enumerate(names):
+        host[i] = 1 if n in touched else 0
+    flags = host.to(flat.grad.device, non_blocking=True)
     dist.all_reduce(flags, op=dist.ReduceOp.MAX)
     flat.touched.update(n for n, f in zip(names, flags.tolist()) if f)
 
@@ -292,6 +305,13 @@ class MTtrainer(object):
     # ---- one iteration (the unit bench.py times)
     def train_step(self, iteration, data_s, target_s, data_u_list=None):
         use_mt = iteration > self.start_mt and self.lambda_value > 0 and data_u_list is not None
+        self._step_start = None
+        if use_mt and self.overlap_teacher and _TEACHER_EARLY:
+            # what the teacher's stream has to wait for: the previous step's EMA / plane re-packing and this step's inputs -- all
+            # on the step stream BEFORE this point.  (Waiting for the stream itself at the time the helper thread starts would put
+            # the teacher's first launch behind the student's N = 4 forward, issued in between: 3.5 ms of an idle side stream.)
+            self._step_start = torch.cuda.Event()
+            self._step_start.record()
         bucketed = self._bucketed_allreduce()
         if bucketed is not None:
             bucketed.install()  # the stage hooks are registered by the forward passes below
@@ -394,7 +414,8 @@ class MTtrainer(object):
         join_wgrads()   # the weight gradients of this step (side stream) before anything reads the flat gradient
         if bucketed is None:
             allreduce_gradients(self.flat_s)
-        sync_touched(self.flat_s)
+        if use_mt:   # (without the consistency branch every rank back-propagates through the same parameters)
+            sync_touched(self.flat_s)
         self.optimizer.step()
         if self.lambda_value > 0 and iteration > (self.start_mt - 10):
             self.update_teacher(iteration - (self.start_mt - 10))
@@ -476,8 +497,12 @@ class MTtrainer(object):
     def _start_teacher(self, data_u_list):
         """launch teacher.forward_teacher on the side stream from a helper thread; -> job dict (joined in forward_unlabel)"""
         import threading
+        resident = all(f.tensors.device == self.device for f in data_u_list[:self.teacher_bs])
         teacher_list = [f.to(self.device) for f in data_u_list[:self.teacher_bs]]
-        self.t_stream.wait_stream(torch.cuda.current_stream())  # EMA / weight packing of the previous step, inputs
+        if getattr(self, "_step_start", None) is not None and resident:   # (host inputs: their copies were just issued on this stream)
+            self.t_stream.wait_event(self._step_start)               # EMA / weight packing of the previous step, inputs
+        else:
+            self.t_stream.wait_stream(torch.cuda.current_stream())
         job = {}
 
         def run():

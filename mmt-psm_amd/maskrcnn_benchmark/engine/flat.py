@@ -176,10 +176,19 @@ class FlatParams(object):
         ent = self.__dict__.get("_flip_entries")
         if not ent or H.get_conv_precision() == 0:
             return
+        d, u, n = self._flip_table_now()
+        if not self._lazy_bf16:
+            H._check(H.lib().mmt_pack_weights_flipped(d.data_ptr(), u.data_ptr(), n, H._stream()), "mmt_pack_weights_flipped")
+        for w, scale, planes, _ in ent.values():
+            H.FLIPPED[w.data_ptr()] = ((id(self), self.plane_gen, H._p(scale), None if scale is None else scale._version), planes)
+
+    def _flip_table_now(self):
+        """descriptor table over the registered data-gradient weights (bf16 planes), rebuilt when an entry was registered
+        since it was made"""
         if self.__dict__.get("_flip_table") is None:
             import struct
             descs, unit_desc, unit0 = [], [], 0
-            for w, scale, planes, (Cout, KH, KW, Cin) in ent.values():
+            for w, scale, planes, (Cout, KH, KW, Cin) in self._flip_entries.values():
                 units = planes.shape[1] // 512
                 descs.append(struct.pack("qqqqiiiiii", w.data_ptr(), 0 if scale is None else scale.data_ptr(), planes.data_ptr(),
                                          planes.stride(0), Cout, KH, KW, Cin, unit0, 0))
@@ -188,11 +197,7 @@ class FlatParams(object):
             dev = self.data.device
             self._flip_table = (torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev),
                                 torch.tensor(unit_desc, dtype=torch.int32, device=dev), unit0)
-        d, u, n = self._flip_table
-        if not self._lazy_bf16:
-            H._check(H.lib().mmt_pack_weights_flipped(d.data_ptr(), u.data_ptr(), n, H._stream()), "mmt_pack_weights_flipped")
-        for w, scale, planes, _ in ent.values():
-            H.FLIPPED[w.data_ptr()] = ((id(self), self.plane_gen, H._p(scale), None if scale is None else scale._version), planes)
+        return self._flip_table
 
     def ensure_bf16(self):
         """the bf16 planes of this parameter generation, packed now if they were deferred (called right before a launch that
@@ -201,8 +206,10 @@ class FlatParams(object):
             return
         from .. import _hip as H
         H.pack_weights(self.data, self.planes, self._pack_descs, self._pack_units, self._n_units)
-        t = self.__dict__.get("_flip_table")
-        if t is not None and self.__dict__.get("_flip_entries"):
+        if self.__dict__.get("_flip_entries"):
+            # a weight registered since the last bulk pack (register_flipped drops the table) must not leave the OTHER entries
+            # un-packed: their H.FLIPPED keys already carry this generation
+            t = self._flip_table_now()
             H._check(H.lib().mmt_pack_weights_flipped(t[0].data_ptr(), t[1].data_ptr(), t[2], H._stream()), "mmt_pack_weights_flipped")
         self.bf16_gen = self.plane_gen
 

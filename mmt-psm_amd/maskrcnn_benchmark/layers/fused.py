@@ -579,6 +579,7 @@ class ForkFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)   # an alias nobody back-propagated through arrives as None, not as a zero-filled tensor
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod

@@ -104,10 +104,11 @@ class BoxList(object):
     def clip_to_image(self, remove_empty=True):
         w, h = self.size
         if self.bbox.is_cuda and self.bbox.dtype == torch.float32 and self.bbox.dim() == 2:
-            # one launch instead of four column clamps: the same comparisons against per-column bounds
-            from maskrcnn_benchmark.utils.miscellaneous import dev_const
+            # one launch instead of four column clamps: the same comparisons against per-column bounds, which travel through
+            # the pinned ring (no blocking pageable copy for an image size not seen before, nothing cached per size: ADVICE r3)
+            from maskrcnn_benchmark.utils.miscellaneous import dev_const, dev_floats
             lo = dev_const([0.0, 0.0, 0.0, 0.0], torch.float32, self.bbox.device)
-            hi = dev_const([w - _TO_REMOVE, h - _TO_REMOVE, w - _TO_REMOVE, h - _TO_REMOVE], torch.float32, self.bbox.device)
+            hi = dev_floats([w - _TO_REMOVE, h - _TO_REMOVE, w - _TO_REMOVE, h - _TO_REMOVE], self.bbox.device)
             torch.clamp(self.bbox, min=lo, max=hi, out=self.bbox)
         else:
             self.bbox[:, 0].clamp_(min=0, max=w - _TO_REMOVE)

@@ -61,6 +61,25 @@ def dev_const(values, dtype, device):
 _INT_RING = {}
 
 
+_FLOAT_RING = {}
+
+
+def dev_floats(values, device):
+    """dev_ints for a short fp32 vector (image bounds of `BoxList.clip_to_image`): pinned ring slot + asynchronous copy"""
+    n = len(values)
+    if n > 16:
+        return torch.tensor(values, dtype=torch.float32).to(device, non_blocking=True)
+    ent = _FLOAT_RING.get(device)
+    if ent is None:
+        ent = _FLOAT_RING[device] = [torch.zeros((1024, 16), dtype=torch.float32).pin_memory(), 0, threading.Lock()]
+    with ent[2]:
+        i = ent[1]
+        ent[1] = (i + 1) & 1023
+    slot = ent[0][i, :n]
+    slot.copy_(torch.tensor(values, dtype=torch.float32))
+    return slot.to(device, non_blocking=True)
+
+
 def dev_ints(values, device):
     """a short int32 vector whose content changes from step to step (per-image proposal counts and their prefix sums) on the
     device WITHOUT draining the stream: the values are written into a slot of a pinned ring and copied asynchronously on the

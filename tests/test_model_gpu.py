@@ -57,9 +57,10 @@ def _targets_product(tgs, dev):
     return out
 
 
-@pytest.fixture(scope="module", params=[3, 0], ids=["bf16x3-split", "fp32-mfma"])
+@pytest.fixture(scope="module", params=[3, 0], ids=["default-f16x2-split", "fp32-mfma"])
 def setup(request, synth, weights):
-    """the whole model-level parity suite runs in both convolution arithmetics: the default 3-term bf16 split and the
+    """the whole model-level parity suite runs in both convolution arithmetics: the default of mode 3 (two-term fp16 split, 3
+    matrix products per multiply; MMT_F16X2=0 would make it the 3-term bf16 split) and the
     fp32-input MFMA (include/mmtpsm.h: mmt_set_conv_precision) -- same tolerances"""
     from maskrcnn_benchmark import _hip
     from maskrcnn_benchmark.config import make_default_cfg
