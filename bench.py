@@ -433,6 +433,9 @@ def main():
         # algorithmic HBM bytes of those launches: input + weights + output once
         alg_bytes = sum(4.0 * (k[1] * k[2] * k[3] * k[4] + k[5] * k[4] * k[6] * k[6]
                                + k[1] * (k[2] // k[7]) * (k[3] // k[7]) * k[5]) for k in (p[3] for p in prof))
+        # ... plus what the fused epilogues of those launches read (residual / top-down add, ReLU mask of a data gradient):
+        # operands of the launch like its input, read once (round 3 left them out and called the difference waste)
+        alg_bytes += sum(p[6] for p in prof if len(p) > 6)
         traffic = None
         try:  # HBM/fabric bytes per launch of this kernel from the committed PMC passes (not measurable live)
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

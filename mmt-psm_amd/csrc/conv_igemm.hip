@@ -944,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
 //   * without a per-wave split the wave grid is free: 2 x 2 waves of 64 x 64 (12 fragment reads per 24 MFMAs, 14 before).
 // A-plane LDS image = the B-plane image: per 32-row block [32 rows][2 halves][8 bf16] with half ^= (row >> 3) & 1; a DMA
 // instruction fills one block of one plane (lane = (row, half): 16 B from the row's pixel, channel c0 + 8 * logical half).
-template <int BM, int BN, int WM, int WN, int NS, int S, int DBG = 0>  // DBG (timing experiments only): 1 no DMA, 2 no fragment reads, 4 no barrier
+template <int BM, int BN, int WM, int WN, int NS, int S>
 __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, const int ksplit, float* __restrict__ ws) {
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int PA = BM * 32, PB = BN * 32;  // bytes of one plane of the A / B tile
@@ -1081,15 +1081,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
   constexpr int M_DMA = NIA + NIB, M_RA = NS * TM, M_RB = NS * TN;
   constexpr int NMICRO = M_DMA + M_RA + M_RB;
   auto micro = [&](int idx, int kt_fill, int stage_free, int stage_next, bf16x8 (&fan)[NS][TM], bf16x8 (&fbn)[NS][TN]) {
-    if (DBG & 16) {  // spread: every third micro-op is a DMA (0,3,6,.. -> DMA 0..5), the others are the fragment reads
-      if (idx % 3 == 0 && idx / 3 < NIA + NIB) idx = idx / 3;
-      else idx = NIA + NIB + (idx - min(idx / 3 + 1, NIA + NIB));
-    }
-    if (idx < NIA) { if (!(DBG & 1) && !((DBG & 8) && (kt_fill % 3))) dma_a(idx, stage_free); return; }
+    if (idx < NIA) { dma_a(idx, stage_free); return; }
     idx -= NIA;
-    if (idx < NIB) { if (!(DBG & 1) && !((DBG & 32) && (kt_fill % 3))) dma_b(idx, kt_fill, stage_free); return; }
+    if (idx < NIB) { dma_b(idx, kt_fill, stage_free); return; }
     idx -= NIB;
-    if (DBG & 2) return;
     const char* st = ring + stage_next * STAGE;
     if (idx < M_RA) { const int q = idx / TM, a = idx % TM; fan[q][a] = *(const bf16x8*)(st + aoff + q * PA + a * 1024); return; }
     idx -= M_RA;
@@ -1104,8 +1099,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
   };
   auto step = [&](int kt, int stage_next, int stage_free, const bf16x8 (&fa)[NS][TM], const bf16x8 (&fb)[NS][TN],
                   bf16x8 (&fan)[NS][TM], bf16x8 (&fbn)[NS][TN]) {
-    if (!(DBG & (1 | 8 | 32))) wait_dma(S - 2); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+    wait_dma(S - 2);
+    __builtin_amdgcn_s_barrier();
     tap_next();
     filling = kt + S < nkt;
     const int kt_fill = min(kt + S, nkt - 1);
@@ -1136,15 +1131,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
   filling = S - 1 < nkt;
   issue_all(min(S - 1, nkt - 1), S - 1);
   bf16x8 fa0[NS][TM], fb0[NS][TN], fa1[NS][TM], fb1[NS][TN];
-  if (DBG & 2) {  // keep the register sets defined
-#pragma unroll
-    for (int q = 0; q < NS; q++) {
-#pragma unroll
-      for (int a = 0; a < TM; a++) fa1[q][a] = *(const bf16x8*)(ring + aoff + q * PA + a * 1024);
-#pragma unroll
-      for (int b = 0; b < TN; b++) fb1[q][b] = *(const bf16x8*)(ring + boff + q * PB + b * 1024);
-    }
-  }
   {
     const char* st = ring;
 #pragma unroll
@@ -1190,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
 // K order: (kh, channel slab, kw) -- the packed weight planes are indexed, not re-packed.  One barrier per super-step
 // (three taps = 72 MFMAs per wave), placed before the last tap: the fragments of that tap are in registers by then, so the
 // stage is free for the copies of super-step s + 2 while tap 0 of s + 1 is pre-read from the other stage.
-template <int TW, int NS, int DBG = 0, bool F16 = false>  // DBG (timing experiments): 1 no copies in the loop, 2 no fragment reads, 4 no barrier / waits; F16: the planes hold fp16 terms (experiment)
+template <int TW, int NS, bool F16 = false>  // F16: the planes hold the two fp16 terms of x * s_x / w * s_w (default arithmetic of mode 3)
 __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, const int ksplit, float* __restrict__ ws) {
   constexpr int BM = 256, BN = 128, R = BM / TW, SW = TW + 32, TM = 2, TN = 2;
   constexpr int PA = R * SW * 32;              // bytes of one A plane of a stage (strip rows x 32 B)
@@ -1367,8 +1353,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
             else
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][a], fb[qb][b], acc[a][b], 0, 0, 0);
             j++;
-            if (ri < (j * NF + NRD - 1) / NRD && ri < NF) { if (do_read && !(DBG & 2)) read_tap(sg_next, kw_next, fan, fbn, ri); ri++; }
-            if (di < (j * ndma + NM - 1) / NM && di < ndma) { if (do_dma && !(DBG & 1)) issue_slot(dma0 + di, stage_fill); di++; }
+            if (ri < (j * NF + NRD - 1) / NRD && ri < NF) { if (do_read) read_tap(sg_next, kw_next, fan, fbn, ri); ri++; }
+            if (di < (j * ndma + NM - 1) / NM && di < ndma) { if (do_dma) issue_slot(dma0 + di, stage_fill); di++; }
             __builtin_amdgcn_sched_barrier(0);
           }
       }
@@ -1385,7 +1371,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   fill_advance();                  // the fill state now describes super-step 2
   bf16x8 fa0[NS][TM], fb0[NS][TN], fa1[NS][TM], fb1[NS][TN];
 #pragma unroll
-  for (int i = 0; i < NF; i++) { read_tap(0, 0, fa0, fb0, i); if (DBG & 2) read_tap(0, 1, fa1, fb1, i); }
+  for (int i = 0; i < NF; i++) read_tap(0, 0, fa0, fb0, i);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   constexpr int D0 = (NSLOT + 1) / 2, D1 = NSLOT - D0;   // copy slots issued behind tap 2 / behind tap 0 of the next super-step
@@ -1399,10 +1385,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
     // tap 1 (regs q) | pre-read tap 2 -> p
     tap(fa_q, fb_q, fa_p, fb_p, SG, 2, true, 0, 0, 0, false);
     // every copy into the other stage has landed, everybody's reads of this stage are complete
-    if (!(DBG & 4)) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     // tap 2 (regs p) | pre-read tap 0 of ss + 1 -> q from the other stage | first half of the copies of ss + 2 into this stage
     // (after the last super-step this pre-read fetches stale bytes nobody uses: unconditional, because a branch around
     // register-producing reads makes the compiler re-pack every bf16 fragment register at the join -- 600 v_perm / v_lshr
@@ -1600,7 +1584,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p, 
 
 template <int BM, int BN>
 static void launch_finish(const ConvP& p, int tiles, int ksplit, const float* ws, hipStream_t s) {
-  static const int parts = getenv("MMT_FINISH_PARTS") ? atoi(getenv("MMT_FINISH_PARTS")) : 4;
+  constexpr int parts = 4;   // (tuned: profiles/r04_dispatch_sweep.txt)
   if (parts == 16)
     hipLaunchKernelGGL((conv_splitk_finish_kernel<BM, BN, 16>), dim3(tiles * 16), dim3(256), (size_t)(BM / 16) * BN * 4, s, p, ksplit, ws);
   else
@@ -3015,8 +2999,8 @@ static int pick_ksplit(const ConvP& p) {
   if ((on_env && atoi(on_env) == 0) || p.Cout < 128) return 1;
   const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
   const int nkt = p.K >> 4;
-  static const int tmax = getenv("MMT_SPLITK_T") ? atoi(getenv("MMT_SPLITK_T")) : 512;
-  static const int kmin = getenv("MMT_SPLITK_NKT") ? atoi(getenv("MMT_SPLITK_NKT")) : 128;
+  constexpr int tmax = 512;   // (tuned: profiles/r04_dispatch_sweep.txt)
+  constexpr int kmin = 128;   // (tuned: profiles/r04_dispatch_sweep.txt)
   if (t128 >= tmax || nkt < kmin) return 1;  // K >= 2048: shorter sums lose more in the second launch than they gain
   int ks = (int)(512 / t128);
   if (ks > nkt / 32) ks = nkt / 32;
@@ -3066,21 +3050,6 @@ int launch_pp(const ConvP& p, hipStream_t s, int ksplit = 1) {
   const size_t ring = (size_t)S * NS * (BM + BN) * 32, epi = (size_t)BM * BN * sizeof(float);
   const size_t lds = ring > epi ? ring : epi;
   void (*kern)(const ConvP, const int, float*) = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S>;
-#ifdef MMT_PP_EXPERIMENTS
-  {
-    const char* d = getenv("MMT_PP_DBG");
-    const int dbg = d ? atoi(d) : 0;
-    if (dbg == 1) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 1>;
-    if (dbg == 2) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 2>;
-    if (dbg == 3) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 3>;
-    if (dbg == 4) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 4>;
-    if (dbg == 7) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 7>;
-    if (dbg == 8) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 8>;
-    if (dbg == 16) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 16>;
-    if (dbg == 24) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 24>;
-    if (dbg == 40) kern = conv_fwd_pp_kernel<BM, BN, WM, WN, NS, S, 40>;
-  }
-#endif
   if (lds > 65536) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -3104,8 +3073,7 @@ static int strip_ksplit(const ConvP& p, int tw) {
   const long tiles = (long)p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
   if (tiles >= 256) return 1;
   const char* e = getenv("MMT_SPLITK");
-  const char* e2 = getenv("MMT_STRIP_SPLITK");
-  if ((e && atoi(e) == 0) || (e2 && atoi(e2) == 0) || p.Wo != tw || (p.Cout & 127) || tiles < 32) return 0;
+  if ((e && atoi(e) == 0) || p.Wo != tw || (p.Cout & 127) || tiles < 32) return 0;
   int ks = (int)((256 + tiles - 1) / tiles);
   const int pairs = 3 * (p.Cin >> 4) / 2;
   if (ks > pairs / 3) ks = pairs / 3;
@@ -3124,7 +3092,7 @@ static int strip_tw(const ConvP& p, bool need_planes = true) {
   int tw = 0;
   if (p.Wo % 128 == 0 && p.Ho % 2 == 0) tw = 128;
   else if (p.Wo % 64 == 0 && p.Ho % 4 == 0) tw = 64;
-  static const int minc = getenv("MMT_STRIP_MINC") ? atoi(getenv("MMT_STRIP_MINC")) : 128;
+  constexpr int minc = 128;   // (tuned: profiles/r04_dispatch_sweep.txt)
   if (!tw || p.Cin < minc) return 0;  // K = 576 (the 64-channel layer1 convs): 12 super-steps do not amortise the fill
   return strip_ksplit(p, tw) ? tw : 0;
 }
@@ -3141,17 +3109,6 @@ int launch_strip(const ConvP& p, hipStream_t s) {
     if (!w.ws) return MMT_EINVAL;
   }
   void (*kern)(const ConvP, const int, float*) = conv3x3_strip_kernel<TW, NS>;
-#ifdef MMT_PP_EXPERIMENTS
-  {
-    const char* d = getenv("MMT_PP_DBG");
-    const int dbg = d ? atoi(d) : 0;
-    if (dbg == 1) kern = conv3x3_strip_kernel<TW, NS, 1>;
-    if (dbg == 2) kern = conv3x3_strip_kernel<TW, NS, 2>;
-    if (dbg == 3) kern = conv3x3_strip_kernel<TW, NS, 3>;
-    if (dbg == 4) kern = conv3x3_strip_kernel<TW, NS, 4>;
-    if (dbg == 7) kern = conv3x3_strip_kernel<TW, NS, 7>;
-  }
-#endif
   {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -3198,8 +3155,8 @@ int launch_rows(const ConvP& p, hipStream_t s) {
 static bool rows_shape(const ConvP& p, bool f16) {
   const char* rows_env = getenv("MMT_ROWS");  // read per call: the parity tests switch it
   const int rows = rows_env ? atoi(rows_env) : 1;
-  static const int rows_min = getenv("MMT_ROWS_MIN") ? atoi(getenv("MMT_ROWS_MIN")) : 256;  // blocks of 128 rows (bf16 split)
-  static const int rows_min16 = getenv("MMT_ROWS_MIN16") ? atoi(getenv("MMT_ROWS_MIN16")) : 16;
+  constexpr int rows_min = 256;   // (tuned: profiles/r04_dispatch_sweep.txt)  // blocks of 128 rows (bf16 split)
+  constexpr int rows_min16 = 16;   // (tuned: profiles/r04_dispatch_sweep.txt)
   if (!rows || p.io || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.Cout < 64 || (p.Cout & 3) || p.res_mode > 2 || p.mul ||
       p.out_stride != 1 || (long)p.M * p.Cin * 4 >= (1L << 31) || (long)p.M * p.Cout * 4 >= (1L << 31))
     return false;
@@ -3211,7 +3168,7 @@ template <int NS>
 int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
   // 1x1 / stride 1 layers with K = 64 or 128 and many rows: one block per 128 rows, all Cout panels (see the kernel)
   if (rows_shape(p, false)) {
-    static const int bn64 = getenv("MMT_ROWS_BN") ? atoi(getenv("MMT_ROWS_BN")) : 32;
+    constexpr int bn64 = 32;   // (tuned: profiles/r04_dispatch_sweep.txt)
     if (p.Cin == 64) return bn64 == 64 ? launch_rows<4, 64, NS>(p, s) : launch_rows<4, 32, NS>(p, s);
     if (p.Cin == 128) return launch_rows<8, 32, NS>(p, s);
   }
@@ -3236,11 +3193,6 @@ int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
     return MMT_EINVAL;
   }
   // activations pre-split into planes by the caller: the all-planes kernel (128 x 128 tiles, 2 x 2 waves)
-#ifdef MMT_PP_EXPERIMENTS   // the all-planes 128 x 128 kernel on the split arithmetics: measured no faster; not in the shipping build
-  static const int use_pp = getenv("MMT_PP") ? atoi(getenv("MMT_PP")) : 0;
-  if (use_pp && p.xpl && NS == 3 && (ksplit > 1 || variant == 1) && !((size_t)p.xpl & 15) && !(p.xpl_stride & 7))
-    return launch_pp<128, 128, 2, 2, NS, 3>(p, s, ksplit);
-#endif
   if (ksplit > 1) return launch_glds<128, 128, 4, 1, NS, 3>(p, s, ksplit);
   switch (variant) {
     case 1: return launch_glds<128, 128, 4, 1, NS, 3>(p, s);
@@ -3458,8 +3410,8 @@ extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x,
     hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit, w.ws);
     return 0;
   };
-  if (tw == 128) e = go(conv3x3_strip_kernel<128, NS, 0, true>, 128);
-  else e = go(conv3x3_strip_kernel<64, NS, 0, true>, 64);
+  if (tw == 128) e = go(conv3x3_strip_kernel<128, NS, true>, 128);
+  else e = go(conv3x3_strip_kernel<64, NS, true>, 64);
   if (e) return e;
   MMT_LAUNCH_CHECK();
   if (ksplit > 1) {
@@ -3488,8 +3440,7 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
     return launch_rows<16, 32, 2, true>(p, s);
   }
   const int ksplit = pick_ksplit(p);
-  static const int stages_env = [] { const char* v = getenv("MMT_GLDS_S"); const int n = v ? atoi(v) : 3; return n >= 3 && n <= 5 ? n : 3; }();
-  const int S = stages_env;
+  constexpr int S = 3;   // LDS stages of the operand ring (4 / 5 measured no faster: 36.4 / 34.8 / 35.0 us, profiles/r03_history.md)
   auto go = [&](auto kern, int BM, int BN, int ks) -> int {
     const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN) * ks;
     SplitWs w{nullptr};
@@ -3515,9 +3466,7 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
     else if (variant == 3) e = go(conv_fwd_glds_kernel<128, 64, 4, 1, 2, SS, true>, 128, 64, 1);            \
     else e = go(conv_fwd_glds_kernel<64, 64, 2, 2, 2, SS, true>, 64, 64, 1);                                \
   } while (0)
-  if (S == 5) MMT_GLDS_GO(5);
-  else if (S == 4) MMT_GLDS_GO(4);
-  else MMT_GLDS_GO(3);
+  MMT_GLDS_GO(3);
 #undef MMT_GLDS_GO
   if (e) return e;
   MMT_LAUNCH_CHECK();
@@ -3540,15 +3489,15 @@ static int pick_variant(const ConvP& p) {
   if (p.Cout <= 32) return 0;
   // K <= 256 (the 1x1 layers of layer1/layer2/FPN laterals): 2-8 k-tiles per output tile, so prologue and epilogue
   // dominate; the 64x64 configuration keeps ~4x more blocks resident to overlap them (measured +10..25 %)
-  static const int lowk = getenv("MMT_LOWK") ? atoi(getenv("MMT_LOWK")) : 256;
-  static const int lowv = getenv("MMT_LOWK_VARIANT") ? atoi(getenv("MMT_LOWK_VARIANT")) : 3;
+  constexpr int lowk = 256;   // (tuned: profiles/r04_dispatch_sweep.txt)
+  constexpr int lowv = 3;   // (tuned: profiles/r04_dispatch_sweep.txt)
   if (p.K <= lowk) return (p.Cout >= 64 && (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 64) >= 768) ? lowv : 2;
   // enough 128x128 tiles to fill 256 CUs (2 resident blocks each) -> 128x128; else 128x64 (twice the blocks, A tile
   // still reused across 64 output channels); else 64x64 (4x the blocks)
   const long t128 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 128);
-  static const int t128min = getenv("MMT_T128") ? atoi(getenv("MMT_T128")) : 256;
+  constexpr int t128min = 256;   // (tuned: profiles/r04_dispatch_sweep.txt)
   if (t128 >= t128min && p.Cout > 64) return 1;
-  static const int mid = getenv("MMT_MID") ? atoi(getenv("MMT_MID")) : 1;
+  constexpr int mid = 1;   // (tuned: profiles/r04_dispatch_sweep.txt)
   const long t12864 = (long)mmt_cdiv(p.M, 128) * mmt_cdiv(p.Cout, 64);
   if (mid && t12864 >= 256 && p.Cout >= 64) return 3;
   return 2;
@@ -3623,8 +3572,8 @@ extern "C" int mmt_conv_wgrad_splits(const mmt_conv_args* a) {
   // all blocks of a launch run equally long: fill the 512 resident slots (256 CUs x 2 blocks) ONCE.  (640 = 1.25
   // rounds cost a second, 20 %-full round: 92 -> 105 TFLOP/s fp32, 103 -> 136 split-bf16 on the FPN 3x3 shapes)
   const long tiles = (long)tx * ty;
-  static const int slots = getenv("MMT_WGRAD_SLOTS") ? atoi(getenv("MMT_WGRAD_SLOTS")) : 512;
-  static const int min_px = getenv("MMT_WGRAD_MINPX") ? atoi(getenv("MMT_WGRAD_MINPX")) : 512;
+  constexpr int slots = 512;   // (tuned: profiles/r04_dispatch_sweep.txt)
+  constexpr int min_px = 512;   // (tuned: profiles/r04_dispatch_sweep.txt)
   int split = (int)(tiles >= slots ? 1 : slots / tiles);
   const int max_split = mmt_cdiv(p.M, min_px);  // at least min_px / 16 k-tiles per block
   if (split > max_split) split = max_split;
@@ -3678,11 +3627,11 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   if (bf && !(prec == 1 && (p.Cout & 3) == 0 && (mps & 15) == 0 && (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) &&
               (long)p.M * p.Cout * 4 < (1L << 31)))
     return MMT_EINVAL;
-  static const int pipe_any = getenv("MMT_WGRAD_PIPE") ? atoi(getenv("MMT_WGRAD_PIPE")) : 1;
+  constexpr int pipe_any = 1;   // (tuned: profiles/r04_dispatch_sweep.txt)
   const bool small_t = (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31);
   if (prec > 0 && ((p.Cout & 3) == 0 || (pipe_any && small_t)) && (mps & 15) == 0) {
     const dim3 grid(tx, ty, split);
-    static const int pipe = getenv("MMT_WGRAD_PIPE") ? atoi(getenv("MMT_WGRAD_PIPE")) : 1;
+    constexpr int pipe = 1;   // (tuned: profiles/r04_dispatch_sweep.txt)
     // the pipelined kernel addresses both operands with 32-bit byte offsets (buffer loads)
     const bool small = (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31);
     const int mode = !(p.Wo >= 8 && p.Ho >= 8) ? 0 : ((p.Wo & 3) == 0 ? 2 : 1);

@@ -148,7 +148,7 @@ _lib = None
 PROFILE = None
 PROFILE_ALL = False
 # eligible 3x3 convolutions split their input into bf16 planes first and run on conv3x3_strip_kernel (csrc/conv_igemm.hip)
-AUTO_PLANES = os.environ.get("MMT_AUTO_PLANES", "1") != "0"
+AUTO_PLANES = True
 # bf16 STORAGE of the ResNet body's activations and activation gradients (BASELINE configs[4] "bf16 MFMA path"): only with
 # the bf16 arithmetic (mode 1).  The producers in layers/fused.py ask `bf16_storage()`; every consumer goes by the dtype
 # of the tensor it is handed.
@@ -161,10 +161,10 @@ _BF16_STORAGE = os.environ.get("MMT_BF16_STORAGE", "0") != "0"
 # against fp64 no larger than the 3-term bf16 split's (tools/bench_f16x2.py, profiles/r03_precision_f16x2.txt).
 F16X2_DEFAULT = os.environ.get("MMT_F16X2", "1") != "0"
 F16X2 = F16X2_DEFAULT
-F16X2_TILED = os.environ.get("MMT_F16X2_TILED", "1") != "0"   # also the tiled kernel (1x1, small-map 3x3, fc), not only the strip kernel
-F16X2_DELAYED = os.environ.get("MMT_F16X2_DELAYED", "0") != "0"   # scale from the previous tensor of the role (one pass less)
+F16X2_TILED = True   # also the tiled kernel (1x1, small-map 3x3, fc), not only the strip kernel
+F16X2_DELAYED = False   # (tools) scale from the previous tensor of the role: one pass less, but the scale lags the data
 F16_STATS = {"wgrad": 0, "conv": 0, "tiled": 0, "amax_pass": 0, "fallback": 0, "weight_pack": 0}   # launches that took the fp16 path (tools, tests)
-WGRAD_F16_MIN_ELEMS = int(os.environ.get("MMT_WGRAD_F16_MIN", str(1 << 22)))
+WGRAD_F16_MIN_ELEMS = 1 << 22
 _F16W = {}   # weight address -> (key, planes, device scale)
 
 
@@ -856,9 +856,8 @@ def rpn_post_select(boxes, scores, idx, reg, keep, keep_cnt, level_off, own_pre,
     return ob, osc, oi, orr, ol, oc
 
 
-SAMPLE_WIDE = os.environ.get("MMT_SAMPLE_WIDE", "0") != "0"   # opt-in: measured no faster in the step (35.5 / 35.8 / 35.5 vs 36.2 / 35.8 / 36.1 ms on one box:
-                                                               # the RPN sampler is not on the step's critical path and four launches replace one)
-SAMPLE_WIDE_MIN = 32768                                        # labels per image from which the wide form is used
+SAMPLE_WIDE = True            # long label vectors (the RPN's 262 k anchors per image) take the many-blocks-wide form of the sampler,
+SAMPLE_WIDE_MIN = 32768       # short ones (the box head's proposals) the one-block-per-image kernel: same masks bit for bit (tests)
 _SAMPLE_WS = {}
 
 
@@ -959,7 +958,7 @@ def planes_of(x):
 _PLAN = {}
 _WPLAN = {}   # weight gradient: (shapes, stride, pad, dtypes) -> (shape half of mmt_conv_args, split count)
 _PLAN_EPOCH = [0]
-FAST_PLANS = os.environ.get("MMT_FAST_PLANS", "1") != "0"
+FAST_PLANS = True
 
 
 def _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask):
@@ -1025,6 +1024,20 @@ def _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, kind,
     if len(_PLAN) > 4096:
         _PLAN.clear()
     _PLAN[key] = (bytes(t), kind, Cout, Ho, Wo, weakref.ref(owner))
+
+
+def _epilogue_bytes(y, res, res_mode, mask, mul):
+    """HBM bytes of the operands a fused epilogue reads besides the convolution's own input / weights (profiling records: the
+    algorithmic traffic of a launch is input + weights + output + THESE, each once): the residual (same pixels, the coarser map of
+    the FPN top-down add, or the four finer pixels of its gradient), the ReLU mask of a data gradient, the dropout multiplier"""
+    n = 0
+    if res is not None:
+        n += res.numel() * res.element_size() if res_mode in (1, 2, 3) else 0
+    if mask is not None:
+        n += y.numel() * mask.element_size()
+    if mul is not None:
+        n += mul.numel() * mul.element_size()
+    return n
 
 
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
@@ -1159,7 +1172,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             e1.record()
             PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1,
                             ("fwd%d" % lib().mmt_conv_variant(ctypes.byref(a)), N, H, W, Cin, Cout, KH, stride, out_stride),
-                            lib().mmt_conv_ksplit(ctypes.byref(a)), None))
+                            lib().mmt_conv_ksplit(ctypes.byref(a)), None, _epilogue_bytes(y, res, res_mode, mask, mul)))
         if amax_slot is not None:
             y._mmt_amax = (amax_slot, y._version)
         return y
@@ -1183,7 +1196,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if rec:
             ev[3].record()
             PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, ev[2], ev[3],
-                            ("fwd4", N, H, W, Cin, Cout, KH, stride, out_stride), 1, (ev[0], ev[1])))
+                            ("fwd4", N, H, W, Cin, Cout, KH, stride, out_stride), 1, (ev[0], ev[1]),
+                            _epilogue_bytes(y, res, res_mode, mask, mul)))
         if amax_slot is not None:
             y._mmt_amax = (amax_slot, y._version)
         return y
@@ -1203,7 +1217,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             e1.record()
             PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, e0, e1,
                             ("fwd%d" % var, N, H, W, Cin, Cout, KH, stride, out_stride),
-                            lib().mmt_conv_ksplit(ctypes.byref(a)), pre))
+                            lib().mmt_conv_ksplit(ctypes.byref(a)), pre, _epilogue_bytes(y, res, res_mode, mask, mul)))
             if y_planes is not None:
                 y._mmt_planes = (y_planes, y._version)
             if amax_slot is not None:

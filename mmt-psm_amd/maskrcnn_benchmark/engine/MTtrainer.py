@@ -19,7 +19,6 @@ from maskrcnn_benchmark.layers import fused
 from maskrcnn_benchmark.utils.miscellaneous import sigmoid_rampdown, sigmoid_rampup
 
 
-_TEACHER_EARLY = os.environ.get("MMT_TEACHER_EARLY", "1") != "0"   # the teacher's stream starts behind the step's FIRST launch, not behind the student's forward
 _WGRAD_DEFER = os.environ.get("MMT_WGRAD_DEFER", "1") != "0"   # supervised weight gradients in one batch after the supervised backward (0: interleaved, the A/B alternative)
 
 
@@ -266,23 +265,16 @@ class MTtrainer(object):
         # so that its large convolutions fill the GPU while the other stream is in launch-latency-bound target / proposal
         # glue, and vice versa.  MMT_OVERLAP_TEACHER=0 restores the serial order.
         self.overlap_teacher = os.environ.get("MMT_OVERLAP_TEACHER", "1") != "0" and self.device.type == "cuda"
-        self.early_sup_backward = os.environ.get("MMT_EARLY_SUP_BACKWARD", "1") != "0"
-        # "pair" (one N = 4 forward, two autograd graphs) | "split" (two passes) | "batched" (one pass, one graph)
-        self.student_passes = os.environ.get("MMT_STUDENT_PASSES", "pair")
-        # hipGraph capture of the three backbone passes (engine/graphs.py); MMT_GRAPHS=0 runs them launch by launch
-        self.use_graphs = os.environ.get("MMT_GRAPHS", "0") != "0" and self.device.type == "cuda"
-        if self.use_graphs:
-            from maskrcnn_benchmark.engine.graphs import BackboneGraphs
-            which = os.environ.get("MMT_GRAPHS", "1")   # 1 both models, 2 student only, 3 teacher only (tuning)
-            self.student.graphs = BackboneGraphs(self.student, self.flat_s) if which in ("1", "2") else None
-            self.teacher.graphs = BackboneGraphs(self.teacher, None) if which in ("1", "3") else None
+        self.early_sup_backward = True
+        # "pair" (one N = 4 forward, two autograd graphs: the default) | "split" (two passes) | "batched" (one pass, one graph):
+        # the alternatives are what tests/test_train_step_gpu.py compares the default schedule with
+        self.student_passes = "pair"
         self.skipped_pairs = 0  # steps whose consistency branch was skipped (no pseudo box on some image)
         # priority -1: HIP maps streams of one priority onto a few hardware queues round-robin; once RCCL has created its own
         # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
         # main stream and the overlap silently disappears (measured: 63.7 vs 59.9 ms/step).  A different priority class
         # has its own queues.
-        self.t_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MMT_TEACHER_PRIORITY", "-1"))) \
-            if self.overlap_teacher else None
+        self.t_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.overlap_teacher else None
         self._bucketed = None  # BucketedAllReduce, built lazily when enabled (see _bucketed_allreduce)
         # One random stream per model: the teacher's forward runs in a helper thread beside the student's, and with the
         # global generator the interleaving of their draws (fg/bg sampler keys, dropout) would depend on thread timing.
@@ -305,33 +297,20 @@ class MTtrainer(object):
     # ---- one iteration (the unit bench.py times)
     def train_step(self, iteration, data_s, target_s, data_u_list=None):
         use_mt = iteration > self.start_mt and self.lambda_value > 0 and data_u_list is not None
-        self._step_start = None
-        if use_mt and self.overlap_teacher and _TEACHER_EARLY:
-            # what the teacher's stream has to wait for: the previous step's EMA / plane re-packing and this step's inputs -- all
-            # on the step stream BEFORE this point.  (Waiting for the stream itself at the time the helper thread starts would put
-            # the teacher's first launch behind the student's N = 4 forward, issued in between: 3.5 ms of an idle side stream.)
-            self._step_start = torch.cuda.Event()
-            self._step_start.record()
         bucketed = self._bucketed_allreduce()
         if bucketed is not None:
             bucketed.install()  # the stage hooks are registered by the forward passes below
         feats_s = feats_u = None
-        early, cut, merged = False, None, None
+        early, cut = False, None
         job = None
-        if use_mt and self.overlap_teacher and os.environ.get("MMT_TEACHER_FIRST") == "1":   # schedule experiment (tools)
-            job = self._start_teacher(data_u_list)
         if use_mt and self.student_bs == 1:
             xs = data_s.tensors.to(self.device)
             xu = data_u_list[-1].tensors.to(self.device)
-            if self.student_passes in ("pair", "pairm") and xs.shape == xu.shape and not self.use_graphs:
+            if self.student_passes == "pair" and xs.shape == xu.shape:
                 # one set of forward launches for both passes (N = 4), two autograd graphs (modeling/backbone/backbone.py:
-                # forward_pair): the schedule below is that of "split".  "pairm": the two graphs end at C2..C5 and the ResNet
-                # body is back-propagated ONCE for both (N = 4) after the consistency branch's backward
+                # forward_pair): the schedule below is that of "split"
                 from maskrcnn_benchmark.modeling.backbone.backbone import forward_pair
-                if self.student_passes == "pairm":
-                    feats_s, fu, merged = forward_pair(self.student.backbone, xs, xu, merged_body=True)
-                else:
-                    feats_s, fu = forward_pair(self.student.backbone, xs, xu)
+                feats_s, fu = forward_pair(self.student.backbone, xs, xu)
                 feats_u = [fu]
                 early = True
             elif self.student_passes in ("split", "pair"):
@@ -343,8 +322,6 @@ class MTtrainer(object):
                 # Measured on the stationary bench (46.4 ms): starting the teacher BEFORE these passes 50.5, the unlabeled
                 # view's pass issued after the supervised backward 46.5, batched 48.0, batched + teacher first 49.0 --
                 # between 8 and 37 ms both streams hold convolution work and the step is the sum of the kernel times.
-                if self.use_graphs:
-                    self._capture_graphs(xs, xu, data_u_list)
                 feats_s = self.student.run_backbone(xs, 0)
                 feats_u = [self.student.run_backbone(xu, 1)]
                 early = True
@@ -392,8 +369,6 @@ class MTtrainer(object):
                 if cut is not None:
                     pairs = [(r, l.grad) for r, l in zip(*cut) if l.grad is not None]
                     torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
-                if merged is not None:
-                    merged.finish()
             else:
                 if use_mt:
                     unl = self.forward_unlabel(data_u_list, feats_u, job)
@@ -422,22 +397,6 @@ class MTtrainer(object):
             if self.teacher_check_period > 0 and iteration % self.teacher_check_period == 0:
                 check_teacher_identity(self.flat_t)
         return losses_dict
-
-    def _capture_graphs(self, xs, xu, data_u_list):
-        """first step with these shapes: capture the two student passes and the teacher's view batch on this thread, before
-        the teacher thread exists (a capture must not see launches of another thread)"""
-        gs, gt = getattr(self.student, "graphs", None), getattr(self.teacher, "graphs", None)
-        if gs is not None and gs.usable():
-            gs.prepare(xs, 0)
-            gs.prepare(xu, 1)
-        tl = data_u_list[:self.teacher_bs]
-        shapes = {tuple(f.tensors.shape) for f in tl}
-        if gt is not None and len(shapes) == 1 and gt.usable():
-            n = tl[0].tensors.shape[0]
-            shape = (2 * len(tl) * n,) + tuple(tl[0].tensors.shape[1:])
-            with torch.no_grad():
-                if gt.key_of(shape, 0) not in gt.table:
-                    gt.prepare(torch.zeros(shape, device=self.device), 0)
 
     def _pad_mt_keys(self, losses):
         """A rank whose teacher found no boxes skips the consistency branch (reference: bare except, MTtrainer.py:258-265)
@@ -497,12 +456,11 @@ class MTtrainer(object):
     def _start_teacher(self, data_u_list):
         """launch teacher.forward_teacher on the side stream from a helper thread; -> job dict (joined in forward_unlabel)"""
         import threading
-        resident = all(f.tensors.device == self.device for f in data_u_list[:self.teacher_bs])
         teacher_list = [f.to(self.device) for f in data_u_list[:self.teacher_bs]]
-        if getattr(self, "_step_start", None) is not None and resident:   # (host inputs: their copies were just issued on this stream)
-            self.t_stream.wait_event(self._step_start)               # EMA / weight packing of the previous step, inputs
-        else:
-            self.t_stream.wait_stream(torch.cuda.current_stream())
+        # EMA / weight packing of the previous step, inputs.  (Round 4: letting the side stream start behind the step's FIRST launch
+        # instead -- the teacher's N = 8 kernels then run beside the student's N = 4 forward -- was measured SLOWER, medians 38.1 /
+        # 38.7 vs 37.6 / 36.1 ms on one box: the student's chain is the critical path and the high-priority side stream starves it.)
+        self.t_stream.wait_stream(torch.cuda.current_stream())
         job = {}
 
         def run():

@@ -56,15 +56,15 @@ def _touch(*slots):
 # of three record_stream calls per job.
 import os as _os
 _WG_ON = _os.environ.get("MMT_WGRAD_STREAM", "1") != "0"
-_WG_BF16 = _os.environ.get("MMT_WGRAD_BF16", "1") != "0"   # bf16 configuration: the DEFERRED (supervised-pass) jobs go to the side stream (0: inline)
-_WG_BATCH = int(_os.environ.get("MMT_WGRAD_BATCH", "8"))   # measured 1 / 4 / 8 / 16: 36.8 / 36.6 / 36.4 / 36.4 ms per step
+_WG_BF16 = True   # bf16 configuration: only the DEFERRED (supervised-pass) jobs go to the side stream
+_WG_BATCH = 8   # jobs handed over behind one stream wait (measured 1 / 4 / 8 / 16: 36.8 / 36.6 / 36.4 / 36.4 ms per step)
 _WG = {}   # device -> [side stream, launches since the last join, end-of-backward callback queued, pending jobs, kept-alive tensors]
 
 
 def _wg_stream(dev):
     ent = _WG.get(dev)
     if ent is None:
-        ent = _WG[dev] = [torch.cuda.Stream(device=dev, priority=int(_os.environ.get("MMT_WGRAD_PRIORITY", "0"))), 0, False, [], []]
+        ent = _WG[dev] = [torch.cuda.Stream(device=dev), 0, False, [], []]
     return ent
 
 
@@ -569,7 +569,7 @@ def split_batch(x, n):
     return SplitBatchFn.apply(x, n)
 
 
-_FORK_ON = _os.environ.get("MMT_FORK_SUM", "1") != "0"
+_FORK_ON = True
 
 
 class ForkFn(torch.autograd.Function):

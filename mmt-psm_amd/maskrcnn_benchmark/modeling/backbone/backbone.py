@@ -165,45 +165,7 @@ def _stage_hook(body, name, x):
         x.register_hook(lambda g, name=name, cb=cb: cb(name, "fired"))
 
 
-class MergedBody(object):
-    """forward_pair(..., merged_body=True): the ResNet body is ONE autograd chain over the concatenated batch, cut from the two
-    FPN / head graphs at C2..C5 (detached leaves per half).  Each half's backward stops at its leaves; `finish()` then runs the
-    body's backward ONCE on the concatenated gradients -- N = 4 launches instead of 2 x N = 2 on the few-tile layers of
-    layer2-4, where a launch costs 40-60 us whatever its size."""
-
-    def __init__(self, roots, leaves, n):
-        self.roots, self.leaves, self.n = roots, leaves, n   # roots[k]: C_k of the batch; leaves[k] = (leaf of half a, of half b)
-
-    def finish(self):
-        roots, grads = [], []
-        for r, (la, lb) in zip(self.roots, self.leaves):
-            if la.grad is None and lb.grad is None:
-                continue
-            g = H.empty_nhwc(r.shape[0], r.shape[1], r.shape[2], r.shape[3], r.device)
-            for lo, leaf in ((0, la), (self.n, lb)):
-                if leaf.grad is not None:
-                    g[lo:lo + self.n].copy_(leaf.grad)
-                else:
-                    g[lo:lo + self.n].zero_()   # a half whose branch did not run (the teacher found no boxes)
-                leaf.grad = None
-            roots.append(r)
-            grads.append(g)
-        if roots:
-            torch.autograd.backward(roots, grads)
-
-
-def _leaf(t, lo, hi):
-    """images lo..hi of a body output as a LEAF of its own graph (planes / statistics of the slice go along)"""
-    v = fused.batch_slice(t, lo, hi)
-    d = v.detach()
-    for a in ("_mmt_planes", "_mmt_amax"):
-        x = getattr(v, a, None)
-        if x is not None:
-            setattr(d, a, (x[0], d._version))
-    return d.requires_grad_(t.requires_grad)
-
-
-def forward_pair(backbone, xa, xb, merged_body=False):
+def forward_pair(backbone, xa, xb):
     """backbone(xa), backbone(xb) for two equally shaped batches that need SEPARATE autograd graphs (the labeled and the
     unlabeled student pass of a mean-teacher step: the supervised backward runs before the consistency branch exists) with
     ONE set of forward launches on the concatenated batch: N = 4 instead of 2 x N = 2 fills the chip better on the few-tile
@@ -233,25 +195,11 @@ def forward_pair(backbone, xa, xb, merged_body=False):
         bl = [getattr(fpn, nm).bias for nm in fpn.layer_blocks]
         inner_cat, outs_cat = fused.fpn_forward([H.nhwc(c) for c in cs_cat], wi, bi_, wl, bl, getattr(fpn, "out_planes", True))
     res = []
-    full, handle = None, None
-    if merged_body:   # one chain of body nodes over the whole batch; the halves get detached slices of its outputs
-        full, x = [], None
-        for i, name in enumerate(body.stages, 1):
-            if i < body.freeze_at:
-                x = frozen[i - 1]
-            else:
-                for bi, blk in enumerate(getattr(body, name)):
-                    x = blk(x, pre=raw[(name, bi)])
-                _stage_hook(body, name, x)
-            full.append(x)
-        handle = MergedBody([t for t in full if t.requires_grad], [], n)
     for lo, hi in halves:
         outs = []
         x = None
         for i, name in enumerate(body.stages, 1):
-            if merged_body:
-                x = _leaf(full[i - 1], lo, hi)
-            elif i < body.freeze_at:
+            if i < body.freeze_at:
                 x = fused.batch_slice(frozen[i - 1], lo, hi)
             else:
                 for bi, blk in enumerate(getattr(body, name)):
@@ -278,11 +226,6 @@ def forward_pair(backbone, xa, xb, merged_body=False):
         if fpn.top_blocks is not None:
             pyr.extend(fpn.top_blocks(pyr[-1]))
         res.append(tuple(pyr))
-        if merged_body:
-            handle.leaves.append([o for o, t in zip(outs, full) if t.requires_grad])
-    if merged_body:
-        handle.leaves = list(zip(*handle.leaves))   # per level: (leaf of half a, leaf of half b)
-        return res[0], res[1], handle
     return res[0], res[1]
 
 

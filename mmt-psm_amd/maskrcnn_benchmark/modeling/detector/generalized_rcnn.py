@@ -44,10 +44,8 @@ class GeneralizedRCNN(nn.Module):
 
     # ---- test instrumentation: replay of recorded random decisions (sampler index sets, dropout masks); see utils/replay.py
     def run_backbone(self, x, slot=0):
-        """backbone(x); as a captured hipGraph when the engine enabled that (engine/graphs.py: `self.graphs`), `slot`
-        telling apart the passes of one step that are alive at the same time"""
-        g = getattr(self, "graphs", None)
-        return g(x, slot) if g is not None else tuple(self.backbone(x))
+        """backbone(x) as a tuple (`slot`: which of the passes of one step, kept for the engine's call sites)"""
+        return tuple(self.backbone(x))
 
     def set_replay(self, replay):
         self._replay = replay

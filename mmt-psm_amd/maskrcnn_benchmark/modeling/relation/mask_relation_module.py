@@ -6,8 +6,9 @@ max-pooled 14x14) is concatenated to the 256-channel ROI feature, pushed through
 mixed across instances by the cross-instance channel attention CIAM, then deconv(16) + 1x1(3) give the second
 mask logits.  Parameter names as in the reference (mask_heads.mask.mask_relation_module.*).  The convolutions run
 on the MFMA implicit GEMM (the 257-channel input is carried as 272 channels, weights zero-padded on the fly);
-CIAM is one launch forward, two backward (csrc/relation.hip: mmt_ciam_fwd / mmt_ciam_bwd); its tensor formulation (two
-batched library GEMMs) stays as the checker of tests/test_relation_kernels_gpu.py and for CPU tensors."""
+CIAM is one launch forward, two backward (csrc/relation.hip: mmt_ciam_fwd / mmt_ciam_bwd) and nothing else: CPU tensors and
+batches beyond the kernel's capacity raise; the formulation with two batched library GEMMs it is tested against lives in
+tests/tensor_formulations.py."""
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -16,7 +17,6 @@ from maskrcnn_benchmark import _hip as _H
 from maskrcnn_benchmark.layers import Conv2d, ConvTranspose2d, fused
 from maskrcnn_benchmark.structures.boxlist_ops import cat_boxlist
 
-_TENSOR_PATH = __import__("os").environ.get("MMT_IRNET_TENSOR", "0") == "1"   # A/B switch: library-GEMM attention
 
 
 class RoiAlignMaskFeatureExtractor(nn.Module):
@@ -60,23 +60,15 @@ class CIAM_Module(nn.Module):
         with the cross-group entries masked out (exp(-inf) = 0 exactly: the same softmax over the same values), so that no
         group size ever has to reach the host."""
         n, C, Hh, Ww = x.size()
-        if (x.is_cuda and group is not None and not getattr(self, "tensor_path", _TENSOR_PATH) and 0 < n <= _H.CIAM_MAX_N and C <= 16
-                and 4 * (C * Hh * Ww + (C + 1) * n) <= 65536):   # (the kernel's LDS: the instance's feature + its energy rows)
-            # one forward launch, two backward launches for all groups of the batch (csrc/relation.hip); `group` is sorted by
-            # the caller (forward_batch orders the instances by (image, class)): equal ids are contiguous
-            return fused.CIAMFn.apply(x, group, self.gamma)
-        cw = x.permute(1, 0, 2, 3).reshape(C, n, -1)
-        energy = torch.bmm(cw, cw.permute(0, 2, 1))
-        if group is not None:
-            same = group[:, None] == group[None, :]
-            energy = torch.where(same[None], energy, torch.full_like(energy, float("-inf")))
-        ne = torch.max(energy, -1, keepdim=True)[0] - energy
-        m = torch.mean(ne, 0)
-        if group is not None:
-            m = torch.where(same, m, torch.full_like(m, float("-inf")))
-        att = F.softmax(m, dim=-1)
-        out = torch.mm(att, x.reshape(n, -1)).view(n, C, Hh, Ww)
-        return self.gamma * out + x
+        if group is None:
+            group = torch.zeros((n,), dtype=torch.int64, device=x.device)     # one group: the reference's per-slice call
+        if not (x.is_cuda and 0 < n <= _H.CIAM_MAX_N and C <= 16 and 4 * (C * Hh * Ww + (C + 1) * n) <= 65536):
+            # (the kernel's LDS: the instance's feature + its energy rows)
+            raise RuntimeError("CIAM: GPU tensors, 1..%d instances per batch, <= 16 channels (csrc/relation.hip is the only "
+                               "implementation)" % _H.CIAM_MAX_N)
+        # one forward launch, two backward launches for all groups of the batch (csrc/relation.hip); `group` is sorted by
+        # the caller (forward_batch orders the instances by (image, class)): equal ids are contiguous
+        return fused.CIAMFn.apply(x, group, self.gamma)
 
 
 class MaskRelationRefineNet(nn.Module):

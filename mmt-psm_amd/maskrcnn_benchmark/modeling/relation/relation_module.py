@@ -10,9 +10,11 @@ USE_IOU False, CLASS_AGNOSTIC False, CLS_WISE_RELATION False, MERGE_METHOD 0.
 
 Execution: the Linear layers run on the MFMA GEMM (layers.Linear); the attention itself (<= 128 boxes per class: scores,
 top-40 softmax, mix, with the 16-group 1x1 conv folded into the value projection) is one launch forward and two backward
-(csrc/relation.hip, layers/fused.py::RelationAttentionFn); its formulation with batched library GEMMs (torch.bmm) stays
-for CPU tensors and as the A/B alternative MMT_IRNET_TENSOR=1; the numpy label preparation of the reference
-(relation_module.py:323-391, a D2H copy + host loops per class) is one launch per image (mmt_relation_reg_labels).
+(csrc/relation.hip, layers/fused.py::RelationAttentionFn); the numpy label preparation of the reference
+(relation_module.py:323-391, a D2H copy + host loops per class) is one launch per image (mmt_relation_reg_labels), the
+geometric embedding one launch (mmt_position_embedding).  These kernels are the only implementation in the package: a shape
+beyond their capacity (more than 128 ranked boxes per class) or a CPU tensor RAISES; the formulations with library tensor
+calls they are tested against live in tests/tensor_formulations.py.
 """
 import math
 
@@ -28,7 +30,6 @@ from maskrcnn_benchmark.structures.boxlist_ops import cat_boxlist
 
 
 _RANK_EMB = {}
-_TENSOR_PATH = __import__("os").environ.get("MMT_IRNET_TENSOR", "0") == "1"   # A/B switch: library-GEMM attention
 
 
 def extract_rank_embedding(rank_dim, feat_dim, wave_length=1000, device="cpu"):
@@ -51,36 +52,23 @@ def _rank_embedding(rank_dim, feat_dim, wave_length, device):
 _POS_FREQ = {}
 
 
-def extract_multi_position_matrix(boxes, iou, dim_g, wave_len, clswise=False, tensor_path=False):
+def extract_multi_position_matrix(boxes, iou, dim_g, wave_len, clswise=False):
+    """relation_module.py:393-431: boxes (n, C, 4) -> (C, n, n, dim_g), one launch (mmt_position_embedding)"""
     if iou is not None or clswise:
         raise NotImplementedError("USE_IOU / CLS_WISE_RELATION are off in the shipped configuration")
-    if boxes.is_cuda and not boxes.requires_grad and not tensor_path and dim_g % 8 == 0:
-        # one launch (mmt_position_embedding) instead of the ~30 elementwise launches below; same fp32 expressions
-        from maskrcnn_benchmark import _hip as H
-        key = (int(dim_g), wave_len, boxes.device)
-        freq = _POS_FREQ.get(key)
-        if freq is None:
-            feat_range = torch.arange(dim_g / 8, device=boxes.device)
-            freq = _POS_FREQ[key] = (1. / (torch.pow(wave_len, feat_range / (dim_g / 8)))).float().contiguous()
-        return H.position_embedding(boxes, dim_g, freq)
-    boxes = boxes.permute(1, 0, 2)
-    x_min, y_min, x_max, y_max = torch.chunk(boxes, 4, dim=2)
-    cx, cy = (x_min + x_max) * 0.5, (y_min + y_max) * 0.5
-    w, h = (x_max - x_min) + 1., (y_max - y_min) + 1.
-    dx = torch.log(torch.clamp(torch.abs((cx - cx.permute(0, 2, 1)) / w), min=1e-3))
-    dy = torch.log(torch.clamp(torch.abs((cy - cy.permute(0, 2, 1)) / h), min=1e-3))
-    dw = torch.log(w / w.permute(0, 2, 1))
-    dh = torch.log(h / h.permute(0, 2, 1))
-    size = dh.size()
-    pm = torch.stack((dx.view(size), dy.view(size), dw.view(size), dh.view(size)), -1)
-    feat_range = torch.arange(dim_g / 8, device=boxes.device)
-    dim_mat = 1. / (torch.pow(wave_len, feat_range / (dim_g / 8)))
-    mul = (100. * pm[..., None] * dim_mat.view(1, 1, 1, 1, -1)).view(size[0], size[1], size[2], -1)
-    return torch.cat((torch.sin(mul), torch.cos(mul)), -1)
+    if not boxes.is_cuda or boxes.requires_grad or dim_g % 8:
+        raise RuntimeError("extract_multi_position_matrix: detached GPU boxes and dim_g % 8 == 0 (the HIP kernel is the only path)")
+    from maskrcnn_benchmark import _hip as H
+    key = (int(dim_g), wave_len, boxes.device)
+    freq = _POS_FREQ.get(key)
+    if freq is None:
+        feat_range = torch.arange(dim_g / 8, device=boxes.device)
+        freq = _POS_FREQ[key] = (1. / (torch.pow(wave_len, feat_range / (dim_g / 8)))).float().contiguous()
+    return H.position_embedding(boxes, dim_g, freq)
 
 
 class _GroupedPointwise(nn.Module):
-    """nn.Conv2d(in, out, 1, groups=g) of RelationModule.conv1 (parameter shapes kept) as g small GEMMs"""
+    """the parameters of nn.Conv2d(in, out, 1, groups=g) of RelationModule.conv1 (names and shapes kept for checkpoints)"""
 
     def __init__(self, in_ch, out_ch, groups):
         super().__init__()
@@ -89,13 +77,7 @@ class _GroupedPointwise(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_ch))
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
 
-    def forward(self, x):  # x (1, in, N, M) -> (1, out, N, M)
-        g = self.groups
-        _, cin, n, m = x.shape
-        o = self.weight.shape[0]
-        xw = x.view(g, cin // g, n * m)
-        y = torch.bmm(self.weight.reshape(g, o // g, cin // g), xw) + self.bias.view(g, o // g, 1)
-        return y.view(1, o, n, m)
+    # (no forward: the grouped convolution is folded into the value projection of the attention kernel, see RelationModule)
 
 
 class RelationModule(nn.Module):
@@ -116,38 +98,17 @@ class RelationModule(nn.Module):
         f_a = f_a.permute(1, 0, 2)
         fr = f_a.contiguous().view(N * ncls, feat_dim)
         dv = self.dim[2] // g
-        if (f_a.is_cuda and not getattr(self, "tensor_path", _TENSOR_PATH) and self.dim[2] == feat_dim and self.dim[0] == self.dim[1]
+        if not (f_a.is_cuda and self.dim[2] == feat_dim and self.dim[0] == self.dim[1]
                 and _H.relation_attention_fits(N, g, self.dim_group[0], dv)):
-            # one launch each way (csrc/relation.hip).  conv1 (16 groups of feat_dim -> dim[2] / 16) is applied to the
-            # features BEFORE the attention mixes them -- sum_m w[n, m] (W_g f[m]) instead of W_g (sum_m w[n, m] f[m]): the
-            # same bilinear form -- so it is one plain Linear over the (class, box) rows and the head outputs are dv wide
-            w_g = self.WG(position_embedding.reshape(-1, self.fc_dim[0]).contiguous(), relu=True)     # (C N N, 16), (c, n, m) rows
-            v = _fused.linear(fr, self.conv1.weight.view(self.dim[2], feat_dim))
-            return _fused.RelationAttentionFn.apply(self.WQ(fr), self.WK(fr), w_g, v, self.conv1.bias, ncls, N, g,
-                                                    min(N, self.topk), 1.0 / math.sqrt(float(self.dim_group[1])))
-        w_g = F.relu(self.WG(position_embedding.reshape(-1, self.fc_dim[0]).contiguous()))
-        w_k = self.WK(fr).view(-1, N, g, self.dim_group[1]).permute(0, 2, 3, 1).contiguous().view(-1, self.dim_group[1], N)
-        w_q = self.WQ(fr).view(-1, N, g, self.dim_group[0]).transpose(1, 2).contiguous().view(-1, N, self.dim_group[0])
-        aff = (1.0 / math.sqrt(float(self.dim_group[1]))) * torch.bmm(w_q, w_k)
-        w_g = w_g.view(-1, N, N, self.fc_dim[1]).permute(0, 3, 1, 2).contiguous().view(-1, N, N)
-        w_mn = torch.log(torch.clamp(w_g, min=1e-6)) + aff
-        k = min(N, self.topk)
-        tv, ti = torch.topk(w_mn, k, dim=2, largest=True, sorted=True)
-        w = torch.zeros_like(w_mn).scatter(2, ti, F.softmax(tv, dim=2)).view(ncls, -1, N)
-        out = torch.bmm(w, f_a).view(ncls, self.fc_dim[1], N, feat_dim).permute(1, 3, 2, 0).contiguous()
-        out = self.conv1(out.view(1, self.fc_dim[1] * feat_dim, N, -1))
-        return out.squeeze(0).permute(1, 2, 0)
-
-
-def _first_argmax(x, dim):
-    """numpy.argmax semantics (FIRST maximal index) on the device, whatever the reduction order"""
-    mx = x.max(dim=dim, keepdim=True)[0]
-    n = x.shape[dim]
-    shape = [1] * x.dim()
-    shape[dim] = n
-    ar = torch.arange(n, device=x.device).view(shape).expand_as(x)
-    # (all-NaN slices have no maximal element; clamp so that a diverged model fails with NaN losses, not an index fault)
-    return torch.where(x == mx, ar, torch.full_like(ar, n)).min(dim=dim)[0].clamp(max=n - 1)
+            raise RuntimeError("RelationModule: GPU tensors, at most %d ranked boxes per class, head width <= 128 / 16 -- the "
+                               "attention kernel (csrc/relation.hip) is the only implementation" % _H.RELATION_ATTENTION_MAX_N)
+        # one launch each way (csrc/relation.hip).  conv1 (16 groups of feat_dim -> dim[2] / 16) is applied to the
+        # features BEFORE the attention mixes them -- sum_m w[n, m] (W_g f[m]) instead of W_g (sum_m w[n, m] f[m]): the
+        # same bilinear form -- so it is one plain Linear over the (class, box) rows and the head outputs are dv wide
+        w_g = self.WG(position_embedding.reshape(-1, self.fc_dim[0]).contiguous(), relu=True)     # (C N N, 16), (c, n, m) rows
+        v = _fused.linear(fr, self.conv1.weight.view(self.dim[2], feat_dim))
+        return _fused.RelationAttentionFn.apply(self.WQ(fr), self.WK(fr), w_g, v, self.conv1.bias, ncls, N, g,
+                                                min(N, self.topk), 1.0 / math.sqrt(float(self.dim_group[1])))
 
 
 class DuplicationRemovalNetwork(nn.Module):
@@ -180,54 +141,21 @@ class DuplicationRemovalNetwork(nn.Module):
 
     # ---- label preparation on the device (relation_module.py:323-391)
     def prepare_reg_label(self, sorted_boxes, sorted_score, targets):
-        """The reference copies to the host and loops over classes with numpy (`eye[argmax]`, `np.intersect1d`).  Here every
-        class works on ALL ground-truth boxes of the image with the other classes' columns masked out, so no shape depends
-        on how many boxes a class has and nothing is read back; numpy's first-index tie rules are kept (`_first_argmax`,
-        first-gt-wins scatter)."""
+        """The reference copies to the host and loops over classes with numpy (`eye[argmax]`, `np.intersect1d`); here one launch
+        per image (`mmt_relation_reg_labels`: every class against ALL ground-truth boxes of the image with the other classes'
+        columns masked out, numpy's first-index tie rules kept), nothing read back.  The tensor formulation it is tested
+        against: tests/tensor_formulations.py::relation_reg_labels."""
         labels = targets.get_field("labels")
         tb = targets.bbox
         n, G = sorted_boxes.shape[0], tb.shape[0]
-        dev = sorted_boxes.device
         if G == 0:
-            return torch.zeros((n, self.fg_class, len(self.target_thresh)), device=dev)
-        if sorted_boxes.is_cuda and not getattr(self, "tensor_labels", False):
-            from maskrcnn_benchmark import _hip as H
-            out = H.relation_reg_labels(sorted_boxes, sorted_score, tb, labels, self.target_thresh)   # one launch per image
-            if out is not None:
-                return out
-        a2 = (tb[:, 2] - tb[:, 0] + 1) * (tb[:, 3] - tb[:, 1] + 1)
-        ar_g = torch.arange(G, device=dev)
-        per_cls = []
-        for i in range(self.fg_class):
-            cm = labels == (i + 1)                               # [G] this class's ground truth
-            score = sorted_score[:, i:i + 1]
-            boxes = sorted_boxes[:, i, :]
-            a1 = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
-            lt = torch.max(boxes[:, None, :2], tb[:, :2])
-            rb = torch.min(boxes[:, None, 2:], tb[:, 2:])
-            wh = (rb - lt + 1).clamp(min=0)
-            inter = wh[:, :, 0] * wh[:, :, 1]
-            iou = inter / (a1[:, None] + a2 - inter)
-            iou_c = torch.where(cm[None, :], iou, torch.full_like(iou, -1.0))
-            best_gt = F.one_hot(_first_argmax(iou_c, 1), G).to(iou.dtype)  # eye[argmax(iou, axis=1)] among this class
-            outs = []
-            for th in self.target_thresh:
-                mask = ((iou > th) & cm[None, :]).to(iou.dtype)
-                osc = score * mask * best_gt
-                oiou = iou * mask * best_gt
-                msi = _first_argmax(osc, 0)                       # best-scoring box of every gt   [G]
-                moi = oiou[msi, ar_g]                             # its IoU                        [G]
-                valid = mask.sum(1) > 0                            # boxes overlapping any gt of the class
-                # np.intersect1d(msi, valid, return_indices=True): for a box chosen by several gts the FIRST gt wins;
-                # other classes' columns scatter into a spill slot
-                first = torch.full((n + 1,), G, dtype=torch.long, device=dev)
-                first = first.scatter_reduce(0, torch.where(cm, msi, torch.full_like(msi, n)), ar_g, reduce="amin",
-                                             include_self=True)[:n]
-                take = valid & (first < G)
-                reg = torch.where(take, moi[first.clamp(max=G - 1)], torch.zeros((), device=dev))
-                outs.append(reg)
-            per_cls.append(torch.stack(outs, -1))
-        return torch.stack(per_cls, 1).float()
+            return torch.zeros((n, self.fg_class, len(self.target_thresh)), device=sorted_boxes.device)
+        from maskrcnn_benchmark import _hip as H
+        out = H.relation_reg_labels(sorted_boxes, sorted_score, tb, labels, self.target_thresh)
+        if out is None:
+            raise RuntimeError("relation NMS labels: at most 128 ranked boxes, 256 ground-truth boxes and 4 thresholds per image "
+                               "(mmt_relation_reg_labels is the only implementation)")
+        return out
 
     def filter_results(self, boxes, targets, scores, image_shape, num_classes, obj):
         """rank the boxes of one image per class (relation_module.py:503-587)"""

@@ -23,7 +23,6 @@ from maskrcnn_benchmark.structures.boxlist_ops import boxlist_iou
 from maskrcnn_benchmark.utils.miscellaneous import batch_boxlist_hflip
 
 
-_TENSOR_GLUE = __import__("os").environ.get("MMT_TENSOR_GLUE", "0") == "1"   # A/B switch: the tensor formulations of the losses / matching
 
 
 class MaskRCNNFPNAdaptor(nn.Module):
@@ -166,15 +165,8 @@ class FastRCNNLossComputation(object):
         props = self._proposals
         labels = torch.cat([p.get_field("labels") for p in props], 0)
         regt = torch.cat([p.get_field("regression_targets") for p in props], 0)
-        if class_logits.is_cuda and not getattr(self, "tensor_loss", _TENSOR_GLUE):
-            return fused.BoxLossFn.apply(class_logits, box_regression, labels, regt)   # one launch (csrc/losses.hip: mmt_box_loss)
-        cls = F.cross_entropy(class_logits, labels)
-        posf = (labels > 0).to(torch.float32)
-        idx = (4 * labels.clamp(min=0))[:, None] + torch.arange(4, device=labels.device)[None, :]
-        sel = torch.gather(box_regression, 1, idx)
-        d = torch.abs(sel - regt)
-        sl1 = torch.where(d < 1.0, 0.5 * d * d, d - 0.5)  # smooth_l1(beta=1, sum)
-        return cls, (sl1 * posf[:, None]).sum() / labels.numel()
+        # one launch (csrc/losses.hip: mmt_box_loss); its tensor formulation is the checker in tests/test_hip_kernels.py
+        return fused.BoxLossFn.apply(class_logits, box_regression, labels, regt)
 
     def evaluatePSM(self, class_logits, class_logits_t, proposals):
         """box_head/loss.py:164-237,267-287: hard-negative mining by teacher disagreement + sharpened soft CE"""
@@ -230,7 +222,6 @@ class PostProcessor(nn.Module):
     def __init__(self, score_thresh=0.05, nms=0.5, detections_per_img=100, box_coder=None, cfg=None):
         super().__init__()
         self.score_thresh, self.nms, self.detections_per_img = score_thresh, nms, detections_per_img
-        self.tensor_path = os.environ.get("MMT_DET_TENSOR", "0") == "1"   # the tensor formulation (tests, A/B runs)
         self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(10., 10., 5., 5.))
 
     def forward(self, x, boxes):
@@ -246,61 +237,20 @@ class PostProcessor(nn.Module):
         dec = H.box_decode(box_regression.reshape(sum(per), -1), cat, self.box_coder.weights, self.box_coder.bbox_xform_clip,
                            dev_const(offs_rows, torch.int32, dev),
                            dev_const([[b.size[0] - 1, b.size[1] - 1] for b in boxes], torch.float32, dev))
-        nc = prob.shape[1]
-        if prob.is_cuda and not getattr(self, "tensor_path", False):
-            # threshold / stable sort / NMS / ascending-row order / DETECTIONS_PER_IMG cut of every (image, class) on the
-            # device (mmt_det_postprocess: five launches), ONE read-back (the detection counts) for the BoxList sizes
-            out = H.det_postprocess(prob, dec, per, self.score_thresh, self.nms, self.detections_per_img)
-            if out is not None:
-                ob, os_, ol, oc = out
-                results = []
-                for i, (b, n) in enumerate(zip(boxes, oc.tolist())):
-                    r = BoxList(ob[i, :n], b.size, "xyxy")
-                    r.add_field("scores", os_[i, :n])
-                    r.add_field("objectness", os_[i, :n])
-                    r.add_field("labels", ol[i, :n])
-                    results.append(r)
-                return results
-        segs, metas = [], []
-        for pr, bx, b in zip(prob.split(per, 0), dec.split(per, 0), boxes):
-            for j in range(1, nc):
-                sc = pr[:, j]
-                masked = torch.where(sc > self.score_thresh, sc, torch.full_like(sc, -1.0))
-                ss, order = torch.sort(masked, descending=True, stable=True)
-                segs.append((bx[:, j * 4:(j + 1) * 4][order], ss, order))
-                metas.append((b.size, j))
-        n_valid = torch.stack([(s[1] >= 0).sum() for s in segs]).tolist()  # host sync (as the reference's nonzero)
-        bl, offs = [], [0]
-        for s, nv in zip(segs, n_valid):
-            bl.append(s[0][:nv])
-            offs.append(offs[-1] + nv)
-        kmax = max(max(n_valid), 1)
-        keep, cnt = H.nms_batched(torch.cat(bl, 0), torch.tensor(offs, dtype=torch.int32, device=dev), kmax, self.nms)  # data-dependent
-        cnts = cnt.tolist()
-        results, si = [], 0
-        for b in boxes:
-            parts = []
-            for j in range(1, nc):
-                bxs, ss, order = segs[si]
-                kp = keep[si, :cnts[si]].long()
-                kp = torch.sort(order[kp])[0]  # `_C.nms` returns ascending ORIGINAL indices (nms_cpu.cpp:64)
-                inv = torch.empty_like(order)
-                inv[order] = torch.arange(order.numel(), device=dev)
-                sel = inv[kp]
-                parts.append((bxs[sel], ss[sel], torch.full((len(kp),), j, dtype=torch.int64, device=dev)))
-                si += 1
-            bb = torch.cat([p[0] for p in parts], 0)
-            sc = torch.cat([p[1] for p in parts], 0)
-            lb = torch.cat([p[2] for p in parts], 0)
-            n = bb.shape[0]
-            if n > self.detections_per_img > 0:
-                thr = torch.kthvalue(sc, n - self.detections_per_img + 1)[0]
-                k = torch.nonzero(sc >= thr).squeeze(1)
-                bb, sc, lb = bb[k], sc[k], lb[k]
-            r = BoxList(bb, b.size, "xyxy")
-            r.add_field("scores", sc)
-            r.add_field("objectness", sc)
-            r.add_field("labels", lb)
+        # threshold / stable sort / NMS / ascending-row order / DETECTIONS_PER_IMG cut of every (image, class) on the
+        # device (mmt_det_postprocess: five launches), ONE read-back (the detection counts) for the BoxList sizes.  The tensor
+        # formulation it replaced is its checker (tests/tensor_formulations.py::det_filter_results)
+        out = H.det_postprocess(prob, dec, per, self.score_thresh, self.nms, self.detections_per_img)
+        if out is None:
+            raise RuntimeError("PostProcessor: at most 2048 proposals per image and 64 classes (mmt_det_postprocess is the only "
+                               "implementation)")
+        ob, os_, ol, oc = out
+        results = []
+        for i, (b, n) in enumerate(zip(boxes, oc.tolist())):
+            r = BoxList(ob[i, :n], b.size, "xyxy")
+            r.add_field("scores", os_[i, :n])
+            r.add_field("objectness", os_[i, :n])
+            r.add_field("labels", ol[i, :n])
             results.append(r)
         return results
 

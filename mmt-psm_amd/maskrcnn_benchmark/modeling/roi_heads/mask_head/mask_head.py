@@ -19,9 +19,6 @@ from maskrcnn_benchmark.utils.miscellaneous import dev_ints
 from maskrcnn_benchmark.modeling.relation.mask_relation_module import MaskRelationRefineNet
 
 
-_TENSOR_GLUE = __import__("os").environ.get("MMT_TENSOR_GLUE", "0") == "1"   # A/B switch: the tensor formulations of the losses / matching
-
-
 def keep_only_positive_boxes(boxes):
     pos_boxes, pos_inds = [], []
     for b in boxes:
@@ -82,7 +79,7 @@ class MaskRCNNLossComputation(object):
         labels, mts = [], []
         pm = self.proposal_matcher
         dev = proposals[0].bbox.device
-        fused_match = (dev.type == "cuda" and not _TENSOR_GLUE and pm.high_threshold == pm.low_threshold and not pm.allow_low_quality_matches
+        fused_match = (dev.type == "cuda" and pm.high_threshold == pm.low_threshold and not pm.allow_low_quality_matches
                        and all(len(p) > 0 and len(t) > 0 for p, t in zip(proposals, targets)))
         if fused_match:
             # IoU + Matcher + label lookup of ALL images in one launch (`mmt_match_targets`, the box head's call): with equal

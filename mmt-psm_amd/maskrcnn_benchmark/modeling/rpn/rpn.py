@@ -28,9 +28,6 @@ from maskrcnn_benchmark.structures.boxlist_ops import box_iou_tensor
 from .anchor_generator import make_anchor_generator
 
 
-_TENSOR_GLUE = __import__("os").environ.get("MMT_TENSOR_GLUE", "0") == "1"   # A/B switch: the tensor formulations of the losses / matching
-
-
 class RPNHead(nn.Module):
     def __init__(self, cfg, in_channels, num_anchors):
         super().__init__()
@@ -61,9 +58,6 @@ def _flat(obj, reg):
     """(N,A,H,W),(N,4A,H,W) NHWC-dense views -> (N, HWA), (N, HWA, 4) without copies when possible"""
     N, A, Hh, Ww = obj.shape
     return obj.permute(0, 2, 3, 1).reshape(N, -1), reg.permute(0, 2, 3, 1).reshape(N, -1, 4)
-
-
-_EARLY_WAIT = os.environ.get("MMT_RPN_EARLY_WAIT", "0") == "1"
 
 
 class RPNPostProcessor(nn.Module):
@@ -191,8 +185,6 @@ class RPNPostProcessor(nn.Module):
         pin[:cnt.numel()].copy_(cnt, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        if _EARLY_WAIT:  # A/B switch: wait first, enqueue afterwards (the old order)
-            ev.synchronize()
         if between is not None:
             self.between_result = between()
         ev.synchronize()
@@ -275,20 +267,9 @@ class RPNLossComputation(object):
         obj = torch.cat(of, 1).reshape(-1)
         reg = torch.cat(rf, 1).reshape(-1, 4)
         labels, regt = torch.cat(labels, 0), torch.cat(regt, 0)
-        if obj.is_cuda and not getattr(self, "tensor_loss", _TENSOR_GLUE):
-            obj_loss, box_loss = fused.RPNLossFn.apply(obj, reg, labels, regt, pos, neg, 1.0 / 9)   # two launches (csrc/losses.hip)
-            return obj_loss, box_loss
-        samp = pos | neg
-        n_samp = samp.sum().clamp(min=1).to(torch.float32)
-        posf = pos.to(torch.float32)
-        # masked sums instead of boolean gathers: same values, no device->host sync (rpn/loss.py:183-194)
-        d = torch.abs(reg - regt)
-        beta = 1.0 / 9
-        sl1 = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
-        box_loss = (sl1 * posf[:, None]).sum() / n_samp
-        bce = F.binary_cross_entropy_with_logits(obj, labels.clamp(min=0), reduction="none")
-        obj_loss = (bce * samp.to(torch.float32)).sum() / n_samp
-        return obj_loss, box_loss
+        # two launches (csrc/losses.hip: mmt_rpn_loss); the tensor formulation of rpn/loss.py:183-194 is its checker in
+        # tests/test_hip_kernels.py
+        return fused.RPNLossFn.apply(obj, reg, labels, regt, pos, neg, 1.0 / 9)
 
 
 def make_rpn_loss_evaluator(cfg, box_coder):

@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-MMT_BENCH_NO_FP32_LEG=1 timeout 600 python bench.py --no-cpu-baseline --steps 50 --warmup 10 --profile-steps 0 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print(d['ms_per_step'], d['median_ms_per_step'], d['p10_p90_ms_per_step'])"
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/gputest_a.log 2>&1; echo rc=$? >> gpurun_out/gputest_a.log
+python bench.py --steps 40 --warmup 10 --no-cpu-baseline > gpurun_out/bench_a.log 2>&1

@@ -18,20 +18,22 @@ for i in range(STEPS):
     il, tg, ul = batch(); trainer.train_step(1410 + i, il, tg, ul)
 torch.cuda.synchronize()
 rec, H.PROFILE = H.PROFILE, None
-agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
 for r in rec:
     fl, e0, e1, key = r[0], r[1], r[2], r[3]
     a = agg[key]
     a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] = fl
+    a[3] += r[6] if len(r) > 6 else 0.0     # bytes of the fused epilogue's operands (residual, ReLU mask, dropout multiplier)
 NPROD = 3 if (H.F16X2 and H.get_conv_precision() == 3) else bench.PRODUCTS[H.get_conv_precision()]   # matrix products per multiply
 rows = []
-for key, (c, ms, fl) in agg.items():
+for key, (c, ms, fl, eb) in agg.items():
     kind, N, Hh, W, Cin, Cout, KH, stride, ostride = key
     Ho, Wo = (Hh + stride - 1) // stride, (W + stride - 1) // stride
     if kind == "wgrad":
         byts = 4.0 * N * (Hh * W * Cin + Ho * Wo * Cout) + 4.0 * Cin * Cout * KH * KH
     else:
         byts = 4.0 * N * (Hh * W * Cin + Ho * Wo * Cout * (ostride if ostride else 1)) + 6.0 * Cin * Cout * KH * KH
+    byts += eb / c
     t_m, t_h = fl / (2500e12 / NPROD) * 1e3, byts / 5e12 * 1e3
     per = ms / c
     rows.append((c / STEPS * (per - max(t_m, t_h)), key, c / STEPS, per, fl / per / 1e9, t_m, t_h))

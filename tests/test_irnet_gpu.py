@@ -183,11 +183,14 @@ def test_relation_label_kernel_matches_tensor_formulation(setup):
                 lab[1] = lab[0]
         t = BoxList(gt.cuda(), (160, 160), "xyxy")
         t.add_field("labels", lab.cuda())
-        net.tensor_labels = True
-        ref = net.prepare_reg_label(boxes.cuda(), score.cuda(), t)
-        net.tensor_labels = False
+        import tensor_formulations as tf
+        ref = tf.relation_reg_labels(boxes.cuda(), score.cuda(), t.bbox, t.get_field("labels"), net.fg_class, net.target_thresh)
         own = net.prepare_reg_label(boxes.cuda(), score.cuda(), t)
         assert own.shape == ref.shape and torch.equal(own, ref), case
+        # ... and against the oracle's numpy restatement of relation_module.py:323-391 itself (CPU; same fp32 IoUs)
+        from oracle import irnet as oi, model as om
+        want = torch.from_numpy(oi.prepare_reg_label(boxes, score, om.Boxes(gt, (160, 160), {"labels": lab}), net.target_thresh))
+        assert own.shape == want.shape and (own.cpu() - want).abs().max().item() <= 1e-6, case
         if G:
             assert (ref > 0).any()
 
@@ -207,7 +210,8 @@ def test_position_embedding_kernel_matches_tensor_formulation(shape):
         boxes[3] = boxes[2]                     # identical boxes: zero centre distance
         boxes[7] = torch.cat([boxes[6, :, :2], boxes[6, :, :2] + wh[7]], 1)   # same corner, different size
     b = boxes.cuda()
-    ref = extract_multi_position_matrix(b, None, 64, 1000, tensor_path=True)
+    import tensor_formulations as tf
+    ref = tf.position_matrix(b, 64, 1000)
     own = extract_multi_position_matrix(b, None, 64, 1000)
     assert own.shape == ref.shape == (C, n, n, 64)
     assert (own - ref).abs().max().item() <= 1e-6

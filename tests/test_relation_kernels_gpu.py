@@ -54,12 +54,12 @@ def test_relation_attention_vs_oracle(N, C, topk):
         # so its reference magnitude is rounding noise: gradients are measured against at least 1e-2, they are O(1..100) here)
         _close(p.grad, sd["r." + k].grad.view_as(p.grad), 2e-4, "d " + k, floor=1e-2)
 
-    # the tensor formulation of the same module (the path CPU tensors take) agrees too
+    # the formulation with batched library GEMMs / top-k / scatter on the same parameters (tests/tensor_formulations.py) agrees too
+    import tensor_formulations as tf
     for p in mod.parameters():
         p.grad = None
-    mod.tensor_path = True
     fa_t = f_a.clone().requires_grad_(True)
-    out_t = mod(fa_t, pos)
+    out_t = tf.relation_attention(mod, fa_t, pos)
     _close(out, out_t, 2e-5, "kernel vs tensor formulation")
     out_t.backward(gout.float().cuda())
     _close(fa_g.grad, fa_t.grad, 2e-4, "d f_a, kernel vs tensor formulation")
@@ -115,10 +115,10 @@ def test_ciam_vs_oracle(sizes):
     _close(xg.grad, xo.grad, 2e-4, "d x")
     _close(mod.gamma.grad, go.grad.view(1), 2e-4, "d gamma")
 
+    import tensor_formulations as tf
     mod.gamma.grad = None
-    mod.tensor_path = True
     xt = x.clone().requires_grad_(True)
-    out_t = mod(xt, group)
+    out_t = tf.ciam(mod.gamma, xt, group)
     _close(out, out_t, 2e-5, "kernel vs tensor formulation")
     out_t.backward(gout.float().cuda())
     _close(xg.grad, xt.grad, 2e-4, "d x, kernel vs tensor formulation")
@@ -142,8 +142,8 @@ def test_ciam_dead_channel():
     gout = torch.randn(n, C, 14, 14, device="cuda")
     xg = x.clone().requires_grad_(True)
     mod(xg, group).backward(gout)
-    mod.tensor_path = True
+    import tensor_formulations as tf
     xt = x.clone().requires_grad_(True)
-    mod(xt, group).backward(gout)
+    tf.ciam(mod.gamma, xt, group).backward(gout)
     m = (x > 0).float()
     _close(xg.grad * m, xt.grad * m, 2e-4, "d x under the ReLU mask")

@@ -221,13 +221,22 @@ def test_det_postprocess_kernel(hip, case):
     pp = PostProcessor(thr, 0.5, D).cuda()
     x = (logits.cuda(), reg.cuda())
     got = pp(x, boxes)
-    pp.tensor_path = True
-    want = pp(x, boxes)
+    # the tensor formulation on the same softmax / decode (tests/tensor_formulations.py::det_filter_results)
+    from maskrcnn_benchmark import _hip as H
+    from maskrcnn_benchmark.utils.miscellaneous import dev_const
+    prob = torch.softmax(x[0], -1)
+    offs = [0]
+    for n in per:
+        offs.append(offs[-1] + n)
+    dec = H.box_decode(x[1].reshape(sum(per), -1), torch.cat([b.bbox for b in boxes], 0), pp.box_coder.weights, pp.box_coder.bbox_xform_clip,
+                       dev_const(offs, torch.int32, prob.device),
+                       dev_const([[b.size[0] - 1, b.size[1] - 1] for b in boxes], torch.float32, prob.device))
+    want = tf.det_filter_results(prob, dec, per, [b.size for b in boxes], thr, 0.5, D, H.nms_batched)
     assert len(got) == len(want) == len(per)
-    for a, b in zip(got, want):
-        assert a.bbox.shape == b.bbox.shape
-        assert torch.equal(a.bbox, b.bbox)
-        assert torch.equal(a.get_field("scores"), b.get_field("scores"))
-        assert torch.equal(a.get_field("labels"), b.get_field("labels"))
+    for a, (bb, sc, lb) in zip(got, want):
+        assert a.bbox.shape == bb.shape
+        assert torch.equal(a.bbox, bb)
+        assert torch.equal(a.get_field("scores"), sc)
+        assert torch.equal(a.get_field("labels"), lb)
     if D > 0 and not ties:
         assert all(len(a) <= D for a in got)

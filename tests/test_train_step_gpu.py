@@ -290,10 +290,6 @@ def test_pair_forward_equals_batched_forward_and_split_backward(small):
         _restore(trainer, snap)
         s_l, s_g, s_s, s_t = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
         _restore(trainer, snap)
-        # "pairm" (forward_pair(merged_body=True), an alternative schedule measured 1 ms slower): the body is back-propagated
-        # once for both halves at N = 4 from the concatenated C3..C5 gradients
-        m_l, m_g, m_s, m_t = _run_schedule(trainer, batch, 1400, True, "pairm", True, 11)
-        _restore(trainer, snap)
     finally:
         trainer.overlap_teacher, trainer.student_passes, trainer.early_sup_backward = keep
         for k, v in old.items():
@@ -307,50 +303,6 @@ def test_pair_forward_equals_batched_forward_and_split_backward(small):
     _close(p_g, s_g, 1e-4, "gradient, pair vs split")
     _close(p_s - snap["s"], s_s - snap["s"], 1e-4, "student update")
     _close(p_t - snap["t"], s_t - snap["t"], 5e-4, "teacher update")
-    for k in s_l:
-        assert m_l[k] == pytest.approx(s_l[k], rel=5e-6), k
-    _close(m_g, s_g, 1e-4, "gradient, merged body vs split")
-    _close(m_s - snap["s"], s_s - snap["s"], 1e-4, "student update, merged body")
-
-
-def test_graph_captured_backbone_equals_eager(small):
-    """engine/graphs.py: the three backbone passes replayed as captured hipGraphs (forward and backward) against the same
-    step launch by launch: same launches on the same data, so losses, the flat gradient and both updates agree up to the
-    order of the fp32 atomics (FPN bias sums, ROIAlign backward)"""
-    from maskrcnn_benchmark.engine.graphs import BackboneGraphs
-    _, trainer, batch = small
-    snap = _snapshot(trainer)
-    keep = trainer.use_graphs
-    try:
-        trainer.use_graphs = False
-        _run_schedule(trainer, batch, 1400, True, "split", True, 3)
-        _restore(trainer, snap)
-        e_l, e_g, e_s, e_t = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
-        _restore(trainer, snap)
-        trainer.use_graphs = True
-        trainer.student.graphs = BackboneGraphs(trainer.student, trainer.flat_s)
-        trainer.teacher.graphs = BackboneGraphs(trainer.teacher, None)
-        _run_schedule(trainer, batch, 1400, True, "split", True, 3)      # captures
-        _restore(trainer, snap)
-        g_l, g_g, g_s, g_t = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
-        _restore(trainer, snap)
-        # a second replay gives the same again (static buffers are fully rewritten)
-        h_l, h_g, _, _ = _run_schedule(trainer, batch, 1400, True, "split", True, 11)
-        _restore(trainer, snap)
-        n_graphs = len(trainer.student.graphs.table), len(trainer.teacher.graphs.table)
-    finally:
-        trainer.use_graphs = keep
-        trainer.student.graphs = trainer.teacher.graphs = None
-    assert n_graphs == (2, 1), n_graphs
-    assert "mt_classifier" in g_l and "mt_fg_loss" in g_l
-    for k in e_l:
-        assert g_l[k] == pytest.approx(e_l[k], rel=1e-6), k
-        assert h_l[k] == pytest.approx(e_l[k], rel=1e-6), k
-    _close(g_g, e_g, 1e-4, "gradient, graphs vs eager")
-    _close(h_g, e_g, 1e-4, "gradient, second replay")
-    _close(g_s - snap["s"], e_s - snap["s"], 1e-4, "student update")
-    _close(g_t - snap["t"], e_t - snap["t"], 1e-4, "teacher update")
-    assert (g_s != snap["s"]).any()
 
 
 def test_bench_schedule_equals_serial_160(small):
