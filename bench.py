@@ -374,6 +374,7 @@ def main():
         return dt, prof, losses, per_step
 
     mode = _hip.get_conv_precision()
+    trace_env = os.environ.get("MMT_DIST_TRACE") == "1"
     for i in range(args.warmup):
         step(i)
     skipped0 = trainer.skipped_pairs
@@ -385,8 +386,12 @@ def main():
         skipped = int(t.item())
     nxt = args.warmup + args.steps
     npf = max(1, min(args.profile_steps, args.steps))
+    if use_dist:   # the bracketed leg also records when each piece of the gradient went out and arrived (`dist_trace`):
+        os.environ["MMT_DIST_TRACE"] = "1"   # the trace synchronises per step, so it is off in the headline leg
     with ClockSampler(local) as clock:
         dtp, groups, _, _ = timed(nxt, npf, True)
+    if use_dist and not trace_env:
+        os.environ.pop("MMT_DIST_TRACE", None)
     nxt += npf
 
     def total(g):

@@ -458,6 +458,12 @@ int mmt_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, 
  * seg[img[d]] (int32 [N,IH,IW], zeroed by the caller) at every pixel above thresh. */
 int mmt_paste_masks(const float* logits, const int32_t* labels, const float* boxes /*[D,4]*/, const int32_t* img,
                     int D, int M, int NC, int IH, int IW, float thresh, int32_t* seg, void* stream);
+/* the evaluator's form of the same paste (Masker.forward_single_image, mask_head/inference.py:221-246, as
+ * data/datasets/evaluation/pap/pap_eval.py:107-109 calls it on predictions whose masks are still M x M): prob [D,M,M] = the
+ * PROBABILITIES of the predicted class (MaskPostProcessor's `mask` field), boxes [D,4] in the target image's frame;
+ * stack uint8 [D,IH,IW], zeroed by the caller, gets 1 wherever detection d's pasted probability exceeds thresh. */
+int mmt_paste_mask_stack(const float* prob, const float* boxes /*[D,4]*/, int D, int M, int IH, int IW, float thresh,
+                         uint8_t* stack, void* stream);
 
 /* polygon -> MxM mask targets (mask_head/loss.py:37-75, structures/segmentation_mask.py:96-133,
  * pycoco/maskApi.c:166-206 rleFrPoly + :53-74 union) for P positive ROIs.

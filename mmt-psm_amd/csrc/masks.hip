@@ -12,20 +12,24 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------ paste
+// STACK: the evaluator's form (mask_head/inference.py:209-246 as pap_eval.py:107-109 calls it): the input holds the
+// PROBABILITIES of the predicted class ((D, 1, M, M): MaskPostProcessor's `mask` field), and every detection gets its own
+// binary canvas stack[d] (bytes) instead of a vote in the integral map of its image.
+template <bool STACK>
 __global__ __launch_bounds__(256) void paste_kernel(const float* __restrict__ logits, const int* __restrict__ labels,
                                                     const float* __restrict__ boxes, const int* __restrict__ img,
                                                     int M, int NC, int IH, int IW, float thresh,
-                                                    int* __restrict__ seg) {
+                                                    int* __restrict__ seg, unsigned char* __restrict__ stack) {
   extern __shared__ float pm[];  // (M+2)^2 padded probabilities
   const int d = blockIdx.x;
   const int P = M + 2;
-  const int lab = labels[d];
+  const int lab = STACK ? 0 : labels[d];
   for (int i = threadIdx.x; i < P * P; i += 256) {
     const int y = i / P, x = i - y * P;
     float v = 0.f;
     if (y >= 1 && y <= M && x >= 1 && x <= M) {
       const float z = logits[(((long)d * M + (y - 1)) * M + (x - 1)) * NC + lab];
-      v = 1.f / (1.f + expf(-z));
+      v = STACK ? z : 1.f / (1.f + expf(-z));
     }
     pm[i] = v;
   }
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(256) void paste_kernel(const float* __restrict__ lo
   if (cw <= 0 || ch <= 0) return;
   // F.interpolate(bilinear, align_corners=False): src = (dst+0.5)*in/out - 0.5 clamped at 0
   const float sy = (float)P / (float)h, sx = (float)P / (float)w;
-  int* out = seg + (long)img[d] * IH * IW;
+  int* out = STACK ? nullptr : seg + (long)img[d] * IH * IW;
+  unsigned char* outb = STACK ? stack + (long)d * IH * IW : nullptr;
   for (int i = threadIdx.x; i < cw * ch; i += 256) {
     const int yy = cy0 + i / cw, xx = cx0 + i % cw;
     const int dy = yy - y0, dx = xx - x0;
@@ -56,7 +61,10 @@ __global__ __launch_bounds__(256) void paste_kernel(const float* __restrict__ lo
     const float ly1 = fy - (float)iy0, ly0 = 1.f - ly1, lx1 = fx - (float)ix0, lx0 = 1.f - lx1;
     const float v = ly0 * (lx0 * pm[iy0 * P + ix0] + lx1 * pm[iy0 * P + ix1]) +
                     ly1 * (lx0 * pm[iy1 * P + ix0] + lx1 * pm[iy1 * P + ix1]);
-    if (v > thresh) atomicAdd(out + (long)yy * IW + xx, 1);
+    if (v > thresh) {
+      if (STACK) outb[(long)yy * IW + xx] = 1;
+      else atomicAdd(out + (long)yy * IW + xx, 1);
+    }
   }
 }
 
@@ -64,8 +72,19 @@ extern "C" int mmt_paste_masks(const float* logits, const int32_t* labels, const
                                int D, int M, int NC, int IH, int IW, float thresh, int32_t* seg, void* stream) {
   if (D <= 0) return 0;
   const size_t lds = (size_t)(M + 2) * (M + 2) * sizeof(float);
-  hipLaunchKernelGGL(paste_kernel, dim3(D), dim3(256), lds, (hipStream_t)stream, logits, labels, boxes, img, M, NC, IH,
-                     IW, thresh, seg);
+  hipLaunchKernelGGL(paste_kernel<false>, dim3(D), dim3(256), lds, (hipStream_t)stream, logits, labels, boxes, img, M, NC, IH,
+                     IW, thresh, seg, (unsigned char*)nullptr);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_paste_mask_stack(const float* prob, const float* boxes, int D, int M, int IH, int IW, float thresh,
+                                    uint8_t* stack, void* stream) {
+  if (D <= 0) return 0;
+  if (!prob || !boxes || !stack || M <= 0 || IH <= 0 || IW <= 0) return MMT_EINVAL;
+  const size_t lds = (size_t)(M + 2) * (M + 2) * sizeof(float);
+  hipLaunchKernelGGL(paste_kernel<true>, dim3(D), dim3(256), lds, (hipStream_t)stream, prob, (const int*)nullptr, boxes,
+                     (const int*)nullptr, M, 1, IH, IW, thresh, (int*)nullptr, stack);
   MMT_LAUNCH_CHECK();
   return 0;
 }

@@ -138,6 +138,7 @@ _SIGS = {
     "mmt_ema_update": [c_void_p, c_void_p, c_int64, c_double, c_void_p],
     "mmt_sgd_momentum": [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int, c_void_p],
     "mmt_paste_masks": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
+    "mmt_paste_mask_stack": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "mmt_polygon_targets": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
 }
 
@@ -1577,6 +1578,17 @@ def paste_masks(logits, labels, boxes, img, N, IH, IW, thresh):
     _check(lib().mmt_paste_masks(_p(logits), _p(labels), _p(boxes), _p(img), D, M, NC, IH, IW, float(thresh), _p(seg),
                                  _stream()), "mmt_paste_masks")
     return seg
+
+
+def paste_mask_stack(prob, boxes, IH, IW, thresh):
+    """prob (D,1,M,M) or (D,M,M) probabilities of the predicted class, boxes (D,4) -> uint8 (D,1,IH,IW): one pasted binary mask
+    per detection (include/mmtpsm.h: mmt_paste_mask_stack)"""
+    prob = _dev(prob, "prob").float().contiguous()
+    D, M = prob.shape[0], prob.shape[-1]
+    boxes = _dev(boxes, "boxes").float().contiguous()
+    out = torch.zeros((D, 1, IH, IW), dtype=torch.uint8, device=prob.device)
+    _check(lib().mmt_paste_mask_stack(_p(prob), _p(boxes), D, M, IH, IW, float(thresh), _p(out), _stream()), "mmt_paste_mask_stack")
+    return out
 
 
 def polygon_targets(poly_xy, poly_off, roi_poly, boxes, M):

@@ -349,9 +349,11 @@ def evaluate_predictions_on_pap(pap_gts, pap_results, json_result_file=None, iou
 
 
 def prepare_for_pap_segmentation(predictions, dataset):
-    """predictions {image index: BoxList with 'mask' (already pasted to the window, (n, 1, H, W)), 'scores', 'labels'} +
-    the dataset's ground truth -> the evaluator's dict lists (pap_eval.py:79-143; masks arrive pasted -- the engine's
-    inference loop runs the Masker on the device, layers `mmt_paste_masks`)"""
+    """predictions {image index: BoxList with 'mask', 'scores', 'labels'} + the dataset's ground truth -> the evaluator's dict
+    lists (pap_eval.py:79-143).  Masks that are not window-sized yet -- the M x M probabilities of MaskPostProcessor, as in a
+    predictions.pth -- are pasted first, as the reference does (pap_eval.py:107-109: Masker(threshold=0.5, padding=1)); the
+    paste is the device kernel `mmt_paste_mask_stack`, so that case needs the GPU (no host implementation: it raises)."""
+    masker = None
     gts, dts = [], []
     for image_id, prediction in predictions.items():
         original_id = dataset.id_to_img_map[image_id]
@@ -364,6 +366,15 @@ def prepare_for_pap_segmentation(predictions, dataset):
             gts.append({"image_id": original_id, "category_id": labels[k], "segmentation": rle, "bbox": boxes[k]})
         prediction = prediction.resize((dataset.maxWS, dataset.maxWS))
         masks = prediction.get_field("mask")
+        if tuple(masks.shape[-2:]) != (dataset.maxWS, dataset.maxWS):
+            if not torch.cuda.is_available():
+                raise RuntimeError("predictions carry %dx%d masks and pasting them into the %d-pixel window runs on the GPU "
+                                   "(mmt_paste_mask_stack); no MI355X visible" % (masks.shape[-2], masks.shape[-1], dataset.maxWS))
+            if masker is None:
+                from maskrcnn_benchmark.modeling.roi_heads.mask_head.mask_head import Masker
+                masker = Masker(threshold=0.5, padding=1)
+            dev = torch.device("cuda", torch.cuda.current_device())
+            masks = masker.forward_single_image(masks.to(dev), prediction.to(dev)).cpu()
         scores = prediction.get_field("scores").tolist()
         labels = [dataset.contiguous_category_id_to_json_id[i] for i in prediction.get_field("labels").tolist()]
         boxes = prediction.bbox.tolist()

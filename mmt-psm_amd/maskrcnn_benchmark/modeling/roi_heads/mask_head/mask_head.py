@@ -174,6 +174,15 @@ class Masker(object):
         return [IntegralMask(s) for s in seg]
 
 
+    def forward_single_image(self, masks, boxes):
+        """the reference's per-detection form (mask_head/inference.py:221-229), used by the evaluator on predictions whose `mask`
+        field is still M x M: masks (n, 1, M, M) probabilities, boxes a BoxList in the target frame -> uint8 (n, 1, H, W)"""
+        w, h = boxes.size
+        if len(boxes) == 0:
+            return torch.zeros((0, 1, h, w), dtype=torch.uint8, device=masks.device)
+        return H.paste_mask_stack(masks, boxes.convert("xyxy").bbox, h, w, self.threshold)
+
+
 class IntegralMask(object):
     """stands in for the (D,1,H,W) uint8 stack of the reference: `.sum(0)[0]` gives the integral mask"""
 

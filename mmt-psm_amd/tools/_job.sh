@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/gputest_a.log 2>&1; echo rc=$? >> gpurun_out/gputest_a.log
-python bench.py --steps 40 --warmup 10 --no-cpu-baseline > gpurun_out/bench_a.log 2>&1
+timeout 1500 python -m pytest tests/test_data_parallel_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "evaluator or bench or two_rank or rccl" > gpurun_out/t_new.log 2>&1; echo rc=$? >> gpurun_out/t_new.log

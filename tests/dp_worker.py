@@ -24,8 +24,12 @@ sys.path.insert(0, ROOT)
 def main():
     out_dir = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    # MMT_DP_BACKEND=nccl (a node with >= 2 GPUs): one GPU per rank, RCCL over xGMI -- the real configs[3] path; default: both
+    # ranks on device 0 with gloo carrying the device tensors (RCCL refuses two ranks on one GPU)
+    backend = os.environ.get("MMT_DP_BACKEND", "gloo")
+    local = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     import bench
     from maskrcnn_benchmark.engine import MTtrainer as MT
     cfg, trainer, batch = bench.build(dev, rank, crop=160, n_inst=4)   # per-rank data: seeds 1234 + rank / 4321 + rank
@@ -67,7 +71,11 @@ def main():
     restore(sn)
     res["skip_keys"] = sorted(l_skip)
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    res["backend"] = dist.get_backend()
     device_collectives = True
     try:
         t = torch.ones(4, device=dev)
@@ -105,6 +113,10 @@ def main():
     res["device_collectives"] = device_collectives
 
     def gathered(t):
+        if backend == "nccl":   # RCCL moves device tensors only
+            parts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(parts, t.contiguous())
+            return [p.cpu() for p in parts]
         parts = [torch.zeros_like(t.cpu()) for _ in range(world)]
         dist.all_gather(parts, t.cpu())
         return parts

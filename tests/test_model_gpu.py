@@ -242,3 +242,81 @@ def test_inference_loop(setup, synth, tmp_path):
         direct = teacher(to_image_list(list(imgs.cuda()), 32))
     assert torch.equal(direct[0].bbox.cpu(), preds[0].bbox)
     teacher.set_module_mode("train")
+
+
+def test_inference_predictions_through_the_pap_evaluator(setup, synth):
+    """the evaluator wired to a GPU run.  engine/inference.py's eval-mode predictions (28 x 28 mask
+    probabilities, the `predictions.pth` form) go through the evaluation dispatch: prepare_for_pap_segmentation pastes them with
+    the device kernel (Masker.forward_single_image -> mmt_paste_mask_stack; reference pap_eval.py:107-109), mask_rle encodes them,
+    Papeval scores them against the dataset's ground truth.  Checked against the same pipeline fed with the ORACLE's paste
+    (oracle/model.py::paste_mask, the restated mask_head/inference.py:169-206) of the same predictions: pasted masks equal up to
+    the bilinear rounding of a few boundary pixels, every statistic equal to 1e-3."""
+    from maskrcnn_benchmark.data.datasets.evaluation.pap.pap_eval import evaluate_predictions_on_pap
+    from maskrcnn_benchmark.data.datasets.evaluation.pap import mask_rle
+    from maskrcnn_benchmark.engine.inference import inference
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head.mask_head import Masker
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    from oracle import model as om
+    cfg, _, teacher = setup
+    teacher.set_module_mode(None)
+    imgs, tgs = synth.make_labeled(2, SIZE, 4, seed=1234)
+
+    def disc(cx, cy, r):
+        yy, xx = np.mgrid[0:SIZE, 0:SIZE]
+        return np.asfortranarray((((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r).astype(np.uint8))
+
+    class DS(object):
+        maxWS = SIZE
+        id_to_img_map = {0: {"file_name": "s0", "location": (0, 0), "id": 0}, 1: {"file_name": "s1", "location": (160, 0), "id": 1}}
+        contiguous_category_id_to_json_id = {1: 1, 2: 2}
+
+        def get_ground_truth(self, original_id):
+            t = tgs[original_id["id"]]
+            b = BoxList(t["boxes"].clone(), (SIZE, SIZE), "xyxy")
+            b.add_field("labels", t["labels"].clone())
+            bx = t["boxes"]
+            rles = [mask_rle.encode(disc(float(x0 + x1) / 2, float(y0 + y1) / 2, float(x1 - x0) / 2)) for x0, y0, x1, y1 in bx.tolist()]
+            for r in rles:
+                r["counts"] = r["counts"].decode("utf-8")
+            b.add_field("masks", rles)
+            return b
+
+    class Loader(list):
+        dataset = DS()
+
+        def __len__(self):
+            return 2
+
+    DS.__len__ = lambda self: 2
+    loader = Loader([(to_image_list(list(imgs), 32), None, (0, 1))])
+    results, pap_results = inference(teacher, loader, "synthetic", iou_types=("segm",))
+    assert len(pap_results) > 0
+    # the same predictions, pasted by the oracle on the host
+    with torch.no_grad():
+        direct = [p.to(torch.device("cpu")) for p in teacher(to_image_list(list(imgs.cuda()), 32))]
+    gts, dts, n_px, n_diff = [], [], 0, 0
+    ds = DS()
+    masker = Masker(threshold=0.5, padding=1)
+    for i, p in enumerate(direct):
+        oid = ds.id_to_img_map[i]
+        g = ds.get_ground_truth(oid)
+        for k, rle in enumerate(g.get_field("masks")):
+            gts.append({"image_id": oid, "category_id": int(g.get_field("labels")[k]), "segmentation": rle, "bbox": g.bbox[k].tolist()})
+        own = masker.forward_single_image(p.get_field("mask").cuda(), p.to(torch.device("cuda"))).cpu()
+        for k in range(len(p)):
+            ref = om.paste_mask(p.get_field("mask")[k, 0], p.bbox[k], SIZE, SIZE, 0.5, 1)
+            n_px += ref.numel()
+            n_diff += int((ref != own[k, 0]).sum())
+            rle = mask_rle.encode(np.asfortranarray(ref.numpy()))
+            rle["counts"] = rle["counts"].decode("utf-8")
+            dts.append({"image_id": oid, "category_id": int(p.get_field("labels")[k]), "segmentation": rle,
+                        "score": float(p.get_field("scores")[k]), "bbox": p.bbox[k].tolist()})
+    assert len(dts) == len(pap_results)
+    assert n_diff <= max(3, 1e-4 * n_px), (n_diff, n_px)      # bilinear boundary pixels (DESIGN section 2)
+    ref = evaluate_predictions_on_pap(gts, dts, None, "segm")
+    for m in ("AJI", "F1", "DSC", "mAP", "AP50"):
+        for k, v in ref.stats[m].items():
+            a = float(np.asarray(results.results["segm"][m][k]).reshape(-1)[0])
+            b = float(np.asarray(v).reshape(-1)[0])
+            assert a == pytest.approx(b, rel=1e-3, abs=1e-6), (m, k, a, b)
