@@ -289,6 +289,19 @@ typedef struct {
    * whether its consumers keep the two-term fp16 split or fall back to the three-term bf16 split (fp16 has 5 exponent
    * bits: a tensor dominated by a few huge elements pushes everything else below the range of the low term) */
   int y_amax_stats;
+  /* fp16 split, range guard (round 4; optional, device pointers).  f16_guard_x: the 33-float statistics slot of `x` as a
+   * producing launch recorded it (y_amax + y_amax_stats) or mmt_amax_stats computed it; f16_guard_dy: the same for `dy`
+   * (mmt_conv_wgrad).  With it every block of an fp16-split launch (mmt_conv_forward_f16x2, mmt_conv3x3_strip_f16x2, the
+   * fp16-split form of mmt_conv_wgrad) first derives the crest factor max / mean of ITS OWN operand on the device; above 2^17
+   * -- one element 10^8 x the rest pushes everything else below the range of the low fp16 term -- the block computes its tile
+   * with exact fp32 products from the fp32 operands instead (slow; until the host has moved the site to the 3-term bf16
+   * split).  w_src / w_src_scale: for a call whose weight exists only as packed planes (`w` null: a data gradient), the
+   * forward weight [Cin][KH][KW][Cout] and its per-row scale (or null) the planes were packed from (mmt_pack_weight_flipped):
+   * the slow path reads the fp32 weights through the same flip / transpose.  Null guards switch the test off. */
+  const void* f16_guard_x;
+  const void* f16_guard_dy;
+  const void* w_src;
+  const void* w_src_scale;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);

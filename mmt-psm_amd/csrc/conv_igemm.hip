@@ -47,7 +47,38 @@ struct ConvP {
   int f16_ax;  // f16_sx points to max |x| (the scale is derived from it) instead of to the scale itself
   const float* f16_sx; const float* f16_sw;  // fp16 two-term split (experiment): device scalars s_x, s_w; the epilogue divides by s_x s_w
   int io;  // bf16 STORAGE of operands (mode 1): IO_X x, IO_Y y, IO_RES res, IO_MASK mask are bf16 tensors of the same indexing
+  // fp16 split, range guard (round 4): the 33-float statistics slots of x (and, weight gradient, of dy) -- max, sampled sum and
+  // count -- from which every block derives the crest factor of ITS OWN operand before its first instruction of arithmetic;
+  // w_src / w_src_scale: where the fp32 weights of a planes-only (data-gradient) call come from (see conv_slow_tile)
+  const float* guard_x; const float* guard_dy;
+  const float* w_src; const float* w_src_scale;
 };
+constexpr float F16_CREST_HI = 131072.f;   // 2^17: max / mean |x| above which fp16's five exponent bits lose the bulk of the tensor
+
+// The unlagged, per-tensor form of the range decision.  The two-term fp16 split represents x s as h + l with
+// s set by max |x|; when ONE element is 10^8 x the rest, everything else lands where l is subnormal and carries 11 bits instead
+// of 22.  The host cannot know that about the tensor at hand (it picks the kernel before the producer has run); the device can:
+// the producer recorded max / sampled mean of x in its statistics slot.  Every block of an fp16-split kernel reads the slot
+// first and, for such a tensor, computes its tile with plain fp32 FMAs from the fp32 operands instead (conv_slow_tile: exact
+// products, ~100 x slower, a handful of launches) -- until the host has seen the same statistics and moved the site to the
+// 3-term bf16 split (_hip._site_ok), which is fast and range-free.  NaN / inf maxima take the slow path too (they propagate).
+// Two halves, so that the slot's scalar loads are ISSUED at the top of a kernel and WAITED FOR behind its prologue copies: read at
+// the point of the branch they cost ~1 us of exposed latency per launch (+0.5 ms of conv time per step, measured; the slot was
+// last written by L2 atomics of several XCDs and misses this XCD's L2).  Nine values: the maximum and the first four of the
+// sixteen (sum, count) partials -- the share of the producer's sampled blocks 0, 64, 128, 192 (mod 1024); block 0 always samples.
+struct F16Guard { float amax, s0, s1, s2, s3, c0, c1, c2, c3; };
+__device__ __forceinline__ F16Guard f16_guard_load(const float* __restrict__ slot) {
+  F16Guard g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (slot) { g.amax = slot[0]; g.s0 = slot[1]; g.s1 = slot[2]; g.s2 = slot[3]; g.s3 = slot[4];
+              g.c0 = slot[17]; g.c1 = slot[18]; g.c2 = slot[19]; g.c3 = slot[20]; }
+  return g;
+}
+__device__ __forceinline__ bool f16_guard_bad(const F16Guard& g) {
+  const float tot = (g.s0 + g.s1) + (g.s2 + g.s3), cnt = (g.c0 + g.c1) + (g.c2 + g.c3);
+  if (!(tot > 0.f)) return false;                       // nothing sampled (or an all-zero sample): no statement
+  if (!(g.amax == g.amax) || g.amax > 3.0e38f) return true;
+  return g.amax * cnt > tot * F16_CREST_HI;
+}
 constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b);
@@ -256,6 +287,86 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
   conv_epilogue_stage<BM, BN, WM, WN>(acc, lds, lane, wm, wn);
   __syncthreads();
   conv_epilogue_finish<BM, BN>(p, lds, m0, n0, tid, HoWo);
+}
+
+// ---- the fp16 split's slow, exact path (see f16_guard_bad): outputs (row i, column c) of a block's tile, i < rows,
+// c < ncols; row i is output pixel m = m_first + (i / run) * run_stride + (i % run) (one run of consecutive pixels for the tiled
+// and row-resident kernels, 256 / TW image rows for the strip kernel), column c is channel n0 + c.  fp32 FMA over the im2col
+// row straight from global memory; the weights are p.w ([Cout][KH][KW][Cin]) or, for a planes-only data-gradient call, read
+// through the flip / transpose / BN scale of pack_flip_unit from the forward weight p.w_src ([Cin'][KH][KW][Cout'], scale per
+// row).  raw != null (split-K forms): the sum times s_x s_w goes to raw[i * ncols + c] -- what the finish launch divides out
+// again -- or zeros when `zero`; else the epilogue of conv_epilogue_finish, element by element, statistics included.
+// The parameter block is read from the KERNEL-ARGUMENT SEGMENT (every kernel that calls this has its ConvP first), not from the
+// caller's registers: inlined with `p` in registers the slow path kept ~60 more scalar values alive across the callers' prologues
+// (SGPR spills 15 -> 80 in the tiled kernel, +0.6 ms of conv time per step); as a real call it costs the callers 288 B of stack.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) ConvP* ConvPK;
+__device__ __forceinline__ ConvPK kernarg_convp() { return (ConvPK)__builtin_amdgcn_kernarg_segment_ptr(); }
+#else   // (host pass of the same translation unit: never executed)
+typedef const ConvP* ConvPK;
+__device__ __forceinline__ ConvPK kernarg_convp() { return nullptr; }
+#endif
+
+__device__ __forceinline__ void conv_slow_tile(const int m_first, const int run, const int run_stride, const int rows,
+                                            const int n0, const int ncols, float* __restrict__ raw, const bool zero,
+                                            const int tid, const int nthreads, const int lin) {
+  const ConvPK pk = kernarg_convp();   // fields are fetched where they are used (scalar loads from the argument segment)
+  const int HoWo = pk->Ho * pk->Wo;
+  const float S = (pk->f16_ax ? f16_scale_of_fwd(*pk->f16_sx) : *pk->f16_sx) * *pk->f16_sw;
+  float amx = 0.f, asum = 0.f, acnt = 0.f;
+  for (int o = tid; o < rows * ncols; o += nthreads) {
+    const int i = o / ncols, c = o - i * ncols;
+    const int m = m_first + (i / run) * run_stride + (i % run), n = n0 + c;
+    if (raw && (zero || m >= pk->M || n >= pk->Cout)) { raw[o] = 0.f; continue; }
+    if (m >= pk->M || n >= pk->Cout) continue;
+    const int img = m / HoWo, rem = m - img * HoWo;
+    const int ho = rem / pk->Wo, wo = rem - ho * pk->Wo;
+    float acc = 0.f;
+    for (int kh = 0; kh < pk->KH; kh++) {
+      const int ih = ho * pk->stride - pk->pad + kh;
+      if ((unsigned)ih >= (unsigned)pk->H) continue;
+      for (int kw = 0; kw < pk->KW; kw++) {
+        const int iw = wo * pk->stride - pk->pad + kw;
+        if ((unsigned)iw >= (unsigned)pk->W) continue;
+        const float* xr = pk->x + ((long)(img * pk->H + ih) * pk->W + iw) * pk->Cin;
+        if (pk->w) {
+          const float* wr = pk->w + ((long)(n * pk->KH + kh) * pk->KW + kw) * pk->Cin;
+          for (int ci = 0; ci < pk->Cin; ci++) acc = fmaf(xr[ci], wr[ci], acc);
+        } else {   // W'(n, (kh, kw), c) = w_src[c][KH - 1 - kh][KW - 1 - kw][n] * scale[c]
+          const int tap = (pk->KH - 1 - kh) * pk->KW + (pk->KW - 1 - kw);
+          const float* wr = pk->w_src + (long)tap * pk->Cout + n;
+          const long cs = (long)pk->KH * pk->KW * pk->Cout;
+          for (int ci = 0; ci < pk->Cin; ci++)
+            acc = fmaf(xr[ci], wr[ci * cs] * (pk->w_src_scale ? pk->w_src_scale[ci] : 1.f), acc);
+        }
+      }
+    }
+    if (raw) { raw[o] = acc * S; continue; }
+    float v = acc * (pk->scale ? pk->scale[n] : 1.f) + (pk->shift ? pk->shift[n] : 0.f);
+    long oidx = (long)m * pk->Cout + n;
+    if (pk->out_stride > 1) oidx = (((long)img * pk->out_H + ho * pk->out_stride) * pk->out_W + wo * pk->out_stride) * pk->Cout + n;
+    if (pk->res_mode == 1) v += pk->res[(long)m * pk->Cout + n];
+    else if (pk->res_mode == 2) v += pk->res[(((long)img * (pk->Ho >> 1) + (ho >> 1)) * (pk->Wo >> 1) + (wo >> 1)) * pk->Cout + n];
+    else if (pk->res_mode == 3) {
+      const int w2 = pk->Wo * 2;
+      const float* rp = pk->res + (((long)img * (pk->Ho * 2) + 2 * ho) * w2 + 2 * wo) * pk->Cout + n;
+      v += (rp[0] + rp[pk->Cout]) + (rp[(long)w2 * pk->Cout] + rp[(long)w2 * pk->Cout + pk->Cout]);
+    }
+    if (pk->relu) v = fmaxf(v, 0.f);
+    if (pk->mask) v = pk->mask[oidx] > 0.f ? v * pk->mask_scale : 0.f;
+    if (pk->mul) v *= pk->mul[(long)m * pk->Cout + n];
+    pk->y[oidx] = v;
+    const float av = fabsf(v);
+    amx = fmaxf(amx, av); asum += av; acnt += 1.f;
+  }
+  if (!raw && pk->amax_out) {
+    if (amx > 0.f) atomicMax(pk->amax_out, __builtin_bit_cast(unsigned, amx));
+    if (pk->amax_stats && (lin & 63) == 0 && acnt > 0.f) {
+      const int k = (lin >> 6) & 15;
+      atomicAdd((float*)pk->amax_out + 1 + k, asum);
+      atomicAdd((float*)pk->amax_out + 17 + k, acnt);
+    }
+  }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -685,7 +796,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int HoWo = p.Ho * p.Wo;
-
+  F16Guard guard = {};
+  if constexpr (F16) guard = f16_guard_load(p.guard_x);   // issued here, tested behind the prologue's copies
   // ---- DMA source geometry.  A instruction i of this wave covers rows (wave + 4 i) * 16 + (lane >> 2), 16-B chunk
   // (lane & 3) of the LDS row, which holds logical chunk (lane & 3) ^ ((row >> 2) & 3).
   unsigned abase[NIA];
@@ -890,6 +1002,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
   };
 #pragma unroll
   for (int t = 0; t < S - 1; t++) { filling = t < nkt; issue_all(min(t, nkt - 1), t); }
+  if constexpr (F16) {
+    // the range guard sits HERE, behind the prologue's copies: the slot's scalar loads ride in the shadow of the HBM latency the
+    // block waits for anyway (at the top of the kernel they cost ~1 us per launch: +0.3 ms of conv time per step, measured)
+    if (f16_guard_bad(guard)) {   // this tensor's dynamic range defeats fp16: exact fp32 products for the tile (uniform branch)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the copies in flight land in LDS nobody reads
+      float* slab = ksplit > 1 ? ws + ((long)bid * ksplit + ks) * (BM * BN) : nullptr;
+      conv_slow_tile(m0, BM, 0, BM, n0, BN, slab, ks != 0, tid, 256, blockIdx.x);
+      return;
+    }
+  }
   wait_dma(S - 2);
   __builtin_amdgcn_s_barrier();
   filling = S - 1 < nkt;
@@ -1209,6 +1331,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   const int slabs = p.Cin >> 4;                      // super-steps: (kh, slab), 3 * slabs of them
   const int pairs = (3 * slabs) >> 1;                // ... handed out in pairs (the loop body is two super-steps)
   const int ss0 = 2 * (int)((long)ks * pairs / ksplit), nss = 2 * (int)((long)(ks + 1) * pairs / ksplit) - ss0;
+  F16Guard guard = {};
+  if constexpr (F16) guard = f16_guard_load(p.guard_x);   // issued here, tested behind the first copies (see conv_fwd_glds_kernel)
 
   // ---- copy slots of this wave.  Slots 0 .. SA-1 carry A items (wave + 8 i < NA: plane, strip row r, 32-pixel block),
   // slots SA .. SA+SB-1 B items (tap, plane, 32-channel block).  Everything that does not change from super-step to
@@ -1364,6 +1488,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
 #pragma unroll
   for (int i = 0; i < NSLOT; i++) issue_slot(i, 0);
   fill_advance();
+  if constexpr (F16) {   // the range guard, in the shadow of the first copies' latency (see conv_fwd_glds_kernel)
+    if (f16_guard_bad(guard)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float* slab = ksplit > 1 ? ws + ((long)tile_lin * ksplit + ks) * (BM * BN) : nullptr;
+      conv_slow_tile((img * p.Ho + ho0) * p.Wo + wo0, TW, p.Wo, BM, n0, BN, slab, ks != 0, tid, 512, blockIdx.x);
+      return;
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -1643,6 +1775,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
   const int nb32 = (p.Cout + 31) >> 5;
   const int npanel = (p.Cout + BN - 1) / BN;
   const int nt_lo = blockIdx.y * ppb, nt_hi = min(npanel, nt_lo + ppb);
+  F16Guard guard = {};
+  if constexpr (F16) guard = f16_guard_load(p.guard_x);   // issued here, tested behind the first weight copies
   auto issue_b = [&](int nt, int buf) {
 #pragma unroll
     for (int i = 0; i < PIECES / 4; i++) {
@@ -1654,6 +1788,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
     }
   };
   issue_b(nt_lo, 0);
+  if constexpr (F16) {   // the range guard, in the shadow of the first weight copies (see conv_fwd_glds_kernel)
+    if (f16_guard_bad(guard)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (nt_lo < nt_hi) conv_slow_tile(m0, 128, 0, 128, nt_lo * BN, (nt_hi - nt_lo) * BN, nullptr, false, tid, 256,
+                                        blockIdx.x + gridDim.x * blockIdx.y);
+      return;
+    }
+  }
   // ---- A: rows m0 + 32 wave + lr, k = 16 kt + 8 kh2 .. + 7 per step; rows past M read zeros (buffer bounds)
   uint4 fa[KT][NS];   // bf16x8 / f16x8 fragments as raw words
   const float sx = F16 ? f16_scale_of_fwd(*p.f16_sx) : 1.f;
@@ -2459,6 +2601,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p,
   }
 }
 
+// the weight gradient's slow, exact path (see f16_guard_bad): the block's 128 x 128 tile of dW over its pixel range [ms, me)
+// with fp32 FMAs straight from global memory, times s (= s_x s_dy: the stores divide it out again), into ct; bias sums by atomics
+__device__ __forceinline__ void wgrad_slow_fill(const float* __restrict__ dy, float* __restrict__ ct, const int co0,
+                                             const int n0, const int ms, const int me, const float s, float* __restrict__ dbias,
+                                             const int tid) {
+  const ConvPK pk = kernarg_convp();   // fields are fetched where they are used (scalar loads from the argument segment)
+  const int NP = pk->KH * pk->KW * pk->Cin, HoWo = pk->Ho * pk->Wo;
+  for (int o = tid; o < 128 * 128; o += 256) {
+    const int row = o >> 7, col = o & 127;
+    const int co = co0 + row, n = n0 + col;
+    float acc = 0.f;
+    if (co < pk->Cout && n < NP) {
+      const int tap = n / pk->Cin, ci = n - tap * pk->Cin, kh = tap / pk->KW, kw = tap - kh * pk->KW;
+      for (int m = ms; m < me; m++) {
+        const int img = m / HoWo, rem = m - img * HoWo;
+        const int ho = rem / pk->Wo, wo = rem - ho * pk->Wo;
+        const int ih = ho * pk->stride - pk->pad + kh, iw = wo * pk->stride - pk->pad + kw;
+        if ((unsigned)ih < (unsigned)pk->H && (unsigned)iw < (unsigned)pk->W)
+          acc = fmaf(dy[(long)m * pk->Cout + co], pk->x[((long)(img * pk->H + ih) * pk->W + iw) * pk->Cin + ci], acc);
+      }
+    }
+    ct[o] = acc * s;
+  }
+  if (dbias && tid < 128 && co0 + tid < pk->Cout) {
+    float b = 0.f;
+    for (int m = ms; m < me; m++) b += dy[(long)m * pk->Cout + co0 + tid];
+    atomicAdd(dbias + co0 + tid, b);
+  }
+}
+
 // Same tile, same LDS image and same arithmetic as conv_wgrad_split_kernel, software-pipelined one step deeper: the
 // global loads of pixel step t+2 are issued behind the first MFMAs of step t, and the split + LDS stores of step t+1
 // (whose loads went out a whole step earlier) are cut into micro-ops that sit behind the individual MFMAs of step t.
@@ -2504,6 +2676,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
   const int me = min(p.M, ms + m_per_split);
   if (ms >= me) return;
   const int HoWo = p.Ho * p.Wo;
+  F16Guard guard_x = {}, guard_dy = {};
+  if constexpr (F16) { guard_x = f16_guard_load(p.guard_x); guard_dy = f16_guard_load(p.guard_dy); }   // tested before the pipeline starts
 
   const bool roleB = wave >= 2;
   const int cq = (wave & 1) * 16 + (lane & 15);
@@ -2778,6 +2952,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
       if (t + 5 < ntile) step(0, 1, fa1, fb1, fa0, fb0, rgQ, rgR);
     }
   };
+  bool slow = false;   // fp16 split: an operand whose dynamic range defeats fp16 (f16_guard_bad) -> exact fp32 products for this tile
+  if constexpr (F16) slow = f16_guard_bad(guard_x) || f16_guard_bad(guard_dy);
+  if (slow) {
+    wgrad_slow_fill(dy, lds, co0, n0, ms, me, f16_s[0] * f16_s[1], dbias != nullptr && bx == 0 ? dbias : nullptr, tid);
+    __syncthreads();
+  } else {
   if (roleB) run(std::true_type{}); else run(std::false_type{});
   if (do_bias) {
 #pragma unroll
@@ -2788,9 +2968,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
       if (pg == 0 && ch + e < p.Cout) atomicAdd(dbias + ch + e, t);
     }
   }
+  }
   {
     float* ct = lds;  // [128][128]
     const int rq = lane >> 5;
+    if (!slow) {
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -2801,6 +2983,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
           ct[(4 * i + wm * 2 + a) * 128 + 4 * lr + wn * 2 + b] = acc[a][b][r];
         }
     __syncthreads();
+    }
     const int cc = tid & 31, r0 = tid >> 5;
     const int n = n0 + cc * 4;
     if (n < NP) {
@@ -2936,6 +3119,8 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.ypl = (unsigned short*)a->y_planes; p.ypl_stride = a->y_plane_stride;
   p.f16_sx = p.f16_sw = nullptr;
   p.f16_ax = 0;
+  p.guard_x = (const float*)a->f16_guard_x; p.guard_dy = (const float*)a->f16_guard_dy;
+  p.w_src = (const float*)a->w_src; p.w_src_scale = (const float*)a->w_src_scale;
   p.amax_out = (unsigned*)a->y_amax;
   p.amax_stats = a->y_amax_stats;
   p.io = a->io_bf16;

@@ -30,7 +30,8 @@ class ConvArgs(ctypes.Structure):
                 ("mask_scale", c_float), ("w_planes", c_void_p), ("w_plane_stride", ctypes.c_long),
                 ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long),
                 ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long), ("io_bf16", c_int), ("y_amax", c_void_p),
-                ("f16_x_amax", c_void_p), ("f16_dy_amax", c_void_p), ("y_amax_stats", c_int)]
+                ("f16_x_amax", c_void_p), ("f16_dy_amax", c_void_p), ("y_amax_stats", c_int),
+                ("f16_guard_x", c_void_p), ("f16_guard_dy", c_void_p), ("w_src", c_void_p), ("w_src_scale", c_void_p)]
 
 
 IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
@@ -294,6 +295,12 @@ def _site_ok(site, x, count=True):
     if not ent[0] and count:
         F16_STATS["fallback"] = F16_STATS.get("fallback", 0) + 1
     return ent[0]
+
+
+def _guard(am):
+    """the address of a full statistics slot (max, sampled sums and counts) for the kernels' on-device range test, or None when
+    only a maximum was recorded (tests attach plain one-element tensors)"""
+    return am[0].ptr if type(am[0]) is _Slot else None
 
 
 def _amax_of(x):
@@ -999,8 +1006,14 @@ def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_
     a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
     if a.KH == 3 and (lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1) != (kind == 1):
         return None   # the library's choice between the strip and the tiled kernel can be switched per call (MMT_STRIP): re-plan
+    # the fp32 weights for the kernels' slow, exact path (a tensor whose range defeats fp16: decided per block on the device)
+    if flipped:
+        a.w_src, a.w_src_scale = wsrc.data_ptr(), _p(f16_src[1])
+    else:
+        a.w = wsrc.data_ptr()
+    am = _amax_of(x)
+    a.f16_guard_x = _guard(am)
     if kind == 0:     # tiled / row-resident kernels: x is split in registers, its recorded maximum gives the scale
-        am = _amax_of(x)
         F16_STATS["tiled"] += 1
         _check(lib().mmt_conv_forward_f16x2(ctypes.byref(a), am[0].data_ptr(), sw.data_ptr(), _stream()), "mmt_conv_forward_f16x2")
     else:             # tap-strip kernel: one split pass over x, then the launch
@@ -1020,6 +1033,7 @@ def _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, kind,
     # everything a call patches is cleared in the template (a stale pointer must never survive into a launch)
     t.x = t.y = t.scale = t.shift = t.res = t.mask = t.mul = t.w = None
     t.w_planes = t.x_planes = t.y_planes = t.y_amax = t.f16_x_amax = t.f16_dy_amax = None
+    t.f16_guard_x = t.f16_guard_dy = t.w_src = t.w_src_scale = None
     t.w_plane_stride = t.x_plane_stride = t.y_plane_stride = 0
     t.mask_scale, t.io_bf16, t.y_amax_stats = 1.0, 0, 1
     if len(_PLAN) > 4096:
@@ -1161,6 +1175,9 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         wp16, sw = f16_weight_planes(f16t[0], f16t[2], f16t[1])
         a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
         a.x_planes = None
+        a.f16_guard_x = _guard(am)
+        if f16t[1]:
+            a.w_src, a.w_src_scale = f16t[0].data_ptr(), _p(f16t[2])
         F16_STATS["tiled"] += 1
         if fast_ok and not io:
             _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, 0, Cout, Ho, Wo)
@@ -1185,6 +1202,10 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         F16_STATS["conv"] += 1
         if fast_ok and not io:
             _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, 1, Cout, Ho, Wo)
+        if not F16X2_DELAYED:
+            a.f16_guard_x = _guard(_amax_of(x))
+        if f16[1]:
+            a.w_src, a.w_src_scale = f16[0].data_ptr(), _p(f16[2])
         xp16, sx = f16_split(x, (f16[0].data_ptr(), f16[1]) if F16X2_DELAYED else None)
         wp16, sw = f16_weight_planes(f16[0], f16[2], f16[1])
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
@@ -1403,6 +1424,7 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
                 and _site_ok(("wgx", dw.data_ptr()), x) and _site_ok(("wgd", dw.data_ptr()), dy)):
             # both operands carry their recorded maximum: two-term fp16 split (3 products instead of 6)
             a.f16_x_amax, a.f16_dy_amax = ax[0].data_ptr(), ad[0].data_ptr()
+            a.f16_guard_x, a.f16_guard_dy = _guard(ax), _guard(ad)
             F16_STATS["wgrad"] += 1
     ws = torch.empty((splits * Cout * KH * KW * Cin,), dtype=torch.float32, device=x.device) if splits > 1 else None
     _TLS.last_ws = ws

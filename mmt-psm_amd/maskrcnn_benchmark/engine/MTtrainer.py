@@ -395,6 +395,7 @@ class MTtrainer(object):
         if self.lambda_value > 0 and iteration > (self.start_mt - 10):
             self.update_teacher(iteration - (self.start_mt - 10))
             if self.teacher_check_period > 0 and iteration % self.teacher_check_period == 0:
+                self.sync_teacher()
                 check_teacher_identity(self.flat_t)
         return losses_dict
 
@@ -445,6 +446,7 @@ class MTtrainer(object):
             return next(self._unl_iter)[0]
 
     def save_model(self, iteration=0, final=False):
+        self.sync_teacher()
         name = "model_final" if final else "model_{:07d}".format(iteration)
         self.ckpt_s.save(name)
         if iteration > self.start_mt and self.ckpt_t is not None:
@@ -499,6 +501,7 @@ class MTtrainer(object):
                     raise job["error"]
                 teacher_results = job["result"]
             else:
+                self.sync_teacher()
                 teacher_list = [f.to(self.device) for f in data_u_list[:self.teacher_bs]]
                 with torch.no_grad():
                     teacher_results = self.teacher.forward_teacher(teacher_list)
@@ -509,7 +512,24 @@ class MTtrainer(object):
         return self.student.forward_student(student, teacher_results, features=features, embeddings=emb)
 
     def update_teacher(self, it):
-        """MTtrainer.py:277-281 as one launch over the flat parameter buffers"""
+        """MTtrainer.py:277-281 as one launch over the flat parameter buffers.  With the teacher on its own stream the update and
+        the re-packing of the teacher's weight planes run THERE (round 4): nothing on the step stream reads the teacher before the
+        next `_start_teacher`, which orders the side stream behind the step stream anyway, so the next step's student forward no
+        longer queues behind ~0.3 ms of full-chip HBM passes.  Whoever reads the teacher from outside a step (checkpoints, the
+        identity check, tests) goes through `sync_teacher()` or a device-wide synchronize."""
         alpha = min(1 - 1 / (it + 1), self.alpha)
+        if self.t_stream is not None and self.overlap_teacher:
+            self.t_stream.wait_stream(torch.cuda.current_stream())     # the student's SGD step
+            with torch.cuda.stream(self.t_stream):
+                H.ema_update(self.flat_t.data, self.flat_s.data, alpha)
+                self.flat_t.refresh_planes()
+            self._teacher_pending = True
+            return
         H.ema_update(self.flat_t.data, self.flat_s.data, alpha)
         self.flat_t.refresh_planes()
+
+    def sync_teacher(self):
+        """the step stream waits for a teacher update still queued on the teacher's stream"""
+        if getattr(self, "_teacher_pending", False):
+            torch.cuda.current_stream().wait_stream(self.t_stream)
+            self._teacher_pending = False

@@ -8,6 +8,8 @@ ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 sys.path.insert(0, ROOT)
 import bench
 from maskrcnn_benchmark import _hip as H
+if os.environ.get("MMT_LIB"):   # A/B of two builds of the library on one box (tools only)
+    H.LIB_PATH = os.path.abspath(os.environ["MMT_LIB"])
 cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, base_lr=bench.BENCH_BASE_LR)
 for i in range(4):
     il, tg, ul = batch(); trainer.train_step(1400 + i, il, tg, ul)

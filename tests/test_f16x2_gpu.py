@@ -226,17 +226,114 @@ def test_f16_weight_cache_is_per_tensor_object(hip):
     H.set_f16x2(False)
 
 
+def _outlier_input(shape, g, kind="act"):
+    """ONE element 10^8 x the rest (profiles/r02_precision_f16x2.txt's weak spot): every other value sits below the range of the
+    fp16 low term when the tensor is scaled by its maximum"""
+    x = _inputs(kind, shape, g)
+    x[shape[0] // 2, 17, shape[2] // 2 - 2, shape[3] // 2 - 1] = 1.0e8
+    return x
+
+
+def _rel_err(y, ref, den):
+    """error of every output against fp64, relative to ITS OWN sum |a||b| (the scale of its rounding)"""
+    return ((y.double() - ref).abs() / den).max().item()
+
+
+# N, Cin, H, W, Cout, k, kernel family the shape runs on (its F16_STATS counter)
+GUARD_CASES = [(2, 256, 64, 64, 256, 3, "conv"),       # tap-strip kernel, split-K form (TW = 64, few tiles)
+               (2, 256, 128, 128, 256, 3, "conv"),     # tap-strip kernel, TW = 128, un-split
+               (2, 1024, 64, 64, 256, 1, "tiled"),     # tiled kernel 128 x 64
+               (8, 1024, 64, 64, 256, 1, "tiled"),     # tiled kernel 128 x 128
+               (2, 512, 32, 32, 512, 3, "tiled"),      # tiled kernel, split-K + finish launch
+               (2, 256, 64, 64, 1024, 1, "tiled"),     # row-resident 1x1 kernel (K = 256)
+               (4, 64, 128, 128, 256, 1, "tiled")]     # row-resident 1x1 kernel (K = 64)
+
+
+@pytest.mark.parametrize("shape", GUARD_CASES)
+def test_range_guard_first_occurrence_on_the_device(hip, shape):
+    """the range decision of the fp16 split is taken ON THE DEVICE, per tensor, unlagged.  A tensor with one
+    element 10^8 x the rest, seen for the FIRST time by a site that knows nothing (no warm-up call, statistics never flushed to
+    the host), comes out at <= 3e-6 of every output's own sum |a||b|: each block reads the producer's statistics slot (max,
+    sampled mean) before its first instruction of arithmetic and computes its tile with exact fp32 products
+    (csrc/conv_igemm.hip::conv_slow_tile).  The host has not switched anything (fallback counter unchanged, the launch counts
+    as an fp16-split launch); an ordinary tensor right afterwards runs the fast path: bit-equal to a library that never saw
+    the outlier.  With residual + ReLU epilogue, recorded output statistics included."""
+    H = hip
+    N, C, Hh, W, Co, k, kind = shape
+    g = torch.Generator().manual_seed(31 + sum(shape[:6]))
+    x = _outlier_input((N, C, Hh, W), g)
+    x2 = _inputs("act", (N, C, Hh, W), g)
+    w = _cl((torch.randn(Co, C, k, k, generator=g) * 0.05).cuda())
+    sc, sh = (torch.rand(Co, generator=g) + 0.5).cuda(), (torch.randn(Co, generator=g) * 0.1).cuda()
+    res = _inputs("signed50", (N, Co, Hh, W), g) * 1e-3
+    H.set_f16x2(True)          # (clears every site's state)
+    c0, f0 = H.F16_STATS[kind], H.F16_STATS["fallback"]
+    y = H.conv_forward(x, w, sc, sh, 1, k // 2, relu=True, res=res, res_mode=1)
+    assert H.F16_STATS[kind] == c0 + 1 and H.F16_STATS["fallback"] == f0
+    xd, wd = x[:1].double(), w.double()
+    lin = F.conv2d(xd, wd, None, 1, k // 2) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res[:1].double()
+    den = F.conv2d(xd.abs(), wd.abs(), None, 1, k // 2) * sc.double().view(1, -1, 1, 1) + res[:1].double().abs() + 1e-30
+    assert _rel_err(y[:1], lin.relu(), den) < 3e-6
+    # the statistics the slow path recorded for ITS output are those of the tensor
+    slot = y._mmt_amax[0]
+    torch.cuda.synchronize()
+    assert float(slot.pool.dev[slot.idx, 0]) == float(y.abs().max())
+    # an ordinary tensor right behind it: the fast path, bit for bit what a fresh library gives
+    y2 = H.conv_forward(x2, w, sc, sh, 1, k // 2, relu=True, res=res, res_mode=1)
+    H.set_f16x2(True)
+    y2b = H.conv_forward(x2, w, sc, sh, 1, k // 2, relu=True, res=res, res_mode=1)
+    assert torch.equal(y2, y2b)
+    lin2 = F.conv2d(x2[:1].double(), wd, None, 1, k // 2) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res[:1].double()
+    assert (y2[:1].double() - lin2.relu()).abs().max().item() < 1e-5 * lin2.abs().max().item()
+
+
+@pytest.mark.parametrize("k", [3, 1])
+def test_range_guard_data_gradient_and_weight_gradient(hip, k):
+    """the same for a backward pass whose incoming gradient carries the outlier (a gradient spike in real training is exactly that
+    tensor): the data gradient -- weights exist only as packed, flipped, BN-scaled planes; the slow path reads the forward weight
+    through the same flip -- with the ReLU mask in the epilogue, and the weight gradient (dy the bad operand)."""
+    H = hip
+    from maskrcnn_benchmark.layers import fused
+    g = torch.Generator().manual_seed(90 + k)
+    N, C, S, Co = 2, 256, 64, 256
+    w = _cl((torch.randn(Co, C, k, k, generator=g) * 0.02).cuda())
+    bn = (torch.rand(Co, generator=g) + 0.5).cuda()
+    dy = _outlier_input((N, Co, S, S), g, "signed50")
+    act = _inputs("act", (N, C, S, S), g)
+    H.set_f16x2(True)
+    f0 = H.F16_STATS["fallback"]
+    dx = fused._dgrad(dy, w, (N, C, S, S), 1, k // 2, bn, mask=act)
+    assert H.F16_STATS["fallback"] == f0
+    wd = (w.double() * bn.double().view(-1, 1, 1, 1)).flip(2, 3).transpose(0, 1)
+    ref = F.conv2d(dy[:1].double(), wd, None, 1, k // 2) * (act[:1] > 0)
+    den = F.conv2d(dy[:1].double().abs(), wd.abs(), None, 1, k // 2) + 1e-30
+    assert _rel_err(dx[:1], ref, den) < 3e-6
+    # weight gradient: x ordinary, dy with the outlier; both carry statistics slots as producing launches attach them
+    x = _inputs("act", (N, C, S, S), g)
+    x._mmt_amax = H._amax_of(x)
+    dy._mmt_amax = H._amax_of(dy)
+    n0 = H.F16_STATS["wgrad"]
+    dw = _cl(torch.zeros((Co, C, k, k), device="cuda"))
+    db = torch.zeros((Co,), device="cuda")
+    H.conv_wgrad(x, dy, (Co, C, k, k), 1, k // 2, dw, bn, db)
+    assert H.F16_STATS["wgrad"] == n0 + 1 and H.F16_STATS["fallback"] == f0
+    xu = F.unfold(x.double(), k, padding=k // 2)
+    refw = torch.einsum("nco,nko->ck", dy.double().flatten(2), xu).view(Co, C, k, k) * bn.double().view(-1, 1, 1, 1)
+    denw = torch.einsum("nco,nko->ck", dy.double().abs().flatten(2), xu.abs()).view(Co, C, k, k) * bn.double().view(-1, 1, 1, 1) + 1e-30
+    assert _rel_err(dw, refw, denw) < 3e-6
+    refb = dy.double().sum((0, 2, 3))
+    assert (db.double() - refb).abs().max().item() < 1e-5 * dy.double().abs().sum((0, 2, 3)).max().item()
+
+
 @pytest.mark.parametrize("shape", [(2, 256, 64, 64, 256, 3), (2, 256, 64, 64, 512, 1)])
-def test_fallback_to_bf16x3_when_the_dynamic_range_defeats_fp16(hip, shape):
-    """ONE element 10^8 x the rest (profiles/r02_precision_f16x2.txt's weak spot): every other value sits below the range of
-    the fp16 low term.  The producing side records max and sum |x| per tensor; when the statistics have reached the host
-    the consuming site sees a crest factor max / mean > 2^17 and runs the 3-term bf16 split (bit-identical to
-    set_f16x2(False)) until tensors with an ordinary range come by again.  Strip kernel (3x3) and tiled kernel (1x1)."""
+def test_host_moves_a_persistently_bad_site_to_bf16x3(hip, shape):
+    """the slow path is for first occurrences: when the statistics have reached the host the consuming site sees the crest factor
+    max / mean > 2^17 itself and runs the 3-term bf16 split (fast, range-free, bit-identical to set_f16x2(False)) until tensors
+    with an ordinary range come by again.  Strip kernel (3x3) and tiled kernel (1x1)."""
     H = hip
     N, C, S, _, Co, k = shape
     g = torch.Generator().manual_seed(77 + k)
-    x = _inputs("act", (N, C, S, S), g)
-    x[1, 17, 30, 31] = 1.0e8
+    x = _outlier_input((N, C, S, S), g)
     x2 = _inputs("act", (N, C, S, S), g)
     w = _cl((torch.randn(Co, C, k, k, generator=g) * 0.05).cuda())
     H.set_f16x2(False)
@@ -244,20 +341,17 @@ def test_fallback_to_bf16x3_when_the_dynamic_range_defeats_fp16(hip, shape):
     H.set_f16x2(True)
     kind = "conv" if k == 3 else "tiled"
     c0, f0 = H.F16_STATS[kind], H.F16_STATS["fallback"]
-    y1 = H.conv_forward(x, w, None, None, 1, k // 2)      # nothing known about this site's inputs yet: fp16 split
+    y1 = H.conv_forward(x, w, None, None, 1, k // 2)      # nothing known about this site's inputs yet: device-side slow path
     y1b = H.conv_forward(x, w, None, None, 1, k // 2)     # (the site now waits for the statistics of this tensor)
-    assert H.F16_STATS[kind] == c0 + 2 and H.F16_STATS["fallback"] == f0 and not torch.equal(y1, y_ref)
+    assert H.F16_STATS[kind] == c0 + 2 and H.F16_STATS["fallback"] == f0
     assert torch.equal(y1, y1b)
     H.f16_flush_stats()
     y2 = H.conv_forward(x, w, None, None, 1, k // 2)
     assert H.F16_STATS["fallback"] == f0 + 1 and H.F16_STATS[kind] == c0 + 2
-    assert torch.equal(y2, y_ref)                          # the fall-back IS the 3-term bf16 split
-    # what the fall-back buys: outputs that do not see the outlier, against fp64
+    assert torch.equal(y2, y_ref)                          # the host's fall-back IS the 3-term bf16 split
     ref = F.conv2d(x[:1].double(), w.double(), None, 1, k // 2)
     den = F.conv2d(x[:1].double().abs(), w.double().abs(), None, 1, k // 2)
-    e_f16 = ((y1[:1].double() - ref).abs() / den).max().item()
-    e_fb = ((y2[:1].double() - ref).abs() / den).max().item()
-    assert e_fb < 3e-6 and e_fb < e_f16, (e_fb, e_f16)
+    assert _rel_err(y1[:1], ref, den) < 3e-6 and _rel_err(y2[:1], ref, den) < 3e-6
     # ordinary tensors again: after their statistics arrive the site returns to the fp16 split
     H.conv_forward(x2, w, None, None, 1, k // 2)           # still falling back; the amax pass of the fallback-less path is
     x2._mmt_amax = H._amax_of(x2)                          # not run there, so record the statistics the way a producer would
