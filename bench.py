@@ -240,7 +240,7 @@ def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, nsteps, dom="fw
     if nprod == 3 and dom == "fwd1":
         kern = "conv_fwd_glds_kernel<128,128,4,1,2,3,true> (activations split into two fp16 terms in registers, v_mfma_f32_32x32x16_f16 x 3 products)"
     if nprod == 3 and dom == "fwd4":
-        kern = ("conv3x3_strip_kernel<TW,2,0,true> (256x128 tiles on 8 waves, two fp16 planes per operand scaled per tensor, "
+        kern = ("conv3x3_strip_kernel<TW,2,true> (256x128 tiles on 8 waves, two fp16 planes per operand scaled per tensor, "
                 "v_mfma_f32_32x32x16_f16 x 3 products; brackets hold the kernel and, in its split-K form, the finish launch)")
     r = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
          "frac": round(ach / peak, 4), "traffic": traffic,
@@ -493,7 +493,7 @@ def main():
             out["roofline"]["other_large_tile_kernel"] = {
                 "kernel": (("conv_fwd_glds_kernel<128,128,4,1,2,3,true> (raw fp32 rows split into two fp16 terms in registers, "
                             "v_mfma_f32_32x32x16_f16 x 3 products)" if odom == "fwd1" else
-                            "conv3x3_strip_kernel<TW,2,0,true> (two fp16 planes per operand, v_mfma_f32_32x32x16_f16 x 3 products)")
+                            "conv3x3_strip_kernel<TW,2,true> (two fp16 planes per operand, v_mfma_f32_32x32x16_f16 x 3 products)")
                            if products_of(mode, odom) == 3 else KERNEL_NAMES[odom](mode)),
                 "launches_per_step": len(other) // npf,
                 "achieved": round(fo / (mo * 1e-3) / 1e12, 2), "frac": round(fo / (mo * 1e-3) / 1e12 / opeak, 4),

@@ -302,6 +302,18 @@ typedef struct {
   const void* f16_guard_dy;
   const void* w_src;
   const void* w_src_scale;
+  /* mmt_conv_wgrad on the fp16 split only, optional (round 4): a SECOND (x, dy) pair of the same shapes whose weight gradient
+   * is accumulated by the same launch -- the labeled and the unlabeled student pass of a mean-teacher step share every weight
+   * (engine/MTtrainer.py): dW = dY1^T im2col(X1) + dY2^T im2col(X2) as one launch over both pixel ranges instead of two
+   * half-sized ones (half the launches, twice the pixels per block).  x2 / dy2 with their own maxima f16_x_amax2 / f16_dy_amax2
+   * (and optional statistics slots f16_guard_x2 / f16_guard_dy2): every block works on one segment with that segment's
+   * scales.  mmt_conv_wgrad_splits counts the slices of the two-segment launch when x2 is set. */
+  const void* x2;
+  const void* dy2;
+  const void* f16_x_amax2;
+  const void* f16_dy_amax2;
+  const void* f16_guard_x2;
+  const void* f16_guard_dy2;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);

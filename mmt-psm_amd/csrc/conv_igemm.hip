@@ -52,6 +52,11 @@ struct ConvP {
   // w_src / w_src_scale: where the fp32 weights of a planes-only (data-gradient) call come from (see conv_slow_tile)
   const float* guard_x; const float* guard_dy;
   const float* w_src; const float* w_src_scale;
+  // weight gradient over TWO segments of pixels (round 4: the two student passes of a step share every weight; their activations
+  // and gradients are separate tensors of one shape): blocks with z >= seg_z work on (x2, dy2) with that segment's own scales /
+  // statistics slots; seg_z == 0: one segment
+  const float* x2; const float* dy2; const float* f16_sx2; const float* f16_sw2; const float* guard_x2; const float* guard_dy2;
+  int seg_z;
 };
 constexpr float F16_CREST_HI = 131072.f;   // 2^17: max / mean |x| above which fp16's five exponent bits lose the bulk of the tensor
 
@@ -2603,7 +2608,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const ConvP p,
 
 // the weight gradient's slow, exact path (see f16_guard_bad): the block's 128 x 128 tile of dW over its pixel range [ms, me)
 // with fp32 FMAs straight from global memory, times s (= s_x s_dy: the stores divide it out again), into ct; bias sums by atomics
-__device__ __forceinline__ void wgrad_slow_fill(const float* __restrict__ dy, float* __restrict__ ct, const int co0,
+__device__ __forceinline__ void wgrad_slow_fill(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ ct, const int co0,
                                              const int n0, const int ms, const int me, const float s, float* __restrict__ dbias,
                                              const int tid) {
   const ConvPK pk = kernarg_convp();   // fields are fetched where they are used (scalar loads from the argument segment)
@@ -2619,7 +2624,7 @@ __device__ __forceinline__ void wgrad_slow_fill(const float* __restrict__ dy, fl
         const int ho = rem / pk->Wo, wo = rem - ho * pk->Wo;
         const int ih = ho * pk->stride - pk->pad + kh, iw = wo * pk->stride - pk->pad + kw;
         if ((unsigned)ih < (unsigned)pk->H && (unsigned)iw < (unsigned)pk->W)
-          acc = fmaf(dy[(long)m * pk->Cout + co], pk->x[((long)(img * pk->H + ih) * pk->W + iw) * pk->Cin + ci], acc);
+          acc = fmaf(dy[(long)m * pk->Cout + co], x[((long)(img * pk->H + ih) * pk->W + iw) * pk->Cin + ci], acc);
       }
     }
     ct[o] = acc * s;
@@ -2645,7 +2650,7 @@ __device__ __forceinline__ void wgrad_slow_fill(const float* __restrict__ dy, fl
 // (p.f16_sx -> max |x|, p.f16_sw -> max |dy|, device scalars), split into two fp16 terms, multiplied with 3 f16 MFMAs, and the
 // tile is divided by s_x s_dy where it is stored (directly, or in wgrad_reduce_kernel for the split form)
 template <int NS, int MODE, bool VEC4, int BF = 0, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p_in, const float* __restrict__ dy_in,
                                                                  const float* __restrict__ rowscale,
                                                                  float* __restrict__ dw, int m_per_split,
                                                                  float* __restrict__ ws, float* __restrict__ dbias) {
@@ -2670,9 +2675,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
     by = t % ty;
     bz = t / ty;
   }
+  // two-segment form (p_in.seg_z > 0): slices z >= seg_z belong to the second (x, dy) pair -- same shapes, its own scales
+  ConvP p = p_in;
+  const float* __restrict__ dy = dy_in;
+  int bzl = bz;
+  if constexpr (F16) {
+    if (p_in.seg_z > 0 && bz >= p_in.seg_z) {
+      p.x = p_in.x2; dy = p_in.dy2; p.f16_sx = p_in.f16_sx2; p.f16_sw = p_in.f16_sw2;
+      p.guard_x = p_in.guard_x2; p.guard_dy = p_in.guard_dy2;
+      bzl = bz - p_in.seg_z;
+    }
+  }
   const int co0 = by * 128, n0 = bx * 128;
   const int NP = p.KH * p.KW * p.Cin;
-  const int ms = bz * m_per_split;
+  const int ms = bzl * m_per_split;
   const int me = min(p.M, ms + m_per_split);
   if (ms >= me) return;
   const int HoWo = p.Ho * p.Wo;
@@ -2955,7 +2971,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
   bool slow = false;   // fp16 split: an operand whose dynamic range defeats fp16 (f16_guard_bad) -> exact fp32 products for this tile
   if constexpr (F16) slow = f16_guard_bad(guard_x) || f16_guard_bad(guard_dy);
   if (slow) {
-    wgrad_slow_fill(dy, lds, co0, n0, ms, me, f16_s[0] * f16_s[1], dbias != nullptr && bx == 0 ? dbias : nullptr, tid);
+    wgrad_slow_fill(p.x, dy, lds, co0, n0, ms, me, f16_s[0] * f16_s[1], dbias != nullptr && bx == 0 ? dbias : nullptr, tid);
     __syncthreads();
   } else {
   if (roleB) run(std::true_type{}); else run(std::false_type{});
@@ -2999,6 +3015,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p, 
           const f32x4 o = *(const f32x4*)q;
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = o[e] + v[e] * sc;
+        } else if constexpr (F16) {   // the slab carries the true partial sum: each segment has its own power-of-two scales
+          const float inv = 1.f / (f16_s[0] * f16_s[1]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] *= inv;
         }
         *(f32x4*)q = v;
       }
@@ -3121,6 +3141,8 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.f16_ax = 0;
   p.guard_x = (const float*)a->f16_guard_x; p.guard_dy = (const float*)a->f16_guard_dy;
   p.w_src = (const float*)a->w_src; p.w_src_scale = (const float*)a->w_src_scale;
+  p.x2 = p.dy2 = p.f16_sx2 = p.f16_sw2 = p.guard_x2 = p.guard_dy2 = nullptr;
+  p.seg_z = 0;
   p.amax_out = (unsigned*)a->y_amax;
   p.amax_stats = a->y_amax_stats;
   p.io = a->io_bf16;
@@ -3760,6 +3782,15 @@ extern "C" int mmt_conv_wgrad_splits(const mmt_conv_args* a) {
   constexpr int slots = 512;   // (tuned: profiles/r04_dispatch_sweep.txt)
   constexpr int min_px = 512;   // (tuned: profiles/r04_dispatch_sweep.txt)
   int split = (int)(tiles >= slots ? 1 : slots / tiles);
+  if (a->x2) {   // two segments of p.M pixels each: the same number of blocks reduces twice the pixels; an even number of slices
+    const int max2 = mmt_cdiv(2 * p.M, min_px);
+    if (split > max2) split = max2;
+    int half = split / 2;
+    if (half < 1) half = 1;
+    int mps2 = mmt_cdiv(p.M, half);
+    mps2 = (mps2 + 31) / 32 * 32;
+    return 2 * mmt_cdiv(p.M, mps2);
+  }
   const int max_split = mmt_cdiv(p.M, min_px);  // at least min_px / 16 k-tiles per block
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
@@ -3779,8 +3810,11 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
   const int NP = p.KH * p.KW * p.Cin;
   const int tx = mmt_cdiv(NP, 128), ty = mmt_cdiv(p.Cout, 128);
   const int split = mmt_conv_wgrad_splits(a);
-  int mps = mmt_cdiv(p.M, split);
+  const bool two = a->x2 != nullptr;
+  int mps = mmt_cdiv(p.M, two ? split / 2 : split);
   mps = (mps + 31) / 32 * 32;
+  if (two && (!a->dy2 || !a->f16_x_amax || !a->f16_dy_amax || !a->f16_x_amax2 || !a->f16_dy_amax2 || split != 2 * mmt_cdiv(p.M, mps)))
+    return MMT_EINVAL;   // the two-segment form exists on the fp16 split only
   if (split > 1 && !workspace) return MMT_EINVAL;
   float* ws = split > 1 ? workspace : nullptr;
   const bool fast = (p.Cout & 3) == 0 && p.Wo >= 8 && p.Ho >= 8;
@@ -3794,6 +3828,12 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
       return MMT_EINVAL;
     p.f16_sx = (const float*)a->f16_x_amax;
     p.f16_sw = (const float*)a->f16_dy_amax;
+    if (two) {
+      p.x2 = (const float*)a->x2; p.dy2 = (const float*)a->dy2;
+      p.f16_sx2 = (const float*)a->f16_x_amax2; p.f16_sw2 = (const float*)a->f16_dy_amax2;
+      p.guard_x2 = (const float*)a->f16_guard_x2; p.guard_dy2 = (const float*)a->f16_guard_dy2;
+      p.seg_z = split / 2;
+    }
     const dim3 grid(tx, ty, split);
     const int mode = !(p.Wo >= 8 && p.Ho >= 8) ? 0 : ((p.Wo & 3) == 0 ? 2 : 1);
 #define WGF(MODE) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<2, MODE, true, 0, true>), grid, dim3(256), (size_t)65536, s, p, dy, rowscale, dw, mps, ws, dbias)   /* 3 stages of 16 KB <= the 64 KB epilogue tile */
@@ -3804,7 +3844,7 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
       const long n4 = (long)p.Cout * NP / 4;
       int blocks = (int)((n4 + 255) / 256);
       if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, split, p.Cout, NP, rowscale, dw, p.f16_sx, p.f16_sw);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, split, p.Cout, NP, rowscale, dw);   // (the slabs are un-scaled)
       MMT_LAUNCH_CHECK();
     }
     return 0;

@@ -31,7 +31,9 @@ class ConvArgs(ctypes.Structure):
                 ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long),
                 ("y_planes", c_void_p), ("y_plane_stride", ctypes.c_long), ("io_bf16", c_int), ("y_amax", c_void_p),
                 ("f16_x_amax", c_void_p), ("f16_dy_amax", c_void_p), ("y_amax_stats", c_int),
-                ("f16_guard_x", c_void_p), ("f16_guard_dy", c_void_p), ("w_src", c_void_p), ("w_src_scale", c_void_p)]
+                ("f16_guard_x", c_void_p), ("f16_guard_dy", c_void_p), ("w_src", c_void_p), ("w_src_scale", c_void_p),
+                ("x2", c_void_p), ("dy2", c_void_p), ("f16_x_amax2", c_void_p), ("f16_dy_amax2", c_void_p),
+                ("f16_guard_x2", c_void_p), ("f16_guard_dy2", c_void_p)]
 
 
 IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
@@ -1373,15 +1375,28 @@ def wgrad_prepare(x, dy):
         _amax_of(nhwc(dy))
 
 
-def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=None, keep=None):
+def wgrad_pair_ok(x, dy, x2, dy2):
+    """can the weight gradients of (x, dy) and (x2, dy2) -- same layer, two passes -- go out as ONE two-segment launch?  fp16 split
+    only, equal shapes, every operand with a recorded maximum (what the producing launches attach)"""
+    if not (F16X2 and get_conv_precision() == 3) or x.shape != x2.shape or dy.shape != dy2.shape:
+        return False
+    for t in (x, dy, x2, dy2):
+        am = getattr(t, "_mmt_amax", None)
+        if t.dtype != torch.float32 or am is None or am[1] != t._version:
+            return False
+    return dy.shape[1] % 4 == 0
+
+
+def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=None, keep=None, pair=None):
     """accumulates into dw (same memory layout as the weight) and dbias.  `side`: a torch stream to launch on instead of the
     current one (the caller orders it against the producers of x / dy and joins it later) -- cheaper than entering a stream
     context per call; the split-K workspace is handed to it with record_stream, or -- `keep`, a list -- simply kept alive by
-    the caller until it has joined the side stream"""
+    the caller until it has joined the side stream.  `pair` = (x2, dy2): a second pass through the same layer whose gradient
+    the SAME launch accumulates (include/mmtpsm.h: mmt_conv_args.x2; the caller checked `wgrad_pair_ok`)"""
     if side is not None:
         _TLS.stream = side.cuda_stream
         try:
-            return conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale, dbias)
+            return conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale, dbias, pair=pair)
         finally:
             _TLS.stream = None
             ws = getattr(_TLS, "last_ws", None)
@@ -1396,7 +1411,9 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
     Cout, Cin, KH, KW = w_shape
     N, _, H, W = x.shape
     # the shape half of the argument block and the split count depend on the shapes only: kept after the first call
-    key = (x.shape, dy.shape, w_shape, stride, pad, x.dtype, dy.dtype)
+    if pair is not None:
+        x2, dy2 = nhwc(pair[0]), nhwc(pair[1])
+    key = (x.shape, dy.shape, w_shape, stride, pad, x.dtype, dy.dtype, pair is not None)
     plan = _WPLAN.get(key)
     if plan is None:
         a = ConvArgs()
@@ -1405,8 +1422,9 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
         a.out_stride = 1
         a.io_bf16 = (IO_X if x.dtype == torch.bfloat16 else 0) | (IO_DY if dy.dtype == torch.bfloat16 else 0)
         a.x = x.data_ptr()
+        a.x2 = x.data_ptr() if pair is not None else None   # (the split count of the two-segment form)
         splits = lib().mmt_conv_wgrad_splits(ctypes.byref(a))
-        a.x = None
+        a.x = a.x2 = None
         if len(_WPLAN) > 4096:
             _WPLAN.clear()
         _WPLAN[key] = (bytes(a), splits)
@@ -1426,6 +1444,17 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
             a.f16_x_amax, a.f16_dy_amax = ax[0].data_ptr(), ad[0].data_ptr()
             a.f16_guard_x, a.f16_guard_dy = _guard(ax), _guard(ad)
             F16_STATS["wgrad"] += 1
+            if pair is not None:
+                ax2, ad2 = x2._mmt_amax, dy2._mmt_amax
+                a.x2, a.dy2 = x2.data_ptr(), dy2.data_ptr()
+                a.f16_x_amax2, a.f16_dy_amax2 = ax2[0].data_ptr(), ad2[0].data_ptr()
+                a.f16_guard_x2, a.f16_guard_dy2 = _guard(ax2), _guard(ad2)
+                F16_STATS["wgrad_pairs"] = F16_STATS.get("wgrad_pairs", 0) + 1
+    if pair is not None and not a.x2:
+        # (a site that fell back to the 3-term bf16 split, an operand without a recorded maximum: two launches after all)
+        conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale, dbias)
+        conv_wgrad(x2, dy2, w_shape, stride, pad, dw, rowscale, dbias)
+        return
     ws = torch.empty((splits * Cout * KH * KW * Cin,), dtype=torch.float32, device=x.device) if splits > 1 else None
     _TLS.last_ws = ws
     if PROFILE is not None and PROFILE_ALL:
@@ -1433,7 +1462,8 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
         e0.record()
         _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _p(ws), _stream()), "mmt_conv_wgrad")
         e1.record()
-        PROFILE.append((2.0 * N * a.Ho * a.Wo * Cout * Cin * KH * KW, e0, e1, ("wgrad", N, H, W, Cin, Cout, KH, stride, 1)))
+        n2 = 2 * N if pair is not None else N
+        PROFILE.append((2.0 * n2 * a.Ho * a.Wo * Cout * Cin * KH * KW, e0, e1, ("wgrad", n2, H, W, Cin, Cout, KH, stride, 1)))
         return
     _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _p(ws), _stream()), "mmt_conv_wgrad")
 

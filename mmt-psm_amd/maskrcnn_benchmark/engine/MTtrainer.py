@@ -19,6 +19,7 @@ from maskrcnn_benchmark.layers import fused
 from maskrcnn_benchmark.utils.miscellaneous import sigmoid_rampdown, sigmoid_rampup
 
 
+_WGRAD_PAIR = os.environ.get("MMT_WGRAD_PAIR", "1") != "0"     # the two student passes' weight gradients of a layer as one two-segment launch (0: A/B)
 _WGRAD_DEFER = os.environ.get("MMT_WGRAD_DEFER", "1") != "0"   # supervised weight gradients in one batch after the supervised backward (0: interleaved, the A/B alternative)
 
 
@@ -158,7 +159,9 @@ class BucketedAllReduce(object):
             self._t0.record()
 
     def _send(self, lo, hi):
-        from maskrcnn_benchmark.layers.fused import join_wgrads
+        from maskrcnn_benchmark.layers.fused import join_wgrads, release_parked
+        g = self.flat.grad
+        release_parked(g.data_ptr() + 4 * lo, g.data_ptr() + 4 * hi)   # supervised-pass jobs still waiting for a partner that will not come
         join_wgrads()   # weight gradients run on a side stream (layers/fused.py): the piece is final when they are done
         if getattr(self, "tracing", False):
             e = torch.cuda.Event(enable_timing=True)
@@ -297,6 +300,7 @@ class MTtrainer(object):
     # ---- one iteration (the unit bench.py times)
     def train_step(self, iteration, data_s, target_s, data_u_list=None):
         use_mt = iteration > self.start_mt and self.lambda_value > 0 and data_u_list is not None
+        fused._WG_PARKED.clear()   # (jobs a failed step left parked must not meet this step's)
         bucketed = self._bucketed_allreduce()
         if bucketed is not None:
             bucketed.install()  # the stage hooks are registered by the forward passes below
@@ -351,19 +355,32 @@ class MTtrainer(object):
             if early:
                 losses_dict = self.weight_sum_loss(loss_dict, iteration)
                 defer = _WGRAD_DEFER and use_mt and job is not None
+                pairing = _WGRAD_PAIR and use_mt
+                from maskrcnn_benchmark.layers import fused as _fused
                 if defer:
-                    from maskrcnn_benchmark.layers import fused as _fused
                     _fused.defer_wgrads(True)
+                if pairing:
+                    # the supervised pass's weight-gradient jobs are PARKED: those of layers the consistency branch runs through
+                    # too (ResNet body, FPN, box head) leave with their partner as one two-segment launch (layers/fused.py)
+                    _fused.wgrad_pair_phase("first")
                 try:
                     sum(v for v in losses_dict.values()).backward()
                 finally:
+                    _fused.wgrad_pair_phase(None)
                     if defer:
                         _fused.defer_wgrads(False)
                         _fused.flush_deferred_wgrads()   # one batch, behind the supervised backward, beside the consistency branch
                 unl = self.weight_sum_loss(self.forward_unlabel(data_u_list, feats_u, job), iteration)
                 job = None
                 if unl:
-                    sum(v for v in unl.values()).backward()
+                    if pairing:
+                        _fused.wgrad_pair_phase("second")
+                    try:
+                        sum(v for v in unl.values()).backward()
+                    finally:
+                        _fused.wgrad_pair_phase(None)
+                if pairing:
+                    _fused.finish_wgrad_pairs()   # jobs that found no partner (RPN / mask head; a skipped consistency branch)
                 losses_dict.update(unl)
                 self._pad_mt_keys(losses_dict)
                 if cut is not None:

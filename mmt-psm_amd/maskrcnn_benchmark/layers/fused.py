@@ -76,12 +76,51 @@ def flush_wgrads(ent, dev):
         return
     side, keep = ent[0], ent[4]
     side.wait_stream(torch.cuda.current_stream(dev))
-    for x, g, shape, stride, pad, dw, rowscale, db in jobs:
-        H.conv_wgrad(x, g, shape, stride, pad, dw, rowscale, db, side=side, keep=keep)
+    for job in jobs:
+        x, g, shape, stride, pad, dw, rowscale, db = job[:8]
+        pair = job[8] if len(job) > 8 else None
+        H.conv_wgrad(x, g, shape, stride, pad, dw, rowscale, db, side=side, keep=keep, pair=pair)
         keep.append(x)    # autograd frees the saved activation / the gradient when the node returns: not before the side
         keep.append(g)    # stream has been joined
+        if pair is not None:
+            keep.extend(pair)
     ent[1] += len(jobs)
     jobs.clear()
+
+
+# Two passes through the same weights in one step (the labeled and the unlabeled student pass: engine/MTtrainer.py): a layer's two
+# weight gradients go out as ONE two-segment launch (mmt_conv_args.x2: half the launches, twice the pixels per block -- the N = 2
+# launches were the least efficient group of the step).  Phase "first" (the supervised backward): jobs are parked by the address of
+# their gradient slot instead of being handed over; phase "second" (the consistency backward): a job that finds its partner takes
+# it along; `finish_wgrad_pairs` hands over whatever found none (a layer only one pass runs through, a skipped consistency branch).
+_WG_PAIR = [None]     # None | "first" | "second"
+_WG_PARKED = {}       # (address of dw, shapes) -> [parked jobs]
+
+
+def wgrad_pair_phase(phase):
+    _WG_PAIR[0] = phase
+
+
+def release_parked(lo_ptr, hi_ptr):
+    """a range of the flat gradient buffer is about to be read (a piece of the data-parallel exchange goes out: everything the
+    second pass contributes to it has been issued): parked jobs writing into it will find no partner any more -- issue them now"""
+    hit = [k for k in _WG_PARKED if lo_ptr <= k[0] < hi_ptr]
+    for k in hit:
+        for job in _WG_PARKED.pop(k):
+            _wg_stream(job[0].device)[3].append(job)
+
+
+def finish_wgrad_pairs():
+    """after the second pass (or instead of it): the parked jobs that found no partner go to the side stream on their own"""
+    _WG_PAIR[0] = None
+    if not _WG_PARKED:
+        return
+    for lst in _WG_PARKED.values():
+        for job in lst:
+            _wg_stream(job[0].device)[3].append(job)   # (the trainer joins the side stream before the optimiser step)
+    _WG_PARKED.clear()
+    for dev, ent in _WG.items():
+        flush_wgrads(ent, dev)
 
 
 # Deferral (MMT_WGRAD_DEFER=1, engine/MTtrainer.py): while it is on, jobs are collected but not handed over, and the end-of-backward
@@ -137,9 +176,19 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
         if not ent[2]:
             ent[2] = True
             torch.autograd.Variable._execution_engine.queue_callback(_join_wgrads_cb)
-        ent[3].append((x, g, tuple(w.shape), stride, pad, dw, rowscale, db))
-        if len(ent[3]) >= _WG_BATCH and not _WG_DEFER[0]:
-            flush_wgrads(ent, x.device)
+        job = (x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
+        phase = _WG_PAIR[0]
+        if phase == "first" and H.F16X2 and H.get_conv_precision() == 3:   # (the two-segment launch exists on the fp16 split only)
+            _WG_PARKED.setdefault((dw.data_ptr(), x.shape, g.shape, stride, pad), []).append(job)
+        else:
+            if phase == "second":
+                lst = _WG_PARKED.get((dw.data_ptr(), x.shape, g.shape, stride, pad))
+                if lst and H.wgrad_pair_ok(lst[0][0], lst[0][1], x, g):
+                    first = lst.pop(0)
+                    job = first + ((x, g),)     # (the parked pass first: its operands are segment one)
+            ent[3].append(job)
+            if len(ent[3]) >= _WG_BATCH and not _WG_DEFER[0]:
+                flush_wgrads(ent, x.device)
     else:
         H.conv_wgrad(x, g, tuple(w.shape), stride, pad, dw, rowscale, db)
     _touch(dst_w, dst_b if with_bias else None)

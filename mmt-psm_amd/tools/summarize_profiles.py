@@ -1,8 +1,8 @@
-"""gpurun_out/prof/* (make_profiles.sh) -> profiles/r03_* + profiles/pmc_traffic.json + profiles/r03_summary.md.
+"""gpurun_out/prof/* (make_profiles.sh) -> profiles/r04_* + profiles/pmc_traffic.json + profiles/r04_summary.md.
 The number of steps a kernel trace holds is COUNTED (one `ema_kernel` launch per step), not assumed."""
 import csv, json, os, shutil
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles"), "r03_"
+SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles"), "r04_"
 ARITH = {"f16x2": "default: two-term fp16 split, 3 products per multiply (peak 2500 / 3 = 833 TFLOP/s)",
          "bf16x3": "`MMT_F16X2=0` / `--bf16x3`: three-term bf16 split, 6 products (round-2 default, now the per-tensor fall-back; peak 417)",
          "mode0": "`MMT_CONV_PRECISION=0`: fp32-input MFMA (peak 157.3)"}
@@ -20,16 +20,16 @@ def is_library(n):
     return n.startswith("void at::") or n.startswith("at::") or "rocprim" in n or "rocclr" in n or "hipcub" in n
 
 
-out = ["# Round 3 -- profiles of `python bench.py` on 1 x MI355X (state at the end of the round)", "",
+out = ["# Round 4 -- profiles of `python bench.py` on 1 x MI355X (state at the end of the round)", "",
        "Produced by `mmt-psm_amd/tools/make_profiles.sh` (GPU box) + `mmt-psm_amd/tools/summarize_profiles.py`. Files: "
-       "`r03_bench_default.json` (un-profiled `python bench.py`: 10 warm-up + 50 timed steps, median next to the mean, event brackets "
-       "in a separate 10-step leg, CPU baseline 1 + 3 steps); per arithmetic `r03_kernel_stats_<tag>.csv` (rocprofv3 --kernel-trace "
-       "--stats of `bench.py --steps 5 --warmup 2 --profile-steps 5 --no-cpu-baseline`), `r03_bench_under_rocprof_<tag>.json` (the line "
-       "that run printed), `r03_pmc_{FETCH,WRITE}_SIZE_by_kernel_<tag>.csv` (two separate --pmc passes, --kernel-trace only); "
-       "`r03_pmc_mfma_busy.txt` (one SQ pass, single-stream); `pmc_traffic.json` = what bench.py reports as roofline.traffic. "
+       "`r04_bench_default.json` (un-profiled `python bench.py`: 10 warm-up + 50 timed steps, median next to the mean, event brackets "
+       "in a separate 10-step leg, CPU baseline 1 + 3 steps); per arithmetic `r04_kernel_stats_<tag>.csv` (rocprofv3 --kernel-trace "
+       "--stats of `bench.py --steps 5 --warmup 2 --profile-steps 5 --no-cpu-baseline`), `r04_bench_under_rocprof_<tag>.json` (the line "
+       "that run printed), `r04_pmc_{FETCH,WRITE}_SIZE_by_kernel_<tag>.csv` (two separate --pmc passes, --kernel-trace only); "
+       "`r04_pmc_mfma_busy.txt` (one SQ pass, single-stream); `pmc_traffic.json` = what bench.py reports as roofline.traffic. "
        "Tags: " + "; ".join("**%s** = %s" % kv for kv in ARITH.items()) + ".", ""]
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) of `python bench.py "
-                     "--steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline`; per-kernel tables profiles/r03_pmc_*_by_kernel_*.csv",
+                     "--steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline`; per-kernel tables profiles/r04_pmc_*_by_kernel_*.csv",
            "fetch_correction": 2.0,
            "note": "FETCH_SIZE on gfx950 reports 1/2 of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section): "
                    "doubled. WRITE_SIZE uncalibrated, taken as is. Infinity-Cache hits are counted, so this is fabric traffic, an "
@@ -107,7 +107,7 @@ for tag in ("f16x2", "bf16x3", "mode0"):
                         (" vs %.1f us measured live by bench.py with events on the launch stream, same command (its brackets also hold "
                          "the split-K finish launch of the call)" % live) if live else "",
                         nd, fkb, 2 * fkb * 1024 / 1e6, wkb, tb / 1e6,
-                        (" vs %.1f MB algorithmic (input + weights + output once) = %.2f x" % (alg / 1e6, tb / alg)) if live and alg else "")]
+                        (" vs %.1f MB algorithmic (input + weights + output + the fused epilogue's operands, each once) = %.2f x" % (alg / 1e6, tb / alg)) if live and alg else "")]
         if "traffic_bytes_per_launch_fwd1" in tm:
             tm["traffic_bytes_per_launch"] = tm["traffic_bytes_per_launch_fwd1"]
     out.append("")
@@ -143,6 +143,6 @@ for f, what in extra:
         out.append(line)
 out.append("")
 out += ["## MFMA-busy (single-stream SQ pass)", "", "```"] + [l.rstrip() for l in open(os.path.join(SRC, "pmc_mfma_busy.txt")) if "mfma_busy_fraction" in l or l.startswith("#")] + ["```", ""]
-hist = open(os.path.join(DST, "r03_history.md")).read() if os.path.exists(os.path.join(DST, "r03_history.md")) else ""
-open(os.path.join(DST, "r03_summary.md"), "w").write("\n".join(out) + "\n" + hist)
+hist = open(os.path.join(DST, "r04_history.md")).read() if os.path.exists(os.path.join(DST, "r04_history.md")) else ""
+open(os.path.join(DST, "r04_summary.md"), "w").write("\n".join(out) + "\n" + hist)
 print("\n".join(out)[:6000])

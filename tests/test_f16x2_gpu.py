@@ -151,6 +151,67 @@ def test_wgrad_f16x2(hip, shape):
     assert eh < 2e-5 and eh <= 2.0 * e3 + 1e-7, (shape, eh, e3)
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 64, 64, 256, 3), (2, 1024, 64, 64, 256, 1), (2, 128, 128, 128, 128, 3), (1, 256, 32, 32, 512, 1)])
+def test_wgrad_two_segments(hip, shape):
+    """mmt_conv_args.x2 / dy2 (round 4): the weight gradients of TWO passes through one layer as one launch -- every block works on
+    one segment with that segment's own power-of-two scales (the operands of the second pass are 10^4 x smaller here), bias sums
+    included.  Against fp64 within the fp16 split's bound, against two separate launches to fp32 rounding of the sums, and with an
+    outlier in the second segment only (its blocks take the exact path, the first segment's stay fast)."""
+    H = hip
+    N, Cin, S, _, Cout, k = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x1, x2 = _inputs("act", (N, Cin, S, S), g), _inputs("act", (N, Cin, S, S), g) * 1e-4
+    d1, d2 = _inputs("grad", (N, Cout, S, S), g), _inputs("grad", (N, Cout, S, S), g) * 1e-4
+    rs = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    H.set_f16x2(True)
+
+    def stats(*ts):
+        for t in ts:
+            t._mmt_amax = H._amax_of(t)
+
+    def ref(xa, da, xb, db_):
+        out = 0
+        for xx, dd in ((xa, da), (xb, db_)):
+            xu = F.unfold(xx.double(), k, padding=k // 2)
+            out = out + torch.einsum("nco,nko->ck", dd.double().flatten(2), xu).view(Cout, Cin, k, k)
+        return out * rs.double().view(-1, 1, 1, 1)
+
+    stats(x1, x2, d1, d2)
+    assert H.wgrad_pair_ok(x1, d1, x2, d2)
+    n0 = H.F16_STATS.get("wgrad_pairs", 0)
+    dw = _cl(torch.zeros((Cout, Cin, k, k), device="cuda"))
+    db = torch.zeros((Cout,), device="cuda")
+    H.conv_wgrad(x1, d1, (Cout, Cin, k, k), 1, k // 2, dw, rs, db, pair=(x2, d2))
+    assert H.F16_STATS["wgrad_pairs"] == n0 + 1
+    dws = _cl(torch.zeros((Cout, Cin, k, k), device="cuda"))
+    dbs = torch.zeros((Cout,), device="cuda")
+    H.conv_wgrad(x1, d1, (Cout, Cin, k, k), 1, k // 2, dws, rs, dbs)
+    H.conv_wgrad(x2, d2, (Cout, Cin, k, k), 1, k // 2, dws, rs, dbs)
+    r = ref(x1, d1, x2, d2)
+    scale = r.abs().max().item()
+    assert (dw.double() - r).abs().max().item() < 2e-5 * scale
+    assert (dw - dws).abs().max().item() < 2e-6 * scale          # the same products, summed in another order
+    rb = (d1.double() + d2.double()).sum((0, 2, 3))
+    assert (db.double() - rb).abs().max().item() < 1e-5 * (d1.double().abs() + d2.double().abs()).sum((0, 2, 3)).max().item()
+    # the second segment's contribution is really there (10^-8 of the first: check it alone through linearity)
+    dw2 = _cl(torch.zeros((Cout, Cin, k, k), device="cuda"))
+    H.conv_wgrad(x2, d2, (Cout, Cin, k, k), 1, k // 2, dw2, rs, None, pair=(x2, d2))
+    r2 = ref(x2, d2, x2, d2)
+    assert (dw2.double() - r2).abs().max().item() < 2e-5 * r2.abs().max().item()
+    # an outlier in the SECOND pass's gradient only
+    d2o = d2.clone()
+    d2o[N // 2, 17, S // 2 - 2, S // 2 - 1] = 1.0e8 * 1e-9
+    stats(d2o)
+    dwo = _cl(torch.zeros((Cout, Cin, k, k), device="cuda"))
+    H.conv_wgrad(x1, d1, (Cout, Cin, k, k), 1, k // 2, dwo, rs, None, pair=(x2, d2o))
+    ro = ref(x1, d1, x2, d2o)
+    den = 0
+    for xx, dd in ((x1, d1), (x2, d2o)):
+        den = den + torch.einsum("nco,nko->ck", dd.double().abs().flatten(2), F.unfold(xx.double(), k, padding=k // 2).abs()).view(Cout, Cin, k, k)
+    den = den * rs.double().view(-1, 1, 1, 1) + 1e-300
+    assert ((dwo.double() - ro).abs() / den).max().item() < 3e-6
+
+
 ROWS_CASES = [  # N, Cin, H, W, Cout, epilogue: the row-resident 1x1 kernel on the fp16 split (K = 64 / 128 / 256)
     (8, 256, 64, 64, 1024, "res"), (2, 256, 64, 64, 1024, "res"), (2, 256, 64, 64, 1024, "mask"), (1, 256, 47, 45, 200, "relu"),
     (4, 64, 128, 128, 256, "res"), (1, 64, 257, 259, 96, ""), (2, 128, 128, 128, 512, "maskres"), (8, 256, 256, 256, 128, ""),
