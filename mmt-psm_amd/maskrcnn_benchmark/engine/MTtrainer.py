@@ -19,7 +19,13 @@ from maskrcnn_benchmark.layers import fused
 from maskrcnn_benchmark.utils.miscellaneous import sigmoid_rampdown, sigmoid_rampup
 
 
-_WGRAD_PAIR = os.environ.get("MMT_WGRAD_PAIR", "1") != "0"     # the two student passes' weight gradients of a layer as one two-segment launch (0: A/B)
+# The two student passes' weight gradients of a layer as ONE two-segment launch (mmt_conv_args.x2).  Built, tested
+# (tests/test_f16x2_gpu.py::test_wgrad_two_segments, test_train_step_gpu.py::test_paired_weight_gradients_equal_separate) and
+# measured: 119 -> 68 weight-gradient launches per step, but the step is SLOWER, 35.7 -> 37.5 ms in three same-box alternations
+# (profiles/r04_history.md): the supervised pass's jobs used to run in the ~4 ms between the supervised backward and the
+# consistency backward, where the device waits for the teacher and the host; paired, they wait for their partner and all
+# weight-gradient work lands beside the consistency backward, the most contended stretch of the step.  Off.
+_WGRAD_PAIR = os.environ.get("MMT_WGRAD_PAIR", "0") != "0"
 _WGRAD_DEFER = os.environ.get("MMT_WGRAD_DEFER", "1") != "0"   # supervised weight gradients in one batch after the supervised backward (0: interleaved, the A/B alternative)
 
 
@@ -272,6 +278,7 @@ class MTtrainer(object):
         # "pair" (one N = 4 forward, two autograd graphs: the default) | "split" (two passes) | "batched" (one pass, one graph):
         # the alternatives are what tests/test_train_step_gpu.py compares the default schedule with
         self.student_passes = "pair"
+        self.pair_wgrads = None   # tests: True / False overrides MMT_WGRAD_PAIR
         self.skipped_pairs = 0  # steps whose consistency branch was skipped (no pseudo box on some image)
         # priority -1: HIP maps streams of one priority onto a few hardware queues round-robin; once RCCL has created its own
         # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
@@ -331,7 +338,6 @@ class MTtrainer(object):
                 early = True
             elif xs.shape[1:] == xu.shape[1:]:
                 # one pass over [labeled crops ; unlabeled student view]; the two forwards consume their slice of the pyramid
-                from maskrcnn_benchmark.layers import fused
                 pyr = self.student.backbone(torch.cat([xs, xu], 0))
                 n = xs.shape[0]
                 parts = [fused.split_batch(l, n) for l in pyr]
@@ -355,7 +361,7 @@ class MTtrainer(object):
             if early:
                 losses_dict = self.weight_sum_loss(loss_dict, iteration)
                 defer = _WGRAD_DEFER and use_mt and job is not None
-                pairing = _WGRAD_PAIR and use_mt
+                pairing = (_WGRAD_PAIR if self.pair_wgrads is None else self.pair_wgrads) and use_mt
                 from maskrcnn_benchmark.layers import fused as _fused
                 if defer:
                     _fused.defer_wgrads(True)

@@ -305,6 +305,35 @@ def test_pair_forward_equals_batched_forward_and_split_backward(small):
     _close(p_t - snap["t"], s_t - snap["t"], 5e-4, "teacher update")
 
 
+def test_paired_weight_gradients_equal_separate(small):
+    """engine/MTtrainer.py `pair_wgrads` (MMT_WGRAD_PAIR, off by default: measured slower in the step): the two student passes'
+    weight gradients of a layer leave as ONE two-segment launch (mmt_conv_args.x2).  Same products, another summation order: the
+    flat gradient and both updates equal those of the separate launches; the pairing really happened (launch counters)."""
+    from maskrcnn_benchmark import _hip as H
+    _, trainer, batch = small
+    snap = _snapshot(trainer)
+    keep = trainer.pair_wgrads
+    try:
+        trainer.pair_wgrads = False
+        _run_schedule(trainer, batch, 1400, True, "pair", True, 3)
+        _restore(trainer, snap)
+        a_l, a_g, a_s, a_t = _run_schedule(trainer, batch, 1400, True, "pair", True, 11)
+        _restore(trainer, snap)
+        trainer.pair_wgrads = True
+        n0, w0 = H.F16_STATS.get("wgrad_pairs", 0), H.F16_STATS["wgrad"]
+        b_l, b_g, b_s, b_t = _run_schedule(trainer, batch, 1400, True, "pair", True, 11)
+        pairs, launches = H.F16_STATS.get("wgrad_pairs", 0) - n0, H.F16_STATS["wgrad"] - w0
+        _restore(trainer, snap)
+    finally:
+        trainer.pair_wgrads = keep
+    assert pairs >= 30 and launches < 100, (pairs, launches)      # ResNet body + FPN + box head went out in pairs
+    for k in a_l:
+        assert b_l[k] == pytest.approx(a_l[k], rel=5e-6), k
+    _close(b_g, a_g, 1e-4, "gradient, paired vs separate weight gradients")
+    _close(b_s - snap["s"], a_s - snap["s"], 1e-4, "student update")
+    _close(b_t - snap["t"], a_t - snap["t"], 5e-4, "teacher update")
+
+
 def test_bench_schedule_equals_serial_160(small):
     _, trainer, batch = small
     _schedule_equivalence(trainer, batch)
