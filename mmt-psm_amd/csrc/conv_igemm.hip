@@ -3539,6 +3539,24 @@ extern "C" int mmt_amax_stats(const float* x, long n, float* slot, void* stream)
   return 0;
 }
 
+// out <- the statistics of a tensor whose every element is a CONVEX combination of elements of the tensors behind `slots`
+// (ROIAlign: bilinear taps of the pyramid levels, averaged): max = the largest of the maxima -- an upper bound, which is all the
+// consumer's power-of-two scale needs -- sums and counts added (the mean of such a tensor is about that of its sources)
+__global__ void stats_combine_kernel(const float* const* __restrict__ slots, const int n, float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i >= 33) return;
+  float v = 0.f;
+  for (int k = 0; k < n; k++) v = i == 0 ? fmaxf(v, slots[k][0]) : v + slots[k][i];
+  out[i] = v;
+}
+
+extern "C" int mmt_stats_combine(const float* const* slots_dev, int n, float* out, void* stream) {
+  if (!slots_dev || !out || n <= 0) return MMT_EINVAL;
+  hipLaunchKernelGGL(stats_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slots_dev, n, out);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
 // y = a + b (+ c) (+ d) elementwise (n % 4 == 0, 16-byte aligned; y may be one of the inputs) and the statistics of y into `slot`
 // (33 floats, zeroed by the caller) as mmt_amax_stats records them
 extern "C" int mmt_sum_stats(const float* a, const float* b, const float* c, const float* d, float* y, long n, float* slot,

@@ -125,6 +125,7 @@ _SIGS = {
     "mmt_ciam_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_ciam_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_void_p, c_void_p, c_void_p],
+    "mmt_stats_combine": [c_void_p, c_int, c_void_p, c_void_p],
     "mmt_sum_stats": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
@@ -322,6 +323,31 @@ def _amax_of(x):
         _check(lib().mmt_amax_stats(x.data_ptr(), x.numel(), slot.ptr, _stream()), "mmt_amax_stats")
         am = x._mmt_amax = (slot, x._version)
     return am
+
+
+_COMBINE_PTRS = {}
+
+
+def stats_of_convex_combination(out, sources):
+    """attach to `out` -- a tensor whose elements are convex combinations of elements of `sources` (ROIAlign of pyramid levels) --
+    a statistics slot derived from theirs (include/mmtpsm.h: mmt_stats_combine): one 64-thread launch instead of a reduction pass
+    over `out`.  Nothing happens unless every source carries a recorded slot."""
+    slots = []
+    for t in sources:
+        am = getattr(t, "_mmt_amax", None)
+        if am is None or am[1] != t._version or type(am[0]) is not _Slot:
+            return
+        slots.append(am[0].ptr)
+    from maskrcnn_benchmark.utils.miscellaneous import dev_const
+    key = tuple(slots)
+    ptrs = _COMBINE_PTRS.get(key)
+    if ptrs is None:
+        if len(_COMBINE_PTRS) > 512:
+            _COMBINE_PTRS.clear()
+        ptrs = _COMBINE_PTRS[key] = torch.tensor(slots, dtype=torch.int64).to(out.device, non_blocking=True)
+    slot = _amax_slot(out.device)
+    _check(lib().mmt_stats_combine(ptrs.data_ptr(), len(slots), slot.ptr, _stream()), "mmt_stats_combine")
+    out._mmt_amax = (slot, out._version)
 
 
 def sum_stats(ts):

@@ -276,13 +276,18 @@ class LinearFn(torch.autograd.Function):
         input_relu, in_mask_scale, has_b = ctx.cfgv
         R, K = x4.shape[:2]
         O = w4.shape[0]
-        g4 = g.contiguous().view(R, O, 1, 1)
+        gc = g.contiguous()
+        g4 = gc.view(R, O, 1, 1)
+        _carry_stats(g, gc)       # the statistics the producing launch recorded survive the reshapes (no reduction pass per fc layer)
+        _carry_stats(gc, g4)
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
             dw, db = _wgrad(x4, g4, w4, 1, 0, None, has_b, *ctx.dst)
             dw = dw.view(O, K) if dw is not None else None
         if ctx.needs_input_grad[0]:
-            dx = _dgrad(g4, w4, x4.shape, 1, 0, None, x4 if input_relu else None, in_mask_scale).view(R, K)
+            d4 = _dgrad(g4, w4, x4.shape, 1, 0, None, x4 if input_relu else None, in_mask_scale)
+            dx = d4.view(R, K)
+            _carry_stats(d4, dx)
         return dx, dw, db, None, None, None, None
 
 
@@ -465,6 +470,8 @@ class RoiAlignFpnFn(torch.autograd.Function):
     def forward(ctx, rois, levels, res, scales, sr, *feats):
         feats = [H.nhwc(f) for f in feats]
         out = H.roi_align_forward(feats, scales, rois, levels, res, res, sr)
+        if out.dtype == torch.float32 and H.F16X2 and H.get_conv_precision() == 3:
+            H.stats_of_convex_combination(out, feats)   # fc6 / the mask head scale the pooled tensor from the levels' maxima
         ctx.save_for_backward(rois, levels)
         ctx.cfgv = (res, scales, sr, [tuple(f.shape) for f in feats])
         ctx.fdt = feats[0].dtype

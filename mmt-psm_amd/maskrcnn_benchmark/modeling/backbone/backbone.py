@@ -219,10 +219,13 @@ def forward_pair(backbone, xa, xb):
             args += [m.weight, m.bias]
         pre = ([fused.batch_slice(t, lo, hi) for t in inner_cat], [fused.batch_slice(t, lo, hi) for t in outs_cat])
         pyr = list(fused.FPNFn.apply(*args, getattr(fpn, "out_planes", True), pre))
-        for p_, o_ in zip(pyr, pre[1]):  # the node's outputs are new tensor objects: the planes of the slices go along
+        for p_, o_ in zip(pyr, pre[1]):  # the node's outputs are new tensor objects: the planes / statistics of the slices go along
             pl = H.planes_of(o_)
             if pl is not None:
                 p_._mmt_planes = (pl, p_._version)
+            am = getattr(o_, "_mmt_amax", None)
+            if am is not None and am[1] == o_._version:
+                p_._mmt_amax = (am[0], p_._version)
         if fpn.top_blocks is not None:
             pyr.extend(fpn.top_blocks(pyr[-1]))
         res.append(tuple(pyr))
@@ -262,7 +265,14 @@ class FPN(nn.Module):
 
 class LastLevelMaxPool(nn.Module):
     def forward(self, x):
-        return [x[:, :, ::2, ::2]]  # max_pool2d(kernel 1, stride 2) == subsampling (fpn.py:72-74)
+        y = x[:, :, ::2, ::2]  # max_pool2d(kernel 1, stride 2) == subsampling (fpn.py:72-74)
+        am = getattr(x, "_mmt_amax", None)
+        if am is not None and am[1] == x._version and x.is_cuda:
+            # dense here (the copy its consumers would make anyway), with P5's statistics slot: the maximum of a subset is bounded
+            # by it -- what the fp16 split's scale needs (no reduction pass over P6)
+            y = y.contiguous(memory_format=torch.channels_last)
+            y._mmt_amax = (am[0], y._version)
+        return [y]
 
 
 def build_resnet_fpn_backbone(cfg):

@@ -216,7 +216,9 @@ class GeneralizedRCNN(nn.Module):
             if all(v.shape == views[0].shape for v in views):
                 pyr = self.run_backbone(torch.cat(views, 0))
                 self._batched_pyr = (pyr, n, len(views))
-                feats = [tuple(level[i * n:(i + 1) * n] for level in pyr) for i in range(len(views))]
+                # (batch_slice: the statistics slot / planes of a level go along with its slices -- no reduction pass per level
+                # in front of the RPN head of the coarse inference)
+                feats = [tuple(fused.batch_slice(level, i * n, (i + 1) * n) for level in pyr) for i in range(len(views))]
             else:
                 feats = [self.backbone(v) for v in views]
         else:

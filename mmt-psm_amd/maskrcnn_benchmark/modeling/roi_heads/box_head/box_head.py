@@ -78,8 +78,9 @@ class FPN2MLPFeatureExtractor(nn.Module):
             sd[k] = self._perm(sd[k], False).contiguous()
 
     def forward(self, x, proposals, filp=False, istrain=False):
-        x = self.pooler(x, proposals)                      # (R, C, 7, 7) NHWC-dense
-        x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)  # (R, 7*7*C) view
+        pooled = self.pooler(x, proposals)                 # (R, C, 7, 7) NHWC-dense
+        x = pooled.permute(0, 2, 3, 1).reshape(pooled.shape[0], -1)  # (R, 7*7*C) view
+        fused._carry_stats(pooled, x)                      # (the statistics slot of the pooled tensor: fc6's scale, no reduction pass)
         x = self.fc6(x, relu=True)
         mul = None
         if self.p_drop > 0 and istrain:

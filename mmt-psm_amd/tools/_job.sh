@@ -1,13 +1,5 @@
 cd $GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/gputest_c.log 2>&1; echo rc=$? >> gpurun_out/gputest_c.log
+python mmt-psm_amd/tools/f16_stats.py 2>/dev/null | grep -v amdgpu.ids | tail -30 > gpurun_out/f16_stats.txt
 export MMT_BENCH_NO_FP32_LEG=1
-python - <<'PY' > gpurun_out/ab_fork.txt 2>&1
-import json, subprocess, sys, os
-for i in range(2):
-    for tag, env in (("chain       ", {"MMT_FORK_TAIL_OFF": "1"}), ("fork prio 0 ", {"MMT_FORK_PRIO": "0"}), ("emb only -1 ", {"MMT_FORK_WHICH": "emb"}),
-                     ("mask only -1", {"MMT_FORK_WHICH": "mask"}), ("emb only 0  ", {"MMT_FORK_WHICH": "emb", "MMT_FORK_PRIO": "0"}),
-                     ("mask only 0 ", {"MMT_FORK_WHICH": "mask", "MMT_FORK_PRIO": "0"}), ("fork prio 1 ", {"MMT_FORK_PRIO": "1"})):
-        p = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--profile-steps", "1"],
-                           env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-        d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
-        print(tag, d["ms_per_step"], d["median_ms_per_step"], d["p10_p90_ms_per_step"], flush=True)
-PY
+for i in 1 2; do python bench.py --steps 60 --warmup 10 --no-cpu-baseline --profile-steps 1 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['ms_per_step'], d['median_ms_per_step'], d['p10_p90_ms_per_step'])"; done > gpurun_out/bench_c.txt
