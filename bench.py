@@ -48,7 +48,7 @@ N_LAB, N_UNLAB, N_INST = 2, 2, 12
 BENCH_BASE_LR = 1e-7
 
 
-def build(device, rank, irnet=False, crop=None, n_inst=None, base_lr=None, n_lab=None, n_unlab=None):
+def build(device, rank, irnet=False, crop=None, n_inst=None, base_lr=None, n_lab=None, n_unlab=None, supervised=False):
     import synthetic
     from maskrcnn_benchmark.config import make_default_cfg
     from maskrcnn_benchmark.modeling.detector import build_detection_model
@@ -68,6 +68,8 @@ def build(device, rank, irnet=False, crop=None, n_inst=None, base_lr=None, n_lab
                              "MODEL.RELATION_NMS.LOSS", 0.01])
     if base_lr is not None:
         cfg.merge_from_list(["SOLVER.BASE_LR", base_lr])
+    if supervised:   # BASELINE configs[1]: MT.LAMBDA 0 -- no teacher pass, no consistency branch, no EMA
+        cfg.merge_from_list(["MT.LAMBDA", 0.0])
     torch.manual_seed(0)
     student = build_detection_model(cfg, is_student=True)
     teacher = build_detection_model(cfg, is_teacher=True)
@@ -295,6 +297,8 @@ def main():
                     "two-term fp16 split: 3 matrix products per multiply instead of 6")
     ap.add_argument("--bf16x3", action="store_true", help="the round-2 default arithmetic, now the per-tensor fall-back: 3-term bf16 "
                     "split, 6 matrix products per multiply (MMT_F16X2=0)")
+    ap.add_argument("--supervised", action="store_true", help="BASELINE configs[1]: Mask R-CNN R50-FPN supervised-only (MT.LAMBDA 0), "
+                    "bs = 4 labeled 1000x1000 crops per GPU, fwd + bwd + SGD; not the headline line")
     ap.add_argument("--bf16", action="store_true", help="BASELINE configs[4]'s arithmetic: bf16 products (fp32 accumulate) and bf16 "
                     "activation storage in the backbone + FPN (MMT_CONV_PRECISION=1 MMT_BF16_STORAGE=1); not the headline line")
     args = ap.parse_args()
@@ -332,7 +336,9 @@ def main():
         _hip.set_f16x2(True)
     if args.bf16x3:
         _hip.set_f16x2(False)
-    cfg, trainer, batch = build(device, rank, args.irnet, base_lr=BENCH_BASE_LR)
+    cfg, trainer, batch = build(device, rank, args.irnet, base_lr=BENCH_BASE_LR, supervised=args.supervised,
+                                n_lab=4 if args.supervised else None)
+    per_gpu = 4 if args.supervised else N_LAB + N_UNLAB
     it0 = cfg.MT.START_MT + cfg.MT.RAMPUP_STEP + 100  # mean-teacher branch active, consistency weight = lambda
 
     def sync():
@@ -343,7 +349,7 @@ def main():
 
     def step(i):
         il, targets, ul = batch()
-        return trainer.train_step(it0 + i, il, targets, ul)
+        return trainer.train_step(it0 + i, il, targets, None if args.supervised else ul)
 
     def timed(first, n, profile):
         """n steps between two (barrier + synchronize) pairs.  profile=False: the headline leg -- nothing but one event per
@@ -422,13 +428,13 @@ def main():
         dt0, _, _, _ = timed(nxt + 1, n0, False)
         _, g0, _, _ = timed(nxt + 1 + n0, n0, True)
         fl0, ms0 = total(g0.get("fwd1", []))
-        ref_fp32 = {"ms_per_step": round(dt0 / n0 * 1e3, 3), "value": round((N_LAB + N_UNLAB) * n0 / dt0, 4),
+        ref_fp32 = {"ms_per_step": round(dt0 / n0 * 1e3, 3), "value": round(per_gpu * n0 / dt0, 4),
                     "steps": n0, "dominant_kernel_tflops": round(fl0 / (ms0 * 1e-3) / 1e12, 2) if ms0 > 0 else None,
                     "frac_of_fp32_mfma_peak": round(fl0 / (ms0 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ms0 > 0 else None}
         _hip.set_conv_precision(mode)
 
     if rank == 0:
-        imgs_per_step = (N_LAB + N_UNLAB) * world
+        imgs_per_step = per_gpu * world
         value = imgs_per_step * args.steps / dt          # whole-job throughput over the K bracketed steps
         import statistics
         med = statistics.median(per_step)                 # per-step durations from the step-boundary events (rank 0)
@@ -459,11 +465,13 @@ def main():
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "backend": (dist.get_backend() + " (RCCL)") if use_dist else "none (single process, no process group)",
             "vs_baseline": None, "dtype": "bf16" if mode == 1 else "f32", "data": "synthetic",
-            "config": {"workload": "MMT-PSM mean-teacher step (BASELINE configs[2]; configs[3] when n_gpus>1): per GPU 2 "
-                                   "labeled + 2 unlabeled 1000x1000x3 crops, AUG_K=2 + flip, AUG_S=1, MT.LAMBDA 5, "
-                                   "PSM+MGD, EMA teacher, fwd+bwd+SGD, R50-FPN fp32, IR-Net %s" % (
+            "config": {"workload": ("Mask R-CNN R50-FPN supervised-only step (BASELINE configs[1]): per GPU 4 labeled 1000x1000x3 "
+                                    "crops, MT.LAMBDA 0, fwd+bwd+SGD, fp32, IR-Net %s" if args.supervised else
+                                    "MMT-PSM mean-teacher step (BASELINE configs[2]; configs[3] when n_gpus>1): per GPU 2 "
+                                    "labeled + 2 unlabeled 1000x1000x3 crops, AUG_K=2 + flip, AUG_S=1, MT.LAMBDA 5, "
+                                    "PSM+MGD, EMA teacher, fwd+bwd+SGD, R50-FPN fp32, IR-Net %s") % (
                                        "ON (relation NMS + mask relation; RELATION_NMS.LOSS 0.01)" if args.irnet else "off"),
-                       "image_forwards_per_step_per_gpu": 12, "parallelism": "dp%d" % world,
+                       "image_forwards_per_step_per_gpu": 4 if args.supervised else 12, "parallelism": "dp%d" % world,
                        "base_lr": BENCH_BASE_LR, "consistency_branch_skipped_steps": skipped,
                        "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}},
             "roofline": roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dtp, npf, dom),

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/gputest_c.log 2>&1; echo rc=$? >> gpurun_out/gputest_c.log
-python mmt-psm_amd/tools/f16_stats.py 2>/dev/null | grep -v amdgpu.ids | tail -30 > gpurun_out/f16_stats.txt
-export MMT_BENCH_NO_FP32_LEG=1
-for i in 1 2; do python bench.py --steps 60 --warmup 10 --no-cpu-baseline --profile-steps 1 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['ms_per_step'], d['median_ms_per_step'], d['p10_p90_ms_per_step'])"; done > gpurun_out/bench_c.txt
+timeout 1500 python -m pytest tests/test_train_step_gpu.py -x -q -m gpu -k "supervised_step or bench_size" -s > gpurun_out/t_sup.log 2>&1; echo rc=$? >> gpurun_out/t_sup.log
+MMT_BENCH_NO_FP32_LEG=1 python bench.py --supervised --steps 40 --warmup 10 --no-cpu-baseline > gpurun_out/bench_supervised.json 2> gpurun_out/bench_supervised.err
+python mmt-psm_amd/tools/f16_stats.py 2>/dev/null | grep -v amdgpu.ids | tail -16 > gpurun_out/f16_stats.txt

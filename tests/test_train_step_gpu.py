@@ -416,6 +416,56 @@ def test_full_step_losses_match_oracle_at_bench_size(synth, state_shapes, weight
         assert e < 2e-4, (k, float(losses[k]), float(ref_losses[k]), e)
 
 
+@pytest.mark.parametrize("mode", [0, 3], ids=["fp32-mfma", "default-f16x2-split"])
+def test_supervised_step_losses_match_oracle_at_bench_size(synth, state_shapes, weights, mode):
+    """BASELINE configs[1] ("supervised-only on 1 x MI355X, fp32 -- validate conv / ROIAlign / NMS HIP kernels vs CPU") at the
+    bench's size: bench.build(supervised=True) with 2 labeled 1000 x 1000 crops (12 instances each), one supervised iteration
+    (MT.LAMBDA 0: no teacher, no EMA) against oracle.model.Trainer.step -- the five losses to 2e-4 relative with only the
+    sampler draws replayed, the proposal list compared through Replay.align."""
+    from maskrcnn_benchmark import _hip
+    from maskrcnn_benchmark.utils.replay import Replay
+    bench = _bench()
+    om, ot = _oracle_trainer(synth, state_shapes, weights)
+    ot.cfg.mt_lambda = 0.0
+    imgs, tgs = synth.make_labeled(2, 1000, 12, seed=1234)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    key = "sup_ref"
+    if key not in _FULLSIZE_ORACLE:
+        _FULLSIZE_ORACLE[key] = ot.step(1400, imgs, _oracle_targets(om, tgs), None, seeds=(99, 100, 101))
+    ref_losses, (ta, _, _) = _FULLSIZE_ORACLE[key]
+    prev = _hip.get_conv_precision()
+    _hip.set_conv_precision(mode)
+    try:
+        cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, n_lab=2, supervised=True)
+        _load(trainer, weights)
+        before_t = trainer.flat_t.data.clone()
+        stu = {"rpn_sampler": ta["rpn_sampler"], "roi_sampler": ta["roi_sampler"], "rpn_proposals": ta["rpn_proposals"],
+               "dropout": list(ta["dropout"])}
+        trainer.student.set_replay(Replay(stu))
+        trainer.student.taps = {}
+        try:
+            il, tg, _ = batch()
+            losses = trainer.train_step(1400, il, tg, None)
+            torch.cuda.synchronize()
+        finally:
+            trainer.student.set_replay(None)
+            own = trainer.student.taps
+            trainer.student.taps = None
+    finally:
+        _hip.set_conv_precision(prev)
+    assert set(losses) == set(ref_losses) == {"loss_classifier", "loss_box_reg", "loss_seg", "loss_objectness", "loss_rpn_box_reg"}
+    assert torch.equal(trainer.flat_t.data, before_t)            # MT.LAMBDA 0: the teacher is never touched
+    moved = own.get("rpn_proposals_moved", [])
+    for n, i, j in moved:
+        sc = ta["rpn_proposals"][n][1]
+        assert abs(float(sc[i]) - float(sc[j])) <= 2e-5 * max(abs(float(sc[i])), 1e-3), (n, i, j)
+    assert len(moved) <= 64
+    err = {k: abs(float(losses[k]) - float(v)) / max(abs(float(v)), 1e-12) for k, v in ref_losses.items()}
+    print("full-size supervised loss parity (mode %d): %s; rows re-aligned: %d" % (mode, {k: "%.2e" % e for k, e in err.items()}, len(moved)))
+    for k, e in err.items():
+        assert e < 2e-4, (k, float(losses[k]), float(ref_losses[k]), e)
+
+
 def test_device_sampler_properties():
     """BalancedPositiveNegativeSampler on the device (what runs when nothing is replayed): counts, membership and the
     positive fraction of balanced_positive_negative_sampler.py:20-72, uniformity of the draw"""
