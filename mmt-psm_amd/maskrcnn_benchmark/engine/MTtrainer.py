@@ -165,10 +165,23 @@ class BucketedAllReduce(object):
             self._t0.record()
 
     def _send(self, lo, hi):
-        from maskrcnn_benchmark.layers.fused import join_wgrads, release_parked
+        """one piece of the flat gradient goes out.  Its last contributions are weight gradients on the SIDE stream (layers/fused.py)
+        and whatever the step stream has issued up to this hook.  Round 4: the collective is issued FROM the side stream, behind a
+        side-waits-for-step-stream edge -- RCCL's stream then orders itself behind both, and the step stream is never made to wait
+        (round 3 joined the side stream into the step stream here: four stalls of the data-gradient chain per backward pass, part of
+        the +2.4 ms a process group cost at world size 1)."""
+        from maskrcnn_benchmark.layers import fused as F_
         g = self.flat.grad
-        release_parked(g.data_ptr() + 4 * lo, g.data_ptr() + 4 * hi)   # supervised-pass jobs still waiting for a partner that will not come
-        join_wgrads()   # weight gradients run on a side stream (layers/fused.py): the piece is final when they are done
+        F_.release_parked(g.data_ptr() + 4 * lo, g.data_ptr() + 4 * hi)   # supervised-pass jobs still waiting for a partner that will not come
+        side = F_.side_stream_for_exchange(g.device) if g.is_cuda else None
+        if side is None:
+            F_.join_wgrads()   # no side stream in this configuration: the piece is final on the step stream
+            self._issue(lo, hi)
+            return
+        with torch.cuda.stream(side):
+            self._issue(lo, hi)
+
+    def _issue(self, lo, hi):
         if getattr(self, "tracing", False):
             e = torch.cuda.Event(enable_timing=True)
             e.record()

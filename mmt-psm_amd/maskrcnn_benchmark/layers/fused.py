@@ -64,7 +64,10 @@ _WG = {}   # device -> [side stream, launches since the last join, end-of-backwa
 def _wg_stream(dev):
     ent = _WG.get(dev)
     if ent is None:
-        ent = _WG[dev] = [torch.cuda.Stream(device=dev), 0, False, [], []]
+        # priority -1 like the teacher's stream (engine/MTtrainer.py): HIP deals the streams of a priority class onto a few hardware
+        # queues, and once RCCL has created its own a default-priority side stream shares one with the step stream -- under a process
+        # group the step cost 37.9 ms with this stream at priority 0 and 36.3 at -1 (world size 1, same box); without one 35.5 either way
+        ent = _WG[dev] = [torch.cuda.Stream(device=dev, priority=-1), 0, False, [], []]
     return ent
 
 
@@ -99,6 +102,19 @@ _WG_PARKED = {}       # (address of dw, shapes) -> [parked jobs]
 
 def wgrad_pair_phase(phase):
     _WG_PAIR[0] = phase
+
+
+def side_stream_for_exchange(dev):
+    """the weight-gradient side stream, with every job collected so far handed over and ordered behind the current stream -- what
+    a piece of the data-parallel exchange is issued from (engine/MTtrainer.py::BucketedAllReduce._send); None when this
+    configuration runs its weight gradients on the step stream"""
+    if not _WG_ON or not (H.get_conv_precision() == 3 or _WG_BF16):
+        return None
+    ent = _wg_stream(dev)
+    flush_wgrads(ent, dev)
+    ent[0].wait_stream(torch.cuda.current_stream(dev))   # gradients the step stream wrote itself (deconvolution, bias sums)
+    ent[1] += 1                                            # (something to join at the end even if no job went over)
+    return ent[0]
 
 
 def release_parked(lo_ptr, hi_ptr):

@@ -199,7 +199,15 @@ def test_bucketed_allreduce_covers_every_gradient_exactly_once(monkeypatch):
     calls = []
 
     class Work(object):
+        """what a process-group work handle does: `wait` orders the CALLER's stream behind the collective, which ran on the stream
+        it was issued from (the weight-gradient side stream, engine/MTtrainer.py::BucketedAllReduce._send)"""
+
+        def __init__(self):
+            self.ev = torch.cuda.Event()
+            self.ev.record()
+
         def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
             return True
 
     def fake_all_reduce(t, op=None, async_op=False):
@@ -207,7 +215,7 @@ def test_bucketed_allreduce_covers_every_gradient_exactly_once(monkeypatch):
             return Work() if async_op else None
         calls.append((t.data_ptr(), t.numel()))
         t.mul_(2.0)
-        return Work() if async_op else None
+        return Work() if async_op else None   # (the event is recorded behind the doubling, on the issuing stream)
 
     monkeypatch.setattr(dist, "is_initialized", lambda: True)
     monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
