@@ -3279,6 +3279,11 @@ int launch_pp(const ConvP& p, hipStream_t s, int ksplit = 1) {
 static int strip_ksplit(const ConvP& p, int tw) {
   const long tiles = (long)p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
   if (tiles >= 256) return 1;
+  // fp32 tensors (the split arithmetics): a few-tile shape is NOT taken -- this kernel needs its input as pre-split planes, a pass
+  // of its own over the tensor (~9 us on the student's N = 2 maps) that the tiled kernel, which splits in registers, does not; with
+  // equal kernel times (profiles/r04_dispatch_sweep.txt: 35.07 vs 35.12-35.23 ms) the pass is what counts: 32 fewer launches per
+  // step, 35.55 -> 35.34 ms in three same-box alternations (round 4).  bf16-stored tensors ARE their plane: split form kept.
+  if (!(p.io & IO_X)) return 0;
   const char* e = getenv("MMT_SPLITK");
   if ((e && atoi(e) == 0) || p.Wo != tw || (p.Cout & 127) || tiles < 32) return 0;
   int ks = (int)((256 + tiles - 1) / tiles);

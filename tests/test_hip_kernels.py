@@ -583,7 +583,7 @@ def test_conv3x3_strip_kernel_planes(hip, restore_mode):
     hip.set_conv_precision(3)
     hip.set_f16x2(False)   # the bf16-plane form of the kernel (the fall-back arithmetic); its fp16 form: tests/test_f16x2_gpu.py
     g = torch.Generator().manual_seed(31)
-    taken = 0  # shapes the library ran on the strip kernel: full grids, and the split-K form (few tiles, Wo == strip width)
+    taken = 0  # shapes the library ran on the strip kernel: grids of >= 256 tiles (round 4: fp32 few-tile shapes go to the tiled kernel)
     for (N, C, H, W, Co, opts) in ((2, 128, 128, 128, 192, "res"), (8, 256, 64, 64, 256, "relu"), (32, 128, 32, 64, 128, "mask"),
                                    (8, 160, 64, 128, 64, ""), (1, 256, 64, 64, 256, "relu"), (2, 256, 64, 64, 256, "res"),
                                    (2, 128, 128, 128, 128, "relu"), (1, 256, 64, 64, 192, ""), (1, 64, 64, 64, 128, "")):
@@ -621,7 +621,7 @@ def test_conv3x3_strip_kernel_planes(hip, restore_mode):
             taken += 1
         else:
             assert torch.equal(y_new, y_old)       # not a shape for it: planes ignored, same kernel as before
-    assert taken >= 6
+    assert taken >= 4
 
 
 def test_box_decode_kernel(hip):
