@@ -766,6 +766,17 @@ __device__ __forceinline__ void dma16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_ptr_t)l, 16, 0, 0);
 }
 
+// The same copy as an instruction the compiler does not see.  It orders every LDS read that might alias an LDS-DMA target
+// behind `s_waitcnt vmcnt(0)`; in a loop that keeps register loads and stores in flight across the copy (the row-resident
+// 1x1 kernel) that wait would drain them all before each matrix phase.  The kernel waits for its copies with counted
+// `s_waitcnt vmcnt(n)` itself.  `l` is wave-uniform (M0 = LDS byte address, lane i lands at + 16 i).
+__device__ __forceinline__ void dma16_unseen(const void* g, void* l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)l);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "m0", "memory");
+#endif
+}
+
 // F16 (opt-in, NS == 2): the weight planes hold the two fp16 terms of w * s_w; the activations are scaled by the power of
 // two of their recorded maximum (p.f16_sx -> max |x|, a device scalar) and split into two fp16 terms in registers; 3 products
 template <int BM, int BN, int WM, int WN, int NS, int S, bool F16 = false>
@@ -1734,16 +1745,17 @@ static void launch_finish(const ConvP& p, int tiles, int ksplit, const float* ws
 // (zeros for rows >= Cout).  One wave produces one 1 KiB unit of each plane: lane = (row, half).
 struct PackDesc { long src_off, dst_off; int Cout, K, unit0, pad; };
 
-// ------------------------------------------------------------------------- 1x1 convolutions with K = 64 / 128
+// ------------------------------------------------------------------------- 1x1 convolutions with K = 64 / 128 / 256
 // The expanding 1x1 layers of layer1 / layer2 (64 -> 256, 128 -> 512: output + residual dominate, 2-6 FLOP/B) are not
 // matrix-bound and not HBM-bound in the tiled kernel above but INSTRUCTION-bound: a block owns one 128 x 64 tile with
 // only 4-8 k-steps, so its ~600-instruction prologue (row decode, ring fill, first split), the per-step bookkeeping
 // and the epilogue are paid per 48 MFMAs (measured: 1230 vector + 630 scalar instructions per wave per tile).
-// Here a block owns 128 ROWS and walks across all Cout panels:
-//   * each wave loads its 32 rows of A straight into registers (no LDS) and splits them into bf16 fragments ONCE for
-//     the whole K and for every panel (instead of once per panel);
+// Here a block owns 128 ROWS and walks across Cout in panels of 32 columns:
+//   * each wave loads its 32 rows of A straight into registers (no LDS) and splits them into bf16 / fp16 fragments ONCE
+//     for the whole K and for every panel (instead of once per panel);
 //   * the pre-split weight planes of panel nt+1 are DMA-copied into the other LDS buffer while panel nt is multiplied;
-//   * per panel: KT x 6 x TN MFMAs from registers / LDS fragments, then the shared epilogue.
+//   * per panel: KT x 6 (x 3 on the fp16 split) MFMAs from registers / LDS fragments, then the epilogue straight from the
+//     accumulator registers.
 // Arithmetic and summation order are those of conv_fwd_glds_kernel (bit-identical results).
 // F16 (round 3): the two-term fp16 split of the default arithmetic -- A scaled by the power of two of its recorded maximum
 // (p.f16_sx -> max |x|) and split ONCE into (h, l) fragments that stay in registers for every panel; weight planes are the
@@ -1752,20 +1764,31 @@ struct PackDesc { long src_off, dst_off; int Cout, K, unit0, pad; };
 // FPN lateral of C2, the hint adaptors and the data gradients of every 1x1 layer with 256 output channels.  In the tiled
 // kernel those re-read the raw fp32 rows once per 64-column tile through the L2 -> LDS path (256 -> 1024 at 8 x 64 x 64:
 // 786 MB for 17 GFLOP, 170 us); here a row is read once per column group.  blockIdx.y = column group (`ppb` panels each):
-// the few-tile student shapes (N = 2: 64 row blocks) still fill the chip.  The (x > 0) mask of a data gradient is applied
-// in the epilogue like the residual (requested before the panel's MFMAs).
-template <int KT, int BN, int NS, bool F16 = false>
+// the few-tile student shapes (N = 2: 64 row blocks) still fill the chip.
+// Epilogue (round 4; plain / residual-add / masked output): an accumulator register of the 32 x 32 tile is one output row x
+// 32 consecutive channels per half wave, so every store / residual / mask instruction of a wave touches two complete
+// 128-byte lines -- nothing is staged through LDS and the weight ring's barrier is the only one.  What bounds these layers
+// is the number of residual bytes a CU keeps in flight (8 waves; 2 - 3 us of loaded HBM latency), so the residual / mask values
+// of LATER panels are requested inside the epilogue of panel nt, each into the register its predecessor was just consumed
+// from: LA = 2 panels ahead (two register sets, the loop unrolled by two), one panel ahead where the mask values need the
+// registers (MASK with K = 256).  They fly through the stores, the barrier and the matrix phases in between.  The staged
+// epilogue of round 3 (tile -> LDS -> float4 rows, two more barriers per panel, requests in flight during the matrix phase
+// only) ran 256 -> 1024 at 8 x 64 x 64 in 128 us; this one in 87 us (profiles/r04_rows_epilogue.txt).
+// Every request is issued unconditionally (an absent operand is a zero-sized buffer: the load returns 0 without touching
+// memory): no branches in the loop and a fixed number of vector memory operations per panel, which the counted wait for
+// the weight planes at the end of an iteration relies on.
+template <int KT, int NS, bool F16 = false, bool MASK = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, const unsigned short* __restrict__ wpl,
                                                               const long wpl_stride, const int ppb) {
-  float amx = 0.f, asum = 0.f, acnt = 0.f;   // max |y| / sum |y| / count over what this thread stores (p.amax_out)
-  constexpr int TN = BN / 32;
-  constexpr int PIECES = KT * NS * TN;       // 1 KiB DMA pieces per panel: [kt][plane][32-column block]
+  constexpr int BN = 32;
+  constexpr int PIECES = KT * NS;            // 1 KiB DMA pieces per panel: [kt][plane]
   constexpr int BBUF = PIECES * 1024;
-  constexpr int CT_BYTES = 128 * BN * 4;     // epilogue staging
+  constexpr int LA = (MASK && KT == 16) ? 1 : 2;   // panels of look-ahead of the residual / mask requests
   static_assert(PIECES % 4 == 0, "pieces per wave");
   static_assert(!F16 || NS == 2, "fp16 split: two terms");
+  static_assert(!MASK || F16, "masked output: fp16 split only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  char* const bring = (char*)lds + CT_BYTES;
+  char* const bring = (char*)lds;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, kh2 = lane >> 5;
@@ -1778,21 +1801,29 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
   const int m0 = bid * 128;
   const int K = 16 * KT;
   const int nb32 = (p.Cout + 31) >> 5;
-  const int npanel = (p.Cout + BN - 1) / BN;
-  const int nt_lo = blockIdx.y * ppb, nt_hi = min(npanel, nt_lo + ppb);
+  const int nt_lo = blockIdx.y * ppb, nt_hi = min(nb32, nt_lo + ppb);
   F16Guard guard = {};
   if constexpr (F16) guard = f16_guard_load(p.guard_x);   // issued here, tested behind the first weight copies
   auto issue_b = [&](int nt, int buf) {
 #pragma unroll
     for (int i = 0; i < PIECES / 4; i++) {
       const int piece = wave + 4 * i;  // wave-uniform
-      const int kt = piece / (NS * TN), q = (piece / TN) % NS, rb = piece % TN;
-      int nb = nt * TN + rb;
-      if (nb >= nb32) nb = nb32 - 1;  // panel hanging over Cout: any valid block (those columns are never stored)
-      dma16(wpl + q * wpl_stride + ((long)kt * nb32 + nb) * 512 + lane * 8, bring + buf * BBUF + piece * 1024);
+      const int kt = piece / NS, q = piece % NS;
+      dma16_unseen(wpl + q * wpl_stride + ((long)kt * nb32 + nt) * 512 + lane * 8, bring + buf * BBUF + piece * 1024);
     }
   };
-  issue_b(nt_lo, 0);
+  // Panel order: block `bid` starts `bid % cnt` panels into its column group and wraps around.  All blocks start together and
+  // run in step; walking the panels in the same order they would all touch the same 128 bytes of their 4 KiB output rows
+  // (Cout = 1024) at the same time, i.e. the same few memory channels.
+  const int cnt = nt_hi - nt_lo;
+  if (cnt <= 0) return;
+  const int rot = bid % cnt;
+  auto pn = [&](int i) {   // i-th panel of this block; past the end: none
+    int t = i + rot;
+    if (t >= cnt) t -= cnt;
+    return i < cnt ? nt_lo + t : -1;
+  };
+  issue_b(pn(0), 0);
   if constexpr (F16) {   // the range guard, in the shadow of the first weight copies (see conv_fwd_glds_kernel)
     if (f16_guard_bad(guard)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1804,6 +1835,64 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
   // ---- A: rows m0 + 32 wave + lr, k = 16 kt + 8 kh2 .. + 7 per step; rows past M read zeros (buffer bounds)
   uint4 fa[KT][NS];   // bf16x8 / f16x8 fragments as raw words
   const float sx = F16 ? f16_scale_of_fwd(*p.f16_sx) : 1.f;
+  const int boff = lr * 32 + (((kh2 ^ (lr >> 3)) & 1) << 4);
+  const int col_l = lane & 31, rq = lane >> 5;
+  const unsigned cout4 = (unsigned)p.Cout * 4u;
+  const int mlane = m0 + wave * 32 + 4 * rq;            // row of accumulator register 0; register r: + 8 (r / 4) + r % 4
+  const unsigned ylane = (unsigned)mlane * cout4;       // rows past M: beyond the buffers' bounds (loads 0, stores dropped)
+  // residual rows of the four 8-row groups: same pixel (mode 1) or the nearest-x2 upsampled coarser map (mode 2: the FPN
+  // top-down add, backbone/fpn.py:57-62; Wo % 8 == 0 -- the launcher checks -- so a group lies in one image row)
+  unsigned rbase[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    rbase[g] = ylane + (unsigned)(8 * g) * cout4;
+    if (p.res_mode == 2) {
+      const int m = m0 + wave * 32 + 8 * g, HoWo = p.Ho * p.Wo;
+      const int img = m / HoWo, rem = m - img * HoWo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      rbase[g] = (unsigned)((img * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1) + 2 * rq) * cout4;
+    }
+  }
+  const int res_rows = p.res_mode == 2 ? p.N * (p.Ho >> 1) * (p.Wo >> 1) : p.M;
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res_mode ? p.res : p.x), 0, p.res_mode ? (int)((long)res_rows * p.Cout * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.mask ? p.mask : p.x), 0, p.mask ? (int)((long)p.M * p.Cout * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)((long)p.M * p.Cout * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.scale ? p.scale : p.x), 0, p.scale ? p.Cout * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.shift ? p.shift : p.x), 0, p.shift ? p.Cout * 4 : 0, 0x00020000);
+  const bool up = p.res_mode == 2, has_res = p.res_mode != 0, has_scale = p.scale != nullptr;
+  const float finv = F16 ? 1.f / (sx * *p.f16_sw) : 1.f;
+  float amx = 0.f, asum = 0.f, acnt = 0.f;   // max |y| / sum |y| / count over what this thread stores (p.amax_out)
+  float ur[LA][16], um[MASK ? LA : 1][16], scn[LA], shn[LA];
+  auto row_off = [&](int r) { return (unsigned)(8 * (r >> 2) + (r & 3)) * cout4; };
+  auto res_off = [&](int r) { return rbase[r >> 2] + (unsigned)(up ? (r & 3) >> 1 : (r & 3)) * cout4; };
+  auto col_bytes = [&](int nt) {   // byte offset of this lane's channel in panel nt; out of range -> beyond every bound
+    const int c = nt * BN + col_l;
+    return (nt >= 0 && c < p.Cout) ? (unsigned)c * 4u : 0x80000000u;
+  };
+  auto request = [&](auto slot, int r, unsigned cb) {
+    constexpr int S = decltype(slot)::value;
+    ur[S][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(res_off(r) + cb), 0, 0));
+    if constexpr (MASK)
+      um[S][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)(ylane + row_off(r) + cb), 0, 0));
+  };
+  auto request_affine = [&](auto slot, unsigned cb) {
+    constexpr int S = decltype(slot)::value;
+    scn[S] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsc, (int)cb, 0, 0));
+    shn[S] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsh, (int)cb, 0, 0));
+  };
+  auto first = [&](auto slot) {
+    const unsigned cb = col_bytes(pn(decltype(slot)::value));
+    request_affine(slot, cb);
+#pragma unroll
+    for (int r = 0; r < 16; r++) request(slot, r, cb);
+  };
+  first(std::integral_constant<int, 0>{});   // before the rows of A: these requests fly through the whole A phase
+  if constexpr (LA == 2) first(std::integral_constant<int, 1>{});
+  asm volatile("" ::: "memory");
   {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long)p.M * K * 4), 0x00020000);
@@ -1834,69 +1923,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
       if (KT > CH) __builtin_amdgcn_sched_barrier(0);
     }
   }
-  const int boff = lr * 32 + (((kh2 ^ (lr >> 3)) & 1) << 4);
-  // Epilogue (plain / residual-add / masked output, Cout % 4 == 0 -- the launcher checks) inlined: the residual and mask rows
-  // of a panel are requested BEFORE its MFMAs, so their latency hides behind the matrix phase instead of sitting in the
-  // epilogue (with two to four blocks per CU nothing else would cover it).  Same expressions as conv_epilogue.
-  constexpr int C4 = BN / 4, RPP = 256 / C4, ROWS = 128 / RPP;
-  const int cc = tid % C4, r0 = tid / C4;
-  // residual rows of this thread, the same for every panel: same pixel (mode 1) or the nearest-x2 upsampled coarser map
-  // (mode 2: the FPN top-down add, backbone/fpn.py:57-62)
-  const int res_rows = p.res_mode == 2 ? p.N * (p.Ho >> 1) * (p.Wo >> 1) : p.M;
-  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res_mode ? p.res : p.x), 0, p.res_mode ? (int)((long)res_rows * p.Cout * 4) : 0, 0x00020000);
-  unsigned rrow[ROWS];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first panel's planes (and everything above)
+  auto panel = [&](auto slot, const int i) {   // i-th panel of this block
+    constexpr int S = decltype(slot)::value;
+    const int buf = i & 1;
+    __syncthreads();  // this panel readable by everybody; everybody is done with the other buffer
+    asm volatile("" ::: "memory");
+    if (i + 1 < cnt) issue_b(pn(i + 1), buf ^ 1);
+    asm volatile("" ::: "memory");
+    f32x16 acc;
 #pragma unroll
-  for (int g = 0; g < ROWS; g++) {
-    const int m = m0 + r0 + g * RPP;
-    rrow[g] = (unsigned)m;
-    if (p.res_mode == 2 && m < p.M) {
-      const int HoWo = p.Ho * p.Wo;
-      const int img = m / HoWo, rem = m - img * HoWo;
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      rrow[g] = (unsigned)((img * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
-    }
-  }
-  const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.mask ? p.mask : p.x), 0, p.mask ? (int)((long)p.M * p.Cout * 4) : 0, 0x00020000);
-  const float finv = F16 ? 1.f / (sx * *p.f16_sw) : 1.f;
-  for (int nt = nt_lo; nt < nt_hi; nt++) {
-    const int buf = (nt - nt_lo) & 1;
-    // own DMA pieces of this panel landed (for later panels they were waited for before the previous epilogue already)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // panel nt readable by everybody; everybody is done with the other buffer and with the staging area
-    if (nt + 1 < nt_hi) issue_b(nt + 1, buf ^ 1);
-    const int c = nt * BN + cc * 4;
-    f32x4 ur[ROWS], um[ROWS], sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-    {
-      const bool cok = c < p.Cout;
-#pragma unroll
-      for (int g = 0; g < ROWS; g++) {
-        const int m = m0 + r0 + g * RPP;
-        const unsigned off = (cok && m < p.M) ? ((unsigned)m * (unsigned)p.Cout + (unsigned)c) * 4u : 0x80000000u;
-        const unsigned roff = (cok && m < p.M) ? (rrow[g] * (unsigned)p.Cout + (unsigned)c) * 4u : 0x80000000u;
-        ur[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)roff, 0, 0));
-        if (p.mask) um[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmask, (int)off, 0, 0));
-      }
-      if (cok) {
-        if (p.scale) sc4 = ldg4(p.scale + c);
-        if (p.shift) sh4 = ldg4(p.shift + c);
-      }
-      if (F16) sc4 *= finv;   // operands were scaled by powers of two: exact rescale of the accumulated sum
-    }
-    f32x16 acc[1][TN];
-#pragma unroll
-    for (int b = 0; b < TN; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[0][b][r] = 0.f;
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
     const char* bb = bring + buf * BBUF + boff;
     // B fragments one k-step ahead, fenced: left alone the compiler hoists the fragment reads of ALL k-steps (and spills)
-    uint4 fb[2][NS][TN];
-    auto read_b = [&](int kt, uint4 (&f)[NS][TN]) {
+    uint4 fb[2][NS];
+    auto read_b = [&](int kt, uint4 (&f)[NS]) {
 #pragma unroll
-      for (int q = 0; q < NS; q++)
-#pragma unroll
-        for (int b = 0; b < TN; b++) f[q][b] = *(const uint4*)(bb + ((kt * NS + q) * TN + b) * 1024);
+      for (int q = 0; q < NS; q++) f[q] = *(const uint4*)(bb + (kt * NS + q) * 1024);
     };
     read_b(0, fb[0]);
 #pragma unroll
@@ -1908,59 +1951,44 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
         for (int qa = 0; qa <= sum; qa++) {
           const int qb = sum - qa;
           if (F16 && qa + qb > 1) continue;   // (never: NS = 2)
-#pragma unroll
-          for (int b = 0; b < TN; b++) {
-            if constexpr (F16)
-              acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[kt][qa]),
-                                                                 __builtin_bit_cast(f16x8, fb[kt & 1][qb][b]), acc[0][b], 0, 0, 0);
-            else
-              acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kt][qa]),
-                                                                  __builtin_bit_cast(bf16x8, fb[kt & 1][qb][b]), acc[0][b], 0, 0, 0);
-          }
+          if constexpr (F16)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[kt][qa]),
+                                                         __builtin_bit_cast(f16x8, fb[kt & 1][qb]), acc, 0, 0, 0);
+          else
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kt][qa]),
+                                                          __builtin_bit_cast(bf16x8, fb[kt & 1][qb]), acc, 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the next panel's planes must have landed before this wave's epilogue puts loads and stores behind them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float* ct = lds;  // [128][BN]
-    {
-      const int col_l = lane & 31, rq = lane >> 5;
+    const unsigned cb = col_bytes(pn(i)), cbn = col_bytes(pn(i + LA));
+    float sc = has_scale ? scn[S] : 1.f;
+    const float sh = shn[S];
+    if (F16) sc *= finv;   // operands were scaled by powers of two: exact rescale of the accumulated sum
+    request_affine(slot, cbn);
 #pragma unroll
-      for (int b = 0; b < TN; b++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-          ct[row * BN + b * 32 + col_l] = acc[0][b][r];
-        }
+    for (int r = 0; r < 16; r++) {   // same expressions as conv_epilogue
+      float v = acc[r] * sc + sh;
+      v += has_res ? ur[S][r] : 0.f;
+      v = p.relu ? fmaxf(v, 0.f) : v;
+      if constexpr (MASK) v = um[S][r] > 0.f ? v * p.mask_scale : 0.f;
+      const bool ok = cb != 0x80000000u && mlane + 8 * (r >> 2) + (r & 3) < p.M;
+      const float av = ok ? fabsf(v) : 0.f;
+      amx = fmaxf(amx, av);
+      asum += av;
+      acnt += ok ? 1.f : 0.f;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)(ylane + row_off(r) + cb), 0, 0);
+      request(slot, r, cbn);
     }
-    __syncthreads();
-    if (c < p.Cout) {
-#pragma unroll
-      for (int g = 0; g < ROWS; g++) {
-        const int row = r0 + g * RPP, m = m0 + row;
-        if (m >= p.M) break;
-        const f32x4 t = *(const f32x4*)(ct + row * BN + cc * 4);
-        float v[4] = {t[0] * sc4[0] + sh4[0], t[1] * sc4[1] + sh4[1], t[2] * sc4[2] + sh4[2], t[3] * sc4[3] + sh4[3]};
-        if (p.res_mode) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += ur[g][e];
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (p.mask) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = um[g][e] > 0.f ? v[e] * p.mask_scale : 0.f;
-        }
-        if (p.amax_out) {
-          amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-          asum += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
-          acnt += 4.f;
-        }
-        *(f32x4*)(p.y + (long)m * p.Cout + c) = f32x4{v[0], v[1], v[2], v[3]};
-      }
-    }
+    // planes of the next panel (issued at the top of this iteration): everything issued after them may stay in flight --
+    // 2 + 16 x (store, residual (, mask)) operations; vector memory operations retire in order
+    // (`s_setprio 0` changes nothing: it marks this wait for tests/test_rows_kernel_isa.py, which counts the operations
+    // between the copies and the wait in the shipped code object)
+    if constexpr (MASK) asm volatile("s_waitcnt vmcnt(50)\n\ts_setprio 0" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(34)\n\ts_setprio 0" ::: "memory");
+  };
+  for (int i = 0; i < cnt; i += 2) {   // unrolled by two: register set and ring buffer of a panel are compile-time
+    panel(std::integral_constant<int, 0>{}, i);
+    if (i + 1 < cnt) panel(std::integral_constant<int, LA == 2 ? 1 : 0>{}, i + 1);
   }
   if (p.amax_out) conv_amax_commit(p, AmaxAcc{amx, asum, acnt}, blockIdx.y * gridDim.x + blockIdx.x);
 }
@@ -3336,19 +3364,19 @@ int launch_strip(const ConvP& p, hipStream_t s) {
 }
 
 // panels per block of the row-resident 1x1 kernel: all of them when the row blocks alone fill the chip (>= 512 resident
-// slots), else column groups so that about 512 blocks exist
-static int rows_ppb(const ConvP& p, int BN) {
-  const int tiles_m = mmt_cdiv(p.M, 128), npanel = mmt_cdiv(p.Cout, BN);
+// slots), else column groups so that about 512 blocks exist (256 / 1024 / 2048 measured slower: profiles/r04_rows_epilogue.txt)
+static int rows_ppb(const ConvP& p) {
+  const int tiles_m = mmt_cdiv(p.M, 128), npanel = mmt_cdiv(p.Cout, 32);
   if (tiles_m >= 512) return npanel;
   int groups = mmt_cdiv(512, tiles_m);
   if (groups > npanel) groups = npanel;
   return mmt_cdiv(npanel, groups);
 }
 
-template <int KT, int BN, int NS, bool F16 = false>
+template <int KT, int NS, bool F16 = false, bool MASK = false>
 int launch_rows(const ConvP& p, hipStream_t s) {
-  const size_t lds = (size_t)128 * BN * 4 + 2 * (size_t)KT * NS * (BN / 32) * 1024;
-  auto kern = conv1x1_rows_kernel<KT, BN, NS, F16>;
+  const size_t lds = 2 * (size_t)KT * NS * 1024;
+  auto kern = conv1x1_rows_kernel<KT, NS, F16, MASK>;
   if (lds > 65536) {
     static bool done = false;  // per instantiation
     if (!done) {
@@ -3357,8 +3385,8 @@ int launch_rows(const ConvP& p, hipStream_t s) {
       done = true;
     }
   }
-  const int ppb = rows_ppb(p, BN);
-  hipLaunchKernelGGL(kern, dim3(mmt_cdiv(p.M, 128), mmt_cdiv(mmt_cdiv(p.Cout, BN), ppb)), dim3(256), lds, s, p, p.wpl, p.wpl_stride, ppb);
+  const int ppb = rows_ppb(p);
+  hipLaunchKernelGGL(kern, dim3(mmt_cdiv(p.M, 128), mmt_cdiv(mmt_cdiv(p.Cout, 32), ppb)), dim3(256), lds, s, p, p.wpl, p.wpl_stride, ppb);
   MMT_LAUNCH_CHECK();
   return 0;
 }
@@ -3370,7 +3398,8 @@ static bool rows_shape(const ConvP& p, bool f16) {
   constexpr int rows_min = 256;   // (tuned: profiles/r04_dispatch_sweep.txt)  // blocks of 128 rows (bf16 split)
   constexpr int rows_min16 = 16;   // (tuned: profiles/r04_dispatch_sweep.txt)
   if (!rows || p.io || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.Cout < 64 || (p.Cout & 3) || p.res_mode > 2 || p.mul ||
-      p.out_stride != 1 || (long)p.M * p.Cin * 4 >= (1L << 31) || (long)p.M * p.Cout * 4 >= (1L << 31))
+      p.out_stride != 1 || (long)p.M * p.Cin * 4 >= (1L << 31) || (long)p.M * p.Cout * 4 >= (1L << 31) ||
+      (p.res_mode == 2 && (p.Wo & 7)))
     return false;
   if (f16) return (p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && p.M >= 128 * rows_min16;
   return !p.mask && p.res_mode <= 1 && (p.Cin == 64 || p.Cin == 128) && p.M >= 128 * rows_min;
@@ -3380,9 +3409,8 @@ template <int NS>
 int launch_glds_variant(int variant, const ConvP& p, hipStream_t s) {
   // 1x1 / stride 1 layers with K = 64 or 128 and many rows: one block per 128 rows, all Cout panels (see the kernel)
   if (rows_shape(p, false)) {
-    constexpr int bn64 = 32;   // (tuned: profiles/r04_dispatch_sweep.txt)
-    if (p.Cin == 64) return bn64 == 64 ? launch_rows<4, 64, NS>(p, s) : launch_rows<4, 32, NS>(p, s);
-    if (p.Cin == 128) return launch_rows<8, 32, NS>(p, s);
+    if (p.Cin == 64) return launch_rows<4, NS>(p, s);
+    if (p.Cin == 128) return launch_rows<8, NS>(p, s);
   }
   if (NS == 3) {
     const int tw = strip_tw(p);
@@ -3665,9 +3693,14 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
   p.f16_sx = x_amax; p.f16_sw = s_w; p.f16_ax = 1;
   hipStream_t s = (hipStream_t)stream;
   if (rows_shape(p, true)) {   // 1x1 layers with K = 64 / 128 / 256: rows resident in registers as fp16 fragments
-    if (p.Cin == 64) return launch_rows<4, 32, 2, true>(p, s);
-    if (p.Cin == 128) return launch_rows<8, 32, 2, true>(p, s);
-    return launch_rows<16, 32, 2, true>(p, s);
+    if (p.mask) {
+      if (p.Cin == 64) return launch_rows<4, 2, true, true>(p, s);
+      if (p.Cin == 128) return launch_rows<8, 2, true, true>(p, s);
+      return launch_rows<16, 2, true, true>(p, s);
+    }
+    if (p.Cin == 64) return launch_rows<4, 2, true>(p, s);
+    if (p.Cin == 128) return launch_rows<8, 2, true>(p, s);
+    return launch_rows<16, 2, true>(p, s);
   }
   const int ksplit = pick_ksplit(p);
   constexpr int S = 3;   // LDS stages of the operand ring (4 / 5 measured no faster: 36.4 / 34.8 / 35.0 us, profiles/r03_history.md)
