@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void paste_kernel(const float* __restrict__ lo
                                                     int* __restrict__ seg, unsigned char* __restrict__ stack) {
   extern __shared__ float pm[];  // (M+2)^2 padded probabilities
   const int d = blockIdx.x;
+  if (!STACK && img[d] < 0) return;   // a row behind its image's count in a fixed-capacity detection list: no vote
   const int P = M + 2;
   const int lab = STACK ? 0 : labels[d];
   for (int i = threadIdx.x; i < P * P; i += 256) {

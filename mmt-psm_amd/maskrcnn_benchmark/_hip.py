@@ -611,7 +611,7 @@ def nms_batched(boxes, seg_off, max_n, thr):
     return keep, cnt
 
 
-def det_postprocess(prob, dec, per, score_thresh, nms_thresh, detections_per_img):
+def det_postprocess(prob, dec, per, score_thresh, nms_thresh, detections_per_img, zero_tails=False):
     """PostProcessor.filter_results for a batch (prob (R, nc), dec (R, nc * 4), per = rows per image) on the device:
     -> boxes (N, cap, 4), scores (N, cap), labels int64 (N, cap), counts int32 (N,) -- or None when an image has more than
     2048 rows / nc > 64 (the caller's tensor formulation takes those)"""
@@ -633,9 +633,10 @@ def det_postprocess(prob, dec, per, score_thresh, nms_thresh, detections_per_img
     if nb < 0:
         return None
     ws = torch.empty((nb // 16 + 1, 4), dtype=torch.float32, device=dev)
-    ob = torch.empty((N, cap, 4), dtype=torch.float32, device=dev)
-    os_ = torch.empty((N, cap), dtype=torch.float32, device=dev)
-    ol = torch.empty((N, cap), dtype=torch.int64, device=dev)
+    alloc = torch.zeros if zero_tails else torch.empty   # zero_tails: rows behind an image's count are read by the caller
+    ob = alloc((N, cap, 4), dtype=torch.float32, device=dev)
+    os_ = alloc((N, cap), dtype=torch.float32, device=dev)
+    ol = alloc((N, cap), dtype=torch.int64, device=dev)
     oc = torch.empty((N,), dtype=torch.int32, device=dev)
     _check(lib().mmt_det_postprocess(_p(prob), _p(dec), _p(row_off), ctypes.cast(host, c_void_p), N, nc, float(score_thresh),
                                      float(nms_thresh), int(detections_per_img), _p(ws), _p(ob), _p(os_), _p(ol), _p(oc),
@@ -861,7 +862,7 @@ def rpn_gather_decode(heads, anchors, topks, A, clip, lim):
 
 
 def rpn_post_select(boxes, scores, idx, reg, keep, keep_cnt, level_off, own_pre, post_n, fpn_post_n, training, cap,
-                    gt=None, gt_off=None, min_size_filter=False):
+                    gt=None, gt_off=None, min_size_filter=False, zero_tails=False):
     """include/mmtpsm.h: mmt_rpn_post_select -> (out_boxes (N,cap,4), out_scores, out_idx, out_reg, out_level, out_cnt (N,))"""
     N, sumk = scores.shape
     L = len(level_off) - 1
@@ -878,8 +879,8 @@ def rpn_post_select(boxes, scores, idx, reg, keep, keep_cnt, level_off, own_pre,
     a.min_size_filter = 1 if min_size_filter else 0
     if gt is not None:
         a.gt, a.gt_off = gt.data_ptr(), gt_off.data_ptr()
-    ob = torch.empty((N, cap, 4), dtype=torch.float32, device=dev)
-    osc = torch.empty((N, cap), dtype=torch.float32, device=dev)
+    ob = (torch.zeros if zero_tails else torch.empty)((N, cap, 4), dtype=torch.float32, device=dev)
+    osc = (torch.zeros if zero_tails else torch.empty)((N, cap), dtype=torch.float32, device=dev)
     oi = torch.empty((N, cap), dtype=torch.int64, device=dev)
     orr = torch.empty((N, cap, 4), dtype=torch.float32, device=dev)
     ol = torch.empty((N, cap), dtype=torch.int32, device=dev)

@@ -25,6 +25,12 @@ class ImageListView(object):
         self.tensors, self.image_sizes = il.tensors, list(il.image_sizes)
 
 
+# SURVEY f-2: the teacher's coarse inference keeps its proposal and detection lists at fixed capacity with device counts (no
+# read-back before the box head, the detection counts read back behind the queued mask head).  False = sliced lists throughout
+# (tests/test_model_gpu.py compares the two).
+_NO_READBACK = True
+
+
 class GeneralizedRCNN(nn.Module):
     def __init__(self, cfg, is_teacher=False, is_student=False):
         super().__init__()
@@ -171,12 +177,26 @@ class GeneralizedRCNN(nn.Module):
         # RPN head outputs and decoded+NMS'ed candidates are shared between the two selector passes on pyramid 0
         self.rpn.shared = {"pre": max(self.rpn.box_selector_train.pre_nms_top_n, self.rpn.box_selector_test.pre_nms_top_n)}
         self.set_module_mode("test")
-        teacher_infer = self.forward(first, features=aug_features[0])
+        # the coarse inference's proposal lists at fixed capacity, no count read-back (rpn.py::select); with taps / replay (tests
+        # that look at these lists) and with IR-Net (its modules take the lists) the lists are sliced as in the reference
+        sel, post = self.rpn.box_selector_test, self.box_heads.box.post_processor
+        fixed = (_NO_READBACK and self.taps is None and getattr(self, "_replay", None) is None and self.relation_nms is None
+                 and not self.mask_heads.mask.use_relation and self.mask_heads.mask.mask_generator.masker is not None
+                 and aug_features[0][0].is_cuda)
+        sel.fixed_capacity = post.defer_counts = fixed
+        try:
+            teacher_infer = self.forward(first, features=aug_features[0])
+        finally:
+            sel.fixed_capacity = post.defer_counts = False
         if self.mt_fg_hint > 0:
             for t in teacher_infer:
                 integral.append(t.get_field("mask").sum(0)[0])
             for t in teacher_infer:
                 t.remove_field("mask")
+        if fixed:
+            # the detection counts, read back with the mask head and the paste already queued behind the box head
+            from ..roi_heads.box_head.box_head import resolve_counts
+            teacher_infer = resolve_counts(teacher_infer)
         self.set_module_mode("train")
         _, _, _, _, proposals, _, ffi_boxes = self.rpn.forward_teacher(images[0], aug_features[0], teacher_infer)
         self.rpn.shared = None

@@ -230,6 +230,13 @@ class PostProcessor(nn.Module):
         prob = F.softmax(class_logits, -1)
         per = [len(b) for b in boxes]
         dev = prob.device
+        if all(getattr(b, "count_dev", None) is not None for b in boxes):
+            # fixed-capacity proposal lists (rpn.py::select): rows behind an image's count are not proposals -- probability 0
+            # keeps them below every score threshold, the valid rows keep their values (x 1.0) and their order
+            assert len(set(per)) == 1
+            counts = torch.cat([b.count_dev for b in boxes]) if len(boxes) > 1 else boxes[0].count_dev
+            valid = torch.arange(per[0], device=dev, dtype=torch.int32)[None, :] < counts[:, None]
+            prob = prob * valid.reshape(-1, 1).to(prob.dtype)
         cat = torch.cat([b.bbox for b in boxes], 0)
         offs_rows = [0]
         for n_ in per:
@@ -241,12 +248,26 @@ class PostProcessor(nn.Module):
         # threshold / stable sort / NMS / ascending-row order / DETECTIONS_PER_IMG cut of every (image, class) on the
         # device (mmt_det_postprocess: five launches), ONE read-back (the detection counts) for the BoxList sizes.  The tensor
         # formulation it replaced is its checker (tests/tensor_formulations.py::det_filter_results)
-        out = H.det_postprocess(prob, dec, per, self.score_thresh, self.nms, self.detections_per_img)
+        defer = getattr(self, "defer_counts", False)
+        out = H.det_postprocess(prob, dec, per, self.score_thresh, self.nms, self.detections_per_img, zero_tails=defer)
         if out is None:
             raise RuntimeError("PostProcessor: at most 2048 proposals per image and 64 classes (mmt_det_postprocess is the only "
                                "implementation)")
         ob, os_, ol, oc = out
         results = []
+        if defer:
+            # SURVEY f-2 (the teacher's coarse inference): detection lists at the fixed capacity DETECTIONS_PER_IMG with the count
+            # as a device scalar; rows behind it are zero boxes with label 0.  The mask head runs on all rows and its paste skips
+            # them (mask_head.py::Masker); `resolve_counts` slices the lists once that work is queued.
+            k = min(self.detections_per_img, ob.shape[1]) if self.detections_per_img > 0 else ob.shape[1]
+            for i, b in enumerate(boxes):
+                r = BoxList(ob[i, :k], b.size, "xyxy")
+                r.add_field("scores", os_[i, :k])
+                r.add_field("objectness", os_[i, :k])
+                r.add_field("labels", ol[i, :k])
+                r.count_dev = oc[i:i + 1]
+                results.append(r)
+            return results
         for i, (b, n) in enumerate(zip(boxes, oc.tolist())):
             r = BoxList(ob[i, :n], b.size, "xyxy")
             r.add_field("scores", os_[i, :n])
@@ -254,6 +275,19 @@ class PostProcessor(nn.Module):
             r.add_field("labels", ol[i, :n])
             results.append(r)
         return results
+
+
+def resolve_counts(boxlists):
+    """fixed-capacity lists (`count_dev`) -> the sliced lists of the reference; ONE read-back for all of them"""
+    counts = (torch.cat([b.count_dev for b in boxlists]) if len(boxlists) > 1 else boxlists[0].count_dev).tolist()
+    out = []
+    for b, n in zip(boxlists, counts):
+        r = BoxList(b.bbox[:n], b.size, b.mode)
+        for f in b.fields():
+            v = b.get_field(f)
+            r.add_field(f, v[:n] if torch.is_tensor(v) else v)
+        out.append(r)
+    return out
 
 
 def make_roi_box_post_processor(cfg):

@@ -150,6 +150,8 @@ class MaskPostProcessor(nn.Module):
             for f in b.fields():
                 r.add_field(f, b.get_field(f))
             r.add_field("mask", s)
+            if getattr(b, "count_dev", None) is not None:
+                r.count_dev = b.count_dev
             out.append(r)
         return out
 
@@ -168,7 +170,16 @@ class Masker(object):
         if len(sizes) != 1:
             raise NotImplementedError("pseudo-mask paste expects equally sized images in a batch")
         w, h = boxes[0].size
-        img = torch.cat([torch.full((len(b),), i, dtype=torch.int32, device=logits.device) for i, b in enumerate(boxes)])
+        if all(getattr(b, "count_dev", None) is not None for b in boxes):
+            # fixed-capacity detection lists (box_head.py::PostProcessor.forward): rows behind an image's count vote nowhere
+            # (image index -1: the paste kernel returns at once)
+            cap = len(boxes[0])
+            counts = torch.cat([b.count_dev for b in boxes]) if len(boxes) > 1 else boxes[0].count_dev
+            rows = torch.arange(cap, device=logits.device, dtype=torch.int32)[None, :]
+            ids = torch.arange(len(boxes), device=logits.device, dtype=torch.int32)[:, None]
+            img = torch.where(rows < counts[:, None], ids, torch.full_like(ids, -1)).reshape(-1).contiguous()
+        else:
+            img = torch.cat([torch.full((len(b),), i, dtype=torch.int32, device=logits.device) for i, b in enumerate(boxes)])
         bb = torch.cat([b.bbox for b in boxes], 0)
         seg = H.paste_masks(logits, labels, bb, img, len(boxes), h, w, self.threshold)
         return [IntegralMask(s) for s in seg]

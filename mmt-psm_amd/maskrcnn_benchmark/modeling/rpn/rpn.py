@@ -157,7 +157,20 @@ class RPNPostProcessor(nn.Module):
         cap = min(fpn, L * per_seg) + max_gt
         ob, osc, oi, orr, ol, oc = H.rpn_post_select(c["boxes"], c["scores"], c["idx"], c["reg"], c["keep"], c["cnt"],
                                                      c["offs"], own_pre, self.post_nms_top_n, fpn, training, cap, gt, gt_off,
-                                                     min_size_filter=self.min_size > 0)
+                                                     min_size_filter=self.min_size > 0,
+                                                     zero_tails=getattr(self, "fixed_capacity", False))
+        if getattr(self, "fixed_capacity", False) and not training and between is None and not (gt is not None):
+            # SURVEY f-2 (the teacher's coarse inference): no read-back -- every image keeps all `cap` rows, the rows behind its
+            # count are zero boxes, and the count travels as a device scalar (`count_dev`).  The one consumer of these lists,
+            # the box head's inference post-processor, gives those rows probability 0: they can never pass its score threshold,
+            # so the detections are those of the sliced lists (box_head.py::PostProcessor.forward).
+            out = []
+            for n in range(N):
+                b = BoxList(ob[n], sizes[n], "xyxy")
+                b.add_field("objectness", osc[n])
+                b.count_dev = oc[n:n + 1]
+                out.append(b)
+            return out
         # the one host sync of the proposal pipeline: the per-image counts, through a pinned buffer and an event, so that
         # whatever `between` enqueues (the RPN losses) keeps the GPU busy while the host is released
         counts = self._counts_to_host(oc, between)

@@ -188,6 +188,62 @@ def test_teacher_student(setup, synth, weights):
     assert sref["mt_fg_loss"].item() > 1e-3
 
 
+def test_teacher_without_count_readback_equals_sliced_lists(setup, synth, monkeypatch):
+    """SURVEY f-2: the teacher's coarse inference keeps its proposal lists at fixed capacity (device counts, rows behind the
+    count masked out of the box head's post-processor) instead of reading the counts back and slicing -- the teacher dict is
+    the same, bit for bit (`rpn.py::select`, `box_head.py::PostProcessor.forward`)."""
+    from maskrcnn_benchmark.modeling.detector import generalized_rcnn as gr
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    cfg, _, teacher = setup
+    unl = synth.make_unlabeled(2, SIZE, 3, seed=991)
+    outs = []
+    for flag in (False, True):
+        monkeypatch.setattr(gr, "_NO_READBACK", flag)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        teacher.set_rng(g)
+        seen = []
+        sel = teacher.rpn.box_selector_test
+        orig = sel.select
+
+        def spy(c, targets=None, between=None, _orig=orig, _seen=seen, _sel=sel):
+            _seen.append(bool(getattr(_sel, "fixed_capacity", False)))
+            return _orig(c, targets, between)
+
+        sel.select = spy
+        try:
+            with torch.no_grad():
+                outs.append(teacher.forward_teacher([to_image_list(list(u.cuda()), 32) for u in unl[:2]]))
+        finally:
+            sel.select = orig
+            teacher.set_rng(None)
+        assert seen == [flag], seen
+    # Not bit for bit: the box head's fc layers see `capacity` rows instead of `count` rows, and the GEMM's split-K depends on the
+    # row count -- the detections' coordinates move in the last bits (measured 7e-6 on the regression targets).  Discrete
+    # outcomes (counts, labels, sampled rows) must agree; values to rounding.
+    a, b = outs
+    for x, y in zip(a["result_t"], b["result_t"]):
+        assert len(x) == len(y)
+        assert (x.bbox - y.bbox).abs().max().item() < 1e-3
+        pos = x.get_field("labels") > 0
+        for f in x.fields():
+            u, v = x.get_field(f), y.get_field(f)
+            if f == "regression_targets":   # (defined for the positives only)
+                u, v = u[pos], v[pos]
+            if u.dtype.is_floating_point:
+                assert (u - v).abs().max().item() < 1e-4, f
+            else:
+                assert torch.equal(u, v), f
+    for x, y in zip(a["class_logit_t"], b["class_logit_t"]):
+        assert (x - y).abs().max().item() < 1e-5 * max(1.0, x.abs().max().item())
+    for ex, ey in zip(a["embedding"], b["embedding"]):
+        for x, y in zip(ex, ey):
+            assert torch.equal(x, y)
+    for x, y in zip(a["seg_mask"], b["seg_mask"]):
+        assert (x != y).float().mean().item() < 1e-4
+    assert sum(int(m.sum()) for m in a["seg_mask"]) > 0
+
+
 def test_teacher_without_detections(setup, synth):
     """An unlabeled image on which the teacher detects nothing: the coarse inference returns empty BoxLists (with an
     all-zero pseudo mask) and forward_teacher raises the Matcher's ValueError exactly like the reference
