@@ -510,13 +510,12 @@ def main():
                 out["roofline"]["other_large_tile_kernel"]["six_product_frac"] = round(
                     fo / (mo * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6), 4)
         out["roofline"]["step_bound"] = (
-            "no single resource: the main stream's device chain (the student's N = 2 / N = 4 launches queue behind the teacher's "
-            "chip-filling N = 8 kernels; ~40 ms of kernel time per step at ~1.1-1.2 x overlap) and the interpreter time of the two "
-            "launch-issuing threads (main / autograd and teacher, one GIL) end within ~2 ms of each other: ~1 ms removed from either "
-            "alone (140 library launches of the main thread; the RPN sampler's place in the student's chain) did not move the step "
-            "at the +-0.4 ms resolution of same-box A/B runs, host work removed from the TEACHER's chain earlier in the round did "
-            "(DESIGN.md sections 5 and 7, profiles/r03_history.md); the kernels' in-step durations are read while up to three "
-            "streams share the GPU")
+            "the device: ~49 ms of kernel time per step over three streams at ~1.45 x overlap; the host runs ahead of the device except "
+            "for ~2.5 ms between the teacher's last result and the consistency backward (profiles/r04_host_device_phases.txt).  What "
+            "moved the step in round 4 was device work removed (row-resident 1x1 kernel's register epilogue -1.7 ms) and a stream "
+            "priority (-1.6 ms under a process group); host work removed, chains shortened, launches folded, ring depths, split-K "
+            "forms and block counts re-tuned did not (DESIGN.md section 5, profiles/r04_history.md); the kernels' in-step durations "
+            "are read while up to three streams share the GPU")
         # the launches of that kernel with an un-split K (the large FPN / layer1-2 shapes); the others are the few-tile,
         # long-K layers, whose bracketed duration also contains their small finish launch
         uns = [q for q in prof if len(q) < 5 or q[4] <= 1]
