@@ -358,6 +358,7 @@ def main():
         sync()
         _hip.PROFILE = [] if profile else None
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        c0 = _hip.C_CALLS[0]
         t0 = time.perf_counter()
         for i in range(n):
             marks[i].record()
@@ -365,6 +366,7 @@ def main():
         marks[n].record()
         sync()
         dt = time.perf_counter() - t0
+        timed.c_calls_per_step = (_hip.C_CALLS[0] - c0) / max(n, 1)
         # the two large-tile forward / data-gradient kernels: 'fwd4' = conv3x3_strip_kernel (its brackets include the
         # plane-split pass of its input), 'fwd1' = conv_fwd_glds_kernel<128,128>; the roofline line is the one with more time
         groups = {}
@@ -385,6 +387,7 @@ def main():
         step(i)
     skipped0 = trainer.skipped_pairs
     dt, _, losses, per_step = timed(args.warmup, args.steps, False)
+    c_calls = timed.c_calls_per_step
     skipped = trainer.skipped_pairs - skipped0
     if use_dist:
         t = torch.tensor([skipped], dtype=torch.int64, device=device)
@@ -462,6 +465,7 @@ def main():
                                     round(sorted(per_step)[(len(per_step) * 9) // 10 - (1 if len(per_step) >= 10 else 0)], 3)],
             "imgs_per_sec_at_median": round(imgs_per_step / (med * 1e-3), 4),
             "higher_is_better": True, "scaling": "weak",
+            "library_calls_per_step": round(c_calls, 1),   # interpreter -> C-ABI calls of both launch-issuing threads
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "backend": (dist.get_backend() + " (RCCL)") if use_dist else "none (single process, no process group)",
             "vs_baseline": None, "dtype": "bf16" if mode == 1 else "f32", "data": "synthetic",

@@ -492,7 +492,11 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
+C_CALLS = [0]   # interpreter -> library calls that issue work (every one passes through _check); bench.py reports them per step
+
+
 def _check(code, what):
+    C_CALLS[0] += 1
     if code != 0:
         raise RuntimeError("%s failed with code %d" % (what, code))
 
