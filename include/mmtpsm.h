@@ -377,6 +377,23 @@ int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a /*[host]*/, const float* s_x 
  * registers after its scaling by the power of two of x_amax (device: max |x|, e.g. recorded through y_amax) */
 int mmt_conv_forward_f16x2(const mmt_conv_args* a /*[host]*/, const float* x_amax /*device*/, const float* s_w /*device*/, void* stream);
 int mmt_get_conv_precision(void);
+/* Round 5: the plane-fed implicit GEMM (csrc/conv_pgemm.hip) -- the same arithmetic (two-term fp16 split, 3 products, mode 3) for
+ * any (KH, KW, stride, pad) with Cin % 16 == 0, Cout > 32, res_mode <= 1, out_stride == 1, no `mul`, fp32 tensors: x_planes = the
+ * two fp16 planes of x * s_x with x's NHWC indexing (mmt_split_planes_f16), w_planes = the packed fp16 planes of w * s_w
+ * (mmt_pack_weight_f16 / _flipped_f16), s_x / s_w device scalars, `x` (and `w`, or w_src) the fp32 tensors for the range guard's
+ * exact path.  Replaces the ATen convolution / addmm behind layers/misc.py:30-43 `Conv2d`, backbone/resnet.py:254-274 (conv2 of
+ * layer3 / layer4), backbone/fpn.py:57-66 and rpn/rpn.py:39-46 (3x3 on the small levels),
+ * roi_heads/mask_head/roi_mask_feature_extractors.py:131-146, box_head/roi_box_feature_extractors.py:97-98 (fc6 / fc7), forward and
+ * data gradient.  tile_rows: 128 | 256 | 0 = the library's choice; ksplit: K ranges (> 1: partial tiles meet in the per-stream
+ * workspace inside the SAME launch -- the last block of a tile to arrive adds them in the order 0 .. ksplit - 1 and runs the
+ * epilogue), 0 = the library's choice.  Results are bit-identical to mmt_conv_forward_f16x2 on the tiled kernel for an equal number
+ * of K ranges.  mmt_conv_pg_plan: the tile height and K ranges the library would pick (both 0: not a shape for this kernel). */
+int mmt_conv_forward_pg(const mmt_conv_args* a /*[host]*/, const float* s_x /*device*/, const float* s_w /*device*/, int tile_rows,
+                        int ksplit, void* stream);
+int mmt_conv_pg_plan(const mmt_conv_args* a /*[host]*/, int* tile_rows, int* ksplit);
+/* 1 when the library wants this call on mmt_conv_forward_pg with a plane-split pass of x in front (3x3 and larger kernels that
+ * are not tap-strip shapes: mmt_conv_wants_planes is asked first); 0 otherwise.  MMT_PG=0 in the environment answers 0. */
+int mmt_conv_pg_wanted(const mmt_conv_args* a /*[host]*/);
 /* Packed bf16 planes of a weight matrix w[Cout][K] (K = KH*KW*Cin in the weight's own memory order, K % 16 == 0) for
  * the split-bf16 modes.  Plane q (q = 0..2, at planes + q*plane_stride bf16 elements) holds the q-th term of the
  * round-to-nearest bf16 expansion w = w0 + w1 + w2 (exact to 2^-27 |w|), tiled as

@@ -27,80 +27,13 @@
 #include <map>
 #include <mutex>
 #include <type_traits>
-#include "common.h"
+#include "conv_shared.h"
 
 namespace {
-
-struct ConvP {
-  const float* x; const float* w; const float* scale; const float* shift; const float* res;
-  const float* mask; const float* mul; float* y;
-  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
-  int relu, res_mode, out_stride, out_H, out_W;
-  float mask_scale;
-  int M, K, cin32, cin4;  // derived
-  const unsigned short* wpl; long wpl_stride;  // pre-split bf16 planes of w (or null)
-  const unsigned short* xpl; long xpl_stride;  // pre-split bf16 planes of x, same NHWC indexing as x (or null)
-  unsigned short* ypl; long ypl_stride;        // also write y as three bf16 planes (for a 3x3 consumer), or null
-  unsigned* amax_out;  // device float (bits) accumulating max |y| of this launch's output, or null (fp16 split: the consumer's scale)
-  int amax_stats;      // amax_out is a 33-float slot: every 64th block adds sum |y| of what it stores to [1 + k] and the element count
-                       // to [17 + k], k = (block >> 6) & 15 (crest factor max / mean of a SAMPLE: the fp16 split's fall-back test)
-  int f16_ax;  // f16_sx points to max |x| (the scale is derived from it) instead of to the scale itself
-  const float* f16_sx; const float* f16_sw;  // fp16 two-term split (experiment): device scalars s_x, s_w; the epilogue divides by s_x s_w
-  int io;  // bf16 STORAGE of operands (mode 1): IO_X x, IO_Y y, IO_RES res, IO_MASK mask are bf16 tensors of the same indexing
-  // fp16 split, range guard (round 4): the 33-float statistics slots of x (and, weight gradient, of dy) -- max, sampled sum and
-  // count -- from which every block derives the crest factor of ITS OWN operand before its first instruction of arithmetic;
-  // w_src / w_src_scale: where the fp32 weights of a planes-only (data-gradient) call come from (see conv_slow_tile)
-  const float* guard_x; const float* guard_dy;
-  const float* w_src; const float* w_src_scale;
-  // weight gradient over TWO segments of pixels (round 4: the two student passes of a step share every weight; their activations
-  // and gradients are separate tensors of one shape): blocks with z >= seg_z work on (x2, dy2) with that segment's own scales /
-  // statistics slots; seg_z == 0: one segment
-  const float* x2; const float* dy2; const float* f16_sx2; const float* f16_sw2; const float* guard_x2; const float* guard_dy2;
-  int seg_z;
-};
-constexpr float F16_CREST_HI = 131072.f;   // 2^17: max / mean |x| above which fp16's five exponent bits lose the bulk of the tensor
-
-// The unlagged, per-tensor form of the range decision.  The two-term fp16 split represents x s as h + l with
-// s set by max |x|; when ONE element is 10^8 x the rest, everything else lands where l is subnormal and carries 11 bits instead
-// of 22.  The host cannot know that about the tensor at hand (it picks the kernel before the producer has run); the device can:
-// the producer recorded max / sampled mean of x in its statistics slot.  Every block of an fp16-split kernel reads the slot
-// first and, for such a tensor, computes its tile with plain fp32 FMAs from the fp32 operands instead (conv_slow_tile: exact
-// products, ~100 x slower, a handful of launches) -- until the host has seen the same statistics and moved the site to the
-// 3-term bf16 split (_hip._site_ok), which is fast and range-free.  NaN / inf maxima take the slow path too (they propagate).
-// Two halves, so that the slot's scalar loads are ISSUED at the top of a kernel and WAITED FOR behind its prologue copies: read at
-// the point of the branch they cost ~1 us of exposed latency per launch (+0.5 ms of conv time per step, measured; the slot was
-// last written by L2 atomics of several XCDs and misses this XCD's L2).  Nine values: the maximum and the first four of the
-// sixteen (sum, count) partials -- the share of the producer's sampled blocks 0, 64, 128, 192 (mod 1024); block 0 always samples.
-struct F16Guard { float amax, s0, s1, s2, s3, c0, c1, c2, c3; };
-__device__ __forceinline__ F16Guard f16_guard_load(const float* __restrict__ slot) {
-  F16Guard g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (slot) { g.amax = slot[0]; g.s0 = slot[1]; g.s1 = slot[2]; g.s2 = slot[3]; g.s3 = slot[4];
-              g.c0 = slot[17]; g.c1 = slot[18]; g.c2 = slot[19]; g.c3 = slot[20]; }
-  return g;
-}
-__device__ __forceinline__ bool f16_guard_bad(const F16Guard& g) {
-  const float tot = (g.s0 + g.s1) + (g.s2 + g.s3), cnt = (g.c0 + g.c1) + (g.c2 + g.c3);
-  if (!(tot > 0.f)) return false;                       // nothing sampled (or an all-zero sample): no statement
-  if (!(g.amax == g.amax) || g.amax > 3.0e38f) return true;
-  return g.amax * cnt > tot * F16_CREST_HI;
-}
-constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;
-
-__device__ __forceinline__ unsigned pk_bf16(float a, float b);
-// power-of-two scale that puts the largest magnitude `amax` into [2^13, 2^14] (an all-zero tensor: 1)
-__device__ __forceinline__ float f16_scale_of_fwd(const float amax) {
-  if (!(amax > 0.f)) return 1.f;
-  int e;
-  frexpf(amax, &e);
-  e = 14 - e;
-  e = e > 100 ? 100 : (e < -100 ? -100 : e);
-  return ldexpf(1.f, e);
-}
 
 template <int NS>
 __device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]);
 
-__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
 
 // ---- shared epilogue of the forward kernels: accumulators -> LDS (the operand ring is free by then) -> row-major
 // float4 rows, so that stores and residual / mask / mul loads are all 16 B per lane and fully coalesced (a 128-wide
@@ -124,7 +57,6 @@ __device__ __forceinline__ void conv_epilogue_stage(f32x16 (&acc)[BM / (32 * WM)
 }
 
 // second half of the epilogue: the [BM][BN] tile in LDS (complete, synchronised) -> scale/shift, residual, ReLU, ... -> y
-struct AmaxAcc { float amx = 0.f, asum = 0.f, acnt = 0.f; };   // max |y| / sum |y| / count over what a thread stores (p.amax_out)
 
 // the block's contribution to the statistics slot of its output: ONE conditional atomic per block (wave reduce, LDS reduce
 // over the waves, then the test against what is already there).  One per wave was measured at 3 - 8 us of a 36 us launch
@@ -294,85 +226,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
   conv_epilogue_finish<BM, BN>(p, lds, m0, n0, tid, HoWo);
 }
 
-// ---- the fp16 split's slow, exact path (see f16_guard_bad): outputs (row i, column c) of a block's tile, i < rows,
-// c < ncols; row i is output pixel m = m_first + (i / run) * run_stride + (i % run) (one run of consecutive pixels for the tiled
-// and row-resident kernels, 256 / TW image rows for the strip kernel), column c is channel n0 + c.  fp32 FMA over the im2col
-// row straight from global memory; the weights are p.w ([Cout][KH][KW][Cin]) or, for a planes-only data-gradient call, read
-// through the flip / transpose / BN scale of pack_flip_unit from the forward weight p.w_src ([Cin'][KH][KW][Cout'], scale per
-// row).  raw != null (split-K forms): the sum times s_x s_w goes to raw[i * ncols + c] -- what the finish launch divides out
-// again -- or zeros when `zero`; else the epilogue of conv_epilogue_finish, element by element, statistics included.
-// The parameter block is read from the KERNEL-ARGUMENT SEGMENT (every kernel that calls this has its ConvP first), not from the
-// caller's registers: inlined with `p` in registers the slow path kept ~60 more scalar values alive across the callers' prologues
-// (SGPR spills 15 -> 80 in the tiled kernel, +0.6 ms of conv time per step); as a real call it costs the callers 288 B of stack.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef const __attribute__((address_space(4))) ConvP* ConvPK;
-__device__ __forceinline__ ConvPK kernarg_convp() { return (ConvPK)__builtin_amdgcn_kernarg_segment_ptr(); }
-#else   // (host pass of the same translation unit: never executed)
-typedef const ConvP* ConvPK;
-__device__ __forceinline__ ConvPK kernarg_convp() { return nullptr; }
-#endif
-
-__device__ __forceinline__ void conv_slow_tile(const int m_first, const int run, const int run_stride, const int rows,
-                                            const int n0, const int ncols, float* __restrict__ raw, const bool zero,
-                                            const int tid, const int nthreads, const int lin) {
-  const ConvPK pk = kernarg_convp();   // fields are fetched where they are used (scalar loads from the argument segment)
-  const int HoWo = pk->Ho * pk->Wo;
-  const float S = (pk->f16_ax ? f16_scale_of_fwd(*pk->f16_sx) : *pk->f16_sx) * *pk->f16_sw;
-  float amx = 0.f, asum = 0.f, acnt = 0.f;
-  for (int o = tid; o < rows * ncols; o += nthreads) {
-    const int i = o / ncols, c = o - i * ncols;
-    const int m = m_first + (i / run) * run_stride + (i % run), n = n0 + c;
-    if (raw && (zero || m >= pk->M || n >= pk->Cout)) { raw[o] = 0.f; continue; }
-    if (m >= pk->M || n >= pk->Cout) continue;
-    const int img = m / HoWo, rem = m - img * HoWo;
-    const int ho = rem / pk->Wo, wo = rem - ho * pk->Wo;
-    float acc = 0.f;
-    for (int kh = 0; kh < pk->KH; kh++) {
-      const int ih = ho * pk->stride - pk->pad + kh;
-      if ((unsigned)ih >= (unsigned)pk->H) continue;
-      for (int kw = 0; kw < pk->KW; kw++) {
-        const int iw = wo * pk->stride - pk->pad + kw;
-        if ((unsigned)iw >= (unsigned)pk->W) continue;
-        const float* xr = pk->x + ((long)(img * pk->H + ih) * pk->W + iw) * pk->Cin;
-        if (pk->w) {
-          const float* wr = pk->w + ((long)(n * pk->KH + kh) * pk->KW + kw) * pk->Cin;
-          for (int ci = 0; ci < pk->Cin; ci++) acc = fmaf(xr[ci], wr[ci], acc);
-        } else {   // W'(n, (kh, kw), c) = w_src[c][KH - 1 - kh][KW - 1 - kw][n] * scale[c]
-          const int tap = (pk->KH - 1 - kh) * pk->KW + (pk->KW - 1 - kw);
-          const float* wr = pk->w_src + (long)tap * pk->Cout + n;
-          const long cs = (long)pk->KH * pk->KW * pk->Cout;
-          for (int ci = 0; ci < pk->Cin; ci++)
-            acc = fmaf(xr[ci], wr[ci * cs] * (pk->w_src_scale ? pk->w_src_scale[ci] : 1.f), acc);
-        }
-      }
-    }
-    if (raw) { raw[o] = acc * S; continue; }
-    float v = acc * (pk->scale ? pk->scale[n] : 1.f) + (pk->shift ? pk->shift[n] : 0.f);
-    long oidx = (long)m * pk->Cout + n;
-    if (pk->out_stride > 1) oidx = (((long)img * pk->out_H + ho * pk->out_stride) * pk->out_W + wo * pk->out_stride) * pk->Cout + n;
-    if (pk->res_mode == 1) v += pk->res[(long)m * pk->Cout + n];
-    else if (pk->res_mode == 2) v += pk->res[(((long)img * (pk->Ho >> 1) + (ho >> 1)) * (pk->Wo >> 1) + (wo >> 1)) * pk->Cout + n];
-    else if (pk->res_mode == 3) {
-      const int w2 = pk->Wo * 2;
-      const float* rp = pk->res + (((long)img * (pk->Ho * 2) + 2 * ho) * w2 + 2 * wo) * pk->Cout + n;
-      v += (rp[0] + rp[pk->Cout]) + (rp[(long)w2 * pk->Cout] + rp[(long)w2 * pk->Cout + pk->Cout]);
-    }
-    if (pk->relu) v = fmaxf(v, 0.f);
-    if (pk->mask) v = pk->mask[oidx] > 0.f ? v * pk->mask_scale : 0.f;
-    if (pk->mul) v *= pk->mul[(long)m * pk->Cout + n];
-    pk->y[oidx] = v;
-    const float av = fabsf(v);
-    amx = fmaxf(amx, av); asum += av; acnt += 1.f;
-  }
-  if (!raw && pk->amax_out) {
-    if (amx > 0.f) atomicMax(pk->amax_out, __builtin_bit_cast(unsigned, amx));
-    if (pk->amax_stats && (lin & 63) == 0 && acnt > 0.f) {
-      const int k = (lin >> 6) & 15;
-      atomicAdd((float*)pk->amax_out + 1 + k, asum);
-      atomicAdd((float*)pk->amax_out + 17 + k, acnt);
-    }
-  }
-}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
@@ -562,14 +415,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
 // which makes the ds_read_b128 fragment reads conflict-free for the four 16-lane service groups; A and B use the same
 // lane->k assignment, so the k order inside the instruction does not matter.  Tile = BM x BN x 16, 2-deep LDS ring.
 // Requires Cin % 16 == 0 (every heavy layer of the path); other shapes run on the fp32 kernel above.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
-}
 
 template <int NS>
 __device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]) {
@@ -587,23 +432,6 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]) {
   }
 }
 
-// ---- EXPERIMENT (mmt_conv3x3_strip_f16x2, tools/bench_f16x2.py): two-term fp16 split of a pre-scaled value, x * s = h + l
-// with h = fp16(x s), l = fp16(x s - h) (the residual is exact in fp32): 22 significant bits, |x s - h - l| <= 2^-22 |x s|.
-// The caller scales each tensor by a power of two so that its largest magnitude sits near 2^14: h is then a normal fp16
-// number down to 2^-28 of the tensor's maximum and l down to 2^-17 of it (below that l turns subnormal: absolute error
-// <= 2^-25 in scaled units, i.e. <= 2^-39 of the maximum).
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split4h(const f32x4 v, const float s, uint2 (&o)[2]) {
-  float r[4] = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
-#pragma unroll
-  for (int e = 0; e < 4; e++) r[e] = fminf(fmaxf(r[e], -65504.f), 65504.f);   // a scale from an older tensor may be too large: saturate
-  _Float16 h[4], l[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) { h[e] = (_Float16)r[e]; l[e] = (_Float16)(r[e] - (float)h[e]); }
-  o[0] = uint2{__builtin_bit_cast(unsigned, f16x2{h[0], h[1]}), __builtin_bit_cast(unsigned, f16x2{h[2], h[3]})};
-  o[1] = uint2{__builtin_bit_cast(unsigned, f16x2{l[0], l[1]}), __builtin_bit_cast(unsigned, f16x2{l[2], l[3]})};
-}
 
 template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvP p) {
@@ -761,7 +589,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_split_kernel(const ConvP p) {
 // the SOURCE address and again on the fragment read (A: 16-B chunk ^= (row>>2)&3 of a 64-B row; B: half ^= (row>>3)&1).
 __device__ __attribute__((aligned(16))) const float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};  // source of halo / OOB lanes
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ void dma16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_ptr_t)l, 16, 0, 0);
 }
@@ -1547,6 +1374,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  // ---- epilogue, round 5: straight from the accumulator registers (conv_shared.h: conv_epilogue_direct) for the un-split form on
+  // fp32 tensors -- a wave's 64 tile rows are 64 consecutive pixels of one image row (TW >= 64).  The staged form below (tile ->
+  // LDS -> float4 rows, whose residual / mask loads are waited for one by one) took 18 - 30 us per tile with the matrix pipe idle
+  // (profiles/r04_history.md); same expressions, bit-identical outputs.
+  static_assert(TW >= 64, "a wave's rows lie in one image row");
+  if (ksplit == 1 && !p.staged_epilogue && !p.io && !p.ypl && !p.mul && p.res_mode <= 1 && (long)p.M * p.Cout * 4 < (1L << 31)) {
+    const int mrow = wm * 64;
+    const unsigned pix = (unsigned)((img * p.Ho + ho0 + mrow / TW) * p.Wo + wo0 + mrow % TW + 4 * (lane >> 5));
+    conv_epilogue_direct(p, acc, pix * ((unsigned)p.Cout * 4u), 1 << 30, n0 + wn * 64 + (lane & 31), 15, (float*)lds + 64, wave, lane,
+                         tid, blockIdx.x);
+    return;
+  }
   // ---- epilogue: the 256 x 128 tile as two 128-row halves, each finished by 256 threads with the shared row epilogue.
   // Tile row m (0..255) = output pixel (ho0 + m / TW, wo0 + m % TW); the row epilogue wants the linear pixel index, which
   // is contiguous only inside one image row, so each 128-row half is handed over in runs of min(TW, 128) rows
@@ -3154,6 +2993,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
   }
 }
 
+}  // namespace
+
+namespace mmtconv {
 int fill(ConvP& p, const mmt_conv_args* a) {
   if (!a || !a->x) return MMT_EINVAL;
   p.x = a->x; p.w = a->w; p.scale = a->scale; p.shift = a->shift; p.res = a->res; p.mask = a->mask;
@@ -3171,6 +3013,7 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.w_src = (const float*)a->w_src; p.w_src_scale = (const float*)a->w_src_scale;
   p.x2 = p.dy2 = p.f16_sx2 = p.f16_sw2 = p.guard_x2 = p.guard_dy2 = nullptr;
   p.seg_z = 0;
+  { const char* e = getenv("MMT_STRIP_EPI"); p.staged_epilogue = e && atoi(e) == 0; }   // read per call (A/B timing)
   p.amax_out = (unsigned*)a->y_amax;
   p.amax_stats = a->y_amax_stats;
   p.io = a->io_bf16;
@@ -3190,6 +3033,9 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.cin4 = (p.Cin % 4) == 0;
   return 0;
 }
+}  // namespace mmtconv
+
+namespace {
 
 template <int BM, int BN, int WM, int WN>
 int launch_fwd(const ConvP& p, hipStream_t s) {
@@ -3209,23 +3055,28 @@ int launch_split(const ConvP& p, hipStream_t s) {
   return 0;
 }
 
-// split-K workspace (partial tiles), one per stream: kernels of a stream run in order and
-// may share it; the teacher's and the student's streams launch concurrently (from two host threads) and may not
-struct SplitWs { float* ws; };
-constexpr size_t SPLITK_WS_BYTES = (size_t)1024 * 128 * 128 * 4;  // 1024 partial tiles of 128 x 128 (64 MiB)
-static SplitWs split_workspace(hipStream_t s) {
+}  // namespace
+
+namespace mmtconv {
+SplitWs split_workspace(hipStream_t s) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, SplitWs> table;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return SplitWs{nullptr};
+  if (hipGetDevice(&dev) != hipSuccess) return SplitWs{nullptr, nullptr};
   std::lock_guard<std::mutex> g(mu);
   auto it = table.find({dev, s});
   if (it != table.end()) return it->second;
-  SplitWs w{nullptr};
-  if (hipMalloc((void**)&w.ws, SPLITK_WS_BYTES) != hipSuccess) return SplitWs{nullptr};
+  SplitWs w{nullptr, nullptr};
+  if (hipMalloc((void**)&w.ws, SPLITK_WS_BYTES) != hipSuccess) return SplitWs{nullptr, nullptr};
+  if (hipMalloc((void**)&w.tickets, SPLITK_TICKETS * sizeof(unsigned)) != hipSuccess ||
+      hipMemset(w.tickets, 0, SPLITK_TICKETS * sizeof(unsigned)) != hipSuccess)
+    return SplitWs{nullptr, nullptr};
   table[{dev, s}] = w;
   return w;
 }
+}  // namespace mmtconv
+
+namespace {
 
 // number of K ranges for the 128 x 128 kernel: fill the 512 resident block slots when the tiles alone do not, keeping
 // at least 32 steps per range
@@ -3246,7 +3097,7 @@ static int pick_ksplit(const ConvP& p) {
 template <int BM, int BN, int WM, int WN, int NS, int S>
 int launch_glds(const ConvP& p, hipStream_t s, int ksplit = 1) {
   const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN) * ksplit;
-  SplitWs w{nullptr};
+  SplitWs w{nullptr, nullptr};
   if (ksplit > 1) {
     w = split_workspace(s);
     if (!w.ws || tiles > 1024) return MMT_EINVAL;
@@ -3277,7 +3128,7 @@ int launch_glds(const ConvP& p, hipStream_t s, int ksplit = 1) {
 template <int BM, int BN, int WM, int WN, int NS, int S>
 int launch_pp(const ConvP& p, hipStream_t s, int ksplit = 1) {
   const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN) * ksplit;
-  SplitWs w{nullptr};
+  SplitWs w{nullptr, nullptr};
   if (ksplit > 1) {
     w = split_workspace(s);
     if (!w.ws || tiles > 1024) return MMT_EINVAL;
@@ -3343,7 +3194,7 @@ int launch_strip(const ConvP& p, hipStream_t s) {
   const size_t ring = (size_t)2 * (NS * R * SW * 32 + 3 * NS * 128 * 32), epi = (size_t)256 * 128 * sizeof(float);
   const size_t lds = ring > epi ? ring : epi;
   const int ksplit = strip_ksplit(p, TW);
-  SplitWs w{nullptr};
+  SplitWs w{nullptr, nullptr};
   if (ksplit > 1) {
     w = split_workspace(s);
     if (!w.ws) return MMT_EINVAL;
@@ -3450,8 +3301,10 @@ int launch_split_variant(int variant, const ConvP& p, hipStream_t s) {
   }
 }
 
-// 0: fp32-input MFMA (exact fp32 products)   1: bf16   2: 2-term split (3 products)   3: 3-term split (6 products)
-int g_precision = -1;
+}  // namespace
+
+namespace mmtconv {
+static int g_precision = -1;
 int precision() {
   if (g_precision < 0) {
     g_precision = getenv("MMT_CONV_PRECISION") ? atoi(getenv("MMT_CONV_PRECISION")) : 3;
@@ -3459,12 +3312,12 @@ int precision() {
   }
   return g_precision;
 }
+}  // namespace mmtconv
 
-}  // namespace
 
 extern "C" int mmt_set_conv_precision(int mode) {
   if (mode < 0 || mode > 3) return MMT_EINVAL;
-  g_precision = mode;
+  mmtconv::g_precision = mode;
   return 0;
 }
 
@@ -3653,7 +3506,7 @@ extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x,
   const int ksplit = strip_ksplit(p, tw);
   constexpr int NS = 2;
   hipStream_t s = (hipStream_t)stream;
-  SplitWs w{nullptr};
+  SplitWs w{nullptr, nullptr};
   if (ksplit > 1) {
     w = split_workspace(s);
     if (!w.ws) return MMT_EINVAL;
@@ -3706,7 +3559,7 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
   constexpr int S = 3;   // LDS stages of the operand ring (4 / 5 measured no faster: 36.4 / 34.8 / 35.0 us, profiles/r03_history.md)
   auto go = [&](auto kern, int BM, int BN, int ks) -> int {
     const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, BN) * ks;
-    SplitWs w{nullptr};
+    SplitWs w{nullptr, nullptr};
     if (ks > 1) {
       w = split_workspace(s);
       if (!w.ws || tiles > 1024) return MMT_EINVAL;

@@ -1,0 +1,302 @@
+// Shared by the convolution translation units (conv_igemm.hip, conv_pgemm.hip): the parameter block of every convolution kernel,
+// the fp16 split's range guard and its slow exact path, small vector types.  Device helpers live in an anonymous namespace (one
+// copy per translation unit); the host-side pieces with one definition (conv_igemm.hip) are declared in namespace mmtconv.
+#pragma once
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+namespace mmtconv {
+
+struct ConvP {
+  const float* x; const float* w; const float* scale; const float* shift; const float* res;
+  const float* mask; const float* mul; float* y;
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+  int relu, res_mode, out_stride, out_H, out_W;
+  float mask_scale;
+  int M, K, cin32, cin4;  // derived
+  const unsigned short* wpl; long wpl_stride;  // pre-split bf16 planes of w (or null)
+  const unsigned short* xpl; long xpl_stride;  // pre-split bf16 planes of x, same NHWC indexing as x (or null)
+  unsigned short* ypl; long ypl_stride;        // also write y as three bf16 planes (for a 3x3 consumer), or null
+  unsigned* amax_out;  // device float (bits) accumulating max |y| of this launch's output, or null (fp16 split: the consumer's scale)
+  int amax_stats;      // amax_out is a 33-float slot: every 64th block adds sum |y| of what it stores to [1 + k] and the element count
+                       // to [17 + k], k = (block >> 6) & 15 (crest factor max / mean of a SAMPLE: the fp16 split's fall-back test)
+  int f16_ax;  // f16_sx points to max |x| (the scale is derived from it) instead of to the scale itself
+  const float* f16_sx; const float* f16_sw;  // fp16 two-term split (experiment): device scalars s_x, s_w; the epilogue divides by s_x s_w
+  int io;  // bf16 STORAGE of operands (mode 1): IO_X x, IO_Y y, IO_RES res, IO_MASK mask are bf16 tensors of the same indexing
+  // fp16 split, range guard (round 4): the 33-float statistics slots of x (and, weight gradient, of dy) -- max, sampled sum and
+  // count -- from which every block derives the crest factor of ITS OWN operand before its first instruction of arithmetic;
+  // w_src / w_src_scale: where the fp32 weights of a planes-only (data-gradient) call come from (see conv_slow_tile)
+  const float* guard_x; const float* guard_dy;
+  const float* w_src; const float* w_src_scale;
+  // weight gradient over TWO segments of pixels (round 4: the two student passes of a step share every weight; their activations
+  // and gradients are separate tensors of one shape): blocks with z >= seg_z work on (x2, dy2) with that segment's own scales /
+  // statistics slots; seg_z == 0: one segment
+  const float* x2; const float* dy2; const float* f16_sx2; const float* f16_sw2; const float* guard_x2; const float* guard_dy2;
+  int seg_z;
+  int staged_epilogue;   // (A/B timing: MMT_STRIP_EPI=0) the tap-strip kernel leaves through its LDS-staged epilogue
+};
+constexpr float F16_CREST_HI = 131072.f;   // 2^17: max / mean |x| above which fp16's five exponent bits lose the bulk of the tensor
+constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;
+
+// mmt_conv_args -> ConvP (conv_igemm.hip); 0 or an MMT_E* code
+int fill(ConvP& p, const mmt_conv_args* a);
+// 0: fp32-input MFMA (exact fp32 products)   1: bf16   2: 2-term split (3 products)   3: 3-term split (6 products)
+int precision();
+// split-K workspace (partial tiles) + arrival counters (zeroed; whoever uses one leaves it zero), one pair per stream: kernels of a
+// stream run in order and may share it; the teacher's and the student's streams launch concurrently (two host threads) and may not
+struct SplitWs { float* ws; unsigned* tickets; };
+constexpr size_t SPLITK_WS_BYTES = (size_t)1024 * 128 * 128 * 4;  // 1024 partial tiles of 128 x 128 (64 MiB)
+constexpr int SPLITK_TICKETS = 4096;
+SplitWs split_workspace(hipStream_t s);
+}  // namespace mmtconv
+
+namespace {
+using namespace mmtconv;
+
+// The unlagged, per-tensor form of the range decision.  The two-term fp16 split represents x s as h + l with
+// s set by max |x|; when ONE element is 10^8 x the rest, everything else lands where l is subnormal and carries 11 bits instead
+// of 22.  The host cannot know that about the tensor at hand (it picks the kernel before the producer has run); the device can:
+// the producer recorded max / sampled mean of x in its statistics slot.  Every block of an fp16-split kernel reads the slot
+// first and, for such a tensor, computes its tile with plain fp32 FMAs from the fp32 operands instead (conv_slow_tile: exact
+// products, ~100 x slower, a handful of launches) -- until the host has seen the same statistics and moved the site to the
+// 3-term bf16 split (_hip._site_ok), which is fast and range-free.  NaN / inf maxima take the slow path too (they propagate).
+// Two halves, so that the slot's scalar loads are ISSUED at the top of a kernel and WAITED FOR behind its prologue copies: read at
+// the point of the branch they cost ~1 us of exposed latency per launch (+0.5 ms of conv time per step, measured; the slot was
+// last written by L2 atomics of several XCDs and misses this XCD's L2).  Nine values: the maximum and the first four of the
+// sixteen (sum, count) partials -- the share of the producer's sampled blocks 0, 64, 128, 192 (mod 1024); block 0 always samples.
+struct F16Guard { float amax, s0, s1, s2, s3, c0, c1, c2, c3; };
+__device__ __forceinline__ F16Guard f16_guard_load(const float* __restrict__ slot) {
+  F16Guard g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (slot) { g.amax = slot[0]; g.s0 = slot[1]; g.s1 = slot[2]; g.s2 = slot[3]; g.s3 = slot[4];
+              g.c0 = slot[17]; g.c1 = slot[18]; g.c2 = slot[19]; g.c3 = slot[20]; }
+  return g;
+}
+__device__ __forceinline__ bool f16_guard_bad(const F16Guard& g) {
+  const float tot = (g.s0 + g.s1) + (g.s2 + g.s3), cnt = (g.c0 + g.c1) + (g.c2 + g.c3);
+  if (!(tot > 0.f)) return false;                       // nothing sampled (or an all-zero sample): no statement
+  if (!(g.amax == g.amax) || g.amax > 3.0e38f) return true;
+  return g.amax * cnt > tot * F16_CREST_HI;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
+}
+// power-of-two scale that puts the largest magnitude `amax` into [2^13, 2^14] (an all-zero tensor: 1)
+__device__ __forceinline__ float f16_scale_of_fwd(const float amax) {
+  if (!(amax > 0.f)) return 1.f;
+  int e;
+  frexpf(amax, &e);
+  e = 14 - e;
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.f, e);
+}
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const f32x4*)p; }
+// ---- EXPERIMENT (mmt_conv3x3_strip_f16x2, tools/bench_f16x2.py): two-term fp16 split of a pre-scaled value, x * s = h + l
+// with h = fp16(x s), l = fp16(x s - h) (the residual is exact in fp32): 22 significant bits, |x s - h - l| <= 2^-22 |x s|.
+// The caller scales each tensor by a power of two so that its largest magnitude sits near 2^14: h is then a normal fp16
+// number down to 2^-28 of the tensor's maximum and l down to 2^-17 of it (below that l turns subnormal: absolute error
+// <= 2^-25 in scaled units, i.e. <= 2^-39 of the maximum).
+__device__ __forceinline__ void split4h(const f32x4 v, const float s, uint2 (&o)[2]) {
+  float r[4] = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
+#pragma unroll
+  for (int e = 0; e < 4; e++) r[e] = fminf(fmaxf(r[e], -65504.f), 65504.f);   // a scale from an older tensor may be too large: saturate
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) { h[e] = (_Float16)r[e]; l[e] = (_Float16)(r[e] - (float)h[e]); }
+  o[0] = uint2{__builtin_bit_cast(unsigned, f16x2{h[0], h[1]}), __builtin_bit_cast(unsigned, f16x2{h[2], h[3]})};
+  o[1] = uint2{__builtin_bit_cast(unsigned, f16x2{l[0], l[1]}), __builtin_bit_cast(unsigned, f16x2{l[2], l[3]})};
+}
+
+struct AmaxAcc { float amx = 0.f, asum = 0.f, acnt = 0.f; };   // max |y| / sum |y| / count over what a thread stores (p.amax_out)
+
+// ---- the fp16 split's slow, exact path (see f16_guard_bad): outputs (row i, column c) of a block's tile, i < rows,
+// c < ncols; row i is output pixel m = m_first + (i / run) * run_stride + (i % run) (one run of consecutive pixels for the tiled
+// and row-resident kernels, 256 / TW image rows for the strip kernel), column c is channel n0 + c.  fp32 FMA over the im2col
+// row straight from global memory; the weights are p.w ([Cout][KH][KW][Cin]) or, for a planes-only data-gradient call, read
+// through the flip / transpose / BN scale of pack_flip_unit from the forward weight p.w_src ([Cin'][KH][KW][Cout'], scale per
+// row).  raw != null (split-K forms): the sum times s_x s_w goes to raw[i * ncols + c] -- what the finish launch divides out
+// again -- or zeros when `zero`; else the epilogue of conv_epilogue_finish, element by element, statistics included.
+// The parameter block is read from the KERNEL-ARGUMENT SEGMENT (every kernel that calls this has its ConvP first), not from the
+// caller's registers: inlined with `p` in registers the slow path kept ~60 more scalar values alive across the callers' prologues
+// (SGPR spills 15 -> 80 in the tiled kernel, +0.6 ms of conv time per step); as a real call it costs the callers 288 B of stack.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) ConvP* ConvPK;
+__device__ __forceinline__ ConvPK kernarg_convp() { return (ConvPK)__builtin_amdgcn_kernarg_segment_ptr(); }
+#else   // (host pass of the same translation unit: never executed)
+typedef const ConvP* ConvPK;
+__device__ __forceinline__ ConvPK kernarg_convp() { return nullptr; }
+#endif
+
+__device__ __forceinline__ void conv_slow_tile(const int m_first, const int run, const int run_stride, const int rows,
+                                            const int n0, const int ncols, float* __restrict__ raw, const bool zero,
+                                            const int tid, const int nthreads, const int lin) {
+  const ConvPK pk = kernarg_convp();   // fields are fetched where they are used (scalar loads from the argument segment)
+  const int HoWo = pk->Ho * pk->Wo;
+  const float S = (pk->f16_ax ? f16_scale_of_fwd(*pk->f16_sx) : *pk->f16_sx) * *pk->f16_sw;
+  float amx = 0.f, asum = 0.f, acnt = 0.f;
+  for (int o = tid; o < rows * ncols; o += nthreads) {
+    const int i = o / ncols, c = o - i * ncols;
+    const int m = m_first + (i / run) * run_stride + (i % run), n = n0 + c;
+    if (raw && (zero || m >= pk->M || n >= pk->Cout)) { raw[o] = 0.f; continue; }
+    if (m >= pk->M || n >= pk->Cout) continue;
+    const int img = m / HoWo, rem = m - img * HoWo;
+    const int ho = rem / pk->Wo, wo = rem - ho * pk->Wo;
+    float acc = 0.f;
+    for (int kh = 0; kh < pk->KH; kh++) {
+      const int ih = ho * pk->stride - pk->pad + kh;
+      if ((unsigned)ih >= (unsigned)pk->H) continue;
+      for (int kw = 0; kw < pk->KW; kw++) {
+        const int iw = wo * pk->stride - pk->pad + kw;
+        if ((unsigned)iw >= (unsigned)pk->W) continue;
+        const float* xr = pk->x + ((long)(img * pk->H + ih) * pk->W + iw) * pk->Cin;
+        if (pk->w) {
+          const float* wr = pk->w + ((long)(n * pk->KH + kh) * pk->KW + kw) * pk->Cin;
+          for (int ci = 0; ci < pk->Cin; ci++) acc = fmaf(xr[ci], wr[ci], acc);
+        } else {   // W'(n, (kh, kw), c) = w_src[c][KH - 1 - kh][KW - 1 - kw][n] * scale[c]
+          const int tap = (pk->KH - 1 - kh) * pk->KW + (pk->KW - 1 - kw);
+          const float* wr = pk->w_src + (long)tap * pk->Cout + n;
+          const long cs = (long)pk->KH * pk->KW * pk->Cout;
+          for (int ci = 0; ci < pk->Cin; ci++)
+            acc = fmaf(xr[ci], wr[ci * cs] * (pk->w_src_scale ? pk->w_src_scale[ci] : 1.f), acc);
+        }
+      }
+    }
+    if (raw) { raw[o] = acc * S; continue; }
+    float v = acc * (pk->scale ? pk->scale[n] : 1.f) + (pk->shift ? pk->shift[n] : 0.f);
+    long oidx = (long)m * pk->Cout + n;
+    if (pk->out_stride > 1) oidx = (((long)img * pk->out_H + ho * pk->out_stride) * pk->out_W + wo * pk->out_stride) * pk->Cout + n;
+    if (pk->res_mode == 1) v += pk->res[(long)m * pk->Cout + n];
+    else if (pk->res_mode == 2) v += pk->res[(((long)img * (pk->Ho >> 1) + (ho >> 1)) * (pk->Wo >> 1) + (wo >> 1)) * pk->Cout + n];
+    else if (pk->res_mode == 3) {
+      const int w2 = pk->Wo * 2;
+      const float* rp = pk->res + (((long)img * (pk->Ho * 2) + 2 * ho) * w2 + 2 * wo) * pk->Cout + n;
+      v += (rp[0] + rp[pk->Cout]) + (rp[(long)w2 * pk->Cout] + rp[(long)w2 * pk->Cout + pk->Cout]);
+    }
+    if (pk->relu) v = fmaxf(v, 0.f);
+    if (pk->mask) v = pk->mask[oidx] > 0.f ? v * pk->mask_scale : 0.f;
+    if (pk->mul) v *= pk->mul[(long)m * pk->Cout + n];
+    pk->y[oidx] = v;
+    const float av = fabsf(v);
+    amx = fmaxf(amx, av); asum += av; acnt += 1.f;
+  }
+  if (!raw && pk->amax_out) {
+    if (amx > 0.f) atomicMax(pk->amax_out, __builtin_bit_cast(unsigned, amx));
+    if (pk->amax_stats && (lin & 63) == 0 && acnt > 0.f) {
+      const int k = (lin >> 6) & 15;
+      atomicAdd((float*)pk->amax_out + 1 + k, asum);
+      atomicAdd((float*)pk->amax_out + 17 + k, acnt);
+    }
+  }
+}
+
+// ---- epilogue straight from the accumulator registers of a wave's 64 x 64 tile (2 x 2 MFMA tiles of 32 x 32; round 5: the plane-fed
+// kernel and the tap-strip kernel).  acc[a][b][r] = tile row 32 a + 8 (r / 4) + r % 4 + 4 (lane / 32), channel 32 b + lane % 32: an
+// accumulator register is one output row x 32 consecutive channels per half wave -- stores, residual and mask loads of a wave touch
+// complete 128-byte lines with nothing staged through LDS.  (The staged epilogue of conv_igemm.hip waits for its residual / mask
+// loads one by one -- the compiler's answer to a load under a lane predicate -- and cost 18 - 30 us per 256 x 128 tile outside the
+// main loop, profiles/r04_history.md; here every request is an unconditional buffer operation: an absent operand is a zero-sized
+// buffer, a row past `rows_left` or a channel past Cout is an offset beyond the buffer.)
+//   ybase      byte offset of (the wave's tile row 0 + 4 (lane / 32), channel 0) in y; the wave's 64 rows are consecutive pixels
+//   rows_left  rows from there to the end of the tensor (<= 0: nothing of this lane's is stored)
+//   c0         channel of (b = 0, this lane)
+//   own        bit i = (2 a + b) set: this wave finishes that sub-tile (groups of waves that share a tile split its sub-tiles)
+//   red        24 floats of LDS free at this point, block-wide (the statistics' reduction); every wave of the block calls this
+// Same expressions, in the same order, as conv_epilogue_finish: bit-identical outputs.  fp32 tensors, res_mode <= 1, out_stride 1.
+__device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x16 (&acc)[2][2], const unsigned ybase, const int rows_left,
+                                                     const int c0, const int own, float* const red, const int wave, const int lane,
+                                                     const int tid, const int lin) {
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned cout4 = (unsigned)p.Cout * 4u;
+  unsigned cb[2];
+  bool cok[2];
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    const int c = c0 + b * 32;
+    cok[b] = c < p.Cout;
+    cb[b] = cok[b] ? (unsigned)c * 4u : OOB;
+  }
+  const int ybytes = (int)((long)p.M * p.Cout * 4);
+  const bool has_res = p.res_mode != 0, has_mask = p.mask != nullptr;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? p.res : p.y), 0, has_res ? ybytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(has_mask ? p.mask : p.y), 0, has_mask ? ybytes : 0, 0x00020000);
+  float sc[2], sh[2];
+  // operands scaled by powers of two (fp16 split): exact rescale of the accumulated sum
+  const float inv = p.f16_sx ? 1.f / ((p.f16_ax ? f16_scale_of_fwd(*p.f16_sx) : *p.f16_sx) * *p.f16_sw) : 1.f;
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    sc[b] = p.scale && cok[b] ? p.scale[c0 + b * 32] : 1.f;
+    if (p.f16_sx) sc[b] *= inv;
+    sh[b] = p.shift && cok[b] ? p.shift[c0 + b * 32] : 0.f;
+  }
+  auto off = [&](int a, int b, int r) { return ybase + (unsigned)(a * 32 + 8 * (r >> 2) + (r & 3)) * cout4 + cb[b]; };
+  float amx = 0.f, asum = 0.f, acnt = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (!((own >> i) & 1)) continue;
+    const int a = i >> 1, b = i & 1;
+    float ur[16], um[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { ur[r] = 0.f; um[r] = 1.f; }
+    if (has_res) {   // whole blocks of 16 requests behind one uniform branch each (an absent operand costs nothing)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        ur[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)off(a, b, r), 0, 0));
+    }
+    if (has_mask) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        um[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)off(a, b, r), 0, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      float v = acc[a][b][r] * sc[b] + sh[b];
+      if (has_res) v += ur[r];
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (has_mask) v = um[r] > 0.f ? v * p.mask_scale : 0.f;
+      const bool ok = cok[b] && a * 32 + 8 * (r >> 2) + (r & 3) < rows_left;
+      const float av = ok ? fabsf(v) : 0.f;
+      amx = fmaxf(amx, av);
+      asum += av;
+      acnt += ok ? 1.f : 0.f;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)(ok ? off(a, b, r) : OOB), 0, 0);
+    }
+  }
+  // statistics of the output (max |y|; sum |y| and count from every 64th block), reduced through `red`: a second __shared__ object
+  // would make the compiler drain the copy queue in front of every fragment read of the main loop
+  if (p.amax_out) {
+    const int nw = (int)(blockDim.x >> 6);
+    const bool stats = p.amax_stats && (lin & 63) == 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+    if (stats) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { asum += __shfl_xor(asum, o, 64); acnt += __shfl_xor(acnt, o, 64); }
+    }
+    if (lane == 0) { red[wave] = amx; red[16 + wave] = asum; red[32 + wave] = acnt; }
+    __syncthreads();
+    if (tid == 0) {
+      float m = red[0], sm = red[16], cn = red[32];
+      for (int i = 1; i < nw; i++) { m = fmaxf(m, red[i]); sm += red[16 + i]; cn += red[32 + i]; }
+      const unsigned bits = __builtin_bit_cast(unsigned, m);
+      if (m > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, bits);
+      if (stats && cn > 0.f) {
+        const int k = (lin >> 6) & 15;
+        atomicAdd((float*)p.amax_out + 1 + k, sm);
+        atomicAdd((float*)p.amax_out + 17 + k, cn);
+      }
+    }
+  }
+}
+
+}  // namespace

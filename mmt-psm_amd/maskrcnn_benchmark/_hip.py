@@ -132,6 +132,9 @@ _SIGS = {
     "mmt_pack_weight_flipped_f16": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mmt_conv3x3_strip_f16x2": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p],
     "mmt_conv_forward_f16x2": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p],
+    "mmt_conv_forward_pg": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "mmt_conv_pg_plan": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p],
+    "mmt_conv_pg_wanted": [ctypes.POINTER(ConvArgs)],
     "mmt_maxpool3x3s2_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_mask_bce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_mgd_level_forward": [c_void_p, ctypes.POINTER(MgdTeachers), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
@@ -168,7 +171,7 @@ F16X2_DEFAULT = os.environ.get("MMT_F16X2", "1") != "0"
 F16X2 = F16X2_DEFAULT
 F16X2_TILED = True   # also the tiled kernel (1x1, small-map 3x3, fc), not only the strip kernel
 F16X2_DELAYED = False   # (tools) scale from the previous tensor of the role: one pass less, but the scale lags the data
-F16_STATS = {"wgrad": 0, "conv": 0, "tiled": 0, "amax_pass": 0, "fallback": 0, "weight_pack": 0}   # launches that took the fp16 path (tools, tests)
+F16_STATS = {"wgrad": 0, "conv": 0, "tiled": 0, "pg": 0, "amax_pass": 0, "fallback": 0, "weight_pack": 0}   # launches that took the fp16 path (tools, tests)
 WGRAD_F16_MIN_ELEMS = 1 << 22
 _F16W = {}   # weight address -> (key, planes, device scale)
 
@@ -1037,8 +1040,9 @@ def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_
     a.y_amax = slot.ptr
     wp16, sw = f16_weight_planes(wsrc, f16_src[1] if flipped else None, flipped)
     a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
-    if a.KH == 3 and (lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1) != (kind == 1):
-        return None   # the library's choice between the strip and the tiled kernel can be switched per call (MMT_STRIP): re-plan
+    if a.KH == 3 and ((lib().mmt_conv_wants_planes(ctypes.byref(a)) == 1) != (kind == 1) or (
+            kind != 1 and (lib().mmt_conv_pg_wanted(ctypes.byref(a)) == 1) != (kind == 2))):
+        return None   # the library's choice between the strip, plane-fed and tiled kernels can be switched per call (MMT_STRIP, MMT_PG): re-plan
     # the fp32 weights for the kernels' slow, exact path (a tensor whose range defeats fp16: decided per block on the device)
     if flipped:
         a.w_src, a.w_src_scale = wsrc.data_ptr(), _p(f16_src[1])
@@ -1049,6 +1053,11 @@ def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_
     if kind == 0:     # tiled / row-resident kernels: x is split in registers, its recorded maximum gives the scale
         F16_STATS["tiled"] += 1
         _check(lib().mmt_conv_forward_f16x2(ctypes.byref(a), am[0].data_ptr(), sw.data_ptr(), _stream()), "mmt_conv_forward_f16x2")
+    elif kind == 2:   # plane-fed implicit GEMM (3x3 on small maps, mask head): one split pass over x, then the launch
+        F16_STATS["pg"] += 1
+        xp16, sx = f16_split(x)
+        a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+        _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), 0, 0, _stream()), "mmt_conv_forward_pg")
     else:             # tap-strip kernel: one split pass over x, then the launch
         F16_STATS["conv"] += 1
         xp16, sx = f16_split(x, (wsrc.data_ptr(), flipped) if F16X2_DELAYED else None)
@@ -1171,6 +1180,10 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         sel = f16 if f16 is not None else f16t
         if sel is not None and not _site_ok((sel[0].data_ptr(), sel[1]), x):
             f16 = f16t = None   # this input's dynamic range defeats fp16 (lagged crest-factor test): 3-term bf16 split
+    pg = None   # the same arithmetic on the plane-fed implicit GEMM (round 5): shapes the library wants there
+    if (f16t is not None and f16 is None and mul is None and out_stride == 1 and res_mode <= 1 and KH * KW >= 4
+            and lib().mmt_conv_pg_wanted(ctypes.byref(a)) == 1):
+        pg, f16t = f16t, None
     if f16 is not None:
         x_planes = None
     if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0 and not io:
@@ -1203,6 +1216,33 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
+    if pg is not None:
+        rec = PROFILE is not None
+        if rec:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        F16_STATS["pg"] += 1
+        if fast_ok and not io:
+            _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, 2, Cout, Ho, Wo)
+        a.f16_guard_x = _guard(_amax_of(x))
+        if pg[1]:
+            a.w_src, a.w_src_scale = pg[0].data_ptr(), _p(pg[2])
+        xp16, sx = f16_split(x)
+        wp16, sw = f16_weight_planes(pg[0], pg[2], pg[1])
+        a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+        a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
+        if rec:
+            ev[1].record()
+            ev[2].record()
+        _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), 0, 0, _stream()), "mmt_conv_forward_pg")
+        if rec:
+            ev[3].record()
+            PROFILE.append((2.0 * N * Ho * Wo * Cout * Cin * KH * KW, ev[2], ev[3],
+                            ("fwd5", N, H, W, Cin, Cout, KH, stride, out_stride), 1, (ev[0], ev[1]),
+                            _epilogue_bytes(y, res, res_mode, mask, mul)))
+        if amax_slot is not None:
+            y._mmt_amax = (amax_slot, y._version)
+        return y
     if f16t is not None:
         am = _amax_of(x)
         wp16, sw = f16_weight_planes(f16t[0], f16t[2], f16t[1])
@@ -1287,6 +1327,65 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if amax_slot is not None:
         y._mmt_amax = (amax_slot, y._version)
     return y
+
+
+def conv_forward_pg(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, mask=None, mask_scale=1.0, w_shape=None,
+                    f16_src=None, tile_rows=0, ksplit=0, xp=None):
+    """the plane-fed implicit GEMM of the default arithmetic (include/mmtpsm.h: mmt_conv_forward_pg; csrc/conv_pgemm.hip): x is split
+    into its two fp16 planes by one pass (or `xp` = (planes, scale) from an earlier call on the same tensor), the weight planes are
+    the packed fp16 planes of `w` -- or, `w` None with `w_shape` and `f16_src` = (forward weight, row scale), of its data-gradient
+    form.  tile_rows / ksplit: 0 = the library's choice.  Raises for shapes the kernel does not take."""
+    x = nhwc(x)
+    N, Cin, H, W = x.shape
+    if w is not None:
+        wsrc, flipped, fscale = nhwc(w), False, None
+        Cout, _, KH, KW = wsrc.shape
+    else:
+        wsrc, flipped, fscale = nhwc(f16_src[0]), True, f16_src[1]
+        Cout, Cin_w, KH, KW = w_shape
+        if Cin_w != Cin:
+            raise RuntimeError("conv channel mismatch: x has %d, w has %d" % (Cin, Cin_w))
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    a = ConvArgs()
+    a.x = x.data_ptr()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
+    a.stride, a.pad, a.Ho, a.Wo = stride, pad, Ho, Wo
+    a.out_stride, a.mask_scale = 1, 1.0
+    y = empty_nhwc(N, Cout, Ho, Wo, x.device)
+    a.y = y.data_ptr()
+    a.scale, a.shift, a.relu = _p(scale), _p(shift), 1 if relu else 0
+    if res is not None:
+        a.res, a.res_mode = nhwc(res).data_ptr(), 1
+    if mask is not None:
+        a.mask, a.mask_scale = nhwc(mask).data_ptr(), float(mask_scale)
+    slot = _amax_slot(x.device)
+    a.y_amax, a.y_amax_stats = slot.ptr, 1
+    if flipped:
+        a.w_src, a.w_src_scale = wsrc.data_ptr(), _p(fscale)
+    else:
+        a.w = wsrc.data_ptr()
+    a.f16_guard_x = _guard(_amax_of(x))
+    xp16, sx = f16_split(x) if xp is None else xp
+    wp16, sw = f16_weight_planes(wsrc, fscale, flipped)
+    a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+    a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
+    _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), int(tile_rows), int(ksplit), _stream()),
+           "mmt_conv_forward_pg")
+    y._mmt_amax = (slot, y._version)
+    return y
+
+
+def conv_pg_plan(N, Cin, H, W, Cout, KH, KW, stride, pad):
+    """(tile rows, K ranges) the library would run this shape with on the plane-fed kernel; (0, 0): not one of its shapes"""
+    a = ConvArgs()
+    a.x = a.w_planes = 16   # placeholders: only the shape is looked at
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
+    a.stride, a.pad, a.out_stride = stride, pad, 1
+    a.Ho, a.Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    rows, ks = c_int(0), c_int(0)
+    _check(lib().mmt_conv_pg_plan(ctypes.byref(a), ctypes.byref(rows), ctypes.byref(ks)), "mmt_conv_pg_plan")
+    return rows.value, ks.value
 
 
 # pre-split bf16 planes of weight tensors (split-bf16 conv modes), keyed by the weight's device address:

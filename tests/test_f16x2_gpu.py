@@ -302,11 +302,11 @@ def _rel_err(y, ref, den):
 
 # N, Cin, H, W, Cout, k, kernel family the shape runs on (its F16_STATS counter)
 GUARD_CASES = [(8, 256, 64, 64, 256, 3, "conv"),       # tap-strip kernel, TW = 64
-               (2, 256, 64, 64, 256, 3, "tiled"),      # few-tile 3x3: tiled kernel, split-K + finish launch
+               (2, 256, 64, 64, 256, 3, "pg"),         # few-tile 3x3: plane-fed implicit GEMM, 64-row tiles, four K groups per block (round 5)
                (2, 256, 128, 128, 256, 3, "conv"),     # tap-strip kernel, TW = 128, un-split
                (2, 1024, 64, 64, 256, 1, "tiled"),     # tiled kernel 128 x 64
                (8, 1024, 64, 64, 256, 1, "tiled"),     # tiled kernel 128 x 128
-               (2, 512, 32, 32, 512, 3, "tiled"),      # tiled kernel, split-K + finish launch
+               (2, 512, 32, 32, 512, 3, "pg"),         # plane-fed implicit GEMM, K ranges across blocks meeting in one launch
                (2, 256, 64, 64, 1024, 1, "tiled"),     # row-resident 1x1 kernel (K = 256)
                (4, 64, 128, 128, 256, 1, "tiled")]     # row-resident 1x1 kernel (K = 64)
 
@@ -507,7 +507,7 @@ def test_detector_f16x2_vs_oracle(hip):
     try:
         for on in (False, True):
             H.set_f16x2(on)
-            n0 = H.F16_STATS["tiled"] + H.F16_STATS["conv"]
+            n0 = H.F16_STATS["tiled"] + H.F16_STATS["conv"] + H.F16_STATS["pg"]
             H.f16_split = lambda x, site=None: (used.append(tuple(x.shape)), orig(x, site))[1]
             for p in student.parameters():
                 p.grad = None
@@ -515,7 +515,7 @@ def test_detector_f16x2_vs_oracle(hip):
             out = student(to_image_list(list(imgs.cuda()), 32), ptg)
             student.set_replay(None)
             sum(out.values()).backward()
-            launched = H.F16_STATS["tiled"] + H.F16_STATS["conv"] - n0
+            launched = H.F16_STATS["tiled"] + H.F16_STATS["conv"] + H.F16_STATS["pg"] - n0
             losses[on] = {k: v.item() for k, v in out.items()}
             grads[on] = {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
     finally:
