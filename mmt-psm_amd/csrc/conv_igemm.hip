@@ -884,6 +884,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvP p, co
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the tail steps must land before LDS is reused
   __syncthreads();
   if (ksplit == 1) {
+    // round 5: straight from the accumulator registers (conv_shared.h: conv_epilogue_direct; bit-identical) wherever an output row's
+    // address is linear in the GEMM row -- fp32 tensors, no residual of another resolution, no scatter; else the staged epilogue
+    if (!p.staged_epilogue && !p.io && !p.ypl && !p.mul && p.res_mode <= 1 && p.out_stride == 1 && (long)p.M * p.Cout * 4 < (1L << 31)) {
+      const int mrow0 = m0 + wm * TM * 32 + 4 * (lane >> 5);
+      conv_epilogue_direct<TM, TN>(p, acc, (unsigned)mrow0 * ((unsigned)p.Cout * 4u), p.M - mrow0, n0 + wn * TN * 32 + (lane & 31),
+                                   (1 << (TM * TN)) - 1, lds + 64, wave, lane, tid, blockIdx.x);
+      return;
+    }
     conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tid, lane, wm, wn, HoWo);
     return;
   }
@@ -1382,8 +1390,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   if (ksplit == 1 && !p.staged_epilogue && !p.io && !p.ypl && !p.mul && p.res_mode <= 1 && (long)p.M * p.Cout * 4 < (1L << 31)) {
     const int mrow = wm * 64;
     const unsigned pix = (unsigned)((img * p.Ho + ho0 + mrow / TW) * p.Wo + wo0 + mrow % TW + 4 * (lane >> 5));
-    conv_epilogue_direct(p, acc, pix * ((unsigned)p.Cout * 4u), 1 << 30, n0 + wn * 64 + (lane & 31), 15, (float*)lds + 64, wave, lane,
-                         tid, blockIdx.x);
+    conv_epilogue_direct<2, 2>(p, acc, pix * ((unsigned)p.Cout * 4u), 1 << 30, n0 + wn * 64 + (lane & 31), 15, (float*)lds + 64, wave,
+                               lane, tid, blockIdx.x);
     return;
   }
   // ---- epilogue: the 256 x 128 tile as two 128-row halves, each finished by 256 threads with the shared row epilogue.
@@ -3013,7 +3021,7 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.w_src = (const float*)a->w_src; p.w_src_scale = (const float*)a->w_src_scale;
   p.x2 = p.dy2 = p.f16_sx2 = p.f16_sw2 = p.guard_x2 = p.guard_dy2 = nullptr;
   p.seg_z = 0;
-  { const char* e = getenv("MMT_STRIP_EPI"); p.staged_epilogue = e && atoi(e) == 0; }   // read per call (A/B timing)
+  { const char* e = getenv("MMT_DIRECT_EPI"); p.staged_epilogue = e && atoi(e) == 0; }   // read per call (A/B timing)
   p.amax_out = (unsigned*)a->y_amax;
   p.amax_stats = a->y_amax_stats;
   p.io = a->io_bf16;

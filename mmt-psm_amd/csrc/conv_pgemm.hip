@@ -382,7 +382,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
   // ---- epilogue from the accumulator registers (conv_shared.h): each group finishes its own sub-tiles
   {
     const int mrow0 = m0 + wm * 64 + 4 * (lane >> 5);
-    conv_epilogue_direct(p, acc, (unsigned)mrow0 * ((unsigned)p.Cout * 4u), p.M - mrow0, n0 + wn * 64 + (lane & 31),
+    conv_epilogue_direct<2, 2>(p, acc, (unsigned)mrow0 * ((unsigned)p.Cout * 4u), p.M - mrow0, n0 + wn * 64 + (lane & 31),
                          copier ? 0 : (KG == 1 ? 15 : (KG == 2 ? (grp ? 10 : 5) : (1 << grp))), (float*)ring + 64, wave, lane, tid, blockIdx.x);
   }
 }

@@ -34,7 +34,7 @@ struct ConvP {
   // statistics slots; seg_z == 0: one segment
   const float* x2; const float* dy2; const float* f16_sx2; const float* f16_sw2; const float* guard_x2; const float* guard_dy2;
   int seg_z;
-  int staged_epilogue;   // (A/B timing: MMT_STRIP_EPI=0) the tap-strip kernel leaves through its LDS-staged epilogue
+  int staged_epilogue;   // (A/B timing: MMT_DIRECT_EPI=0) the tiled and tap-strip kernels leave through the LDS-staged epilogue
 };
 constexpr float F16_CREST_HI = 131072.f;   // 2^17: max / mean |x| above which fp16's five exponent bits lose the bulk of the tensor
 constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;
@@ -209,18 +209,19 @@ __device__ __forceinline__ void conv_slow_tile(const int m_first, const int run,
 //   ybase      byte offset of (the wave's tile row 0 + 4 (lane / 32), channel 0) in y; the wave's 64 rows are consecutive pixels
 //   rows_left  rows from there to the end of the tensor (<= 0: nothing of this lane's is stored)
 //   c0         channel of (b = 0, this lane)
-//   own        bit i = (2 a + b) set: this wave finishes that sub-tile (groups of waves that share a tile split its sub-tiles)
+//   own        bit i = (TN a + b) set: this wave finishes that sub-tile (groups of waves that share a tile split its sub-tiles)
 //   red        24 floats of LDS free at this point, block-wide (the statistics' reduction); every wave of the block calls this
 // Same expressions, in the same order, as conv_epilogue_finish: bit-identical outputs.  fp32 tensors, res_mode <= 1, out_stride 1.
-__device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x16 (&acc)[2][2], const unsigned ybase, const int rows_left,
+template <int TM, int TN>   // the wave's tile: TM x TN MFMA tiles of 32 x 32 (2 x 2: the plane-fed and tap-strip kernels; 1 x 4 / 1 x 2 / 1 x 1: the tiled kernel)
+__device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x16 (&acc)[TM][TN], const unsigned ybase, const int rows_left,
                                                      const int c0, const int own, float* const red, const int wave, const int lane,
                                                      const int tid, const int lin) {
   constexpr unsigned OOB = 0x80000000u;
   const unsigned cout4 = (unsigned)p.Cout * 4u;
-  unsigned cb[2];
-  bool cok[2];
+  unsigned cb[TN];
+  bool cok[TN];
 #pragma unroll
-  for (int b = 0; b < 2; b++) {
+  for (int b = 0; b < TN; b++) {
     const int c = c0 + b * 32;
     cok[b] = c < p.Cout;
     cb[b] = cok[b] ? (unsigned)c * 4u : OOB;
@@ -230,11 +231,11 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x1
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? p.res : p.y), 0, has_res ? ybytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(has_mask ? p.mask : p.y), 0, has_mask ? ybytes : 0, 0x00020000);
-  float sc[2], sh[2];
+  float sc[TN], sh[TN];
   // operands scaled by powers of two (fp16 split): exact rescale of the accumulated sum
   const float inv = p.f16_sx ? 1.f / ((p.f16_ax ? f16_scale_of_fwd(*p.f16_sx) : *p.f16_sx) * *p.f16_sw) : 1.f;
 #pragma unroll
-  for (int b = 0; b < 2; b++) {
+  for (int b = 0; b < TN; b++) {
     sc[b] = p.scale && cok[b] ? p.scale[c0 + b * 32] : 1.f;
     if (p.f16_sx) sc[b] *= inv;
     sh[b] = p.shift && cok[b] ? p.shift[c0 + b * 32] : 0.f;
@@ -242,9 +243,9 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x1
   auto off = [&](int a, int b, int r) { return ybase + (unsigned)(a * 32 + 8 * (r >> 2) + (r & 3)) * cout4 + cb[b]; };
   float amx = 0.f, asum = 0.f, acnt = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < TM * TN; i++) {
     if (!((own >> i) & 1)) continue;
-    const int a = i >> 1, b = i & 1;
+    const int a = i / TN, b = i % TN;
     float ur[16], um[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) { ur[r] = 0.f; um[r] = 1.f; }
