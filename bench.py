@@ -217,16 +217,30 @@ ARITH_BF16_STORAGE = ("bf16 products, fp32 accumulate; activations and activatio
 KERNEL_NAMES = {
     "fwd1": lambda mode: ("conv_fwd_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)" if mode == 0 else
                           "conv_fwd_glds_kernel<128,128,4,1,%d,3> (v_mfma_f32_32x32x16_bf16 x %d products)" % (mode, PRODUCTS[mode])),
+    "fwd5": lambda mode: "conv_pg_kernel<WM,KG,S> (plane-fed implicit GEMM, 64 WM x 128 tiles, 8 matrix + 4 copy waves, KG K groups per "
+                         "block, v_mfma_f32_32x32x16_f16 x 3 products; brackets hold the kernel, the plane-split pass is bracketed apart)",
     "fwd4": lambda mode: "conv3x3_strip_kernel<TW,%d> (256x128 tiles on 8 waves, %s, v_mfma_f32_32x32x16_bf16 x %d "
                          "products; brackets hold the kernel and, in its split-K form, the finish launch)" % (
                              mode, "pre-split planes" if mode == 3 else "bf16 tensors as stored", PRODUCTS[mode]),
 }
 
 
+def csrc_sha1():
+    """hash of the kernel sources (mmt-psm_amd/csrc/*.hip, *.h): ties profiles/pmc_traffic.json to the library it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "mmt-psm_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def products_of(mode, dom):
     """matrix products per algorithmic multiply-add of a bracketed kernel group"""
     from maskrcnn_benchmark import _hip
-    if mode == 3 and _hip.F16X2 and (dom == "fwd4" or _hip.F16X2_TILED):
+    if mode == 3 and _hip.F16X2 and (dom in ("fwd4", "fwd5") or _hip.F16X2_TILED):
         return 3   # the two-term fp16 split: the strip kernel, and (F16X2_TILED) the tiled kernel too
     return PRODUCTS[mode]
 
@@ -241,6 +255,8 @@ def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, nsteps, dom="fw
     kern = KERNEL_NAMES[dom](mode)
     if nprod == 3 and dom == "fwd1":
         kern = "conv_fwd_glds_kernel<128,128,4,1,2,3,true> (activations split into two fp16 terms in registers, v_mfma_f32_32x32x16_f16 x 3 products)"
+    if dom == "fwd5":
+        kern = KERNEL_NAMES["fwd5"](mode)
     if nprod == 3 and dom == "fwd4":
         kern = ("conv3x3_strip_kernel<TW,2,true> (256x128 tiles on 8 waves, two fp16 planes per operand scaled per tensor, "
                 "v_mfma_f32_32x32x16_f16 x 3 products; brackets hold the kernel and, in its split-K form, the finish launch)")
@@ -407,9 +423,10 @@ def main():
         return sum(q[0] for q in g), sum(q[1].elapsed_time(q[2]) for q in g)
 
     # dominant kernel = the large-tile forward kernel with more bracketed time in this leg
-    dom = max(("fwd1", "fwd4"), key=lambda k: total(groups.get(k, []))[1])
+    ranked = sorted(("fwd1", "fwd4", "fwd5"), key=lambda k: -total(groups.get(k, []))[1])
+    dom, odom_ = ranked[0], ranked[1]
     prof = groups.get(dom, [])
-    other = groups.get("fwd4" if dom == "fwd1" else "fwd1", [])
+    other = groups.get(odom_, [])
     single = None
     if world == 1 and trainer.overlap_teacher and not os.environ.get("MMT_BENCH_NO_FP32_LEG"):
         # the same launches with the teacher on the main stream: kernel durations without a second stream sharing the GPU
@@ -450,11 +467,16 @@ def main():
         # ... plus what the fused epilogues of those launches read (residual / top-down add, ReLU mask of a data gradient):
         # operands of the launch like its input, read once (round 3 left them out and called the difference waste)
         alg_bytes += sum(p[6] for p in prof if len(p) > 6)
-        traffic = None
-        try:  # HBM/fabric bytes per launch of this kernel from the committed PMC passes (not measurable live)
+        traffic, traffic_note = None, None
+        try:  # HBM/fabric bytes per launch of this kernel from the committed PMC passes (not measurable live) -- quoted only while
+            # the kernels are the ones the counters were collected on: the file carries the hash of csrc/ 
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = tj["by_mode"][str(mode)].get("traffic_bytes_per_launch_" + dom, tj["by_mode"][str(mode)].get(
-                "traffic_bytes_per_launch") if dom == "fwd1" else None)
+            if tj.get("csrc_sha1") == csrc_sha1():
+                traffic = tj["by_mode"][str(mode)].get("traffic_bytes_per_launch_" + dom, tj["by_mode"][str(mode)].get(
+                    "traffic_bytes_per_launch") if dom == "fwd1" else None)
+            else:
+                traffic_note = ("profiles/pmc_traffic.json was collected on other kernel sources (csrc hash %s, now %s): re-run "
+                                "mmt-psm_amd/tools/make_profiles.sh" % (str(tj.get("csrc_sha1"))[:12], csrc_sha1()[:12]))
         except Exception:
             pass
         out = {
@@ -478,7 +500,8 @@ def main():
                        "image_forwards_per_step_per_gpu": 4 if args.supervised else 12, "parallelism": "dp%d" % world,
                        "base_lr": BENCH_BASE_LR, "consistency_branch_skipped_steps": skipped,
                        "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}},
-            "roofline": roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dtp, npf, dom),
+            "roofline": dict(roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dtp, npf, dom),
+                             **({"traffic_note": traffic_note} if traffic_note else {})),
         }
         pres = [q[5] for q in prof if len(q) > 5 and q[5] is not None]
         if pres:
@@ -500,11 +523,12 @@ def main():
             out["roofline"]["clock"] = ck
         if other:
             fo, mo = total(other)
-            odom = "fwd4" if dom == "fwd1" else "fwd1"
+            odom = odom_
             opeak = PEAK_FP32_MFMA_TFLOPS if mode == 0 else PEAK_BF16_MFMA_TFLOPS / products_of(mode, odom)
             out["roofline"]["other_large_tile_kernel"] = {
                 "kernel": (("conv_fwd_glds_kernel<128,128,4,1,2,3,true> (raw fp32 rows split into two fp16 terms in registers, "
                             "v_mfma_f32_32x32x16_f16 x 3 products)" if odom == "fwd1" else
+                            KERNEL_NAMES["fwd5"](mode) if odom == "fwd5" else
                             "conv3x3_strip_kernel<TW,2,true> (two fp16 planes per operand, v_mfma_f32_32x32x16_f16 x 3 products)")
                            if products_of(mode, odom) == 3 else KERNEL_NAMES[odom](mode)),
                 "launches_per_step": len(other) // npf,

@@ -361,9 +361,10 @@ int mmt_sum_stats(const float* a, const float* b, const float* c, const float* d
                   float* slot /*device, zeroed*/, void* stream);
 /* statistics slot of a tensor whose elements are convex combinations of elements of n source tensors (the pooled features of
  * mmt_roi_align_forward: bilinear taps of the pyramid levels, poolers.py:91-121): out[0] = the largest of the sources' maxima (an
- * upper bound: what a consumer's power-of-two scale needs), sums / counts added.  slots_dev: DEVICE array of n device pointers to
- * 33-float slots.  Replaces a reduction pass over the 51-205 MB pooled tensor in front of fc6 / the mask head. */
-int mmt_stats_combine(const float* const* slots_dev /*device*/, int n, float* out /*device, 33 floats*/, void* stream);
+ * upper bound: what a consumer's power-of-two scale needs), sums / counts added.  slots: HOST array of n <= 8 device pointers to
+ * 33-float slots (they travel in the kernel arguments).  Replaces a reduction pass over the 51-205 MB pooled tensor in front of
+ * fc6 / the mask head. */
+int mmt_stats_combine(const float* const* slots /*[host]*/, int n, float* out /*device, 33 floats*/, void* stream);
 int mmt_split_planes_f16(const float* x, void* planes, long plane_stride, long n, float scale, const float* amax /*device or NULL*/,
                          float* scale_out /*device or NULL*/, float* amax_next /*device or NULL: max |x| of THIS tensor is
                          accumulated here, for the scale of the next tensor in the same role (delayed scaling)*/,

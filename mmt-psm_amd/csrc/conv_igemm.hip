@@ -2968,6 +2968,10 @@ __global__ void weight_flip_kernel(const float* __restrict__ w, const float* __r
 template <bool HALF>  // HALF: x and y are bf16 tensors (max of bf16 values is a bf16 value: exact)
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
                                                       int H, int W, int C, int Ho, int Wo) {
+  // 3 x 3 / stride 2 / pad 1.  Taps outside the image are CLAMPED to the nearest inside one instead of skipped: the maximum does not
+  // change (a clamped tap repeats a value of the window) and the nine loads of an output are unconditional, all in flight at once
+  // (round 5: the skipping form -- a branch around each load -- waited for every load in turn: 230 us for the teacher's 8 x 64 x 512^2
+  // stem output, 1.7 x its HBM time)
   const long total = (long)N * Ho * Wo * (C / 4);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c4 = (int)(i % (C / 4));
@@ -2975,26 +2979,28 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
     const int wo = (int)(r % Wo); r /= Wo;
     const int ho = (int)(r % Ho);
     const int n = (int)(r / Ho);
-    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 v[9];
+#pragma unroll
     for (int dh = 0; dh < 3; dh++) {
-      const int ih = ho * 2 - 1 + dh;
-      if ((unsigned)ih >= (unsigned)H) continue;
+      const int ih = min(max(ho * 2 - 1 + dh, 0), H - 1);
+#pragma unroll
       for (int dwi = 0; dwi < 3; dwi++) {
-        const int iw = wo * 2 - 1 + dwi;
-        if ((unsigned)iw >= (unsigned)W) continue;
+        const int iw = min(max(wo * 2 - 1 + dwi, 0), W - 1);
         const long xi = (((long)n * H + ih) * W + iw) * C + c4 * 4;
-        f32x4 v;
         if (HALF) {
           const uint2 t = *(const uint2*)((const unsigned short*)x + xi);
-          v = f32x4{__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
-                    __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u)};
+          v[dh * 3 + dwi] = f32x4{__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
+                                  __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u)};
         } else {
-          v = ldg4(x + xi);
+          v[dh * 3 + dwi] = ldg4(x + xi);
         }
-#pragma unroll
-        for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
       }
     }
+    f32x4 m = v[0];
+#pragma unroll
+    for (int t = 1; t < 9; t++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[t][e]);
     const long yi = (((long)n * Ho + ho) * Wo + wo) * C + c4 * 4;
     if (HALF) *(uint2*)((unsigned short*)y + yi) = uint2{pk_bf16(m[0], m[1]), pk_bf16(m[2], m[3])};
     else *(f32x4*)(y + yi) = m;
@@ -3436,17 +3442,27 @@ extern "C" int mmt_amax_stats(const float* x, long n, float* slot, void* stream)
 // out <- the statistics of a tensor whose every element is a CONVEX combination of elements of the tensors behind `slots`
 // (ROIAlign: bilinear taps of the pyramid levels, averaged): max = the largest of the maxima -- an upper bound, which is all the
 // consumer's power-of-two scale needs -- sums and counts added (the mean of such a tensor is about that of its sources)
-__global__ void stats_combine_kernel(const float* const* __restrict__ slots, const int n, float* __restrict__ out) {
+struct StatSlots { const float* s[8]; };
+__global__ void stats_combine_kernel(const StatSlots slots, const int n, float* __restrict__ out) {
   const int i = threadIdx.x;
   if (i >= 33) return;
   float v = 0.f;
-  for (int k = 0; k < n; k++) v = i == 0 ? fmaxf(v, slots[k][0]) : v + slots[k][i];
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (k < n) v = i == 0 ? fmaxf(v, slots.s[k][0]) : v + slots.s[k][i];
   out[i] = v;
 }
 
-extern "C" int mmt_stats_combine(const float* const* slots_dev, int n, float* out, void* stream) {
-  if (!slots_dev || !out || n <= 0) return MMT_EINVAL;
-  hipLaunchKernelGGL(stats_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slots_dev, n, out);
+// (round 5, ADVICE r4: the slot addresses travel in the kernel arguments -- the per-call device table of round 4 was a pageable
+// host-to-device copy on the ROIAlign path of both launch threads)
+extern "C" int mmt_stats_combine(const float* const* slots, int n, float* out, void* stream) {
+  if (!slots || !out || n <= 0 || n > 8) return MMT_EINVAL;
+  StatSlots t{};
+  for (int k = 0; k < n; k++) {
+    if (!slots[k]) return MMT_EINVAL;
+    t.s[k] = slots[k];
+  }
+  hipLaunchKernelGGL(stats_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, n, out);
   MMT_LAUNCH_CHECK();
   return 0;
 }

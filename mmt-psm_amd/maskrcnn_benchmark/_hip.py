@@ -328,28 +328,21 @@ def _amax_of(x):
     return am
 
 
-_COMBINE_PTRS = {}
-
-
 def stats_of_convex_combination(out, sources):
     """attach to `out` -- a tensor whose elements are convex combinations of elements of `sources` (ROIAlign of pyramid levels) --
     a statistics slot derived from theirs (include/mmtpsm.h: mmt_stats_combine): one 64-thread launch instead of a reduction pass
-    over `out`.  Nothing happens unless every source carries a recorded slot."""
+    over `out`; the (at most 8) slot addresses are kernel arguments.  Nothing happens unless every source carries a recorded slot."""
     slots = []
     for t in sources:
         am = getattr(t, "_mmt_amax", None)
         if am is None or am[1] != t._version or type(am[0]) is not _Slot:
             return
         slots.append(am[0].ptr)
-    from maskrcnn_benchmark.utils.miscellaneous import dev_const
-    key = tuple(slots)
-    ptrs = _COMBINE_PTRS.get(key)
-    if ptrs is None:
-        if len(_COMBINE_PTRS) > 512:
-            _COMBINE_PTRS.clear()
-        ptrs = _COMBINE_PTRS[key] = torch.tensor(slots, dtype=torch.int64).to(out.device, non_blocking=True)
+    if not slots or len(slots) > 8:
+        return
+    arr = (c_void_p * len(slots))(*slots)
     slot = _amax_slot(out.device)
-    _check(lib().mmt_stats_combine(ptrs.data_ptr(), len(slots), slot.ptr, _stream()), "mmt_stats_combine")
+    _check(lib().mmt_stats_combine(arr, len(slots), slot.ptr, _stream()), "mmt_stats_combine")
     out._mmt_amax = (slot, out._version)
 
 

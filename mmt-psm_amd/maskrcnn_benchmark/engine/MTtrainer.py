@@ -81,31 +81,53 @@ def allreduce_gradients(flat):
             flat.grad.mul_(1.0 / ws)
 
 
+_FLAG_SYNC = {}   # process-wide: the flag exchange's own communicator and stream (built once, collectively)
+
+
 def sync_touched(flat):
     """Which parameters "have a gradient" this step must be the same on every rank: the all-reduce hands every rank the same
     averaged gradient, but `flat.touched` (what FlatSGD.step updates, torch SGD's `p.grad is None: continue`) is filled by
     THIS rank's backward nodes.  A rank whose teacher found no boxes skipped the consistency branch and never touched the
-    hint adaptors while the others did; updating them on some ranks only would let the students -- and with them the EMA
-    teachers -- drift apart for good.  The update set is therefore the UNION over ranks: one MAX all-reduce of
-    a per-parameter flag vector (a few hundred bytes) and one read-back.  The trainer calls it only on steps whose set CAN
-    differ between ranks (the mean-teacher branch is active); the name list and the pinned staging buffer are built once
-    (no pageable copy, no per-step sort)."""
+    hint adaptors while the others did -- and a supervised pass can take a degenerate route on one rank only (crops without
+    ground truth: no mask-head positives) --; updating parameters on some ranks only would let the students, and with them the
+    EMA teachers, drift apart for good.  The update set is therefore the UNION over ranks, EVERY step: one MAX
+    all-reduce of a per-parameter flag vector (a few hundred bytes).
+    Round 5: the flags are host data (filled while backward was ISSUED), so their exchange does not have to wait for the device:
+    it runs on a communicator and a stream of its own -- behind nothing the step has queued -- and the read-back returns as soon
+    as those few hundred bytes have crossed, with the backward pass still running (round 4 issued it on the gradient's
+    communicator, behind every gradient piece, and read it back with a blocking `.tolist()`: a device drain in front of SGD)."""
     if get_world_size() < 2:
         return
     ent = flat.__dict__.get("_touch_sync")
     if ent is None:
         names = [n for n, (o, _) in sorted(flat.index.items(), key=lambda kv: kv[1][0]) if o < flat.n_trainable]
         host = torch.zeros((len(names),), dtype=torch.int32)
+        back = torch.zeros((len(names),), dtype=torch.int32)
         if flat.grad.is_cuda:
-            host = host.pin_memory()
-        ent = flat._touch_sync = (names, host)
-    names, host = ent
+            host, back = host.pin_memory(), back.pin_memory()
+        ent = flat._touch_sync = (names, host, back)
+    names, host, back = ent
     touched = flat.touched
     for i, n in enumerate(names):
         host[i] = 1 if n in touched else 0
-    flags = host.to(flat.grad.device, non_blocking=True)
-    dist.all_reduce(flags, op=dist.ReduceOp.MAX)
-    flat.touched.update(n for n, f in zip(names, flags.tolist()) if f)
+    if "group" not in _FLAG_SYNC:   # (collective: every rank reaches its first step's exchange)
+        _FLAG_SYNC["group"] = dist.new_group()
+        _FLAG_SYNC["stream"] = torch.cuda.Stream(device=flat.grad.device) if flat.grad.is_cuda else None
+    side = _FLAG_SYNC["stream"]
+    if side is None:
+        flags = host.clone()
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=_FLAG_SYNC["group"])
+        got = flags.tolist()
+    else:
+        with torch.cuda.stream(side):
+            flags = host.to(flat.grad.device, non_blocking=True)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=_FLAG_SYNC["group"])
+            back.copy_(flags, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        done.synchronize()        # the side stream's few operations only
+        got = back.tolist()
+    flat.touched.update(n for n, f in zip(names, got) if f)
 
 
 class BucketedAllReduce(object):
@@ -122,17 +144,24 @@ class BucketedAllReduce(object):
     and the consistency branch was skipped, so the second backbone pass was never back-propagated -- is sent from
     finish() as its own collective instead of being merged into a neighbour (ranks that did fire it sent exactly that)."""
 
-    # a hook on the output of stage K fires when everything AFTER stage K is done
-    AFTER = {"layer4": "backbone.fpn.", "layer3": "backbone.body.layer4.", "layer2": "backbone.body.layer3.",
+    # a hook on the output of stage K fires when everything AFTER stage K is done; "heads" = hooks on the pyramid levels (round 5):
+    # the RPN / box / mask heads, adaptors and relation modules -- half of the 82 MB that used to leave with the FPN -- go out when
+    # the heads' backward ends, ~10 ms before the FPN's (profiles/r04_bench_rccl_world1.json: that piece was issued 3.5 ms before
+    # the end of a 36 ms backward)
+    AFTER = {"heads": None, "layer4": "backbone.fpn.", "layer3": "backbone.body.layer4.", "layer2": "backbone.body.layer3.",
              "layer1": "backbone.body.layer2."}
-    ORDER = ("layer4", "layer3", "layer2", "layer1")  # firing order of the hooks in a backward pass
+    ORDER = ("heads", "layer4", "layer3", "layer2", "layer1")  # firing order of the hooks in a backward pass
 
     def __init__(self, flat, body):
         self.flat, self.body = flat, body
         names = [n for n, _ in flat._named if n in flat.index and flat.index[n][0] < flat.n_weights]
         cuts = {}
         for stage, prefix in self.AFTER.items():
-            first = next((n for n in names if n.startswith(prefix)), None)
+            if prefix is None:   # everything behind the backbone, in parameter order
+                last_bb = max((i for i, n in enumerate(names) if n.startswith("backbone.")), default=-1)
+                first = names[last_bb + 1] if 0 <= last_bb < len(names) - 1 else None
+            else:
+                first = next((n for n in names if n.startswith(prefix)), None)
             if first is not None:
                 cuts[stage] = flat.index[first][0]
         # piece that becomes final when `stage` fires: [cut(stage), cut(previous firing stage) or n_weights)
@@ -174,6 +203,10 @@ class BucketedAllReduce(object):
         g = self.flat.grad
         F_.release_parked(g.data_ptr() + 4 * lo, g.data_ptr() + 4 * hi)   # supervised-pass jobs still waiting for a partner that will not come
         side = F_.side_stream_for_exchange(g.device) if g.is_cuda else None
+        if getattr(self, "tracing", False):   # when backward reached this hook, on the STEP stream's clock (the mark used
+            e = torch.cuda.Event(enable_timing=True)   # to be recorded inside the side-stream context and measured that queue)
+            e.record()
+            self._marks.append([lo, hi, e, None, time.perf_counter()])
         if side is None:
             F_.join_wgrads()   # no side stream in this configuration: the piece is final on the step stream
             self._issue(lo, hi)
@@ -182,10 +215,6 @@ class BucketedAllReduce(object):
             self._issue(lo, hi)
 
     def _issue(self, lo, hi):
-        if getattr(self, "tracing", False):
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            self._marks.append([lo, hi, e, None, time.perf_counter()])
         self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def _event(self, stage, what):
@@ -233,6 +262,8 @@ class BucketedAllReduce(object):
             torch.cuda.synchronize()
             self.last_trace = {
                 "backward_end_ms": round(self._t0.elapsed_time(bw_end), 3), "pieces_sent_before_backward_end": n_early,
+                # what the exchange costs the step: from the end of backward to the arrival of the last piece (0 = fully hidden)
+                "exposed_comm_ms": round(max([self._t0.elapsed_time(m[3]) for m in self._marks] + [0.0]) - self._t0.elapsed_time(bw_end), 3),
                 "pieces": [{"range": [lo, hi], "mbytes": round((hi - lo) * 4 / 1e6, 2), "issued_ms": round(self._t0.elapsed_time(a), 3),
                             "arrived_ms": round(self._t0.elapsed_time(b), 3)} for lo, hi, a, b, _ in self._marks]}
         self.reset()
@@ -425,8 +456,10 @@ class MTtrainer(object):
         join_wgrads()   # the weight gradients of this step (side stream) before anything reads the flat gradient
         if bucketed is None:
             allreduce_gradients(self.flat_s)
-        if use_mt:   # (without the consistency branch every rank back-propagates through the same parameters)
-            sync_touched(self.flat_s)
+        sync_touched(self.flat_s)   # every step: a degenerate route on one rank touches another set than its peers'
+        # the previous step's EMA reads the student on the teacher's stream: SGD must not overwrite it first.  On a mean-teacher step
+        # forward_unlabel's join has ordered the two already; before START_MT (and with no unlabeled batch) nothing else does
+        self.sync_teacher()
         self.optimizer.step()
         if self.lambda_value > 0 and iteration > (self.start_mt - 10):
             self.update_teacher(iteration - (self.start_mt - 10))
@@ -530,9 +563,11 @@ class MTtrainer(object):
         try:
             if job is not None:
                 job["thread"].join()
-                # everything the teacher produced is read on this stream from here on; the side stream is not touched again
-                # before the next step re-synchronises it (see _start_teacher), which also orders the re-use of its memory
+                # everything the teacher produced is read on this stream from here on.  (The side stream IS used again in this
+                # step: update_teacher queues the EMA and the teacher's plane re-pack there -- behind the step stream -- and the
+                # next step's SGD waits for them through sync_teacher.)  This join also covers an EMA still pending from the last step
                 torch.cuda.current_stream().wait_stream(self.t_stream)
+                self._teacher_pending = False
                 if "error" in job:
                     raise job["error"]
                 teacher_results = job["result"]

@@ -219,6 +219,8 @@ def forward_pair(backbone, xa, xb):
             args += [m.weight, m.bias]
         pre = ([fused.batch_slice(t, lo, hi) for t in inner_cat], [fused.batch_slice(t, lo, hi) for t in outs_cat])
         pyr = list(fused.FPNFn.apply(*args, getattr(fpn, "out_planes", True), pre))
+        for p_ in pyr:
+            _stage_hook(body, "heads", p_)   # fires when the heads' backward has delivered this level's gradient
         for p_, o_ in zip(pyr, pre[1]):  # the node's outputs are new tensor objects: the planes / statistics of the slices go along
             pl = H.planes_of(o_)
             if pl is not None:
@@ -258,6 +260,10 @@ class FPN(nn.Module):
         # out_planes: the pyramid levels go to the RPN head's 3x3 convolution as they are (False for the teacher, whose
         # RPN head sees one view's slice of the batched pyramid)
         res = list(fused.FPNFn.apply(*args, getattr(self, "out_planes", True)))
+        body = self.__dict__.get("_body_ref")   # (a plain reference, not a registered sub-module: build_resnet_fpn_backbone)
+        if body is not None:
+            for t in res:
+                _stage_hook(body, "heads", t)   # fires when the heads' backward has delivered this level's gradient
         if self.top_blocks is not None:
             res.extend(self.top_blocks(res[-1]))
         return tuple(res)
@@ -279,6 +285,7 @@ def build_resnet_fpn_backbone(cfg):
     body = ResNet(cfg)
     c2 = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
     fpn = FPN([c2, c2 * 2, c2 * 4, c2 * 8], cfg.MODEL.BACKBONE.OUT_CHANNELS, LastLevelMaxPool())
+    fpn.__dict__["_body_ref"] = body   # where the training engine hangs its `grad_ready` callback (not a sub-module of the FPN)
     return nn.Sequential(OrderedDict([("body", body), ("fpn", fpn)]))
 
 

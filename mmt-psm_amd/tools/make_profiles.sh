@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates profiles/ evidence on the GPU box (writes to gpurun_out/prof; summarize_profiles.py copies what is judged into
-# profiles/r04_*): un-profiled default bench line; per arithmetic (f16x2 = default two-term fp16 split, bf16x3 = MMT_F16X2=0,
+# profiles/r05_*): un-profiled default bench line; per arithmetic (f16x2 = default two-term fp16 split, bf16x3 = MMT_F16X2=0,
 # mode0 = fp32-input MFMA) rocprofv3 kernel stats of the same command; two separate PMC passes (FETCH_SIZE / WRITE_SIZE)
 # reduced per kernel for the default and mode 0; one SQ pass (MFMA busy); the per-shape conv table; other configurations.
 set -u

@@ -1,12 +1,13 @@
-"""gpurun_out/prof/* (make_profiles.sh) -> profiles/r04_* + profiles/pmc_traffic.json + profiles/r04_summary.md.
+"""gpurun_out/prof/* (make_profiles.sh) -> profiles/r05_* + profiles/pmc_traffic.json + profiles/r05_summary.md.
 The number of steps a kernel trace holds is COUNTED (one `ema_kernel` launch per step), not assumed."""
-import csv, json, os, shutil
+import csv, json, os, shutil, sys
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles"), "r04_"
+sys.path.insert(0, ROOT)
+SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles"), "r05_"
 ARITH = {"f16x2": "default: two-term fp16 split, 3 products per multiply (peak 2500 / 3 = 833 TFLOP/s)",
          "bf16x3": "`MMT_F16X2=0` / `--bf16x3`: three-term bf16 split, 6 products (round-2 default, now the per-tensor fall-back; peak 417)",
          "mode0": "`MMT_CONV_PRECISION=0`: fp32-input MFMA (peak 157.3)"}
-KERN = {"f16x2": {"fwd4": "conv3x3_strip_kernel<", "fwd1": "conv_fwd_glds_kernel<128, 128, 4, 1, 2, 3, true>"},
+KERN = {"f16x2": {"fwd4": "conv3x3_strip_kernel<", "fwd1": "conv_fwd_glds_kernel<128, 128, 4, 1, 2, 3, true>", "fwd5": "conv_pg_kernel<"},
         "bf16x3": {"fwd4": "conv3x3_strip_kernel<", "fwd1": "conv_fwd_glds_kernel<128, 128, 4, 1, 3, 3, false>"},
         "mode0": {"fwd1": "conv_fwd_kernel<128, 128, 2, 2>"}}
 MODE_OF = {"f16x2": "3", "bf16x3": "3_bf16x3", "mode0": "0"}
@@ -20,17 +21,17 @@ def is_library(n):
     return n.startswith("void at::") or n.startswith("at::") or "rocprim" in n or "rocclr" in n or "hipcub" in n
 
 
-out = ["# Round 4 -- profiles of `python bench.py` on 1 x MI355X (state at the end of the round)", "",
+out = ["# Round 5 -- profiles of `python bench.py` on 1 x MI355X (state at the end of the round)", "",
        "Produced by `mmt-psm_amd/tools/make_profiles.sh` (GPU box) + `mmt-psm_amd/tools/summarize_profiles.py`. Files: "
-       "`r04_bench_default.json` (un-profiled `python bench.py`: 10 warm-up + 50 timed steps, median next to the mean, event brackets "
-       "in a separate 10-step leg, CPU baseline 1 + 3 steps); per arithmetic `r04_kernel_stats_<tag>.csv` (rocprofv3 --kernel-trace "
-       "--stats of `bench.py --steps 5 --warmup 2 --profile-steps 5 --no-cpu-baseline`), `r04_bench_under_rocprof_<tag>.json` (the line "
-       "that run printed), `r04_pmc_{FETCH,WRITE}_SIZE_by_kernel_<tag>.csv` (two separate --pmc passes, --kernel-trace only); "
-       "`r04_pmc_mfma_busy.txt` (one SQ pass, single-stream); `pmc_traffic.json` = what bench.py reports as roofline.traffic. "
+       "`r05_bench_default.json` (un-profiled `python bench.py`: 10 warm-up + 50 timed steps, median next to the mean, event brackets "
+       "in a separate 10-step leg, CPU baseline 1 + 3 steps); per arithmetic `r05_kernel_stats_<tag>.csv` (rocprofv3 --kernel-trace "
+       "--stats of `bench.py --steps 5 --warmup 2 --profile-steps 5 --no-cpu-baseline`), `r05_bench_under_rocprof_<tag>.json` (the line "
+       "that run printed), `r05_pmc_{FETCH,WRITE}_SIZE_by_kernel_<tag>.csv` (two separate --pmc passes, --kernel-trace only); "
+       "`r05_pmc_mfma_busy.txt` (one SQ pass, single-stream); `pmc_traffic.json` = what bench.py reports as roofline.traffic. "
        "Tags: " + "; ".join("**%s** = %s" % kv for kv in ARITH.items()) + ".", ""]
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) of `python bench.py "
-                     "--steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline`; per-kernel tables profiles/r04_pmc_*_by_kernel_*.csv",
-           "fetch_correction": 2.0,
+                     "--steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline`; per-kernel tables profiles/r05_pmc_*_by_kernel_*.csv",
+           "fetch_correction": 2.0, "csrc_sha1": __import__("importlib").import_module("bench").csrc_sha1(),
            "note": "FETCH_SIZE on gfx950 reports 1/2 of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section): "
                    "doubled. WRITE_SIZE uncalibrated, taken as is. Infinity-Cache hits are counted, so this is fabric traffic, an "
                    "upper bound on HBM traffic.  by_mode['3'] = the default arithmetic of mode 3 (two-term fp16 split).", "by_mode": {}}
@@ -143,6 +144,6 @@ for f, what in extra:
         out.append(line)
 out.append("")
 out += ["## MFMA-busy (single-stream SQ pass)", "", "```"] + [l.rstrip() for l in open(os.path.join(SRC, "pmc_mfma_busy.txt")) if "mfma_busy_fraction" in l or l.startswith("#")] + ["```", ""]
-hist = open(os.path.join(DST, "r04_history.md")).read() if os.path.exists(os.path.join(DST, "r04_history.md")) else ""
-open(os.path.join(DST, "r04_summary.md"), "w").write("\n".join(out) + "\n" + hist)
+hist = open(os.path.join(DST, "r05_history.md")).read() if os.path.exists(os.path.join(DST, "r05_history.md")) else ""
+open(os.path.join(DST, "r05_summary.md"), "w").write("\n".join(out) + "\n" + hist)
 print("\n".join(out)[:6000])

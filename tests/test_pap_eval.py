@@ -61,6 +61,31 @@ def test_iou_int_uni_matches_reference(fixture, data):
     assert mu.iouIntUni([], [x["segmentation"] for x in g], []) == []
 
 
+def test_iouintuni_cells_of_disjoint_boxes_are_zero_by_contract():
+    """D14: for a pair whose bounding boxes do not overlap the reference's C code writes iou = 0 and leaves
+    the intersection / union cells of its malloc'ed arrays UNWRITTEN (/root/reference/pycoco/maskApi.c:238-259), yet
+    caclulateMetrics divides the whole arrays (data/datasets/evaluation/pap/pap_eval.py:425-477): its per-window DSC / TPRp / FNRo /
+    FDR depend on what the allocator returned.  The fixture pins the realisation of a fresh process -- zero pages -- and this
+    build's iouIntUni returns exactly that BY CONTRACT: intersection 0 and union 0 wherever the boxes are disjoint, whatever ran
+    before in the process (fresh arrays, poisoned heap, second call)."""
+    from maskrcnn_benchmark.data.datasets.evaluation.pap import mask_rle as mu
+    a = np.zeros((40, 40), np.uint8); a[2:8, 3:9] = 1          # three masks with pairwise disjoint boxes ...
+    b = np.zeros((40, 40), np.uint8); b[20:30, 22:31] = 1
+    c = np.zeros((40, 40), np.uint8); c[33:39, 1:5] = 1
+    o = np.zeros((40, 40), np.uint8); o[5:25, 5:25] = 1        # ... and one that overlaps a and b
+    e = np.zeros((40, 40), np.uint8)                           # an empty mask: box [0, 0, 0, 0]
+    R = [mu.encode(np.asfortranarray(m)) for m in (a, b, c, o, e)]
+    junk = [np.full((64, 64), 1e300) for _ in range(8)]        # freed float64 blocks of the result arrays' size class
+    del junk
+    for _ in range(2):
+        iou, inter, uni = mu.iouIntUni(R, R[:4], [0, 0, 0, 0])
+        disjoint = np.array([[0, 1, 1, 0], [1, 0, 1, 0], [1, 1, 0, 1], [0, 0, 1, 0], [1, 1, 1, 1]], bool)
+        assert (iou[disjoint] == 0).all() and (inter[disjoint] == 0).all() and (uni[disjoint] == 0).all()
+        assert inter[0, 0] == 36 and uni[0, 0] == 36 and iou[0, 0] == 1.0
+        assert inter[3, 0] == 12 and uni[3, 0] == 36 + 400 - 12 and inter[3, 1] == 15
+        assert inter[1, 3] == 15 and uni[1, 3] == 90 + 400 - 15
+
+
 def test_papeval_statistics_match_reference(fixture, data):
     from maskrcnn_benchmark.data.datasets.evaluation.pap.pap_eval import evaluate_predictions_on_pap, PapResults
     gts, dts = data

@@ -367,8 +367,8 @@ def test_full_step_losses_match_oracle_at_bench_size(synth, state_shapes, weight
     trainer at 1000 x 1000 (padded to 1024), 12 instances per labeled crop, 1 labeled + 1 unlabeled crop (what `cpu_baseline`
     runs), one whole mean-teacher iteration of the default schedule against oracle.model.Trainer.step (reference
     engine/MTtrainer.py:165-229 through the pinned restatement).  Only the random draws are replayed; whatever Replay.align
-    moved must be a near-tie of the ORACLE's scores, as in test_full_step_matches_oracle.  The seven weighted losses to 2e-4
-    relative, in the default arithmetic and on the fp32-input MFMA."""
+    moved must be a near-tie of the ORACLE's scores, as in test_full_step_matches_oracle.  The seven weighted losses to 1e-4
+    relative -- the north star's own tolerance (measured: <= 3e-6) --, in the default arithmetic and on the fp32-input MFMA."""
     from maskrcnn_benchmark import _hip
     from maskrcnn_benchmark.utils.replay import Replay
     bench = _bench()
@@ -413,30 +413,31 @@ def test_full_step_losses_match_oracle_at_bench_size(synth, state_shapes, weight
     err = {k: abs(float(losses[k]) - float(v)) / max(abs(float(v)), 1e-12) for k, v in ref_losses.items()}
     print("full-size loss parity (mode %d): %s; rows re-aligned: %d" % (mode, {k: "%.2e" % e for k, e in err.items()}, moved))
     for k, e in err.items():
-        assert e < 2e-4, (k, float(losses[k]), float(ref_losses[k]), e)
+        assert e < 1e-4, (k, float(losses[k]), float(ref_losses[k]), e)
 
 
-@pytest.mark.parametrize("mode", [0, 3], ids=["fp32-mfma", "default-f16x2-split"])
-def test_supervised_step_losses_match_oracle_at_bench_size(synth, state_shapes, weights, mode):
-    """BASELINE configs[1] ("supervised-only on 1 x MI355X, fp32 -- validate conv / ROIAlign / NMS HIP kernels vs CPU") at the
-    bench's size: bench.build(supervised=True) with 2 labeled 1000 x 1000 crops (12 instances each), one supervised iteration
-    (MT.LAMBDA 0: no teacher, no EMA) against oracle.model.Trainer.step -- the five losses to 2e-4 relative with only the
-    sampler draws replayed, the proposal list compared through Replay.align."""
+@pytest.mark.parametrize("n_lab,mode", [(2, 0), (2, 3), (4, 3)], ids=["bs2-fp32-mfma", "bs2-default-f16x2-split", "bs4-default-f16x2-split"])
+def test_supervised_step_losses_match_oracle_at_bench_size(synth, state_shapes, weights, n_lab, mode):
+    """BASELINE configs[1] ("supervised-only on 1 x MI355X, bs = 4, fp32 -- validate conv / ROIAlign / NMS HIP kernels vs CPU") at the
+    bench's size: bench.build(supervised=True) with 2 labeled 1000 x 1000 crops (12 instances each; a size the oracle walks in ~12 s)
+    and with the LITERAL configuration, 4 crops = what `bench.py --supervised` times, one supervised iteration
+    (MT.LAMBDA 0: no teacher, no EMA) against oracle.model.Trainer.step -- the five losses to 1e-4 relative (the north star's
+    tolerance; measured <= 3e-6) with only the sampler draws replayed, the proposal list compared through Replay.align."""
     from maskrcnn_benchmark import _hip
     from maskrcnn_benchmark.utils.replay import Replay
     bench = _bench()
     om, ot = _oracle_trainer(synth, state_shapes, weights)
     ot.cfg.mt_lambda = 0.0
-    imgs, tgs = synth.make_labeled(2, 1000, 12, seed=1234)
+    imgs, tgs = synth.make_labeled(n_lab, 1000, 12, seed=1234)
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    key = "sup_ref"
+    key = "sup_ref%d" % n_lab
     if key not in _FULLSIZE_ORACLE:
         _FULLSIZE_ORACLE[key] = ot.step(1400, imgs, _oracle_targets(om, tgs), None, seeds=(99, 100, 101))
     ref_losses, (ta, _, _) = _FULLSIZE_ORACLE[key]
     prev = _hip.get_conv_precision()
     _hip.set_conv_precision(mode)
     try:
-        cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, n_lab=2, supervised=True)
+        cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, n_lab=n_lab, supervised=True)
         _load(trainer, weights)
         before_t = trainer.flat_t.data.clone()
         stu = {"rpn_sampler": ta["rpn_sampler"], "roi_sampler": ta["roi_sampler"], "rpn_proposals": ta["rpn_proposals"],
@@ -461,9 +462,9 @@ def test_supervised_step_losses_match_oracle_at_bench_size(synth, state_shapes, 
         assert abs(float(sc[i]) - float(sc[j])) <= 2e-5 * max(abs(float(sc[i])), 1e-3), (n, i, j)
     assert len(moved) <= 64
     err = {k: abs(float(losses[k]) - float(v)) / max(abs(float(v)), 1e-12) for k, v in ref_losses.items()}
-    print("full-size supervised loss parity (mode %d): %s; rows re-aligned: %d" % (mode, {k: "%.2e" % e for k, e in err.items()}, len(moved)))
+    print("full-size supervised loss parity (bs %d, mode %d): %s; rows re-aligned: %d" % (n_lab, mode, {k: "%.2e" % e for k, e in err.items()}, len(moved)))
     for k, e in err.items():
-        assert e < 2e-4, (k, float(losses[k]), float(ref_losses[k]), e)
+        assert e < 1e-4, (k, float(losses[k]), float(ref_losses[k]), e)
 
 
 def test_device_sampler_properties():
