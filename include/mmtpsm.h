@@ -378,6 +378,18 @@ int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a /*[host]*/, const float* s_x 
  * registers after its scaling by the power of two of x_amax (device: max |x|, e.g. recorded through y_amax) */
 int mmt_conv_forward_f16x2(const mmt_conv_args* a /*[host]*/, const float* x_amax /*device*/, const float* s_w /*device*/, void* stream);
 int mmt_get_conv_precision(void);
+/* Round 5: the ResNet stem as one launch (csrc/conv_stem.hip) -- conv 7x7 / stride 2 / pad 3 (3 -> 64) + FrozenBatchNorm + ReLU + max
+ * pool 3x3 / stride 2 / pad 1: reference modeling/backbone/resnet.py:288-293 (StemWithFixedBatchNorm.forward) with
+ * layers/batch_norm.py:19-24 folded into scale / shift.  x [N][3][H][W] fp32 NCHW (H, W multiples of 4), y [N][H/4][W/4][64] fp32
+ * NHWC.  w_s2d: the filter as the 4x4 / stride-1 filter over the 2x2 space-to-depth image, [64][4][4][16] fp32 (channel =
+ * (row parity, column parity, RGB + zero)); w_planes / s_w: its packed fp16 planes and their device scale (mmt_pack_weight_f16);
+ * x_slot: 33-float statistics slot of x (mmt_amax_stats: [0] = max |x| gives the power-of-two scale of the fp16 split on the
+ * device, the sums the range guard -- an image whose crest factor defeats fp16 takes exact fp32 products); y_slot (optional):
+ * statistics of y are accumulated there like mmt_conv_args.y_amax with y_amax_stats.  Mode 3 (two-term fp16 split) only; results
+ * are bit-identical to mmt_conv_forward_f16x2 on the space-to-depth image followed by mmt_maxpool3x3s2. */
+int mmt_stem_fused(const float* x, int N, int H, int W, const float* w_s2d, const void* w_planes, long w_plane_stride,
+                   const float* s_w /*device*/, const float* scale, const float* shift, const float* x_slot /*device*/, float* y,
+                   float* y_slot /*device, zeroed, or NULL*/, void* stream);
 /* Round 5: the plane-fed implicit GEMM (csrc/conv_pgemm.hip) -- the same arithmetic (two-term fp16 split, 3 products, mode 3) for
  * any (KH, KW, stride, pad) with Cin % 16 == 0, Cout > 32, res_mode <= 1, out_stride == 1, no `mul`, fp32 tensors: x_planes = the
  * two fp16 planes of x * s_x with x's NHWC indexing (mmt_split_planes_f16), w_planes = the packed fp16 planes of w * s_w

@@ -135,6 +135,8 @@ _SIGS = {
     "mmt_conv_forward_pg": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_int, c_int, c_void_p],
     "mmt_conv_pg_plan": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p],
     "mmt_conv_pg_wanted": [ctypes.POINTER(ConvArgs)],
+    "mmt_stem_fused": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                       c_void_p, c_void_p],
     "mmt_maxpool3x3s2_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mmt_mask_bce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_mgd_level_forward": [c_void_p, ctypes.POINTER(MgdTeachers), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
@@ -1365,6 +1367,27 @@ def conv_forward_pg(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, r
     a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
     _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), int(tile_rows), int(ksplit), _stream()),
            "mmt_conv_forward_pg")
+    y._mmt_amax = (slot, y._version)
+    return y
+
+
+def stem_fused(x, w_s2d, scale, shift):
+    """conv 7x7 / 2 + FrozenBN + ReLU + max pool 3x3 / 2 of the ResNet stem in one launch (include/mmtpsm.h: mmt_stem_fused).
+    x (N, 3, H, W) fp32 NCHW-contiguous with H, W multiples of 4; w_s2d the (64, 16, 4, 4) channels_last space-to-depth filter
+    (modeling/backbone/backbone.py: StemWithFixedBatchNorm._s2d_weight).  -> (N, 64, H / 4, W / 4) channels_last, statistics attached."""
+    _dev(x)
+    N, C, Hh, W = x.shape
+    if C != 3 or not x.is_contiguous() or x.dtype != torch.float32 or (Hh & 3) or (W & 3) or tuple(w_s2d.shape) != (64, 16, 4, 4):
+        raise RuntimeError("stem_fused: (N, 3, H, W) fp32 NCHW with H, W % 4 == 0 and the 64 x 16 x 4 x 4 space-to-depth filter")
+    w = nhwc(w_s2d)
+    am = _amax_of(x)
+    if type(am[0]) is not _Slot:
+        raise RuntimeError("stem_fused: the input needs a full statistics slot")
+    wp16, sw = f16_weight_planes(w)
+    y = empty_nhwc(N, 64, Hh // 4, W // 4, x.device)
+    slot = _amax_slot(x.device)
+    _check(lib().mmt_stem_fused(x.data_ptr(), N, Hh, W, w.data_ptr(), wp16.data_ptr(), wp16.stride(0), sw.data_ptr(), _p(scale), _p(shift),
+                                am[0].ptr, y.data_ptr(), slot.ptr, _stream()), "mmt_stem_fused")
     y._mmt_amax = (slot, y._version)
     return y
 

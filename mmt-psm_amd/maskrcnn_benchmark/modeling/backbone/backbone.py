@@ -14,6 +14,10 @@ from maskrcnn_benchmark import _hip as H
 from maskrcnn_benchmark.layers import Conv2d, FrozenBatchNorm2d, fused
 
 
+import os as _os
+_STEM_FUSED = [_os.environ.get("MMT_STEM_FUSED", "1") != "0"]   # (A/B timing, parity tests: [0] = False -> the three-launch stem)
+
+
 class StemWithFixedBatchNorm(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -40,6 +44,12 @@ class StemWithFixedBatchNorm(nn.Module):
     def forward(self, x):
         n, c, h, w = x.shape
         s, b = self.bn1.folded()
+        if (h % 4 == 0 and w % 4 == 0 and c == 3 and H.F16X2 and H.get_conv_precision() == 3 and not H.bf16_storage()
+                and x.dtype == torch.float32 and x.is_contiguous() and self.conv1.out_channels == 64 and _STEM_FUSED[0]
+                and H._site_ok(("stem", self.conv1.weight.data_ptr()), x)):
+            # round 5: the whole stem -- convolution, FrozenBN, ReLU, max pool -- as one launch (csrc/conv_stem.hip): the 537 MB of
+            # un-pooled output (8 x 1024^2) never exist; bit-identical to the three launches below
+            return H.stem_fused(x, self._s2d_weight(), s, b)
         if h % 2 == 0 and w % 2 == 0:
             # 16-channel space-to-depth image -> the DMA-fed split-bf16 kernel instead of the 4-channel fp32 one:
             # out(ho) = sum_kh x(2 ho - 3 + kh) w(kh) = sum_{a,b} z(ho - 2 + a, b) w8(2 a + b),  z(i, b) = x(2 i + b)
