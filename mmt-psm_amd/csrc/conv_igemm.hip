@@ -3569,6 +3569,7 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
   if (variant == 0) return MMT_EINVAL;
   p.f16_sx = x_amax; p.f16_sw = s_w; p.f16_ax = 1;
   hipStream_t s = (hipStream_t)stream;
+  if (c64_shape(p)) return launch_c64(p, s);   // layer1's 3x3, 64 -> 64 channels: the patch kernel (conv_stem.hip, round 5)
   if (rows_shape(p, true)) {   // 1x1 layers with K = 64 / 128 / 256: rows resident in registers as fp16 fragments
     if (p.mask) {
       if (p.Cin == 64) return launch_rows<4, 2, true, true>(p, s);

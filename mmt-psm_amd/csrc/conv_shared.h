@@ -49,6 +49,9 @@ struct SplitWs { float* ws; unsigned* tickets; };
 constexpr size_t SPLITK_WS_BYTES = (size_t)1024 * 128 * 128 * 4;  // 1024 partial tiles of 128 x 128 (64 MiB)
 constexpr int SPLITK_TICKETS = 4096;
 SplitWs split_workspace(hipStream_t s);
+// layer1's 3x3 (64 -> 64 channels) on the patch kernel of conv_stem.hip: is this call one, and its launch
+bool c64_shape(const ConvP& p);
+int launch_c64(const ConvP& p, hipStream_t s);
 }  // namespace mmtconv
 
 namespace {

@@ -265,7 +265,181 @@ __global__ __launch_bounds__(512) void stem_fused_kernel(const StemP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------ 3x3, 64 -> 64 channels (layer1's conv2)
+// The 3x3 convolutions of layer1 (backbone/resnet.py:254-274 with 64 bottleneck channels, frozen: forward only, the teacher's
+// 8 x 256^2 and the student's 4 x 256^2 maps) ran on the tiled kernel's 128 x 64 tile at 3.5 x their HBM time (188 us for 268 MB):
+// K = 576 is 36 steps, each re-fetching its rows' pixels through the L2 -> LDS path nine times over, behind a per-tile prologue.
+// Same recipe as the stem: a block owns 8 x 16 output pixels, gathers their 10 x 18 input patch ONCE (fp32, 16-byte loads,
+// coalesced), scales and splits it into the two fp16 terms on the way into LDS ([16-channel slab][pixel][32 B] per plane), and the
+// nine taps read their fragments from the patch at pixel offset 18 kh + kw.  The weight planes stream through two 16 KB buffers,
+// one tap (four steps) ahead.  4 waves (2 output rows x 16 columns x 64 channels each), 80 KB of LDS: two blocks per CU.
+// Same products, same order as the tiled kernel: bit-identical (tests/test_stem_gpu.py).
+constexpr int C64_PW = 18, C64_PIX = 180, C64_SLAB = 192 * 32, C64_PL = 4 * C64_SLAB, C64_BOFF = 2 * C64_PL;
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const sm = (char*)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (p.Wo + 15) >> 4, tiles_y = (p.Ho + 7) >> 3;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int img = bid / tiles_y;
+  const int oy0 = ty * 8, ox0 = tx * 16;
+  const F16Guard guard = f16_guard_load(p.guard_x);
+  const float sx = f16_scale_of_fwd(*p.f16_sx);
+  if (f16_guard_bad(guard)) {   // (uniform over the grid) exact fp32 products; pixels of a ragged tile that wrap are written twice
+    conv_slow_tile((img * p.Ho + oy0) * p.Wo + ox0, 16, p.Wo, 128, 0, 64, nullptr, false, tid, 256, blockIdx.x);
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpl, 0, 0x7ffffff0, 0x00020000);
+  auto copy_chunk = [&](int t, int buf) {   // the weight planes of tap t: 4 steps x 2 planes x 2 blocks of 1 KiB, four per wave
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int item = wave * 4 + i, st = item >> 2, q = (item >> 1) & 1, blk = item & 1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(sm + C64_BOFF + buf * 16384 + ((st * 2 + q) * 2 + blk) * 1024), 16,
+                                               (int)((q * p.wpl_stride + (long)((t * 4 + st) * 2 + blk) * 512 + lane * 8) * 2), 0, 0, 0);
+    }
+  };
+  copy_chunk(0, 0);
+  // ---- the patch: item = (pixel, 4-channel quad): one 16-byte load, two 8-byte LDS stores (h, l)
+  {
+    f32x4 v[12];
+#pragma unroll
+    for (int rnd = 0; rnd < 12; rnd++) {
+      const int item = tid + 256 * rnd;
+      const int pix = item >> 4, cq = item & 15;
+      const int pr = pix / C64_PW, pc = pix - pr * C64_PW;
+      const int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
+      const bool ok = pix < C64_PIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      v[rnd] = ok ? ldg4(p.x + (((long)img * p.H + iy) * p.W + ix) * 64 + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int rnd = 0; rnd < 12; rnd++) {
+      const int item = tid + 256 * rnd;
+      const int pix = item >> 4, cq = item & 15;
+      if (pix < C64_PIX) {
+        uint2 o[2];
+        split4h(v[rnd], sx, o);
+        char* const dst = sm + (cq >> 2) * C64_SLAB + pix * 32 + (((((cq & 3) >> 1) ^ (pix >> 3)) & 1) << 4) + (cq & 1) * 8;
+        *(uint2*)dst = o[0];
+        *(uint2*)(dst + C64_PL) = o[1];
+      }
+    }
+  }
+  // ---- main loop.  Wave w: output rows 2 w, 2 w + 1 of the tile; MFMA row i = (i / 16, i % 16); 2 column tiles of 32 channels
+  const int lr = lane & 31, kh2 = lane >> 5;
+  const int prow = 2 * wave + (lr >> 4), pcol = lr & 15;
+  const int boff = C64_BOFF + lr * 32 + (((kh2 ^ (lr >> 3)) & 1) << 4);
+  f32x16 acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+#pragma unroll 1
+  for (int t = 0; t < 9; t++) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tap t's planes (and, first time, the patch) are in LDS
+    __syncthreads();
+    if (t + 1 < 9) copy_chunk(t + 1, (t + 1) & 1);                // into the buffer everybody finished reading before this barrier
+    const int kh = t / 3, kw = t - kh * 3;
+    const int pidx = (prow + kh) * C64_PW + pcol + kw;
+    const char* const pa = sm + pidx * 32 + (((kh2 ^ (pidx >> 3)) & 1) << 4);
+    const char* const pb = sm + boff + (t & 1) * 16384;
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+      f16x8 fa[2], fb[2][2];
+      fa[0] = *(const f16x8*)(pa + st * C64_SLAB);
+      fa[1] = *(const f16x8*)(pa + st * C64_SLAB + C64_PL);
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) fb[q][b] = *(const f16x8*)(pb + ((st * 2 + q) * 2 + b) * 1024);
+#pragma unroll
+      for (int pr = 0; pr < 3; pr++) {   // products (h, l), (l, h), (h, h): the tiled kernel's order
+        const int qa = pr == 1 ? 1 : 0, qb = pr == 0 ? 1 : 0;
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[qa], fb[qb][b], acc[b], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue from the registers: acc[b][r] = MFMA row i = 8 (r / 4) + r % 4 + 4 (lane / 32), channel 32 b + lane % 32
+  const int col_l = lane & 31, rq = lane >> 5;
+  const float inv = 1.f / (sx * *p.f16_sw);
+  const int ybytes = (int)((long)p.M * 64 * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
+  float amx = 0.f, asum = 0.f, acnt = 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    const float sc = (p.scale ? p.scale[b * 32 + col_l] : 1.f) * inv, sh = p.shift ? p.shift[b * 32 + col_l] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int i = 8 * (r >> 2) + (r & 3) + 4 * rq;
+      const int oy = oy0 + 2 * wave + (i >> 4), ox = ox0 + (i & 15);
+      float v = acc[b][r] * sc + sh;
+      if (p.relu) v = fmaxf(v, 0.f);
+      const bool ok = oy < p.Ho && ox < p.Wo;
+      const float av = ok ? fabsf(v) : 0.f;
+      amx = fmaxf(amx, av);
+      asum += av;
+      acnt += ok ? 1.f : 0.f;
+      const unsigned off = ok ? (unsigned)(((img * p.Ho + oy) * p.Wo + ox) * 64 + b * 32 + col_l) * 4u : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)off, 0, 0);
+    }
+  }
+  if (p.amax_out) {
+    __syncthreads();
+    float* const red = lds;
+    const bool stats = p.amax_stats && (blockIdx.x & 63) == 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+    if (stats) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { asum += __shfl_xor(asum, o, 64); acnt += __shfl_xor(acnt, o, 64); }
+    }
+    if (lane == 0) { red[wave] = amx; red[16 + wave] = asum; red[32 + wave] = acnt; }
+    __syncthreads();
+    if (tid == 0) {
+      float m = red[0], sm_ = red[16], cn = red[32];
+      for (int i = 1; i < 4; i++) { m = fmaxf(m, red[i]); sm_ += red[16 + i]; cn += red[32 + i]; }
+      const unsigned bits = __builtin_bit_cast(unsigned, m);
+      if (m > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, bits);
+      if (stats && cn > 0.f) {
+        const int k = (blockIdx.x >> 6) & 15;
+        atomicAdd((float*)p.amax_out + 1 + k, sm_);
+        atomicAdd((float*)p.amax_out + 17 + k, cn);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+namespace mmtconv {
+// 3x3 / stride 1 / pad 1 with 64 input and 64 output channels on fp32 tensors, plain affine (+ ReLU) epilogue: layer1's conv2
+bool c64_shape(const ConvP& p) {
+  const char* e = getenv("MMT_C64");   // read per call (A/B timing, parity tests)
+  if (e && atoi(e) == 0) return false;
+  return p.Cin == 64 && p.Cout == 64 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.H && p.Wo == p.W && !p.io &&
+         !p.ypl && !p.mul && !p.mask && p.res_mode == 0 && p.out_stride == 1 && p.wpl && p.w && p.f16_sx && p.f16_ax && p.f16_sw &&
+         (long)p.M * 64 * 4 < (1L << 31);
+}
+
+int launch_c64(const ConvP& p, hipStream_t s) {
+  constexpr int LDS = C64_BOFF + 2 * 16384;
+  static bool done = false;
+  if (!done) {
+    const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  const int tiles = p.N * ((p.Ho + 7) >> 3) * ((p.Wo + 15) >> 4);
+  hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(tiles), dim3(256), LDS, s, p);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace mmtconv
 
 extern "C" int mmt_stem_fused(const float* x, int N, int H, int W, const float* w_s2d, const void* w_planes, long w_plane_stride,
                               const float* s_w, const float* scale, const float* shift, const float* x_slot, float* y, float* y_slot,

@@ -91,3 +91,50 @@ def test_fused_stem_range_guard(stem):
     ref = F.max_pool2d(F.relu(lin * s.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)), 3, 2, 1)
     bound = F.max_pool2d(den, 3, 2, 1)
     assert ((y.double() - ref).abs() / bound).max().item() < 3e-6
+
+
+@pytest.mark.parametrize("shape,opts", [((2, 256, 256), "bn relu"), ((8, 64, 64), "bn relu"), ((2, 40, 40), "bias"), ((3, 24, 56), "relu"),
+                                        ((1, 8, 16), "bn"), ((2, 13, 21), "bn relu")])
+def test_layer1_3x3_patch_kernel_equals_the_tiled_kernel(stem, shape, opts):
+    """conv 3x3, 64 -> 64 channels (+ FrozenBN + ReLU): layer1's conv2 on conv3x3_c64_kernel (csrc/conv_stem.hip) -- one gather of the
+    input patch per 8 x 16 output tile instead of nine trips through the L2 -> LDS path; same products in the same order as the tiled
+    kernel it replaces: bit-identical, ragged maps included"""
+    H, B, m = stem
+    n, h, w_ = shape
+    g = torch.Generator().manual_seed(sum(shape) + len(opts))
+    x = torch.randn(n, 64, h, w_, generator=g).relu().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.06).cuda().contiguous(memory_format=torch.channels_last)
+    sc = (torch.rand(64, generator=g) + 0.5).cuda() if "bn" in opts else None
+    sh = (torch.randn(64, generator=g) * 0.1).cuda() if ("bn" in opts or "bias" in opts) else None
+    y = H.conv_forward(x, w, sc, sh, 1, 1, relu="relu" in opts)
+    os.environ["MMT_C64"] = "0"
+    try:
+        y_old = H.conv_forward(x, w, sc, sh, 1, 1, relu="relu" in opts)
+    finally:
+        os.environ.pop("MMT_C64", None)
+    assert torch.equal(y, y_old), (y - y_old).abs().max().item()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    if sc is not None:
+        ref = ref * sc.double().view(1, -1, 1, 1)
+    if sh is not None:
+        ref = ref + sh.double().view(1, -1, 1, 1)
+    if "relu" in opts:
+        ref = ref.relu()
+    assert (y.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+    torch.cuda.synchronize()
+    slot = y._mmt_amax[0]
+    assert slot.pool.dev[slot.idx, 0].item() == y.abs().max().item()
+
+
+def test_layer1_3x3_patch_kernel_range_guard(stem):
+    H, B, m = stem
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 24, 40, generator=g).relu()
+    x[1, 7, 3, 30] = 4e8
+    x = x.cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.06).cuda().contiguous(memory_format=torch.channels_last)
+    H.set_f16x2(True)
+    y = H.conv_forward(x, w, None, None, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    bound = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+    assert ((y.double() - ref).abs() / bound.clamp_min(1e-30)).max().item() < 3e-6
