@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const ConvP p) {
   }
 }
 
+
 }  // namespace
 
 namespace mmtconv {

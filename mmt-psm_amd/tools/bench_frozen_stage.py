@@ -1,3 +1,5 @@
+"""Device time (graph replay) of the frozen-stage / special-shape kernels of csrc/conv_stem.hip against the launches they replace:
+layer1's 3x3 (MMT_C64), the RPN predictors (MMT_THIN), the fused stem (backbone._STEM_FUSED)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "mmt-psm_amd"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "mmt-psm_amd", "tools"))
