@@ -26,6 +26,7 @@ from maskrcnn_benchmark.utils.miscellaneous import sigmoid_rampdown, sigmoid_ram
 # consistency backward, where the device waits for the teacher and the host; paired, they wait for their partner and all
 # weight-gradient work lands beside the consistency backward, the most contended stretch of the step.  Off.
 _WGRAD_PAIR = os.environ.get("MMT_WGRAD_PAIR", "0") != "0"
+_WGRAD_GATE = os.environ.get("MMT_WGRAD_GATE", "0") != "0"     # ... or as they come, behind the end of the teacher's backbone (round 5: +0.3 .. +0.8 ms, off)
 _WGRAD_DEFER = os.environ.get("MMT_WGRAD_DEFER", "1") != "0"   # supervised weight gradients in one batch after the supervised backward (0: interleaved, the A/B alternative)
 
 
@@ -328,7 +329,7 @@ class MTtrainer(object):
         # streams (torch.distributed initialised) a default-priority side stream lands on the SAME hardware queue as the
         # main stream and the overlap silently disappears (measured: 63.7 vs 59.9 ms/step).  A different priority class
         # has its own queues.
-        self.t_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.overlap_teacher else None
+        self.t_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MMT_TEACHER_PRIO", "-1"))) if self.overlap_teacher else None
         self._bucketed = None  # BucketedAllReduce, built lazily when enabled (see _bucketed_allreduce)
         # One random stream per model: the teacher's forward runs in a helper thread beside the student's, and with the
         # global generator the interleaving of their draws (fg/bg sampler keys, dropout) would depend on thread timing.
@@ -407,6 +408,10 @@ class MTtrainer(object):
                 defer = _WGRAD_DEFER and use_mt and job is not None
                 pairing = (_WGRAD_PAIR if self.pair_wgrads is None else self.pair_wgrads) and use_mt
                 from maskrcnn_benchmark.layers import fused as _fused
+                gated = defer and _WGRAD_GATE and not pairing
+                if gated:
+                    defer = False
+                    _fused.gate_wgrads(lambda j=job: j.get("backbone_done"))
                 if defer:
                     _fused.defer_wgrads(True)
                 if pairing:
@@ -417,6 +422,9 @@ class MTtrainer(object):
                     sum(v for v in losses_dict.values()).backward()
                 finally:
                     _fused.wgrad_pair_phase(None)
+                    if gated:
+                        _fused.gate_wgrads(None)
+                        _fused.flush_deferred_wgrads()   # (jobs collected while the teacher's backbone had not been issued yet)
                     if defer:
                         _fused.defer_wgrads(False)
                         _fused.flush_deferred_wgrads()   # one batch, behind the supervised backward, beside the consistency branch
@@ -534,9 +542,15 @@ class MTtrainer(object):
         self.t_stream.wait_stream(torch.cuda.current_stream())
         job = {}
 
+        def mark():   # called by the teacher when its K x flip backbone pass has been issued (on the teacher's stream)
+            ev = torch.cuda.Event()
+            ev.record(self.t_stream)
+            job["backbone_done"] = ev
+
         def run():
             try:
                 torch.cuda.set_device(self.device)
+                self.teacher.on_backbone_issued = mark
                 with torch.cuda.stream(self.t_stream), torch.no_grad():
                     job["result"] = self.teacher.forward_teacher(teacher_list)
             except BaseException as e:  # re-raised (or handled) by the step thread

@@ -78,6 +78,12 @@ def flush_wgrads(ent, dev):
     if not jobs:
         return
     side, keep = ent[0], ent[4]
+    gate = _WG_GATE[0]
+    if gate is not None:
+        ev = gate()
+        if ev is None:
+            return            # the gate's event does not exist yet: the jobs stay collected (the end of the pass hands them over)
+        side.wait_event(ev)
     side.wait_stream(torch.cuda.current_stream(dev))
     for job in jobs:
         x, g, shape, stride, pad, dw, rowscale, db = job[:8]
@@ -144,10 +150,20 @@ def finish_wgrad_pairs():
 # (before it waits for the teacher), behind the whole supervised backward, and run beside the consistency branch, where the GPU
 # has room, instead of beside the teacher's backbone, where it has none.
 _WG_DEFER = [False]
+# Gate (round 5, MMT_WGRAD_GATE=1): instead of holding the supervised pass's jobs back until its backward has been issued, they are
+# handed over as they come -- to a side stream that first waits for an EVENT: the end of the teacher's backbone.  From there to the
+# teacher's last result the teacher runs latency-bound selection / head kernels and the GPU has room (profiles/r05_phases.txt:
+# T.backbone ends at 15.5 ms, the supervised backward at 23.3 ms, and all of its weight gradients used to start only then, beside
+# the consistency backward, which is the step's critical chain).  gate() -> the event, or None while it does not exist yet.
+_WG_GATE = [None]
 
 
 def defer_wgrads(on):
     _WG_DEFER[0] = bool(on)
+
+
+def gate_wgrads(fn):
+    _WG_GATE[0] = fn
 
 
 def flush_deferred_wgrads():
@@ -156,6 +172,11 @@ def flush_deferred_wgrads():
 
 
 def _join_wgrads_cb():
+    if _WG_GATE[0] is not None:
+        for dev, ent in _WG.items():
+            ent[2] = False
+            flush_wgrads(ent, dev)  # what is left of the pass; NO join: the step stream meets the side stream before the optimiser
+        return
     if _WG_DEFER[0]:
         for ent in _WG.values():
             ent[2] = False          # the next backward pass queues its own callback

@@ -173,6 +173,9 @@ class GeneralizedRCNN(nn.Module):
         # reference (a second, identical backbone pass on view 0, generalized_rcnn.py:126-127) reuses pyramid 0
         first = ImageListView(images[0])
         aug_features = self.extract_aug_feat(images)
+        cb = self.__dict__.get("on_backbone_issued")   # the training engine's cue: from here on the teacher issues small kernels
+        if cb is not None:
+            cb()
         batched = getattr(self, "_batched_pyr", None)
         # RPN head outputs and decoded+NMS'ed candidates are shared between the two selector passes on pyramid 0
         self.rpn.shared = {"pre": max(self.rpn.box_selector_train.pre_nms_top_n, self.rpn.box_selector_test.pre_nms_top_n)}
