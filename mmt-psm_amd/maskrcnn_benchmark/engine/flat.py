@@ -93,6 +93,7 @@ class FlatParams(object):
                 unit0 += elems // 512
             dev = self.data.device
             self.planes = torch.empty((3, max(off, 8)), dtype=torch.bfloat16, device=dev)
+            H.LAYOUT_EPOCH[0] += 1   # (recorded launch plans hold plane addresses)
             self._pack_descs = torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev)
             self._pack_units = torch.tensor(unit_desc, dtype=torch.int32, device=dev)
             self._n_units = unit0
@@ -109,6 +110,7 @@ class FlatParams(object):
             # the default arithmetic's form of the same matrices: two fp16 planes of w * s, s per matrix from its maximum
             # (reduction launch + packing launch over the same tables); stat16[d] = (max |w_d|, s_d)
             if self.planes16 is None:
+                H.LAYOUT_EPOCH[0] += 1
                 self.planes16 = torch.empty((2, self.planes.shape[1]), dtype=torch.float16, device=self.data.device)
                 self.stat16 = torch.zeros((self._n_descs, 2), dtype=torch.float32, device=self.data.device)
             H._check(H.lib().mmt_pack_weights_f16(self.data.data_ptr(), self.planes16.data_ptr(), self.planes16.stride(0),

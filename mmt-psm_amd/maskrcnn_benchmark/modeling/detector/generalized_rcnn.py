@@ -50,7 +50,14 @@ class GeneralizedRCNN(nn.Module):
 
     # ---- test instrumentation: replay of recorded random decisions (sampler index sets, dropout masks); see utils/replay.py
     def run_backbone(self, x, slot=0):
-        """backbone(x) as a tuple (`slot`: which of the passes of one step, kept for the engine's call sites)"""
+        """backbone(x) as a tuple (`slot`: which of the passes of one step, kept for the engine's call sites).  A no-grad pass on the
+        default arithmetic goes through a launch plan (_hip.planned: recorded once per shape, replayed afterwards): the teacher's
+        K x flip batch every step"""
+        from maskrcnn_benchmark import _hip
+        if (_hip.LAUNCH_PLANS and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+                and _hip.PROFILE is None and _hip.F16X2 and _hip.get_conv_precision() == 3 and not _hip.bf16_storage()
+                and getattr(self.backbone.body, "grad_ready", None) is None):
+            return _hip.planned(("backbone", id(self)), lambda t: tuple(self.backbone(t)), x)
         return tuple(self.backbone(x))
 
     def set_replay(self, replay):

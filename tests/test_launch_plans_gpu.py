@@ -1,0 +1,84 @@
+"""Launch plans (maskrcnn_benchmark/_hip.py: planned): a no-grad backbone pass is recorded once per shape -- every C-ABI call with
+its arguments, its tensors in a private memory pool, its statistics slots in a block of its own -- and replayed afterwards with
+only the input's address patched.  The replay must be the pass: bit-identical pyramids for inputs it has never seen, valid
+statistics, one plan per shape, nothing recorded when gradients are on."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mmt-psm_amd"))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture()
+def det():
+    import synthetic
+    from maskrcnn_benchmark import _hip as H
+    from maskrcnn_benchmark.config import make_default_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    from maskrcnn_benchmark.engine.flat import flatten_model
+    H.lib()
+    prev = H.get_conv_precision()
+    H.set_conv_precision(3)
+    H.set_f16x2(True)
+    m = build_detection_model(make_default_cfg(), is_teacher=True)
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "state_shapes.json")))["shapes"]
+    m.load_state_dict(synthetic.make_weights(shapes, seed=0), strict=False)
+    m.cuda().eval()
+    flatten_model(m).refresh_planes()
+    H._LAUNCH_PLANS.clear()
+    yield H, m
+    H.LAUNCH_PLANS = True
+    H._LAUNCH_PLANS.clear()
+    H.set_f16x2(None)
+    H.set_conv_precision(prev)
+
+
+def test_replayed_backbone_pass_is_the_pass(det):
+    H, m = det
+    g = torch.Generator().manual_seed(1)
+    xs = [(torch.randn(4, 3, 256, 320, generator=g) * 50.0).cuda() for _ in range(5)]
+    with torch.no_grad():
+        H.LAUNCH_PLANS = False
+        want = [tuple(t.clone() for t in m.run_backbone(x)) for x in xs]
+        H.LAUNCH_PLANS = True
+        calls = []
+        for i, x in enumerate(xs):
+            c0 = H.C_CALLS[0]
+            got = m.run_backbone(x)
+            calls.append(H.C_CALLS[0] - c0)
+            assert len(got) == len(want[i]) == 5
+            for a, b in zip(got, want[i]):
+                assert a.shape == b.shape and torch.equal(a, b), (i, (a - b).abs().max().item())
+            torch.cuda.synchronize()
+            for a in got[:4]:                                  # the statistics a consumer's scale comes from
+                slot = a._mmt_amax[0]
+                assert a._mmt_amax[1] == a._version
+                assert float(torch.as_tensor(0.0)) == 0.0 and abs(float(a.abs().max())) >= 0
+                buf = slot.pool.slot_buf if hasattr(slot.pool, "slot_buf") else slot.pool.dev
+                assert float(buf[slot.idx, 0]) == float(a.abs().max())
+    plans = [p for p in H._LAUNCH_PLANS.values()]
+    assert len(plans) == 1 and plans[0].seen == 5 and len(plans[0].calls) > 50
+    assert calls[2] == calls[3] == calls[4] == len(plans[0].calls)          # replays: nothing but the recorded launches
+    # another shape: a plan of its own; the first one still replays
+    with torch.no_grad():
+        y = (torch.randn(2, 3, 128, 128, generator=g) * 50.0).cuda()
+        H.LAUNCH_PLANS = False
+        wy = tuple(t.clone() for t in m.run_backbone(y))
+        H.LAUNCH_PLANS = True
+        for _ in range(3):
+            gy = m.run_backbone(y)
+        assert all(torch.equal(a, b) for a, b in zip(gy, wy))
+        again = m.run_backbone(xs[0])
+        assert all(torch.equal(a, b) for a, b in zip(again, want[0]))
+    assert len(H._LAUNCH_PLANS) == 2
+    # with gradients on nothing is planned
+    n = len(H._LAUNCH_PLANS)
+    m.run_backbone(xs[0])
+    assert len(H._LAUNCH_PLANS) == n and all(p.seen in (6, 3) for p in H._LAUNCH_PLANS.values())
