@@ -19,9 +19,14 @@
 //     block of one plane for one 16-channel step (lane = (row, 16-byte half); the half-swizzle half ^= (row >> 3) & 1 is applied on
 //     the source channel offset and again on the fragment read).  The per-lane offset (pixel of the row for the current tap, or
 //     out of range = zeros for halo / rows past M) is recomputed when the filled step enters a new tap -- Cin / 16 steps apart;
-//   * tile = 64 WM x 128 on 2 WM x 2 waves of 64 x 64 (WM = 2: 128 x 128, 4 waves, two blocks per CU; WM = 4: 256 x 128, 8 waves);
-//     ring of S stages, one raw s_barrier per 16-k step, counted vmcnt: the copies of step t + S go out behind the MFMAs of step t,
-//     the fragments of step t + 1 are read behind the MFMAs of step t (8 ds_read_b128 per 12 MFMAs per wave);
+//   * a block = 8 matrix waves + 4 copy waves (768 threads, one block per CU).  The matrix waves are KG groups of WM x 2 waves of
+//     64 x 64: (WM, KG) = (4, 1): one 256 x 128 tile; (2, 2): a 128 x 128 tile over two K ranges side by side; (1, 4): a 64 x 128
+//     tile over four -- split-K INSIDE the block, summed through LDS in a fixed order, so a few-tile shape still has two waves on
+//     every SIMD.  The copy waves issue every buffer_load ... lds (no MFMA wave computes an address or waits for vmcnt); ring of S
+//     stages, one raw s_barrier per 16-k step, counted vmcnt in the copy waves: the copies of step t + S go out while the matrix
+//     waves are in step t, the fragments of step t + 1 are read behind the MFMAs of step t (8 ds_read_b128 per 12 MFMAs per wave).
+//     What the loop waits for (tools/bench_pg.py --ablate, profiles/r05_pg_ablate.txt): copy time ADDS to fragment-read time on
+//     the LDS port whoever issues it (about 100 GB/s per CU of DMA writes) -- the bound of every plane-fed loop on this part;
 //   * epilogue straight from the accumulator registers (an accumulator register = one output row x 32 consecutive channels per
 //     half wave = complete 128-byte lines): no LDS staging, every residual / mask value of a 32 x 32 sub-tile requested before the
 //     previous sub-tile is finished, unconditional buffer operations (absent operand = zero-sized buffer, row past M / column past

@@ -179,6 +179,155 @@ __global__ __launch_bounds__(256) void roi_align_kernel(Pyr p, const float* __re
   }
 }
 
+// ---- backward without atomics (round 5): one block per 8 x 8 pixel tile of one (level, image) map.  The block
+// lists the ROIs of its image and level whose footprint can touch the tile (ordered compaction over k), then every wave walks the
+// listed ROIs' bins in (k, ph, pw) order and adds  g / count * WY[y] * WX[x]  (the factored weights of the scatter kernel above) into
+// ITS 64-channel slice of a tile accumulator in LDS -- no two waves share a cell, so plain read-modify-write, a fixed summation
+// order, and every element of every level is written exactly once (zeros where no ROI reaches: the caller does not clear).
+// Against the scatter form: 9 fp32 atomics per (bin, channel) + a 178 MB clear per call become one coalesced store per element.
+struct TileMap { int first[5]; int tx[4], ty[4]; };   // first[l] = index of level l's first tile, first[4] = all tiles
+
+__global__ __launch_bounds__(256) void roi_align_bwd_tiles_kernel(Pyr p, TileMap tm, const float* __restrict__ rois,
+                                                                  const int* __restrict__ levels, int K, int PH, int PW,
+                                                                  const float* __restrict__ gout) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];   // [64 pixels][C] then the ROI list (K ints) and 8 counters
+  const int C = p.C;
+  int* const list = (int*)(acc + 64 * C);
+  int* const wcnt = list + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int lv = 0;
+#pragma unroll
+  for (int l = 1; l < 4; l++) if ((int)blockIdx.x >= tm.first[l]) lv = l;
+  const int t = blockIdx.x - tm.first[lv];
+  const int per = tm.tx[lv] * tm.ty[lv];
+  const int b = t / per, ty0 = ((t % per) / tm.tx[lv]) * 8, tx0 = ((t % per) % tm.tx[lv]) * 8;
+  const int H = p.H[lv], W = p.W[lv];
+  const float scale = p.scale[lv];
+  // ---- the tile's ROI list, ascending k
+  int n = 0;
+  for (int k0 = 0; k0 < K; k0 += 256) {
+    const int k = k0 + tid;
+    bool hit = false;
+    if (k < K && levels[k] == lv) {
+      const float* r = rois + (long)k * 5;
+      if ((int)r[0] == b) {
+        const float rsw = r[1] * scale, rsh = r[2] * scale, rew = r[3] * scale, reh = r[4] * scale;
+        const float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+        // samples lie in (rsh, rsh + rh) x (rsw, rsw + rw); one at y touches rows floor(y), floor(y) + 1 (clamped into the map)
+        const float ylo = floorf(rsh), yhi = floorf(rsh + rh) + 1.f, xlo = floorf(rsw), xhi = floorf(rsw + rw) + 1.f;
+        hit = yhi >= (float)ty0 && ylo <= (float)(ty0 + 7) && xhi >= (float)tx0 && xlo <= (float)(tx0 + 7);
+        hit = hit || (ty0 == 0 && yhi < 0.f && yhi >= -1.f) || (tx0 == 0 && xhi < 0.f && xhi >= -1.f);   // (clamped up to row / column 0)
+        hit = hit || (ty0 + 8 >= H && ylo > (float)(H - 1)) || (tx0 + 8 >= W && xlo > (float)(W - 1));   // (clamped down to the last one)
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int base = n;
+    for (int w = 0; w < wave; w++) base += wcnt[w];
+    if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
+    n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  const int npx = 64 * C / 4;
+  if (n == 0) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < npx; i += 256) {
+      const int pix = i / (C / 4), y = ty0 + (pix >> 3), x = tx0 + (pix & 7);
+      if (y < H && x < W) *(f32x4*)(p.grad[lv] + (((long)b * H + y) * W + x) * C + (i % (C / 4)) * 4) = z;
+    }
+    return;
+  }
+  for (int i = tid; i < npx; i += 256) ((f32x4*)acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const float count = 4.f;
+  for (int q = 0; q < n; q++) {
+    const int k = list[q];
+    const float* r = rois + (long)k * 5;
+    const float rsw = r[1] * scale, rsh = r[2] * scale, rew = r[3] * scale, reh = r[4] * scale;
+    const float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+    const float bh = rh / (float)PH, bw = rw / (float)PW;
+    // bins whose samples can touch the tile (one bin of slack on either side; the exact test is per sample below)
+    int ph0 = (int)floorf(((float)(ty0 - 1) - rsh) / bh) - 1, ph1 = (int)floorf(((float)(ty0 + 8) - rsh) / bh) + 1;
+    int pw0 = (int)floorf(((float)(tx0 - 1) - rsw) / bw) - 1, pw1 = (int)floorf(((float)(tx0 + 8) - rsw) / bw) + 1;
+    if (ty0 == 0) ph0 = 0;
+    if (tx0 == 0) pw0 = 0;
+    if (ty0 + 8 >= H) ph1 = PH - 1;
+    if (tx0 + 8 >= W) pw1 = PW - 1;
+    ph0 = max(ph0, 0); pw0 = max(pw0, 0); ph1 = min(ph1, PH - 1); pw1 = min(pw1, PW - 1);
+    for (int ph = ph0; ph <= ph1; ph++) {
+      int ry[4]; float wy[4];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        float y = rsh + ph * bh + (float)(i + .5f) * bh / 2.f;
+        const bool yok = !(y < -1.0f || y > (float)H);
+        if (y <= 0) y = 0;
+        int yl = (int)y, yh;
+        if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+        const float ly = y - yl;
+        ry[2 * i] = yok ? yl : 0; ry[2 * i + 1] = yok ? yh : 0;
+        wy[2 * i] = yok ? 1.f - ly : 0.f; wy[2 * i + 1] = yok ? ly : 0.f;
+      }
+#pragma unroll
+      for (int a = 1; a < 4; a++)
+#pragma unroll
+        for (int c = 0; c < a; c++)
+          if (ry[a] == ry[c] && wy[a] != 0.f) { wy[c] += wy[a]; wy[a] = 0.f; }
+      bool any = false;
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        ry[a] -= ty0;
+        if (ry[a] < 0 || ry[a] > 7) wy[a] = 0.f;
+        any = any || wy[a] != 0.f;
+      }
+      if (!any) continue;
+      for (int pw = pw0; pw <= pw1; pw++) {
+        int rx[4]; float wx[4];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          float x = rsw + pw * bw + (float)(i + .5f) * bw / 2.f;
+          const bool xok = !(x < -1.0f || x > (float)W);
+          if (x <= 0) x = 0;
+          int xl = (int)x, xh;
+          if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+          const float lx = x - xl;
+          rx[2 * i] = xok ? xl : 0; rx[2 * i + 1] = xok ? xh : 0;
+          wx[2 * i] = xok ? 1.f - lx : 0.f; wx[2 * i + 1] = xok ? lx : 0.f;
+        }
+#pragma unroll
+        for (int a = 1; a < 4; a++)
+#pragma unroll
+          for (int c = 0; c < a; c++)
+            if (rx[a] == rx[c] && wx[a] != 0.f) { wx[c] += wx[a]; wx[a] = 0.f; }
+        bool anyx = false;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          rx[a] -= tx0;
+          if (rx[a] < 0 || rx[a] > 7) wx[a] = 0.f;
+          anyx = anyx || wx[a] != 0.f;
+        }
+        if (!anyx) continue;
+        const float* o = gout + (((long)k * PH + ph) * PW + pw) * C;
+        for (int c = wave * 64 + lane; c < C; c += 256) {
+          const float g = o[c] / count;
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const float wgt = wy[a] * wx[e];
+              if (wgt != 0.f) acc[(ry[a] * 8 + rx[e]) * C + c] += g * wgt;
+            }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < npx; i += 256) {
+    const int pix = i / (C / 4), y = ty0 + (pix >> 3), x = tx0 + (pix & 7);
+    if (y < H && x < W) *(f32x4*)(p.grad[lv] + (((long)b * H + y) * W + x) * C + (i % (C / 4)) * 4) = ((const f32x4*)acc)[i];
+  }
+}
+
 static int fill(Pyr& q, const mmt_pyramid* p) {
   if (!p || p->num_levels < 1 || p->num_levels > 4 || p->C < 1) return MMT_EINVAL;
   for (int l = 0; l < 4; l++) {
@@ -234,6 +383,38 @@ extern "C" int mmt_roi_align_backward(const mmt_pyramid* pyr, const float* rois,
   else
     hipLaunchKernelGGL((roi_align_kernel<true, 4>), dim3(mmt_cdiv(nbins, 4)), dim3(256), 0, (hipStream_t)stream, q,
                        rois, levels, K, PH, PW, sampling_ratio, const_cast<float*>(grad_out));
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_roi_align_backward_dense(const mmt_pyramid* pyr, const float* rois, const int32_t* levels, int K,
+                                            int PH, int PW, int sampling_ratio, const float* grad_out, void* stream) {
+  Pyr q;
+  int e = fill(q, pyr);
+  if (e) return e;
+  const char* env = getenv("MMT_ROI_BWD_DENSE");
+  if (sampling_ratio != 2 || (q.C & 63) || q.C > 256 || K > 8192 || PH < 1 || PW < 1 || (env && !atoi(env))) return 1;   // not taken
+  TileMap tm;
+  int tiles = 0;
+  for (int l = 0; l < 4; l++) {
+    tm.first[l] = tiles;
+    const bool live = l < pyr->num_levels;
+    tm.tx[l] = live ? mmt_cdiv(q.W[l], 8) : 1;
+    tm.ty[l] = live ? mmt_cdiv(q.H[l], 8) : 1;
+    if (live) tiles += tm.tx[l] * tm.ty[l] * q.N;
+  }
+  tm.first[4] = tiles;
+  for (int l = pyr->num_levels; l < 4; l++) tm.first[l] = tiles;   // (absent levels own no tile)
+  if (tiles == 0) return 0;
+  const size_t lds = (size_t)64 * q.C * 4 + (size_t)K * 4 + 32;
+  if (lds > 160 * 1024) return 1;
+  static bool done = false;
+  if (!done) {
+    const hipError_t er = hipFuncSetAttribute((const void*)roi_align_bwd_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er != hipSuccess) return (int)er;
+    done = true;
+  }
+  hipLaunchKernelGGL(roi_align_bwd_tiles_kernel, dim3(tiles), dim3(256), lds, (hipStream_t)stream, q, tm, rois, levels, K, PH, PW, grad_out);
   MMT_LAUNCH_CHECK();
   return 0;
 }

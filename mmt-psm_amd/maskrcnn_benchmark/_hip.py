@@ -73,6 +73,7 @@ _SIGS = {
     "mmt_roi_align_forward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_roi_align_forward_bf16": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_roi_align_backward": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mmt_roi_align_backward_dense": [ctypes.POINTER(Pyramid), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mmt_nms_batched": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_resample_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "mmt_aug_views": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float),
@@ -693,8 +694,17 @@ def roi_align_backward(grad_out, shapes, scales, rois, levels, ph, pw, sr):
     g = nhwc(grad_out)
     rois = _dev(rois).float().contiguous()
     levels = _dev(levels).to(torch.int32).contiguous()
-    grads = [empty_nhwc(s[0], s[1], s[2], s[3], g.device, zero=True) for s in shapes]
     K = rois.shape[0]
+    if g.is_cuda and g.dtype == torch.float32:
+        # the tile-gather form writes every element of every level once: no clear, no atomics (csrc/roi_align.hip)
+        grads = [empty_nhwc(s[0], s[1], s[2], s[3], g.device) for s in shapes]
+        p = _pyramid(grads, scales, grads)
+        rc = lib().mmt_roi_align_backward_dense(ctypes.byref(p), _p(rois), _p(levels), K, ph, pw, sr, _p(g), _stream())
+        if rc == 0:
+            return grads
+        if rc != 1:
+            _check(rc, "mmt_roi_align_backward_dense")
+    grads = [empty_nhwc(s[0], s[1], s[2], s[3], g.device, zero=True) for s in shapes]
     if K:
         p = _pyramid(grads, scales, grads)
         _check(lib().mmt_roi_align_backward(ctypes.byref(p), _p(rois), _p(levels), K, ph, pw, sr, _p(g), _stream()),

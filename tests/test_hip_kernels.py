@@ -72,6 +72,57 @@ def test_roi_align_fpn_fused_and_backward(hip):
             np.testing.assert_allclose(grads[l].cpu().numpy(), gr.numpy(), rtol=1e-4, atol=5e-6 * max(1.0, float(gr.abs().max())))
 
 
+@pytest.mark.parametrize("C,sizes", [(64, [(50, 67), (25, 34), (13, 17), (7, 9)]), (256, [(64, 80), (32, 40), (16, 20), (8, 10)]),
+                                     (128, [(40, 40)])])
+def test_roi_align_backward_tile_gather(hip, C, sizes, monkeypatch):
+    """the backward without atomics (mmt_roi_align_backward_dense: one block per 8 x 8 pixel tile gathers the bins that reach it)
+    against the oracle's restatement of cuda/ROIAlign_cuda.cu:177-254 and against the scatter kernel; every element of every
+    level written (buffers pre-filled with NaN), repeatable bit for bit; ROIs hanging over every border, sub-pixel ROIs,
+    maps that are no multiple of the tile, ROIs of other images / levels"""
+    import ctypes
+    from oracle import native
+    H_ = hip
+    g = torch.Generator().manual_seed(C + len(sizes))
+    L = len(sizes)
+    N = 2
+    scales = [0.25 / (1 << l) for l in range(L)]
+    K = 260
+    W0, H0 = sizes[0][1] * 4, sizes[0][0] * 4
+    xy = torch.rand(K, 2, generator=g) * torch.tensor([W0 + 40., H0 + 40.]) - 30
+    wh = torch.rand(K, 2, generator=g) * 150 + 1
+    wh[::7] = torch.rand(wh[::7].shape, generator=g) * 3      # sub-pixel at every level
+    wh[3::11] = 400.                                          # larger than the map
+    rois = torch.cat([(torch.arange(K) % N).float()[:, None], xy, xy + wh], 1)
+    lv = (torch.rand(K, generator=g) * L).long().clamp(max=L - 1)
+    shapes = [(N, C, h, w) for h, w in sizes]
+    for res in (7, 14):
+        go = torch.randn(K, C, res, res, generator=g)
+        n0 = H_.C_CALLS[0]
+        dense = H_.roi_align_backward(cl(go), shapes, scales, rois.cuda(), lv.cuda().int(), res, res, 2)
+        # really the tile kernel, on buffers that held NaN: called once more through the C ABI
+        bufs = [torch.full((N, h, w, C), float("nan"), device="cuda") for h, w in sizes]
+        p = H_._pyramid([b.permute(0, 3, 1, 2) for b in bufs], scales, bufs)
+        r_d, l_d, g_d = rois.cuda(), lv.cuda().int(), cl(go)
+        rc = H_.lib().mmt_roi_align_backward_dense(ctypes.byref(p), r_d.data_ptr(), l_d.data_ptr(), K, res, res, 2,
+                                                   g_d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        for l in range(L):
+            assert torch.equal(bufs[l].permute(0, 3, 1, 2), dense[l])     # no NaN left, repeatable
+        monkeypatch.setenv("MMT_ROI_BWD_DENSE", "0")
+        scatter = H_.roi_align_backward(cl(go), shapes, scales, rois.cuda(), lv.cuda().int(), res, res, 2)
+        monkeypatch.delenv("MMT_ROI_BWD_DENSE")
+        for l in range(L):
+            idx = (lv == l).nonzero().squeeze(1)
+            gr = native.roi_align_backward(go[idx], rois[idx], scales[l], res, res, *shapes[l], 2)
+            tol = 5e-6 * max(1.0, float(gr.abs().max()))
+            np.testing.assert_allclose(dense[l].cpu().numpy(), gr.numpy(), rtol=1e-4, atol=tol)
+            np.testing.assert_allclose(dense[l].cpu().numpy(), scatter[l].cpu().numpy(), rtol=1e-4, atol=tol)
+    # no ROI at all: zeros everywhere
+    z = H_.roi_align_backward(cl(torch.zeros(0, C, 7, 7)), shapes, scales, torch.zeros(0, 5).cuda(), torch.zeros(0).int().cuda(), 7, 7, 2)
+    assert all(float(t.abs().max()) == 0.0 for t in z)
+
+
 # ------------------------------------------------------------------------------------------ NMS
 def _nms_via_hip(hip, boxes, scores, thr):
     order = torch.sort(scores, descending=True, stable=True)[1]
