@@ -56,8 +56,9 @@ int mmt_roi_align_backward(const mmt_pyramid* pyr /*[host]*/, const float* rois,
 /* The same gradient without atomics and without the caller's clear (round 5): one block per 8 x 8 pixel tile of every level gathers
  * the bins that reach it in (k, ph, pw) order and WRITES every element of every grad_feat[l] once (zeros where no ROI reaches) --
  * a fixed summation order instead of the atomics' (cuda/ROIAlign_cuda.cu:177-254 adds in arrival order too).  Returns 1 and
- * touches nothing when it does not take the call (sampling_ratio != 2, C % 64 != 0, C > 256, K > 8192; MMT_ROI_BWD_DENSE=0):
- * the caller then clears and calls mmt_roi_align_backward. */
+ * touches nothing when it does not take the call (sampling_ratio != 2, C % 64 != 0, C > 256, K > 8192, or MMT_ROI_BWD_DENSE unset /
+ * 0 -- it is OPT-IN: repeatable results, but crowded tiles serialise on one CU and the step is 0.3 ms slower than with the
+ * atomics): the caller then clears and calls mmt_roi_align_backward. */
 int mmt_roi_align_backward_dense(const mmt_pyramid* pyr /*[host]*/, const float* rois, const int32_t* levels,
                                  int K, int PH, int PW, int sampling_ratio, const float* grad_out, void* stream);
 

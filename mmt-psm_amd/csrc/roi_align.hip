@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(Pyr p, const float* __re
 // listed ROIs' bins in (k, ph, pw) order and adds  g / count * WY[y] * WX[x]  (the factored weights of the scatter kernel above) into
 // ITS 64-channel slice of a tile accumulator in LDS -- no two waves share a cell, so plain read-modify-write, a fixed summation
 // order, and every element of every level is written exactly once (zeros where no ROI reaches: the caller does not clear).
-// Against the scatter form: 9 fp32 atomics per (bin, channel) + a 178 MB clear per call become one coalesced store per element.
+// Against the scatter form: 9 fp32 atomics per (bin, channel) + a 178 MB clear per call become one coalesced store per element --
+// and the additions of a crowded tile become the work of ONE block: slower on the bench's proposals (see the entry point), opt-in.
 struct TileMap { int first[5]; int tx[4], ty[4]; };   // first[l] = index of level l's first tile, first[4] = all tiles
 
 __global__ __launch_bounds__(256) void roi_align_bwd_tiles_kernel(Pyr p, TileMap tm, const float* __restrict__ rois,
@@ -392,8 +393,11 @@ extern "C" int mmt_roi_align_backward_dense(const mmt_pyramid* pyr, const float*
   Pyr q;
   int e = fill(q, pyr);
   if (e) return e;
+  // opt-in (MMT_ROI_BWD_DENSE=1): repeatable bit for bit, but proposals cluster on the objects -- a tile under 100 ROIs keeps one CU
+  // busy for 0.4-6 ms while the scatter kernel spreads the same additions over the L2 atomic units of the whole chip in 0.2 ms
+  // (profiles/r05_history.md): the step is 0.3 ms slower with it
   const char* env = getenv("MMT_ROI_BWD_DENSE");
-  if (sampling_ratio != 2 || (q.C & 63) || q.C > 256 || K > 8192 || PH < 1 || PW < 1 || (env && !atoi(env))) return 1;   // not taken
+  if (sampling_ratio != 2 || (q.C & 63) || q.C > 256 || K > 8192 || PH < 1 || PW < 1 || !env || !atoi(env)) return 1;   // not taken
   TileMap tm;
   int tiles = 0;
   for (int l = 0; l < 4; l++) {

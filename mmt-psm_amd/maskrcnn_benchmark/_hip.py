@@ -695,8 +695,8 @@ def roi_align_backward(grad_out, shapes, scales, rois, levels, ph, pw, sr):
     rois = _dev(rois).float().contiguous()
     levels = _dev(levels).to(torch.int32).contiguous()
     K = rois.shape[0]
-    if g.is_cuda and g.dtype == torch.float32:
-        # the tile-gather form writes every element of every level once: no clear, no atomics (csrc/roi_align.hip)
+    if g.is_cuda and g.dtype == torch.float32 and os.environ.get("MMT_ROI_BWD_DENSE", "0") != "0":
+        # opt-in: the tile-gather form writes every element of every level once -- no clear, no atomics, repeatable (csrc/roi_align.hip)
         grads = [empty_nhwc(s[0], s[1], s[2], s[3], g.device) for s in shapes]
         p = _pyramid(grads, scales, grads)
         rc = lib().mmt_roi_align_backward_dense(ctypes.byref(p), _p(rois), _p(levels), K, ph, pw, sr, _p(g), _stream())

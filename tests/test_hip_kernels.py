@@ -97,7 +97,7 @@ def test_roi_align_backward_tile_gather(hip, C, sizes, monkeypatch):
     shapes = [(N, C, h, w) for h, w in sizes]
     for res in (7, 14):
         go = torch.randn(K, C, res, res, generator=g)
-        n0 = H_.C_CALLS[0]
+        monkeypatch.setenv("MMT_ROI_BWD_DENSE", "1")
         dense = H_.roi_align_backward(cl(go), shapes, scales, rois.cuda(), lv.cuda().int(), res, res, 2)
         # really the tile kernel, on buffers that held NaN: called once more through the C ABI
         bufs = [torch.full((N, h, w, C), float("nan"), device="cuda") for h, w in sizes]
@@ -119,6 +119,7 @@ def test_roi_align_backward_tile_gather(hip, C, sizes, monkeypatch):
             np.testing.assert_allclose(dense[l].cpu().numpy(), gr.numpy(), rtol=1e-4, atol=tol)
             np.testing.assert_allclose(dense[l].cpu().numpy(), scatter[l].cpu().numpy(), rtol=1e-4, atol=tol)
     # no ROI at all: zeros everywhere
+    monkeypatch.setenv("MMT_ROI_BWD_DENSE", "1")
     z = H_.roi_align_backward(cl(torch.zeros(0, C, 7, 7)), shapes, scales, torch.zeros(0, 5).cuda(), torch.zeros(0).int().cuda(), 7, 7, 2)
     assert all(float(t.abs().max()) == 0.0 for t in z)
 
