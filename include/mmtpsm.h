@@ -322,6 +322,10 @@ typedef struct {
   const void* f16_dy_amax2;
   const void* f16_guard_x2;
   const void* f16_guard_dy2;
+  /* mmt_conv_forward_pg only (round 5): 0 = x_planes indexed like x ([N][H][W][Cin]); 1 = ROW-BLOCKED planes
+   * [N * H][Cin / 16][W][16] (mmt_split_planes_f16_rb): the 16 channels of a 16-k step of consecutive pixels of an image row are
+   * contiguous, so a copy instruction of the kernel reads runs of up to 1 KiB instead of 32-byte pieces of 32 cache lines */
+  int x_planes_layout;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
@@ -398,6 +402,12 @@ int mmt_get_conv_precision(void);
 int mmt_stem_fused(const float* x, int N, int H, int W, const float* w_s2d, const void* w_planes, long w_plane_stride,
                    const float* s_w /*device*/, const float* scale, const float* shift, const float* x_slot /*device*/, float* y,
                    float* y_slot /*device, zeroed, or NULL*/, void* stream);
+/* x (NHWC fp32: `rows` = N * H image rows of W pixels, C channels, C % 16 == 0) -> the two fp16 planes of x * s in the row-blocked
+ * order [rows][C / 16][W][16] that mmt_conv_forward_pg takes with mmt_conv_args.x_planes_layout = 1; s = the power of two derived on
+ * the device from *amax (max |x|, e.g. a producer's statistics slot), also written to *scale_out.  Same values as
+ * mmt_split_planes_f16, another order. */
+int mmt_split_planes_f16_rb(const float* x, void* planes, long plane_stride, int rows, int W, int C, const float* amax,
+                            float* scale_out, void* stream);
 /* Round 5: the plane-fed implicit GEMM (csrc/conv_pgemm.hip) -- the same arithmetic (two-term fp16 split, 3 products, mode 3) for
  * any (KH, KW, stride, pad) with Cin % 16 == 0, Cout > 32, res_mode <= 1, out_stride == 1, no `mul`, fp32 tensors: x_planes = the
  * two fp16 planes of x * s_x with x's NHWC indexing (mmt_split_planes_f16), w_planes = the packed fp16 planes of w * s_w

@@ -3021,6 +3021,7 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.wpl = (const unsigned short*)a->w_planes; p.wpl_stride = a->w_plane_stride;
   p.xpl = (const unsigned short*)a->x_planes; p.xpl_stride = a->x_plane_stride;
   p.ypl = (unsigned short*)a->y_planes; p.ypl_stride = a->y_plane_stride;
+  p.xpl_rb = a->x_planes_layout;
   p.f16_sx = p.f16_sw = nullptr;
   p.f16_ax = 0;
   p.guard_x = (const float*)a->f16_guard_x; p.guard_dy = (const float*)a->f16_guard_dy;
@@ -3523,7 +3524,7 @@ extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x,
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
-  if (!p.y || !p.xpl || !p.wpl || !s_x || !s_w || p.io || p.ypl) return MMT_EINVAL;
+  if (!p.y || !p.xpl || !p.wpl || !s_x || !s_w || p.io || p.ypl || p.xpl_rb) return MMT_EINVAL;
   p.f16_sx = s_x; p.f16_sw = s_w;
   const int tw = strip_tw(p);
   if (!tw) return MMT_EINVAL;
@@ -3563,7 +3564,7 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
-  if (!p.y || !p.wpl || !x_amax || !s_w || p.io || p.ypl || (p.Cin & 15) || ((size_t)p.wpl & 15) || (p.wpl_stride & 7)) return MMT_EINVAL;
+  if (!p.y || !p.wpl || !x_amax || !s_w || p.io || p.ypl || p.xpl_rb || (p.Cin & 15) || ((size_t)p.wpl & 15) || (p.wpl_stride & 7)) return MMT_EINVAL;
   if (p.M == 0 || p.Cout == 0) return 0;
   const int variant = pick_variant(p);
   if (variant == 0) return MMT_EINVAL;

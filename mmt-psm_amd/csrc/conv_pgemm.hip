@@ -118,8 +118,9 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
     // ================================================================ copy wave
     const int sub = cw % PPG;                          // which part of the group's items
     // A: row blocks 2 sub, 2 sub + 1 of the group's tile (32 rows each), both planes; lane = (row r, physical 16-byte half)
-    const int ar = lane >> 1;
-    const int alh = (lane & 1) ^ ((ar >> 3) & 1);      // logical 8-channel half this lane fetches
+    // (DBG & 32 / & 64, timing only: 4 / 8 lanes share a row -- 64- / 128-byte contiguous pieces instead of 32-byte ones)
+    const int ar = (DBG & 64) ? lane >> 3 : (DBG & 32) ? lane >> 2 : lane >> 1;
+    const int alh = (DBG & 64) ? (lane & 7) : (DBG & 32) ? (lane & 3) : (lane & 1) ^ ((ar >> 3) & 1);      // logical 8-channel half this lane fetches
     int aih0[2], aiw0[2];
     unsigned apix[2];                                  // pixel index of the image's first pixel
     bool aok[2];
@@ -159,21 +160,26 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
       f_kh = tap0 / p.KW;
       f_kw = tap0 - f_kh * p.KW;
     }
-    int soff_a = f_ci * 32, soff_b = kt0 * b_step;
+    // bytes from one 16-channel step to the next inside a tap: 32 with planes indexed like x, one image row of the block (W x 32)
+    // with row-blocked planes [N H][Cin / 16][W][16]
+    const int a_step = p.xpl_rb ? p.W * 32 : 32;
+    int soff_a = f_ci * a_step, soff_b = kt0 * b_step;
     unsigned vo_a[2] = {PG_OOB, PG_OOB};
     auto enter_tap = [&]() {   // per-lane offset of (row's pixel for tap (f_kh, f_kw), this lane's 8 channels); halo / past M: zeros
 #pragma unroll
       for (int t = 0; t < 2; t++) {
         const int ih = aih0[t] + f_kh, iw = aiw0[t] + f_kw;
         const bool ok = aok[t] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        vo_a[t] = ok ? ((apix[t] + (unsigned)(ih * p.W + iw)) * (unsigned)p.Cin + (unsigned)(alh * 8)) * 2u : PG_OOB;
+        vo_a[t] = !ok ? PG_OOB
+                  : p.xpl_rb ? (((apix[t] + (unsigned)(ih * p.W)) * (unsigned)spt + (unsigned)iw) * 16u + (unsigned)(alh * 8)) * 2u
+                             : ((apix[t] + (unsigned)(ih * p.W + iw)) * (unsigned)p.Cin + (unsigned)(alh * 8)) * 2u;
       }
     };
     enter_tap();
     auto advance = [&]() {
       f_n++;
       if constexpr (DBG & 1) { soff_b += (DBG & 2) ? 0 : b_step; return; }
-      soff_a += 32;
+      soff_a += a_step;
       soff_b += (DBG & 2) ? 0 : b_step;
       if (++f_ci == spt) {
         f_ci = 0;
@@ -201,6 +207,61 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
     auto wait_copies = [&]() {   // the newest S - 2 steps of this wave's copies may stay pending
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * NI) : "memory");
     };
+    if constexpr (DBG & 16) {
+      // ---- register-staged copies (experiment): the same LDS image, filled by buffer_load_b128 into a ring of S register sets and
+      // ds_write_b128 one step later instead of by LDS-DMA.  pump(n): store step n (set n % S) into stage n % S, then request step
+      // n + S into the freed set
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 rg[S][NI];
+      auto load_step = [&](auto setc) {
+        constexpr int set = decltype(setc)::value;
+        const bool real = f_n < nkt;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const int va = (int)(real ? vo_a[t] : PG_OOB);
+          rg[set][2 * t] = __builtin_amdgcn_raw_buffer_load_b128(rs_a0, va, soff_a, 0);
+          rg[set][2 * t + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs_a1, va, soff_a, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NBP; i++) rg[set][4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(real ? vo_b[i] : PG_OOB), soff_b, 0);
+        advance();
+      };
+      auto store_step = [&](auto setc, int stage) {
+        constexpr int set = decltype(setc)::value;
+        char* const st = gring + stage * STAGE + lane * 16;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          *(u32x4*)(st + (2 * sub + t) * 1024) = rg[set][2 * t];
+          *(u32x4*)(st + PA + (2 * sub + t) * 1024) = rg[set][2 * t + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NBP; i++) *(u32x4*)(st + dst_b[i]) = rg[set][4 + i];
+      };
+      auto pump = [&](auto setc) {
+        constexpr int set = decltype(setc)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * NI) : "memory");   // the set's loads (S slots old) have arrived
+        store_step(setc, set);
+        load_step(setc);
+      };
+      pg_unroll<0, S>([&](auto ic) { load_step(ic); });
+      if (!f16_guard_bad(guard)) {
+        pg_unroll<0, S - 1>([&](auto ic) { pump(ic); });   // steps 0 .. S - 2 into stages 0 .. S - 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // (0) step 0 has landed
+        pump(std::integral_constant<int, S - 1>{});
+        for (int kt = 0; kt < nkt_max; kt += S) {
+          pg_unroll<0, S>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (i == 0 || kt + i < nkt_max) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stores of the previous slot are in LDS
+              __builtin_amdgcn_s_barrier();
+              pump(ic);
+            }
+          });
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
     for (int t = 0; t < S - 1; t++) copy_step(t);      // prologue: steps 0 .. S - 2 into stages 0 .. S - 2
     if (!f16_guard_bad(guard)) {
@@ -221,6 +282,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero copies of the tail steps land before LDS is reused
+    }
   } else {
     // ================================================================ matrix wave
     // fragment reads: row = lane & 31 of a 32-row block, 16-byte half (lane >> 5) ^ ((row >> 3) & 1)
@@ -392,6 +454,37 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
   }
 }
 
+// x (NHWC fp32, R = N H image rows of W pixels, C channels) -> two fp16 planes of x * s in the ROW-BLOCKED order
+// [R][C / 16][W][16]: what a copy instruction of conv_pg_kernel wants for 32 consecutive pixels of an image row and one 16-channel
+// step is then ONE run of 1 KiB instead of 32 pieces of 32 bytes in 32 cache lines (the vector memory path handles a 64-byte
+// sector per clock whatever part of it is asked for: profiles/r05_pg_ablate.txt, "A pieces of 64 / 128 B").  One block = 32 pixels
+// of a row x up to 256 channels: coalesced float4 reads, transposed through LDS, written as runs of (pixels x 32) bytes.
+__global__ __launch_bounds__(256) void split_planes_f16_rb_kernel(const float* __restrict__ x, unsigned short* __restrict__ pl,
+                                                                  const long plane_stride, const int W, const int C, const int segs,
+                                                                  const float* __restrict__ amax, float* __restrict__ s_out) {
+  constexpr int CBS = 1024 + 32;   // bytes of one 16-channel block of the tile in LDS (32 pixels x 32 bytes, padded)
+  __shared__ __attribute__((aligned(16))) char tile[2 * 16 * CBS];
+  const float s = f16_scale_of_fwd(*amax);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && s_out) *s_out = s;
+  const int row = blockIdx.x / segs, w0 = (blockIdx.x % segs) * 32, c0 = blockIdx.y * 256;
+  const int cc = min(256, C - c0), c4n = cc >> 2, ncb = cc >> 4, npx = min(32, W - w0);
+  const float* const src = x + ((long)row * W + w0) * C + c0;
+  for (int i = threadIdx.x; i < npx * c4n; i += 256) {
+    const int px = i / c4n, c4 = i - px * c4n;
+    uint2 o[2];
+    split4h(ldg4(src + (long)px * C + c4 * 4), s, o);
+#pragma unroll
+    for (int q = 0; q < 2; q++) *(uint2*)(tile + (q * 16 + (c4 >> 2)) * CBS + px * 32 + (c4 & 3) * 8) = o[q];
+  }
+  __syncthreads();
+  const int per_cb = npx * 2;   // 16-byte pieces of one (plane, block) run
+  for (int j = threadIdx.x; j < 2 * ncb * per_cb; j += 256) {
+    const int q = j / (ncb * per_cb), r = j - q * (ncb * per_cb), cb = r / per_cb, k = r - cb * per_cb;
+    const uint4 v = *(const uint4*)(tile + (q * 16 + cb) * CBS + k * 16);
+    *(uint4*)(pl + q * plane_stride + (((long)row * (C >> 4) + (c0 >> 4) + cb) * W + w0) * 16 + k * 8) = v;
+  }
+}
+
 // is this call one the plane-fed kernel takes?  (shape / epilogue form only; the caller checked planes and arithmetic)
 bool pg_shape(const ConvP& p) {
   return p.xpl && p.wpl && !p.io && !p.ypl && !p.mul && p.out_stride == 1 && p.res_mode <= 1 && (p.Cin & 15) == 0 && p.Cout > 32 &&
@@ -473,6 +566,20 @@ extern "C" int mmt_conv_pg_wanted(const mmt_conv_args* a) {
   return pg_shape(p) ? 1 : 0;
 }
 
+extern "C" int mmt_split_planes_f16_rb(const float* x, void* planes, long plane_stride, int rows, int W, int C, const float* amax,
+                                       float* scale_out, void* stream) {
+  const long n = (long)rows * W * C;
+  if (!x || !planes || !amax || rows < 0 || W < 1 || C < 16 || (C & 15) || plane_stride < n || (plane_stride & 7) || ((size_t)planes & 15) ||
+      ((size_t)x & 15) || n >= (1L << 30))
+    return MMT_EINVAL;
+  if (n == 0) return 0;
+  const int segs = mmt_cdiv(W, 32);
+  hipLaunchKernelGGL(split_planes_f16_rb_kernel, dim3(rows * segs, mmt_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (unsigned short*)planes, plane_stride, W, C, segs, amax, scale_out);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmt_conv_forward_pg(const mmt_conv_args* a, const float* s_x, const float* s_w, int tile_rows, int ksplit, void* stream) {
   ConvP p;
   int e = fill(p, a);
@@ -488,6 +595,15 @@ extern "C" int mmt_conv_forward_pg(const mmt_conv_args* a, const float* s_x, con
   hipStream_t s = (hipStream_t)stream;
   if (const char* d = getenv("MMT_PG_DBG")) {   // ablations of the main loop (wrong results; tools/bench_pg.py --ablate)
     const int dbg = atoi(d);
+    if (dbg == 32 || dbg == 64) {
+      if (rows == 256) return dbg == 32 ? launch_pg<4, 1, 4, 32>(p, s, ks) : launch_pg<4, 1, 4, 64>(p, s, ks);
+      if (rows == 64) return dbg == 32 ? launch_pg<1, 4, 3, 32>(p, s, ks) : launch_pg<1, 4, 3, 64>(p, s, ks);
+    }
+    if (dbg == 16) {
+      if (rows == 256) return launch_pg<4, 1, 4, 16>(p, s, ks);
+      if (rows == 128) return launch_pg<2, 2, 4, 16>(p, s, ks);
+      return launch_pg<1, 4, 3, 16>(p, s, ks);
+    }
     if (rows == 64) switch (dbg) {
       case 1: return launch_pg<1, 4, 3, 1>(p, s, ks);
       case 2: return launch_pg<1, 4, 3, 2>(p, s, ks);

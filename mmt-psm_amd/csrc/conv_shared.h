@@ -35,6 +35,7 @@ struct ConvP {
   const float* x2; const float* dy2; const float* f16_sx2; const float* f16_sw2; const float* guard_x2; const float* guard_dy2;
   int seg_z;
   int staged_epilogue;   // (A/B timing: MMT_DIRECT_EPI=0) the tiled and tap-strip kernels leave through the LDS-staged epilogue
+  int xpl_rb;            // xpl is row-blocked: [N * H][Cin / 16][W][16] per plane (conv_pg_kernel only; mmt_conv_args.x_planes_layout)
 };
 constexpr float F16_CREST_HI = 131072.f;   // 2^17: max / mean |x| above which fp16's five exponent bits lose the bulk of the tensor
 constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;

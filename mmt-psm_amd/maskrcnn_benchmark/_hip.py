@@ -33,7 +33,7 @@ class ConvArgs(ctypes.Structure):
                 ("f16_x_amax", c_void_p), ("f16_dy_amax", c_void_p), ("y_amax_stats", c_int),
                 ("f16_guard_x", c_void_p), ("f16_guard_dy", c_void_p), ("w_src", c_void_p), ("w_src_scale", c_void_p),
                 ("x2", c_void_p), ("dy2", c_void_p), ("f16_x_amax2", c_void_p), ("f16_dy_amax2", c_void_p),
-                ("f16_guard_x2", c_void_p), ("f16_guard_dy2", c_void_p)]
+                ("f16_guard_x2", c_void_p), ("f16_guard_dy2", c_void_p), ("x_planes_layout", c_int)]
 
 
 IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
@@ -129,6 +129,7 @@ _SIGS = {
     "mmt_stats_combine": [c_void_p, c_int, c_void_p, c_void_p],
     "mmt_sum_stats": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_split_planes_f16_rb": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_flipped_f16": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mmt_conv3x3_strip_f16x2": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p],
@@ -419,6 +420,25 @@ def f16_split(x, site=None):
                                       base + 4 * (k % 3), base + 4 * ((k + 1) % 3), _stream()), "mmt_split_planes_f16")
     ent[1] = k + 1
     return xp, st
+
+
+PG_RB = os.environ.get("MMT_PG_RB", "1") != "0"   # the plane-fed kernel's input planes in the row-blocked order (A/B timing: 0)
+
+
+def f16_split_pg(x):
+    """x (dense NHWC fp32) -> (planes, scale tensor, layout) for the plane-fed implicit GEMM: the two fp16 planes of x * s in the
+    row-blocked order [N H][C / 16][W][16] (layout 1: mmt_split_planes_f16_rb) -- runs of up to 1 KiB per copy instruction of the
+    kernel instead of 32-byte pieces -- or, MMT_PG_RB=0, indexed like x (layout 0: f16_split).  The same values either way."""
+    if not PG_RB:
+        xp, st = f16_split(x)
+        return xp, st, 0
+    N, C, Hh, W = x.shape
+    am = _amax_of(x)
+    xp = torch.empty((2, x.numel()), dtype=torch.float16, device=x.device)
+    st = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _check(lib().mmt_split_planes_f16_rb(x.data_ptr(), xp.data_ptr(), xp.stride(0), N * Hh, W, C, am[0].data_ptr(), st.data_ptr(), _stream()),
+           "mmt_split_planes_f16_rb")
+    return xp, st, 1
 
 
 def f16_weight_planes(w, flip_scale=None, flipped=False):
@@ -1166,7 +1186,7 @@ def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_
         _check(lib().mmt_conv_forward_f16x2(ctypes.byref(a), am[0].data_ptr(), sw.data_ptr(), _stream()), "mmt_conv_forward_f16x2")
     elif kind == 2:   # plane-fed implicit GEMM (3x3 on small maps, mask head): one split pass over x, then the launch
         F16_STATS["pg"] += 1
-        xp16, sx = f16_split(x)
+        xp16, sx, a.x_planes_layout = f16_split_pg(x)
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), 0, 0, _stream()), "mmt_conv_forward_pg")
     else:             # tap-strip kernel: one split pass over x, then the launch
@@ -1187,7 +1207,7 @@ def _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, kind,
     t.x = t.y = t.scale = t.shift = t.res = t.mask = t.mul = t.w = None
     t.w_planes = t.x_planes = t.y_planes = t.y_amax = t.f16_x_amax = t.f16_dy_amax = None
     t.f16_guard_x = t.f16_guard_dy = t.w_src = t.w_src_scale = None
-    t.w_plane_stride = t.x_plane_stride = t.y_plane_stride = 0
+    t.w_plane_stride = t.x_plane_stride = t.y_plane_stride = t.x_planes_layout = 0
     t.mask_scale, t.io_bf16, t.y_amax_stats = 1.0, 0, 1
     if len(_PLAN) > 4096:
         _PLAN.clear()
@@ -1338,7 +1358,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         a.f16_guard_x = _guard(_amax_of(x))
         if pg[1]:
             a.w_src, a.w_src_scale = pg[0].data_ptr(), _p(pg[2])
-        xp16, sx = f16_split(x)
+        xp16, sx, a.x_planes_layout = f16_split_pg(x)
         wp16, sw = f16_weight_planes(pg[0], pg[2], pg[1])
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
@@ -1477,7 +1497,7 @@ def conv_forward_pg(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, r
     else:
         a.w = wsrc.data_ptr()
     a.f16_guard_x = _guard(_amax_of(x))
-    xp16, sx = f16_split(x) if xp is None else xp
+    xp16, sx, a.x_planes_layout = f16_split_pg(x) if xp is None else (tuple(xp) + (0,))[:3]
     wp16, sw = f16_weight_planes(wsrc, fscale, flipped)
     a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
     a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)

@@ -72,9 +72,9 @@ def timed(fn, reps, stream):
 def ablate(args, stream):
     """what the main loop waits for: the same launch with parts of it compiled out (results are wrong by construction)"""
     names = {0: "as shipped", 1: "A copies re-read one step", 2: "B copies re-read one step", 3: "A and B re-read", 4: "no copies (zeros)",
-             8: "no fragment reads", 12: "neither"}
+             8: "no fragment reads", 12: "neither", 16: "register-staged copies (correct results)", 32: "A pieces of 64 B", 64: "A pieces of 128 B"}
     for sh, rows in [((2, 256, 64, 64, 256, 3, 1, 1), 64), ((2, 1024, 64, 64, 256, 1, 1, 0), 64), ((400, 256, 14, 14, 256, 3, 1, 1), 256),
-                     ((8, 256, 64, 64, 256, 3, 1, 1), 256)]:
+                     ((8, 256, 64, 64, 256, 3, 1, 1), 256), ((4, 256, 64, 64, 256, 3, 1, 1), 128), ((2, 512, 32, 32, 512, 3, 1, 1), 128)]:
         N, C, Hh, W, Co, k, s, p = sh
         g = torch.Generator().manual_seed(1)
         x = cl(torch.randn(N, C, Hh, W, generator=g).relu().cuda())
@@ -82,9 +82,15 @@ def ablate(args, stream):
         b = torch.randn(Co, generator=g).cuda()
         with torch.cuda.stream(stream):
             H._amax_of(x)
-            xp = H.f16_split(x)
+            xp = H.f16_split_pg(x)
         out = []
-        for dbg in (0, 1, 2, 3, 4, 8, 12):
+        y0 = H.conv_forward_pg(x, w, None, b, s, p, relu=True, tile_rows=rows, ksplit=1, xp=xp)
+        os.environ["MMT_PG_DBG"] = "16"
+        y16 = H.conv_forward_pg(x, w, None, b, s, p, relu=True, tile_rows=rows, ksplit=1, xp=xp)
+        os.environ.pop("MMT_PG_DBG")
+        torch.cuda.synchronize()
+        out.append("register-staged == shipped: %s" % bool(torch.equal(y0, y16)))
+        for dbg in ((0, 16, 4) if rows == 128 else (0, 16, 32, 64, 1, 2, 3, 4, 8, 12)):
             if rows == 256 and dbg == 3:
                 continue
             os.environ["MMT_PG_DBG"] = str(dbg)
@@ -121,9 +127,9 @@ def main():
         flop = 2.0 * N * Ho * Wo * Co * C * k * k
         with torch.cuda.stream(stream):
             H._amax_of(x)
-            xp = H.f16_split(x)
+            xp = H.f16_split_pg(x)
         t_old, mode = timed(lambda: H.conv_forward(x, w, None, b, s, p, relu=True), args.reps, stream)
-        t_split, _ = timed(lambda: H.f16_split(x), args.reps, stream)
+        t_split, _ = timed(lambda: H.f16_split_pg(x), args.reps, stream)
         rows0, ks0 = H.conv_pg_plan(N, C, Hh, W, Co, k, k, s, p)
         variants = [(rows0, ks0)]
         for rows in (64, 128, 256):

@@ -303,3 +303,29 @@ def test_library_plan(hip):
     assert H.conv_pg_plan(2, 512, 32, 32, 512, 3, 3, 1, 1) == (64, 2)
     assert H.conv_pg_plan(2, 3, 64, 64, 64, 7, 7, 2, 3) == (0, 0)          # Cin % 16 != 0
     assert H.conv_pg_plan(2, 256, 64, 64, 15, 1, 1, 1, 0) == (0, 0)        # Cout <= 32
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_row_blocked_planes_equal_planes_indexed_like_x(hip, case):
+    """the input planes in the row-blocked order [N H][C / 16][W][16] (mmt_split_planes_f16_rb; what the step uses: runs of up to
+    1 KiB per copy instruction) are a re-ordering of the planes indexed like x, and the kernel returns the same bits from either"""
+    H = hip
+    N, C, Hh, W, Co, k, stride, pad, opts = case
+    x, w, sc, sh, kw = _make(case)
+    xp0 = H.f16_split(x)
+    assert H.PG_RB
+    xp1 = H.f16_split_pg(x)
+    assert xp1[2] == 1
+    a = xp0[0].view(2, N, Hh, W, C // 16, 16).permute(0, 1, 2, 4, 3, 5).contiguous().view(2, -1)
+    assert torch.equal(a, xp1[0])
+    assert torch.equal(xp0[1][:1], xp1[1][:1])
+    for rows in (256, 128, 64):
+        if not _fits(case, rows, 1):
+            continue
+        y0 = H.conv_forward_pg(x, w, sc, sh, stride, pad, tile_rows=rows, ksplit=1, xp=xp0, **kw)
+        y1 = H.conv_forward_pg(x, w, sc, sh, stride, pad, tile_rows=rows, ksplit=1, xp=xp1, **kw)
+        assert torch.equal(y0, y1), (case, rows)
+    # the library's own choice of tile and K ranges, the split done inside the call
+    y2 = H.conv_forward_pg(x, w, sc, sh, stride, pad, **kw)
+    y3 = H.conv_forward_pg(x, w, sc, sh, stride, pad, xp=xp0, **kw)
+    assert torch.equal(y2, y3), case
