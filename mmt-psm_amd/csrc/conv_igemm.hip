@@ -1212,7 +1212,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
       const int px = blk * 32 + lpx, iw = wo0 - 1 + px;
       const bool ok = px < TW + 2 && (unsigned)iw < (unsigned)p.W;
       // input row ho0 + r + kh - 1: the (kh - 1) rows and the channel slab go into the scalar offset
-      const long e = q * p.xpl_stride + ((long)(img * p.H + ho0 + r) * p.W + iw) * p.Cin + achunk;
+      // (row-blocked planes [N H][Cin / 16][W][16], p.xpl_rb: the 32 pixels of an item are one run of 1 KiB instead of 32 pieces of
+      // 32 bytes in 32 cache lines; the channel slab moves by W x 32 bytes in the scalar offset)
+      const long e = p.xpl_rb ? q * p.xpl_stride + ((long)(img * p.H + ho0 + r) * slabs * p.W + iw) * 16 + achunk
+                              : q * p.xpl_stride + ((long)(img * p.H + ho0 + r) * p.W + iw) * p.Cin + achunk;
       voff[i] = ok ? (unsigned)(e * 2) : OOB;
       sdst[i] = q * PA + (r * SW + blk * 32) * 32;
       srow[i] = r;
@@ -1233,6 +1236,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   // per input-row offset kh the A slots' VGPR offsets are fixed (a slot whose input row does not exist reads zeros);
   // recomputed when the super-step being FILLED enters a new kh (three times per kernel), never inside the slab loop
   const int row_bytes = p.W * p.Cin * 2;
+  const int a_step = p.xpl_rb ? p.W * 32 : 32;   // bytes from one 16-channel slab to the next
   unsigned vo_a[SA];
   int f_kh = ss0 / slabs, f_cs = ss0 % slabs;   // (kh, slab) of the super-step whose copies are being issued
   const int b_step = (int)(kt_stride * 2);
@@ -1245,11 +1249,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
       // voff addresses input row ho0 + r; kh = 0 wants the row above (offsets are unsigned: subtract here, add in soff else)
       vo_a[i] = (rowok && voff[i] != OOB) ? (f_kh == 0 ? voff[i] - (unsigned)row_bytes : voff[i]) : OOB;
     }
-    soff_a = (f_kh >= 1 ? (f_kh - 1) * row_bytes : 0) + f_cs * 32;
+    soff_a = (f_kh >= 1 ? (f_kh - 1) * row_bytes : 0) + f_cs * a_step;
   };
   fill_enter_kh();
   auto fill_advance = [&]() {      // next super-step to fill
-    soff_a += 32;
+    soff_a += a_step;
     soff_b += b_step;
     if (++f_cs == slabs) {
       f_cs = 0;
@@ -3524,7 +3528,7 @@ extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x,
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
-  if (!p.y || !p.xpl || !p.wpl || !s_x || !s_w || p.io || p.ypl || p.xpl_rb) return MMT_EINVAL;
+  if (!p.y || !p.xpl || !p.wpl || !s_x || !s_w || p.io || p.ypl) return MMT_EINVAL;
   p.f16_sx = s_x; p.f16_sw = s_w;
   const int tw = strip_tw(p);
   if (!tw) return MMT_EINVAL;
@@ -3678,7 +3682,7 @@ extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
-  if (!p.y) return MMT_EINVAL;
+  if (!p.y || p.xpl_rb) return MMT_EINVAL;   // (row-blocked planes: the fp16-split entry points only)
   if (p.M == 0 || p.Cout == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int variant = pick_variant(p);

@@ -422,7 +422,7 @@ def f16_split(x, site=None):
     return xp, st
 
 
-PG_RB = os.environ.get("MMT_PG_RB", "1") != "0"   # the plane-fed kernel's input planes in the row-blocked order (A/B timing: 0)
+PG_RB = os.environ.get("MMT_PG_RB", "1") != "0"   # input planes of the plane-fed and tap-strip kernels in the row-blocked order (A/B timing: 0)
 
 
 def f16_split_pg(x):
@@ -1191,7 +1191,10 @@ def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_
         _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), 0, 0, _stream()), "mmt_conv_forward_pg")
     else:             # tap-strip kernel: one split pass over x, then the launch
         F16_STATS["conv"] += 1
-        xp16, sx = f16_split(x, (wsrc.data_ptr(), flipped) if F16X2_DELAYED else None)
+        if F16X2_DELAYED:
+            xp16, sx = f16_split(x, (wsrc.data_ptr(), flipped))
+        else:
+            xp16, sx, a.x_planes_layout = f16_split_pg(x)
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         _check(lib().mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), _stream()), "mmt_conv3x3_strip_f16x2")
     y._mmt_amax = (slot, y._version)
@@ -1410,7 +1413,10 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             a.f16_guard_x = _guard(_amax_of(x))
         if f16[1]:
             a.w_src, a.w_src_scale = f16[0].data_ptr(), _p(f16[2])
-        xp16, sx = f16_split(x, (f16[0].data_ptr(), f16[1]) if F16X2_DELAYED else None)
+        if F16X2_DELAYED:
+            xp16, sx = f16_split(x, (f16[0].data_ptr(), f16[1]))
+        else:
+            xp16, sx, a.x_planes_layout = f16_split_pg(x)
         wp16, sw = f16_weight_planes(f16[0], f16[2], f16[1])
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)

@@ -100,17 +100,34 @@ def ablate(args, stream):
         print("%s rows %d: %s" % (sh, rows, " | ".join(out)), flush=True)
 
 
+def split_passes(args, stream):
+    """the plane-split pass in the two orders (indexed like x / row-blocked): us per launch, GB/s of 8 bytes per element"""
+    for sh in [(8, 256, 256, 256), (4, 256, 256, 256), (2, 256, 256, 256), (8, 128, 128, 128), (2, 256, 64, 64), (2, 512, 32, 32),
+               (400, 256, 14, 14), (25, 256, 14, 14), (2, 2048, 32, 32)]:
+        x = cl(torch.randn(*sh).relu().cuda())
+        with torch.cuda.stream(stream):
+            H._amax_of(x)
+        t0, _ = timed(lambda: H.f16_split(x), args.reps, stream)
+        t1, _ = timed(lambda: H.f16_split_pg(x), args.reps, stream)
+        gb = x.numel() * 8 / 1e9
+        print("%-22s indexed like x %7.1f us %5.0f GB/s | row-blocked %7.1f us %5.0f GB/s" % (sh, t0 * 1e3, gb / t0 * 1e3, t1 * 1e3, gb / t1 * 1e3),
+              flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="main-loop ablations (MMT_PG_DBG) of the 64- and 256-row forms on a few shapes")
+    ap.add_argument("--split", action="store_true", help="time the plane-split pass in both plane orders")
     args = ap.parse_args()
     H.lib()
     H.set_conv_precision(3)
     H.set_f16x2(True)
     H.FAST_PLANS = True
     stream = torch.cuda.Stream()
+    if args.split:
+        return split_passes(args, stream)
     if args.ablate:
         return ablate(args, stream)
     print("# us per launch (graph replay of %d calls, best of 5); TF = algorithmic TFLOP/s; peak 833" % args.reps)

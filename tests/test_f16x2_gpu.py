@@ -96,6 +96,33 @@ def test_strip_f16x2_error_not_above_bf16x3(hip, case):
     assert eh <= 2.0 * e3 + 1e-7, (case, eh, e3)   # ... nor at the worst element (the bound the strip kernel's own test uses)
 
 
+@pytest.mark.parametrize("case", CASES + [(3, 256, 64, 192, 256, "act", "relu"), (2, 512, 64, 64, 128, "act", "")])
+def test_strip_row_blocked_planes_same_bits(hip, case, monkeypatch):
+    """the tap-strip kernel fed from row-blocked input planes [N H][Cin / 16][W][16] (round 5, the default: an item's 32 pixels are
+    one contiguous run) returns the bits it returns from planes indexed like x; full-width, 64-pixel and split-K forms"""
+    H = hip
+    N, C, Hh, W, Co, kind, opts = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = _inputs(kind, (N, C, Hh, W), g)
+    w = _cl((torch.randn(Co, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda())
+    sc, sh = (torch.rand(Co, generator=g) + 0.5).cuda(), (torch.randn(Co, generator=g) * 0.1).cuda()
+    res = _cl(torch.randn(N, Co, Hh, W, generator=g).cuda()) if opts == "res" else None
+    mask = _cl(torch.randn(N, Co, Hh, W, generator=g).cuda()) if opts == "mask" else None
+    kw = dict(relu=opts in ("res", "relu"), res=res, res_mode=1 if res is not None else 0, mask=mask, mask_scale=2.0)
+    H.set_f16x2(True)
+    try:
+        assert H.PG_RB
+        n0 = H.F16_STATS["conv"] + H.F16_STATS["pg"]
+        y1 = H.conv_forward(x, w, sc, sh, 1, 1, **kw)
+        y1b = H.conv_forward(x, w, sc, sh, 1, 1, **kw)       # (second call: the cached-plan path)
+        monkeypatch.setattr(H, "PG_RB", False)
+        y0 = H.conv_forward(x, w, sc, sh, 1, 1, **kw)
+        assert H.F16_STATS["conv"] + H.F16_STATS["pg"] == n0 + 3     # a plane-fed kernel (tap-strip; few-tile shapes: the implicit GEMM), three times
+        assert torch.equal(y0, y1) and torch.equal(y0, y1b)
+    finally:
+        H.set_f16x2(False)
+
+
 def test_strip_f16x2_data_gradient(hip):
     """the data gradient of a 3x3 convolution (flipped, transposed, BN-scaled weights packed as fp16 terms on the device)"""
     H = hip
