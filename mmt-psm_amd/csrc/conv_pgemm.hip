@@ -59,7 +59,10 @@ __device__ __forceinline__ void pg_unroll(F&& f) {
 // (2, 2), (1, 4)) work on KG consecutive K ranges of the same tile side by side and add their accumulators through LDS at the end --
 // split-K INSIDE the block: a few-tile shape keeps two waves on every SIMD and its tile count is 256 / (64 WM) per 256 rows without a
 // trip through memory.  ksplit > 1 adds K ranges across blocks (R = ksplit * KG ranges in all, range r = ks * KG + group).
-template <int WM, int KG, int S, int DBG = 0>   // DBG (tools/bench_pg.py --ablate): 1 A copies re-read one step, 2 B copies, 4 no copies, 8 no fragment reads
+// AF: the A operand comes from the fp32 tensor itself (no plane-split pass in front of the launch): the copy waves fetch the raw rows
+// into registers, split them into the two fp16 terms of x * s_x there -- vector work on waves that have nothing else to do -- and
+// store the same LDS image; p.f16_sx then points to max |x| (p.f16_ax)
+template <int WM, int KG, int S, int DBG = 0, bool AF = false>   // DBG (tools/bench_pg.py --ablate): 1 A copies re-read one step, 2 B copies, 4 no copies, 8 no fragment reads
 __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int ksplit, float* __restrict__ ws,
                                                       unsigned* __restrict__ tickets) {
   constexpr int BM = 64 * WM, BN = 128, GW = 2 * WM, NT = 512, GT = 64 * GW, NTALL = 768;
@@ -136,8 +139,10 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
       apix[t] = (unsigned)img * (unsigned)(p.H * p.W);
     }
     const long n_x = (long)p.N * p.H * p.W * p.Cin;
-    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.xpl, 0, (int)(n_x * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xpl + p.xpl_stride), 0, (int)(n_x * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a0 = AF ? __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(n_x * 4), 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)p.xpl, 0, (int)(n_x * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a1 = AF ? rs_a0
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)(p.xpl + p.xpl_stride), 0, (int)(n_x * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpl, 0, 0x7ffffff0, 0x00020000);
     // B: items NBP sub .. NBP sub + NBP - 1 of the group's eight: item t -> plane t / 4, 32-channel block t % 4 of the tile
     const int nb32 = (p.Cout + 31) >> 5;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
     }
     // bytes from one 16-channel step to the next inside a tap: 32 with planes indexed like x, one image row of the block (W x 32)
     // with row-blocked planes [N H][Cin / 16][W][16]
-    const int a_step = p.xpl_rb ? p.W * 32 : 32;
+    const int a_step = AF ? 64 : (p.xpl_rb ? p.W * 32 : 32);   // (AF: 16 fp32 channels)
     int soff_a = f_ci * a_step, soff_b = kt0 * b_step;
     unsigned vo_a[2] = {PG_OOB, PG_OOB};
     auto enter_tap = [&]() {   // per-lane offset of (row's pixel for tap (f_kh, f_kw), this lane's 8 channels); halo / past M: zeros
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
         const int ih = aih0[t] + f_kh, iw = aiw0[t] + f_kw;
         const bool ok = aok[t] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         vo_a[t] = !ok ? PG_OOB
+                  : AF ? ((apix[t] + (unsigned)(ih * p.W + iw)) * (unsigned)p.Cin + (unsigned)(alh * 8)) * 4u
                   : p.xpl_rb ? (((apix[t] + (unsigned)(ih * p.W)) * (unsigned)spt + (unsigned)iw) * 16u + (unsigned)(alh * 8)) * 2u
                              : ((apix[t] + (unsigned)(ih * p.W + iw)) * (unsigned)p.Cin + (unsigned)(alh * 8)) * 2u;
       }
@@ -207,12 +213,13 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
     auto wait_copies = [&]() {   // the newest S - 2 steps of this wave's copies may stay pending
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * NI) : "memory");
     };
-    if constexpr (DBG & 16) {
+    if constexpr (AF || (DBG & 16)) {
       // ---- register-staged copies (experiment): the same LDS image, filled by buffer_load_b128 into a ring of S register sets and
       // ds_write_b128 one step later instead of by LDS-DMA.  pump(n): store step n (set n % S) into stage n % S, then request step
       // n + S into the freed set
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       u32x4 rg[S][NI];
+      const float s_a = AF ? f16_scale_of_fwd(*p.f16_sx) : 1.f;
       auto load_step = [&](auto setc) {
         constexpr int set = decltype(setc)::value;
         const bool real = f_n < nkt;
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
         for (int t = 0; t < 2; t++) {
           const int va = (int)(real ? vo_a[t] : PG_OOB);
           rg[set][2 * t] = __builtin_amdgcn_raw_buffer_load_b128(rs_a0, va, soff_a, 0);
-          rg[set][2 * t + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs_a1, va, soff_a, 0);
+          rg[set][2 * t + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs_a1, AF ? va + 16 : va, soff_a, 0);   // (AF: the lane's channels 4 .. 7)
         }
 #pragma unroll
         for (int i = 0; i < NBP; i++) rg[set][4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(real ? vo_b[i] : PG_OOB), soff_b, 0);
@@ -231,8 +238,16 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
         char* const st = gring + stage * STAGE + lane * 16;
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-          *(u32x4*)(st + (2 * sub + t) * 1024) = rg[set][2 * t];
-          *(u32x4*)(st + PA + (2 * sub + t) * 1024) = rg[set][2 * t + 1];
+          if constexpr (AF) {   // eight fp32 channels of the lane's row -> their (h, l) terms: the split of mmt_split_planes_f16, here
+            uint2 o0[2], o1[2];
+            split4h(__builtin_bit_cast(f32x4, rg[set][2 * t]), s_a, o0);
+            split4h(__builtin_bit_cast(f32x4, rg[set][2 * t + 1]), s_a, o1);
+            *(u32x4*)(st + (2 * sub + t) * 1024) = u32x4{o0[0].x, o0[0].y, o1[0].x, o1[0].y};
+            *(u32x4*)(st + PA + (2 * sub + t) * 1024) = u32x4{o0[1].x, o0[1].y, o1[1].x, o1[1].y};
+          } else {
+            *(u32x4*)(st + (2 * sub + t) * 1024) = rg[set][2 * t];
+            *(u32x4*)(st + PA + (2 * sub + t) * 1024) = rg[set][2 * t + 1];
+          }
         }
 #pragma unroll
         for (int i = 0; i < NBP; i++) *(u32x4*)(st + dst_b[i]) = rg[set][4 + i];
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(256) void split_planes_f16_rb_small_kernel(const fl
 // is this call one the plane-fed kernel takes?  (shape / epilogue form only; the caller checked planes and arithmetic)
 bool pg_shape(const ConvP& p) {
   return p.xpl && p.wpl && !p.io && !p.ypl && !p.mul && p.out_stride == 1 && p.res_mode <= 1 && (p.Cin & 15) == 0 && p.Cout > 32 &&
-         (long)p.N * p.H * p.W * p.Cin < (1L << 30) && (long)p.M * p.Cout * 4 < (1L << 31) && ((size_t)p.xpl & 15) == 0 &&
+         (long)p.N * p.H * p.W * p.Cin < (1L << 29) && (long)p.M * p.Cout * 4 < (1L << 31) && ((size_t)p.xpl & 15) == 0 &&
          (p.xpl_stride & 7) == 0 && ((size_t)p.wpl & 15) == 0 && (p.wpl_stride & 7) == 0;
 }
 
@@ -548,7 +563,7 @@ void pg_plan(const ConvP& p, int& rows, int& ksplit) {
   if (e && atoi(e) == 0) ksplit = 1;
 }
 
-template <int WM, int KG, int S, int DBG = 0>
+template <int WM, int KG, int S, int DBG = 0, bool AF = false>
 int launch_pg(const ConvP& p, hipStream_t s, int ksplit) {
   constexpr int BM = 64 * WM;
   const int tiles = mmt_cdiv(p.M, BM) * mmt_cdiv(p.Cout, 128);
@@ -560,7 +575,7 @@ int launch_pg(const ConvP& p, hipStream_t s, int ksplit) {
   constexpr size_t ring = (size_t)S * KG * (BM * 64 + 2 * 128 * 32), xch = KG > 1 ? (size_t)4 * (KG - 1) * 4 * (128 * WM) * 16 : 0;
   constexpr size_t lds = ring > xch ? ring : xch;
   static_assert(lds <= 160 * 1024, "LDS");
-  auto kern = conv_pg_kernel<WM, KG, S, DBG>;
+  auto kern = conv_pg_kernel<WM, KG, S, DBG, AF>;
   static bool done = false;   // per instantiation
   if (!done) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -627,16 +642,22 @@ extern "C" int mmt_conv_forward_pg(const mmt_conv_args* a, const float* s_x, con
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
+  // x_planes null: the A operand is read from x itself and split by the kernel's copy waves; s_x then points to max |x|
+  const bool af = p.xpl == nullptr;
+  if (af) {
+    if (!p.x || ((size_t)p.x & 15)) return MMT_EINVAL;
+    p.xpl = (const unsigned short*)p.x; p.xpl_stride = 0; p.xpl_rb = 0;   // (the shape test below wants an aligned pointer)
+  }
   if (!p.y || !s_x || !s_w || precision() != 3 || !pg_shape(p)) return MMT_EINVAL;
   if (p.M == 0 || p.Cout == 0) return 0;
-  p.f16_sx = s_x; p.f16_sw = s_w;
+  p.f16_sx = s_x; p.f16_sw = s_w; p.f16_ax = af ? 1 : 0;
   int rows, ks;
   pg_plan(p, rows, ks);
   if (tile_rows == 64 || tile_rows == 128 || tile_rows == 256) rows = tile_rows; else if (tile_rows != 0) return MMT_EINVAL;
   if (ksplit > 0) ks = ksplit;
   if (ks < 1 || ks * (256 / rows) > (p.K >> 4)) return MMT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (const char* d = getenv("MMT_PG_DBG")) {   // ablations of the main loop (wrong results; tools/bench_pg.py --ablate)
+  if (const char* d = af ? nullptr : getenv("MMT_PG_DBG")) {   // ablations of the main loop (wrong results; tools/bench_pg.py --ablate)
     const int dbg = atoi(d);
     if (dbg == 32 || dbg == 64) {
       if (rows == 256) return dbg == 32 ? launch_pg<4, 1, 4, 32>(p, s, ks) : launch_pg<4, 1, 4, 64>(p, s, ks);
@@ -664,6 +685,11 @@ extern "C" int mmt_conv_forward_pg(const mmt_conv_args* a, const float* s_x, con
       case 12: return launch_pg<4, 1, 4, 12>(p, s, ks);
       default: break;
     }
+  }
+  if (af) {
+    if (rows == 256) return launch_pg<4, 1, 4, 0, true>(p, s, ks);
+    if (rows == 128) return launch_pg<2, 2, 4, 0, true>(p, s, ks);
+    return launch_pg<1, 4, 3, 0, true>(p, s, ks);
   }
   if (rows == 256) return launch_pg<4, 1, 4>(p, s, ks);
   if (rows == 128) return launch_pg<2, 2, 4>(p, s, ks);

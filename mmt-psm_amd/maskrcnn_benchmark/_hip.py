@@ -422,6 +422,7 @@ def f16_split(x, site=None):
     return xp, st
 
 
+PG_AF = os.environ.get("MMT_PG_AF", "0") != "0"   # the plane-fed kernel reads fp32 x and splits it in its copy waves: no split pass
 PG_RB = os.environ.get("MMT_PG_RB", "1") != "0"   # input planes of the plane-fed and tap-strip kernels in the row-blocked order (A/B timing: 0)
 
 
@@ -1186,8 +1187,11 @@ def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_
         _check(lib().mmt_conv_forward_f16x2(ctypes.byref(a), am[0].data_ptr(), sw.data_ptr(), _stream()), "mmt_conv_forward_f16x2")
     elif kind == 2:   # plane-fed implicit GEMM (3x3 on small maps, mask head): one split pass over x, then the launch
         F16_STATS["pg"] += 1
-        xp16, sx, a.x_planes_layout = f16_split_pg(x)
-        a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+        if PG_AF:
+            sx = am[0]
+        else:
+            xp16, sx, a.x_planes_layout = f16_split_pg(x)
+            a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), 0, 0, _stream()), "mmt_conv_forward_pg")
     else:             # tap-strip kernel: one split pass over x, then the launch
         F16_STATS["conv"] += 1
@@ -1361,9 +1365,13 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         a.f16_guard_x = _guard(_amax_of(x))
         if pg[1]:
             a.w_src, a.w_src_scale = pg[0].data_ptr(), _p(pg[2])
-        xp16, sx, a.x_planes_layout = f16_split_pg(x)
         wp16, sw = f16_weight_planes(pg[0], pg[2], pg[1])
-        a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+        if PG_AF:
+            sx = _amax_of(x)[0]
+            a.x_planes, a.x_plane_stride = None, 0
+        else:
+            xp16, sx, a.x_planes_layout = f16_split_pg(x)
+            a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
         if rec:
             ev[1].record()
@@ -1503,9 +1511,12 @@ def conv_forward_pg(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, r
     else:
         a.w = wsrc.data_ptr()
     a.f16_guard_x = _guard(_amax_of(x))
-    xp16, sx, a.x_planes_layout = f16_split_pg(x) if xp is None else (tuple(xp) + (0,))[:3]
     wp16, sw = f16_weight_planes(wsrc, fscale, flipped)
-    a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+    if xp == "fp32" or (xp is None and PG_AF):   # no planes: the kernel's copy waves split the fp32 rows themselves
+        sx = _amax_of(x)[0]
+    else:
+        xp16, sx, a.x_planes_layout = f16_split_pg(x) if xp is None else (tuple(xp) + (0,))[:3]
+        a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
     a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
     _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), int(tile_rows), int(ksplit), _stream()),
            "mmt_conv_forward_pg")
