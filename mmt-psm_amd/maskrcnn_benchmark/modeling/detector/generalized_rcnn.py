@@ -173,7 +173,10 @@ class GeneralizedRCNN(nn.Module):
 
     def forward_teacher(self, images, targets=None):
         if targets is not None:
-            raise NotImplementedError("forward_teacher with ground-truth targets is not used by MTtrainer")
+            # reference generalized_rcnn.py:133-139: ground truth in place of the coarse inference, its masks decoded at a hard-coded
+            # 800 x 800 (`get_field('masks').decode(800, 800)`); engine/MTtrainer.py:247-275 never passes targets
+            raise NotImplementedError("forward_teacher(images, targets): the ground-truth branch of the reference "
+                                      "(generalized_rcnn.py:133-139) is not built; MTtrainer never takes it")
         integral = []
         images = [to_image_list(im) for im in images]
         # all AUG_K x {plain, mirrored} views go through the backbone as ONE batch; the coarse inference of the
@@ -276,7 +279,8 @@ def fg_hint_loss(teachers, students, masks):
     """MGD (generalized_rcnn.py:243-282): teachers = list over views of 5-level embeddings (odd views were
     computed on mirrored inputs and are un-mirrored inside the kernel), students = [5-level embeddings]."""
     if len(students) != 1:
-        raise NotImplementedError("AUG_S > 1 (mirrored student views) is not on the shipped recipe")
+        raise NotImplementedError("MT.AUG_S > 1: the mirrored student views of the reference (generalized_rcnn.py:253-255, 274-280; "
+                                  "forward_student's per-view loop, :164-205) are not built -- every shipped recipe has AUG_S = 1")
     seg = torch.stack([m.to(torch.int32) for m in masks]).contiguous()
     s = students[0]
     nl = len(s)

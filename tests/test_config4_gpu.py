@@ -3,9 +3,10 @@ products with bf16 activation storage in the backbone + FPN (`bench.py --bf16 --
 [A]-[E] of engine/MTtrainer.py, against the fp32 CPU oracle's trainer (oracle/model.py::Trainer with oracle/irnet.py; pinned
 to the reference by tests/golden/model160_irnet.npz) at bf16 tolerances:
 
-  * every loss of the step (supervised, nms_loss, two-stage loss_seg, mt_fg_loss, mt_classifier) within 5e-2 relative;
+  * every loss of the step (supervised, nms_loss, two-stage loss_seg, mt_fg_loss, mt_classifier) within 1e-2 relative (measured
+    <= 1.6e-3);
   * the SGD update of a subset of tensors along the whole path (FPN, RPN head, fc7, mask head, relation modules, hint adaptor,
-    a layer3 weight) against the oracle's at 0.1 relative in the L2 norm (relation-NMS parameters 0.75: their gradient hangs on
+    a layer3 weight) against the oracle's at 0.08 relative in the L2 norm (measured <= 0.056; relation-NMS parameters 0.75: their gradient hangs on
     discrete selections) -- the gradient is d(update): weight decay is 1e-4;
   * the teacher after the EMA;
   * only the RANDOM draws are replayed; a proposal / detection list stays the product's own when ALL its discrete decisions agree
@@ -24,7 +25,7 @@ from conftest import GOLD, ROOT
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, ROOT)
-BF16_TOL = 5e-2
+BF16_TOL = 1e-2   # (round 5: measured <= 1.6e-3 on every loss with the lists substituted where bf16 flipped a decision; was 5e-2)
 
 
 @pytest.fixture()
@@ -94,6 +95,7 @@ def test_irnet_bf16_storage_full_mean_teacher_step_vs_fp32_oracle(bf16_mode, syn
     assert agree and all(v > (0.6 if "detections" in k else 0.9) for k, v in agree.items()), agree
     assert set(losses) == set(ref_losses), (sorted(losses), sorted(ref_losses))
     dev = {k: abs(float(losses[k]) - float(v)) / max(abs(float(v)), 1e-6) for k, v in ref_losses.items()}
+    print("relative deviation of the losses:", {k: round(v, 5) for k, v in dev.items()})
     assert all(v == v and v < BF16_TOL for v in dev.values()), dev
     worst = {}
     for n in names:
@@ -108,7 +110,7 @@ def test_irnet_bf16_storage_full_mean_teacher_step_vs_fp32_oracle(bf16_mode, syn
     # measured 0.01-0.06 on the trunk, the heads, the mask relation module and the adaptors.  The relation-NMS parameters hang on
     # DISCRETE selections (rank embedding of score-sorted boxes, top-40 attention partners, argmax label preparation,
     # relation_module.py:137-391): a bf16-flipped selection changes which rows receive a gradient at all (0.2-0.6 measured)
-    assert all(v < (0.75 if n.startswith("relation_nms.") else 0.1) for n, v in worst.items()), worst
+    assert all(v < (0.75 if n.startswith("relation_nms.") else 0.08) for n, v in worst.items()), worst
 
 
 def test_bench_bf16_irnet_runs():
