@@ -402,6 +402,19 @@ int mmt_get_conv_precision(void);
 int mmt_stem_fused(const float* x, int N, int H, int W, const float* w_s2d, const void* w_planes, long w_plane_stride,
                    const float* s_w /*device*/, const float* scale, const float* shift, const float* x_slot /*device*/, float* y,
                    float* y_slot /*device, zeroed, or NULL*/, void* stream);
+/* Weight gradient of a stride-1, "same"-padded convolution from ROW-BLOCKED fp16 planes of both operands (round 5; replaces the
+ * conv2d weight gradient behind layers/misc.py:30-43 where the planes exist anyway: the forward launch's input planes and the
+ * data-gradient launch's gradient planes, mmt_split_planes_f16_rb): dw += rowscale[co] * dy^T im2col(x), dbias += column sums of dy.
+ * a: shapes (+ x for the exact path, f16_guard_x / f16_guard_dy); s_x / s_dy: device scalars, the planes' scales.
+ * mmt_conv_wgrad_planes_splits: 0 when the layer is not taken (needs W % 32 == 0, Cin % 128 == 0, Cout % 128 == 0, odd square
+ * kernel with pad (k - 1) / 2, stride 1, mode 3; MMT_WGRAD_PLANES=0), else the number of pixel ranges across blocks: workspace
+ * (device, splits * Cout * KH * KW * Cin floats) is needed when it is > 1.  mmt_conv_wgrad_planes returns 1 and touches nothing
+ * when the layer is not taken.  Products (h l), (l h), (h h) per 16 pixels, fp32 accumulation: the arithmetic of mmt_conv_wgrad's
+ * fp16-split form, another summation order. */
+int mmt_conv_wgrad_planes_splits(const mmt_conv_args* a /*[host]*/);
+int mmt_conv_wgrad_planes(const mmt_conv_args* a /*[host]*/, const float* dy, const void* x_planes, long x_plane_stride,
+                          const void* dy_planes, long dy_plane_stride, const float* s_x, const float* s_dy, const float* rowscale,
+                          float* dw, float* dbias, float* workspace, void* stream);
 /* x (NHWC fp32: `rows` = N * H image rows of W pixels, C channels, C % 16 == 0) -> the two fp16 planes of x * s in the row-blocked
  * order [rows][C / 16][W][16] that mmt_conv_forward_pg takes with mmt_conv_args.x_planes_layout = 1; s = the power of two derived on
  * the device from *amax (max |x|, e.g. a producer's statistics slot), also written to *scale_out.  Same values as

@@ -130,6 +130,9 @@ _SIGS = {
     "mmt_sum_stats": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_split_planes_f16_rb": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mmt_conv_wgrad_planes_splits": [ctypes.POINTER(ConvArgs)],
+    "mmt_conv_wgrad_planes": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_f16": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "mmt_pack_weight_flipped_f16": [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mmt_conv3x3_strip_f16x2": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p],
@@ -422,6 +425,8 @@ def f16_split(x, site=None):
     return xp, st
 
 
+WG_PLANES = os.environ.get("MMT_WGRAD_PLANES", "1") != "0"   # weight gradients of 3x3 layers from the row-blocked planes of both operands
+_WPLAN_PL = {}
 PG_AF = os.environ.get("MMT_PG_AF", "0") != "0"   # the plane-fed kernel reads fp32 x and splits it in its copy waves: no split pass
 PG_RB = os.environ.get("MMT_PG_RB", "1") != "0"   # input planes of the plane-fed and tap-strip kernels in the row-blocked order (A/B timing: 0)
 
@@ -439,6 +444,9 @@ def f16_split_pg(x):
     st = torch.empty((1,), dtype=torch.float32, device=x.device)
     _check(lib().mmt_split_planes_f16_rb(x.data_ptr(), xp.data_ptr(), xp.stride(0), N * Hh, W, C, am[0].data_ptr(), st.data_ptr(), _stream()),
            "mmt_split_planes_f16_rb")
+    # the planes stay with the tensor: the weight gradient of the same layer takes BOTH operands from planes (conv_wgrad: the input's
+    # from the forward launch, the gradient's from the data-gradient launch) -- alive as long as the tensor is
+    x._mmt_rb = (xp, st, x._version)
     return xp, st, 1
 
 
@@ -1686,6 +1694,45 @@ def wgrad_pair_ok(x, dy, x2, dy2):
     return dy.shape[1] % 4 == 0
 
 
+def _conv_wgrad_planes(x, dy, xr, dr, w_shape, stride, pad, dw, rowscale, dbias):
+    """the weight gradient from the row-blocked fp16 planes both operands already have (include/mmtpsm.h: mmt_conv_wgrad_planes;
+    csrc/conv_wgpl.hip) -> False when the library does not take the layer"""
+    Cout, Cin, KH, KW = w_shape
+    N, _, H, W = x.shape
+    key = (x.shape, dy.shape, w_shape, stride, pad)
+    plan = _WPLAN_PL.get(key)
+    if plan is None:
+        a = ConvArgs()
+        a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
+        a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
+        a.out_stride = 1
+        splits = lib().mmt_conv_wgrad_planes_splits(ctypes.byref(a))
+        if len(_WPLAN_PL) > 4096:
+            _WPLAN_PL.clear()
+        plan = _WPLAN_PL[key] = (bytes(a), splits)
+    if plan[1] <= 0:
+        return False
+    ax, ad = getattr(x, "_mmt_amax", None), getattr(dy, "_mmt_amax", None)
+    if ax is None or ad is None or ax[1] != x._version or ad[1] != dy._version:
+        return False
+    if not (_site_ok(("wgx", dw.data_ptr()), x) and _site_ok(("wgd", dw.data_ptr()), dy)):
+        return False
+    a = ConvArgs.from_buffer_copy(plan[0])
+    a.x = x.data_ptr()
+    a.f16_guard_x, a.f16_guard_dy = _guard(ax), _guard(ad)
+    splits = plan[1]
+    ws = torch.empty((splits * Cout * KH * KW * Cin,), dtype=torch.float32, device=x.device) if splits > 1 else None
+    _TLS.last_ws = ws
+    rc = lib().mmt_conv_wgrad_planes(ctypes.byref(a), dy.data_ptr(), xr[0].data_ptr(), xr[0].stride(0), dr[0].data_ptr(), dr[0].stride(0),
+                                     xr[1].data_ptr(), dr[1].data_ptr(), _p(rowscale), _p(dw), _p(dbias), _p(ws), _stream())
+    if rc == 1:
+        _TLS.last_ws = None
+        return False
+    _check(rc, "mmt_conv_wgrad_planes")
+    F16_STATS["wgrad_pl"] = F16_STATS.get("wgrad_pl", 0) + 1
+    return True
+
+
 def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=None, keep=None, pair=None):
     """accumulates into dw (same memory layout as the weight) and dbias.  `side`: a torch stream to launch on instead of the
     current one (the caller orders it against the producers of x / dy and joins it later) -- cheaper than entering a stream
@@ -1709,6 +1756,11 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
     dy = nhwc(dy)
     Cout, Cin, KH, KW = w_shape
     N, _, H, W = x.shape
+    if WG_PLANES and pair is None and F16X2 and x.dtype == torch.float32 and dy.dtype == torch.float32:
+        xr, dr = getattr(x, "_mmt_rb", None), getattr(dy, "_mmt_rb", None)
+        if (xr is not None and dr is not None and xr[2] == x._version and dr[2] == dy._version and get_conv_precision() == 3
+                and _conv_wgrad_planes(x, dy, xr, dr, w_shape, stride, pad, dw, rowscale, dbias)):
+            return
     # the shape half of the argument block and the split count depend on the shapes only: kept after the first call
     if pair is not None:
         x2, dy2 = nhwc(pair[0]), nhwc(pair[1])

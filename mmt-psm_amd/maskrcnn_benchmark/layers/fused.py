@@ -342,6 +342,10 @@ def batch_slice(t, lo, hi):
     am = getattr(t, "_mmt_amax", None)
     if am is not None and am[1] == t._version:
         v._mmt_amax = (am[0], v._version)   # max over the whole batch: an upper bound for the slice (fp16 split scale)
+    rb = getattr(t, "_mmt_rb", None)      # row-blocked fp16 planes [N H][C / 16][W][16]: image-major, so a batch slice is a slice
+    if rb is not None and rb[2] == t._version:
+        per = t.numel() // t.shape[0]
+        v._mmt_rb = (rb[0][:, lo * per:hi * per], rb[1], v._version)
     return v
 
 

@@ -114,12 +114,38 @@ def split_passes(args, stream):
               flush=True)
 
 
+def wgrads(args, stream):
+    """weight gradient of the step's 3x3 layers: the register-splitting kernel (fp32 operands) against the plane-fed one (both operands'
+    row-blocked planes given), us per call incl. the slab-sum launch"""
+    for sh in [(2, 256, 64, 64, 256, 3), (2, 128, 128, 128, 128, 3), (2, 512, 32, 32, 512, 3), (2, 256, 128, 128, 256, 3),
+               (2, 256, 256, 256, 256, 3), (2, 256, 32, 32, 256, 3), (4, 256, 64, 64, 256, 3)]:
+        N, C, Hh, W, Co, k = sh
+        g = torch.Generator().manual_seed(1)
+        x = cl(torch.randn(N, C, Hh, W, generator=g).relu().cuda())
+        dy = cl((torch.randn(N, Co, Hh, W, generator=g) * 1e-3).cuda())
+        dw = cl(torch.zeros(Co, C, k, k).cuda())
+        db = torch.zeros(Co).cuda()
+        with torch.cuda.stream(stream):
+            for t in (x, dy):
+                t._mmt_amax = H._amax_of(t)
+                H.f16_split_pg(t)
+        out = []
+        for planes in (False, True):
+            H.WG_PLANES = planes
+            t, _ = timed(lambda: H.conv_wgrad(x, dy, (Co, C, k, k), 1, k // 2, dw, None, db), args.reps, stream)
+            out.append(t)
+        flop = 2.0 * N * Hh * W * Co * C * k * k
+        print("%-28s registers %7.1f us %5.0f TF | planes %7.1f us %5.0f TF" % (sh, out[0] * 1e3, flop / out[0] / 1e9, out[1] * 1e3, flop / out[1] / 1e9),
+              flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="main-loop ablations (MMT_PG_DBG) of the 64- and 256-row forms on a few shapes")
     ap.add_argument("--split", action="store_true", help="time the plane-split pass in both plane orders")
+    ap.add_argument("--wgrad", action="store_true", help="weight gradient of the 3x3 layers: register-splitting vs plane-fed kernel")
     args = ap.parse_args()
     H.lib()
     H.set_conv_precision(3)
@@ -128,6 +154,8 @@ def main():
     stream = torch.cuda.Stream()
     if args.split:
         return split_passes(args, stream)
+    if args.wgrad:
+        return wgrads(args, stream)
     if args.ablate:
         return ablate(args, stream)
     print("# us per launch (graph replay of %d calls, best of 5); TF = algorithmic TFLOP/s; peak 833" % args.reps)

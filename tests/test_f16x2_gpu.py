@@ -147,6 +147,62 @@ def test_strip_f16x2_data_gradient(hip):
     assert eh < 1e-5 and eh <= 2.0 * e3 + 1e-7, (eh, e3)
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 64, 64, 256, 3, "act", "grad"), (2, 128, 128, 128, 128, 3, "act", "grad"),
+                                   (2, 512, 32, 32, 512, 3, "act", "act"), (1, 256, 32, 96, 128, 3, "signed50", "grad"),
+                                   (3, 128, 32, 32, 256, 1, "act", "grad"), (2, 256, 64, 64, 256, 3, "huge", "tiny"),
+                                   (2, 128, 64, 64, 128, 5, "act", "grad")])
+def test_wgrad_from_row_blocked_planes(hip, shape, monkeypatch):
+    """mmt_conv_wgrad_planes (csrc/conv_wgpl.hip): the weight gradient of a stride-1 layer from the row-blocked fp16 planes both
+    operands already have -- LDS-DMA of 1 KiB runs, ds_read_b64_tr_b16 fragments, no vector arithmetic -- against fp64 within the
+    default arithmetic's bound and against the register-splitting kernel (same products, another summation order); accumulation
+    into a non-zero buffer, row scale, bias gradient, one and several pixel ranges across blocks, batch slices of the planes"""
+    H = hip
+    N, Cin, Hh, W, Cout, k, kx, kd = shape
+    g = torch.Generator().manual_seed(sum(shape[:6]))
+    x = _inputs(kx, (N, Cin, Hh, W), g)
+    dy = _inputs(kd, (N, Cout, Hh, W), g)
+    rs = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    dw0 = _cl((torch.randn((Cout, Cin, k, k), generator=g) * 1e-3 * float(x.abs().max() * dy.abs().max())).cuda())
+    H.set_f16x2(True)
+    try:
+        for t in (x, dy):
+            t._mmt_amax = H._amax_of(t)
+            H.f16_split_pg(t)           # what the forward / data-gradient launch of the layer leaves behind
+        assert x._mmt_rb[2] == x._version and dy._mmt_rb[2] == dy._version
+
+        def run(planes, xx=x, dd=dy):
+            monkeypatch.setattr(H, "WG_PLANES", planes)
+            dw = dw0.clone(memory_format=torch.preserve_format)
+            db = torch.zeros((Cout,), device="cuda")
+            H.conv_wgrad(xx, dd, (Cout, Cin, k, k), 1, k // 2, dw, rs, db)
+            torch.cuda.synchronize()
+            return dw, db
+        n0 = H.F16_STATS.get("wgrad_pl", 0)
+        d_pl, b_pl = run(True)
+        assert H.F16_STATS.get("wgrad_pl", 0) == n0 + 1
+        d_old, b_old = run(False)
+        assert H.F16_STATS.get("wgrad_pl", 0) == n0 + 1
+        xu = F.unfold(x.double(), k, padding=k // 2)
+        ref = torch.einsum("nco,nko->ck", dy.double().flatten(2), xu).view(Cout, Cin, k, k) * rs.double().view(-1, 1, 1, 1)
+        scale = ref.abs().max().item()
+        e_pl = (d_pl.double() - dw0.double() - ref).abs().max().item() / scale
+        e_old = (d_old.double() - dw0.double() - ref).abs().max().item() / scale
+        assert e_pl < 1e-5 and e_pl <= 2.0 * e_old + 2e-7, (e_pl, e_old)
+        rb = dy.double().sum((0, 2, 3))
+        bs = dy.double().abs().sum((0, 2, 3)).max().item()
+        assert (b_pl.double() - rb).abs().max().item() < 1e-5 * bs and (b_old.double() - rb).abs().max().item() < 1e-5 * bs
+        if N > 1:   # a batch slice of the tensors (the pair schedule's backward: N = 2 views of the N = 4 forward) takes sliced planes
+            from maskrcnn_benchmark.layers import fused
+            xs, ds = fused.batch_slice(x, 1, N), fused.batch_slice(dy, 1, N)
+            d_s, _ = run(True, xs, ds)
+            assert H.F16_STATS.get("wgrad_pl", 0) == n0 + 2
+            xu = F.unfold(x[1:].double(), k, padding=k // 2)
+            r_s = torch.einsum("nco,nko->ck", dy[1:].double().flatten(2), xu).view(Cout, Cin, k, k) * rs.double().view(-1, 1, 1, 1)
+            assert (d_s.double() - dw0.double() - r_s).abs().max().item() < 1e-5 * max(r_s.abs().max().item(), 1e-30)
+    finally:
+        H.set_f16x2(False)
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 64, 64, 128, 3, "act", "grad"), (2, 256, 64, 64, 256, 3, "act", "grad"),
                                    (2, 256, 128, 128, 256, 3, "signed50", "tiny"), (8, 128, 32, 32, 128, 3, "act", "act")])
 def test_wgrad_f16x2(hip, shape):
