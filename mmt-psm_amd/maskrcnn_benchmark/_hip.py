@@ -438,9 +438,8 @@ def f16_split_pg(x):
     if not PG_RB:
         xp, st = f16_split(x)
         return xp, st, 0
-    rb = getattr(x, "_mmt_rb", None)
-    if rb is not None and rb[2] == x._version and rb[0].stride(0) == x.numel():   # a second plane-fed consumer of the same tensor
-        return rb[0], rb[1], 1
+    # (no reuse of planes an earlier consumer left on the tensor: a launch plan's replay rewrites its result tensors in place without
+    # touching their version counters -- the teacher's pyramid levels -- and planes made from the previous step's values would pass)
     N, C, Hh, W = x.shape
     am = _amax_of(x)
     xp = torch.empty((2, x.numel()), dtype=torch.float16, device=x.device)
