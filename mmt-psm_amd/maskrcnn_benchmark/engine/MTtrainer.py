@@ -26,6 +26,7 @@ from maskrcnn_benchmark.utils.miscellaneous import sigmoid_rampdown, sigmoid_ram
 # consistency backward, where the device waits for the teacher and the host; paired, they wait for their partner and all
 # weight-gradient work lands beside the consistency backward, the most contended stretch of the step.  Off.
 _WGRAD_PAIR = os.environ.get("MMT_WGRAD_PAIR", "0") != "0"
+_LOSS_ROOTS = os.environ.get("MMT_LOSS_ROOTS", "1") != "0"   # backward from the losses as roots with the weights as seeds (see _backward_roots)
 _WGRAD_GATE = os.environ.get("MMT_WGRAD_GATE", "0") != "0"     # ... or as they come, behind the end of the teacher's backbone (round 5: +0.3 .. +0.8 ms, off)
 _WGRAD_DEFER = os.environ.get("MMT_WGRAD_DEFER", "1") != "0"   # supervised weight gradients in one batch after the supervised backward (0: interleaved, the A/B alternative)
 
@@ -404,7 +405,6 @@ class MTtrainer(object):
                 self.optimizer.zero_grad()
             loss_dict = self.forward_source(data_s, target_s, feats_s)
             if early:
-                losses_dict = self.weight_sum_loss(loss_dict, iteration)
                 defer = _WGRAD_DEFER and use_mt and job is not None
                 pairing = (_WGRAD_PAIR if self.pair_wgrads is None else self.pair_wgrads) and use_mt
                 from maskrcnn_benchmark.layers import fused as _fused
@@ -419,7 +419,8 @@ class MTtrainer(object):
                     # too (ResNet body, FPN, box head) leave with their partner as one two-segment launch (layers/fused.py)
                     _fused.wgrad_pair_phase("first")
                 try:
-                    sum(v for v in losses_dict.values()).backward()
+                    self._backward_roots(loss_dict, iteration)
+                    losses_dict = self._weighted_detached(loss_dict, iteration)   # (for the log: behind the backward's launches)
                 finally:
                     _fused.wgrad_pair_phase(None)
                     if gated:
@@ -428,13 +429,15 @@ class MTtrainer(object):
                     if defer:
                         _fused.defer_wgrads(False)
                         _fused.flush_deferred_wgrads()   # one batch, behind the supervised backward, beside the consistency branch
-                unl = self.weight_sum_loss(self.forward_unlabel(data_u_list, feats_u, job), iteration)
+                unl_raw = self.forward_unlabel(data_u_list, feats_u, job)
+                unl = unl_raw
                 job = None
                 if unl:
                     if pairing:
                         _fused.wgrad_pair_phase("second")
                     try:
-                        sum(v for v in unl.values()).backward()
+                        self._backward_roots(unl_raw, iteration)
+                        unl = self._weighted_detached(unl_raw, iteration)
                     finally:
                         _fused.wgrad_pair_phase(None)
                 if pairing:
@@ -531,6 +534,45 @@ class MTtrainer(object):
 
     def forward_source(self, image, target, features=None):
         return self.student(image.to(self.device), [t.to(self.device) for t in target], features=features)
+
+    def _loss_coeff(self, k, w):
+        return (w if "mt" in k else 1.0) * (self.balanced_weight[k] if k in self.balanced_weight else 1.0)
+
+    def _weighted_detached(self, loss_dict, iteration):
+        """the weighted losses of `weight_sum_losses` as detached values (what a step returns for the log), in one multi-tensor launch"""
+        w = mt_weight(iteration, self.cfg.MT.RAMPUP_STEP, self.cfg.MT.RAMPDOWN_STEP, self.max_iter, self.lambda_value, self.start_mt)
+        keys = [k for k, v in loss_dict.items() if torch.is_tensor(v)]
+        out = {k: v for k, v in loss_dict.items() if not torch.is_tensor(v)}
+        if keys:
+            vals = torch._foreach_mul([loss_dict[k].detach() for k in keys], [float(self._loss_coeff(k, w)) for k in keys])
+            out.update(zip(keys, vals))
+        return {k: out[k] for k in loss_dict}
+
+    def _backward_roots(self, loss_dict, iteration):
+        """backward of sum_k c_k loss_k (c_k = the weights of `weight_sum_losses`, MTtrainer.py:67-109) WITHOUT forming the sum: the
+        losses are the roots, the weights their seed gradients.  `sum(weighted.values()).backward()` put ~20 scalar launches (the
+        weighting multiplies, the chain of adds, their backward nodes) in front of the first kernel of each backward pass -- on the
+        step's critical chain, at a point where the host is not ahead of the device."""
+        if not _LOSS_ROOTS:   # (A/B timing: the sum formed by tensor arithmetic, as the reference writes it)
+            sum(v for v in self.weight_sum_loss(loss_dict, iteration).values()).backward()
+            return
+        w = mt_weight(iteration, self.cfg.MT.RAMPUP_STEP, self.cfg.MT.RAMPDOWN_STEP, self.max_iter, self.lambda_value, self.start_mt)
+        roots, seeds = [], []
+        cache = self.__dict__.setdefault("_seed_cache", {})
+        for k, v in loss_dict.items():
+            if not (torch.is_tensor(v) and v.requires_grad):
+                continue
+            c = self._loss_coeff(k, w)
+            key = (float(c), v.dtype, v.device, tuple(v.shape))
+            t = cache.get(key)
+            if t is None:
+                if len(cache) > 64:
+                    cache.clear()
+                t = cache[key] = torch.full(v.shape, float(c), dtype=v.dtype, device=v.device)
+            roots.append(v)
+            seeds.append(t)
+        if roots:
+            torch.autograd.backward(roots, seeds)
 
     def _start_teacher(self, data_u_list):
         """launch teacher.forward_teacher on the side stream from a helper thread; -> job dict (joined in forward_unlabel)"""
