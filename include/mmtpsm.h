@@ -415,6 +415,15 @@ int mmt_conv_wgrad_planes_splits(const mmt_conv_args* a /*[host]*/);
 int mmt_conv_wgrad_planes(const mmt_conv_args* a /*[host]*/, const float* dy, const void* x_planes, long x_plane_stride,
                           const void* dy_planes, long dy_plane_stride, const float* s_x, const float* s_dy, const float* rowscale,
                           float* dw, float* dbias, float* workspace, void* stream);
+/* Host-side helper (no device work of its own): calls n recorded entry points of this library in order, each with its 16 recorded
+ * integer / pointer arguments (entry points with fewer parameters ignore the rest; none with floating-point parameters may be
+ * recorded), and stops at the first nonzero return code (-> that code, *failed_index = its position).  What the Python layer's
+ * launch plans replay a no-grad pass through: one call from the interpreter instead of one per launch. */
+typedef struct {
+  void* fn;
+  long a[16];
+} mmt_call;
+int mmt_replay(const mmt_call* calls /*[host]*/, int n, int* failed_index /*[host] or NULL*/);
 /* x (NHWC fp32: `rows` = N * H image rows of W pixels, C channels, C % 16 == 0) -> the two fp16 planes of x * s in the row-blocked
  * order [rows][C / 16][W][16] that mmt_conv_forward_pg takes with mmt_conv_args.x_planes_layout = 1; s = the power of two derived on
  * the device from *amax (max |x|, e.g. a producer's statistics slot), also written to *scale_out.  Same values as

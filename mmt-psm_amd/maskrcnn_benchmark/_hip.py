@@ -130,6 +130,7 @@ _SIGS = {
     "mmt_sum_stats": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p],
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_split_planes_f16_rb": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mmt_replay": [c_void_p, c_int, c_void_p],
     "mmt_conv_wgrad_planes_splits": [ctypes.POINTER(ConvArgs)],
     "mmt_conv_wgrad_planes": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -525,6 +526,11 @@ def lib():
     return _lib
 
 
+def _lib_raw():
+    """the CDLL itself (calls through it are never recorded by a launch plan)"""
+    return lib()._L
+
+
 # ---- launch plans (round 5).  The step is bound by the interpreter time of its two launch-issuing threads under one GIL (DESIGN.md
 # section 5: the student's head phases are host-bound while the teacher thread issues its backbone).  A no-grad backbone pass over a
 # batch of a fixed shape issues the SAME launches every step -- same kernels, same weight / plane / workspace addresses, outputs of
@@ -560,8 +566,60 @@ class _LibProxy(object):
         return w
 
 
+class _Call(ctypes.Structure):   # include/mmtpsm.h: mmt_call
+    _fields_ = [("fn", c_void_p), ("a", ctypes.c_long * 16)]
+
+
+C_REPLAY = os.environ.get("MMT_C_REPLAY", "1") != "0"   # a plan's runs of C-ABI calls replayed by ONE library call (mmt_replay), the lock released
+
+
+def _compile_plan(plan):
+    """plan.calls -> segments: ("c", array of mmt_call, n, [(index, argument) positions holding the recorded input pointer]) for runs of
+    recorded library calls with integer / pointer arguments, ("py", f, args) for everything else (record_torch closures, entry
+    points with a floating-point parameter)"""
+    segs, run = [], []
+
+    def flush():
+        if run:
+            arr = (_Call * len(run))()
+            patch = []
+            for i, (addr, vals) in enumerate(run):
+                arr[i].fn = addr
+                for j, v in enumerate(vals):
+                    arr[i].a[j] = v
+                    if v == plan.in_ptr:
+                        patch.append((i, j))
+            segs.append(("c", arr, len(run), patch))
+            run.clear()
+    for f, args in plan.calls:
+        enc = None
+        at = getattr(f, "argtypes", None)
+        if at is not None and len(args) <= 16 and len(at) == len(args) and not any(t in (c_float, ctypes.c_double) for t in at):
+            enc = []
+            for a in args:
+                if a is None:
+                    enc.append(0)
+                elif isinstance(a, int):
+                    enc.append(a)
+                elif hasattr(a, "_obj"):                      # ctypes.byref(structure): the structure stays alive with the plan's argument tuple
+                    enc.append(ctypes.addressof(a._obj))
+                elif isinstance(a, ctypes.Array) or isinstance(a, ctypes.Structure):
+                    enc = None                                # (by-value aggregates: not through the integer prototype)
+                    break
+                else:
+                    enc = None
+                    break
+        if enc is None:
+            flush()
+            segs.append(("py", f, args))
+        else:
+            run.append((ctypes.cast(f, c_void_p).value, enc))
+    flush()
+    return segs
+
+
 class LaunchPlan(object):
-    __slots__ = ("calls", "result", "in_ptr", "slot_buf", "slot_next", "pool", "base", "gen", "host_gen", "event", "host", "seen")
+    __slots__ = ("calls", "result", "in_ptr", "slot_buf", "slot_next", "pool", "base", "gen", "host_gen", "event", "host", "seen", "segs")
 
     def __init__(self, device):
         self.calls, self.result, self.in_ptr, self.seen = [], None, None, 0
@@ -612,6 +670,21 @@ def planned(tag, fn, x):
         return plan.result
     plan.slot_buf.zero_()
     old, new = plan.in_ptr, x.data_ptr()
+    if C_REPLAY:
+        segs = getattr(plan, "segs", None)
+        if segs is None:
+            segs = plan.segs = _compile_plan(plan)
+        replay = _lib_raw().mmt_replay
+        for sg in segs:
+            if sg[0] == "c":
+                for i, j in sg[3]:
+                    sg[1][i].a[j] = new
+                if replay(sg[1], sg[2], None):
+                    raise RuntimeError("a replayed launch failed")
+            elif sg[1](*[new if (type(a) is int and a == old) else a for a in sg[2]]):
+                raise RuntimeError("a replayed launch failed")
+        C_CALLS[0] += len(plan.calls)
+        return plan.result
     if old == new:
         for f, args in plan.calls:
             if f(*args):
