@@ -470,6 +470,38 @@ def test_range_guard_data_gradient_and_weight_gradient(hip, k):
     assert (db.double() - refb).abs().max().item() < 1e-5 * dy.double().abs().sum((0, 2, 3)).max().item()
 
 
+@pytest.mark.parametrize("bad", ["dy", "x"])
+def test_range_guard_of_the_plane_fed_weight_gradient(hip, bad):
+    """mmt_conv_wgrad_planes behind the range guard: one operand with an element 10^8 x the rest -- its planes are useless (everything
+    else sits below the low term's range) -- and every block computes its part of the tile with exact fp32 products from the fp32
+    tensors instead (csrc/conv_wgpl.hip, the `slow` branch): <= 3e-6 of every output's own sum |a||b|, bias gradient included, on the
+    first occurrence"""
+    H = hip
+    g = torch.Generator().manual_seed(17 + len(bad))
+    N, C, S, Co, k = 2, 128, 64, 256, 3
+    x = _outlier_input((N, C, S, S), g) if bad == "x" else _inputs("act", (N, C, S, S), g)
+    dy = _outlier_input((N, Co, S, S), g, "signed50") if bad == "dy" else _inputs("grad", (N, Co, S, S), g)
+    bn = (torch.rand(Co, generator=g) + 0.5).cuda()
+    H.set_f16x2(True)
+    try:
+        for t in (x, dy):
+            t._mmt_amax = H._amax_of(t)
+            H.f16_split_pg(t)
+        n0, f0 = H.F16_STATS.get("wgrad_pl", 0), H.F16_STATS["fallback"]
+        dw = _cl(torch.zeros((Co, C, k, k), device="cuda"))
+        db = torch.zeros((Co,), device="cuda")
+        H.conv_wgrad(x, dy, (Co, C, k, k), 1, k // 2, dw, bn, db)
+        assert H.F16_STATS.get("wgrad_pl", 0) == n0 + 1 and H.F16_STATS["fallback"] == f0
+        xu = F.unfold(x.double(), k, padding=k // 2)
+        refw = torch.einsum("nco,nko->ck", dy.double().flatten(2), xu).view(Co, C, k, k) * bn.double().view(-1, 1, 1, 1)
+        denw = torch.einsum("nco,nko->ck", dy.double().abs().flatten(2), xu.abs()).view(Co, C, k, k) * bn.double().view(-1, 1, 1, 1) + 1e-30
+        assert _rel_err(dw, refw, denw) < 3e-6
+        refb = dy.double().sum((0, 2, 3))
+        assert (db.double() - refb).abs().max().item() < 1e-5 * dy.double().abs().sum((0, 2, 3)).max().item()
+    finally:
+        H.set_f16x2(False)
+
+
 @pytest.mark.parametrize("shape", [(8, 256, 64, 64, 256, 3), (2, 256, 64, 64, 512, 1)])
 def test_host_moves_a_persistently_bad_site_to_bf16x3(hip, shape):
     """the slow path is for first occurrences: when the statistics have reached the host the consuming site sees the crest factor
