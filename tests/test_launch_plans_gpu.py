@@ -40,8 +40,12 @@ def det():
     H.set_conv_precision(prev)
 
 
-def test_replayed_backbone_pass_is_the_pass(det):
+@pytest.mark.parametrize("c_replay", [True, False])
+def test_replayed_backbone_pass_is_the_pass(det, c_replay, monkeypatch):
+    """c_replay: the recorded calls go out through ONE library call per run (include/mmtpsm.h: mmt_replay, the interpreter lock
+    released) or one interpreter call each"""
     H, m = det
+    monkeypatch.setattr(H, "C_REPLAY", c_replay)
     g = torch.Generator().manual_seed(1)
     xs = [(torch.randn(4, 3, 256, 320, generator=g) * 50.0).cuda() for _ in range(5)]
     with torch.no_grad():
@@ -65,6 +69,9 @@ def test_replayed_backbone_pass_is_the_pass(det):
                 assert float(buf[slot.idx, 0]) == float(a.abs().max())
     plans = [p for p in H._LAUNCH_PLANS.values()]
     assert len(plans) == 1 and plans[0].seen == 5 and len(plans[0].calls) > 50
+    if c_replay:   # nearly everything went through mmt_replay: a handful of runs, the ATen closures / by-value aggregates between them
+        segs = plans[0].segs
+        assert sum(s[2] for s in segs if s[0] == "c") >= len(plans[0].calls) - 8 and sum(1 for s in segs if s[0] == "c") <= 8
     assert calls[2] == calls[3] == calls[4] == len(plans[0].calls)          # replays: nothing but the recorded launches
     # another shape: a plan of its own; the first one still replays
     with torch.no_grad():
