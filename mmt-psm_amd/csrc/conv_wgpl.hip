@@ -13,8 +13,8 @@
 //     operand of v_mfma_f32_32x32x16_f16.  No vector arithmetic, no LDS stores in the loop.
 // Block = 8 matrix waves + 4 copy waves (the recipe of conv_pg_kernel): two GROUPS of 2 x 2 waves work on two consecutive pixel
 // ranges of one 128 (co) x 128 (tap, ci) tile and add their accumulators through LDS; pixel ranges across blocks go to slabs of the
-// caller's workspace that wgrad_reduce_kernel's launch sums (in-launch reduction was measured slower for this kernel's short
-// ranges: profiles/r05_history.md).  Cin % 128 == 0 puts a column tile inside ONE tap: the x offset of a block is fixed.
+// caller's workspace that a second launch (wgrad_pl_reduce_kernel) sums (in-launch reduction was measured slower for the weight
+// gradient's short ranges: profiles/r05_history.md).  Cin % 128 == 0 puts a column tile inside ONE tap: the x offset of a block is fixed.
 // Products and their order per 16-pixel step: (h l), (l h), (h h), fp32 accumulation -- the arithmetic of the default mode.
 // Roofline: MFMA, 833 TFLOP/s algorithmic; copies 32 KB per 32-pixel super-step and group = 96 MFMAs.
 #include "conv_shared.h"
