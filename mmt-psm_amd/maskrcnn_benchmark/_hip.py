@@ -7,6 +7,7 @@ autograd bookkeeping only; tensors cross the boundary as raw device pointers.
 import ctypes
 import weakref
 import os
+import threading as _threading
 
 import torch
 
@@ -311,8 +312,9 @@ def _site_ok(site, x, count=True):
             ent[1] = None    # overwritten before anybody looked
     if ent[1] is None:
         am = getattr(x, "_mmt_amax", None)
-        if am is not None and am[1] == x._version and type(am[0]) is _Slot:
-            ent[1] = am[0]
+        if am is not None and am[1] == x._version and type(am[0]) is _Slot and type(am[0].pool) is _StatPool:
+            ent[1] = am[0]   # (a launch plan's slots never travel to the host: they would sit here for ever and switch the lagged
+                             # test off for the site -- replayed passes rely on the kernels' device-side guard alone)
     if not ent[0] and count:
         F16_STATS["fallback"] = F16_STATS.get("fallback", 0) + 1
     return ent[0]
@@ -543,7 +545,9 @@ _NO_RECORD = frozenset(("mmt_conv_wants_planes", "mmt_conv_pg_wanted", "mmt_conv
 LAYOUT_EPOCH = [0]    # bumped when a flat model (re)allocates its plane buffers (engine/flat.py)
 LAUNCH_PLANS = os.environ.get("MMT_LAUNCH_PLANS", "1") != "0"
 _LP_SLOTS = 512
-_LAUNCH_PLANS = {}
+_LP_MAX = 4           # plans kept (least recently used first out)
+_LAUNCH_PLANS = {}    # insertion-ordered: the least recently used plan first
+_LP_LOCK = _threading.Lock()
 
 
 class _LibProxy(object):
@@ -619,10 +623,11 @@ def _compile_plan(plan):
 
 
 class LaunchPlan(object):
-    __slots__ = ("calls", "result", "in_ptr", "slot_buf", "slot_next", "pool", "base", "gen", "host_gen", "event", "host", "seen", "segs")
+    __slots__ = ("calls", "result", "in_ptr", "slot_buf", "slot_next", "pool", "base", "gen", "host_gen", "event", "host", "seen", "segs",
+                 "dead")
 
     def __init__(self, device):
-        self.calls, self.result, self.in_ptr, self.seen = [], None, None, 0
+        self.calls, self.result, self.in_ptr, self.seen, self.dead = [], None, None, 0, False
         self.slot_buf = torch.zeros((_LP_SLOTS, STAT_W), dtype=torch.float32, device=device)
         self.slot_next = 0
         self.pool = torch.cuda.MemPool()
@@ -648,13 +653,18 @@ def planned(tag, fn, x):
     env = os.environ.get   # (the library's per-call switches -- A/B timing, parity tests -- choose kernels: part of the key)
     key = (tag, tuple(x.shape), x.dtype, _stream(), _PLAN_EPOCH[0], PLANES_EPOCH, LAYOUT_EPOCH[0], F16X2, _PREC, _BF16_STORAGE,
            env("MMT_STRIP"), env("MMT_SPLITK"), env("MMT_ROWS"), env("MMT_PG"), env("MMT_C64"), env("MMT_DIRECT_EPI"))
-    plan = _LAUNCH_PLANS.get(key)
-    if plan is None:
-        if len(_LAUNCH_PLANS) > 32:
-            _LAUNCH_PLANS.clear()
-        plan = _LAUNCH_PLANS[key] = LaunchPlan(x.device)
+    with _LP_LOCK:
+        plan = _LAUNCH_PLANS.pop(key, None)
+        if plan is None:
+            # a small LRU: every plan pins the activations of a whole pass in a private memory pool, and batches of
+            # varying shape would otherwise pile up one footprint per shape; eviction is per key, never a blanket clear under
+            # another thread's replay
+            while len(_LAUNCH_PLANS) >= _LP_MAX:
+                _LAUNCH_PLANS.pop(next(iter(_LAUNCH_PLANS)))
+            plan = LaunchPlan(x.device)
+        _LAUNCH_PLANS[key] = plan   # (re-inserted at the recent end)
     plan.seen += 1
-    if plan.seen == 1 or getattr(_TLS, "rec", None) is not None:
+    if plan.seen == 1 or plan.dead or getattr(_TLS, "rec", None) is not None:
         return fn(x)
     if plan.seen == 2:
         _TLS.rec = plan
@@ -662,11 +672,16 @@ def planned(tag, fn, x):
             with torch.cuda.use_mem_pool(plan.pool):
                 plan.result = fn(x)
         except BaseException:
-            _LAUNCH_PLANS.pop(key, None)
+            with _LP_LOCK:
+                _LAUNCH_PLANS.pop(key, None)
             raise
         finally:
             _TLS.rec = None
         plan.in_ptr = x.data_ptr()
+        # the input must have reached the recorded launches as a direct pointer argument -- the only thing a replay patches.  A pass
+        # that read it through a tensor operation or an argument block would replay the recorded batch for ever: never replayed
+        if not any(type(a) is int and a == plan.in_ptr for _f, args in plan.calls for a in args):
+            plan.dead, plan.calls, plan.pool = True, [], None
         return plan.result
     plan.slot_buf.zero_()
     old, new = plan.in_ptr, x.data_ptr()
@@ -714,7 +729,6 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device   # (the C call, without torch.cuda's lazy-init wrapper: ~700 calls per step)
 
 
-import threading as _threading
 _TLS = _threading.local()   # .stream: raw handle that replaces the current stream for the launches of this thread (side-stream weight gradients)
 
 

@@ -41,12 +41,19 @@ class StemWithFixedBatchNorm(nn.Module):
             self._s2d_key = key
         return self._s2d_w
 
+    def fused_ok(self, x, count=True):
+        """does `x` take the one-launch stem?  (also asked by the detector's run_backbone: only that branch issues nothing but
+        C-ABI launches on the image itself, which is what a launch plan can replay -- the two branches below build a re-arranged
+        copy of the image with tensor operations a plan never records)"""
+        n, c, h, w = x.shape
+        return (h % 4 == 0 and w % 4 == 0 and c == 3 and H.F16X2 and H.get_conv_precision() == 3 and not H.bf16_storage()
+                and x.dtype == torch.float32 and x.is_contiguous() and self.conv1.out_channels == 64 and _STEM_FUSED[0]
+                and H._site_ok(("stem", self.conv1.weight.data_ptr()), x, count=count))
+
     def forward(self, x):
         n, c, h, w = x.shape
         s, b = self.bn1.folded()
-        if (h % 4 == 0 and w % 4 == 0 and c == 3 and H.F16X2 and H.get_conv_precision() == 3 and not H.bf16_storage()
-                and x.dtype == torch.float32 and x.is_contiguous() and self.conv1.out_channels == 64 and _STEM_FUSED[0]
-                and H._site_ok(("stem", self.conv1.weight.data_ptr()), x)):
+        if self.fused_ok(x):
             # round 5: the whole stem -- convolution, FrozenBN, ReLU, max pool -- as one launch (csrc/conv_stem.hip): the 537 MB of
             # un-pooled output (8 x 1024^2) never exist; bit-identical to the three launches below
             return H.stem_fused(x, self._s2d_weight(), s, b)

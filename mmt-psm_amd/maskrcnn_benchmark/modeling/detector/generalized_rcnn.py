@@ -56,9 +56,20 @@ class GeneralizedRCNN(nn.Module):
         from maskrcnn_benchmark import _hip
         if (_hip.LAUNCH_PLANS and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
                 and _hip.PROFILE is None and _hip.F16X2 and _hip.get_conv_precision() == 3 and not _hip.bf16_storage()
-                and getattr(self.backbone.body, "grad_ready", None) is None):
-            return _hip.planned(("backbone", id(self)), lambda t: tuple(self.backbone(t)), x)
+                and getattr(self.backbone.body, "grad_ready", None) is None
+                and self.backbone.body.stem.fused_ok(x, count=False)):
+            # (only the fused stem reads the image through C-ABI launches alone; the key carries what else selects
+            # launches or addresses: the stem switch and this model's weight epoch -- bumped by load_state_dict)
+            from maskrcnn_benchmark.modeling.backbone.backbone import _STEM_FUSED
+            return _hip.planned(("backbone", id(self), _STEM_FUSED[0], getattr(self, "_weights_epoch", 0)),
+                                lambda t: tuple(self.backbone(t)), x)
         return tuple(self.backbone(x))
+
+    def load_state_dict(self, *args, **kwargs):
+        """nn.Module.load_state_dict; the folded-BN / space-to-depth tensors and packed planes a recorded launch plan points at may be
+        re-made afterwards, so plans recorded for the old weights are never replayed again"""
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
+        return super().load_state_dict(*args, **kwargs)
 
     def set_replay(self, replay):
         self._replay = replay

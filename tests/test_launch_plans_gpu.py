@@ -89,3 +89,56 @@ def test_replayed_backbone_pass_is_the_pass(det, c_replay, monkeypatch):
     n = len(H._LAUNCH_PLANS)
     m.run_backbone(xs[0])
     assert len(H._LAUNCH_PLANS) == n and all(p.seen in (6, 3) for p in H._LAUNCH_PLANS.values())
+
+
+def test_only_the_fused_stem_is_planned_and_new_weights_retire_a_plan(det):
+    """the un-fused stems rebuild the image with tensor operations a plan never records -- such passes are not
+    planned at all; the plan key carries the stem switch and the model's weight epoch; a pass whose recorded launches never saw the
+    input pointer is never replayed"""
+    import synthetic
+    H, m = det
+    from maskrcnn_benchmark.modeling.backbone import backbone as B
+    g = torch.Generator().manual_seed(3)
+    xs = [(torch.randn(2, 3, 128, 160, generator=g) * 50.0).cuda() for _ in range(4)]
+    with torch.no_grad():
+        H.LAUNCH_PLANS = False
+        want = [tuple(t.clone() for t in m.run_backbone(x)) for x in xs]
+        H.LAUNCH_PLANS = True
+        B._STEM_FUSED[0] = False
+        try:
+            for x, w in zip(xs, want):      # (the three-launch stem: same bits as the fused one, every input seen afresh)
+                got = m.run_backbone(x)
+                assert all(torch.equal(a, b) for a, b in zip(got, w))
+            assert len(H._LAUNCH_PLANS) == 0
+        finally:
+            B._STEM_FUSED[0] = True
+        odd = (torch.randn(2, 3, 126, 158, generator=g) * 50.0).cuda()   # H, W not multiples of 4: the space-to-depth stem
+        a = tuple(t.clone() for t in m.run_backbone(odd))
+        for _ in range(3):
+            b = m.run_backbone(odd)
+        assert len(H._LAUNCH_PLANS) == 0 and all(torch.equal(p, q) for p, q in zip(a, b))
+        for x in xs:
+            m.run_backbone(x)
+        assert len(H._LAUNCH_PLANS) == 1
+        # new weights: a new key, the old plan is not replayed (its result would be the old model's)
+        shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "state_shapes.json")))["shapes"]
+        m.load_state_dict({k: v.cuda() for k, v in synthetic.make_weights(shapes, seed=5).items()}, strict=False)
+        from maskrcnn_benchmark.engine.flat import flatten_model
+        flatten_model(m).refresh_planes()
+        H.LAUNCH_PLANS = False
+        want2 = [tuple(t.clone() for t in m.run_backbone(x)) for x in xs]
+        H.LAUNCH_PLANS = True
+        assert not torch.equal(want2[0][0], want[0][0])
+        for x, w in zip(xs, want2):
+            got = m.run_backbone(x)
+            assert all(torch.equal(p, q) for p, q in zip(got, w))
+        # a pass that does not hand its input to a launch directly: recorded once, found out, never replayed
+        seen = []
+
+        def indirect(t):
+            seen.append(1)
+            return (H.maxpool3x3s2(H.nhwc(t.clone().view(2, 3, 128, 160)[:, :, :, :].contiguous(memory_format=torch.channels_last).repeat(1, 4, 1, 1)[:, :12])),)
+
+        outs = [H.planned(("indirect",), indirect, x)[0].clone() for x in xs]
+        assert len(seen) == len(xs) and not torch.equal(outs[2], outs[3])
+        assert len(H._LAUNCH_PLANS) <= H._LP_MAX
