@@ -137,7 +137,9 @@ def test_only_the_fused_stem_is_planned_and_new_weights_retire_a_plan(det):
 
         def indirect(t):
             seen.append(1)
-            return (H.maxpool3x3s2(H.nhwc(t.clone().view(2, 3, 128, 160)[:, :, :, :].contiguous(memory_format=torch.channels_last).repeat(1, 4, 1, 1)[:, :12])),)
+            z = t.new_zeros((t.shape[0], 4, t.shape[2], t.shape[3]))   # (tensor operations: invisible to a plan)
+            z[:, :3] = t
+            return (H.maxpool3x3s2(H.nhwc(z)),)
 
         outs = [H.planned(("indirect",), indirect, x)[0].clone() for x in xs]
         assert len(seen) == len(xs) and not torch.equal(outs[2], outs[3])
