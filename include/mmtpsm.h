@@ -326,6 +326,23 @@ typedef struct {
    * [N * H][Cin / 16][W][16] (mmt_split_planes_f16_rb): the 16 channels of a 16-k step of consecutive pixels of an image row are
    * contiguous, so a copy instruction of the kernel reads runs of up to 1 KiB instead of 32-byte pieces of 32 cache lines */
   int x_planes_layout;
+  /* Round 6: planes out of the PRODUCER's epilogue (the split pass in front of a plane-fed consumer disappears).  y_rb != NULL: the
+   * launch also writes y as the two fp16 planes of y * s in the row-blocked order [N * Ho][Cout / 16][Wo][16] (plane q at y_rb +
+   * q * y_rb_stride elements), s = *y_rb_scale -- a power of two the CALLER chose before the values exist (the host side keeps one
+   * per producing site: the largest |y| any call of the site recorded during the previous step x 8 head-room, mmt_rb_scales_update).
+   * Needs Cout % 16 == 0, out_stride == 1, fp32 y, N * Ho * Wo * Cout < 2^30; honoured by every epilogue form of
+   * mmt_conv_forward_f16x2 / mmt_conv3x3_strip_f16x2 / mmt_conv_forward_pg (register-direct, LDS-staged, split-K finish,
+   * row-resident), refused (MMT_EINVAL) elsewhere.  y_amax_next: a second device word that receives max |y| like y_amax[0]
+   * (conditional atomic, once per block) -- the site's pending maximum, folded into its scale by mmt_rb_scales_update.
+   * x_planes_lag = 1 tells a CONSUMER that the scale of its x_planes (*s_x) was chosen that way: its range guard then tests
+   * max |x| * s_x against the fp16 range and the sampled mean against the low term's, with the actual scale, and takes the exact
+   * fp32 path for the launch when either fails (a tensor that outgrew last step's head-room, or shrank below it).
+   * mmt_conv_wgrad_planes: bit 0 = the planes of x, bit 1 = the planes of dy. */
+  void* y_rb;
+  long y_rb_stride;
+  const float* y_rb_scale;
+  void* y_amax_next;
+  int x_planes_lag;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);
@@ -430,6 +447,21 @@ int mmt_replay(const mmt_call* calls /*[host]*/, int n, int* failed_index /*[hos
  * mmt_split_planes_f16, another order. */
 int mmt_split_planes_f16_rb(const float* x, void* planes, long plane_stride, int rows, int W, int C, const float* amax,
                             float* scale_out, void* stream);
+/* Round 6 (planes out of the producers, see mmt_conv_args.y_rb).
+ * mmt_conv_writes_rb: 1 when the launch mmt_conv_forward_f16x2 / mmt_conv3x3_strip_f16x2 / mmt_conv_forward_pg would take for
+ *   these shapes writes y_rb from its epilogue (asked by the host before it allocates the planes); 0: the consumer splits itself.
+ * mmt_sum_stats_rb: mmt_sum_stats (y = a + b (+ c) (+ d), statistics into `slot`) over an NHWC tensor of `rows` = N * H image rows
+ *   of W pixels x C channels that also writes y's row-blocked fp16 planes with *scale (planes NULL: the sum and its statistics
+ *   alone -- a site's first step), and max |y| into *amax_next (or NULL) --
+ *   replaces autograd's AccumulateGrad additions of a multi-consumer tensor (layers/fused.py::ForkFn) AND the split pass of the
+ *   3x3 data gradient behind it (reference: autograd of backbone/fpn.py:57-69 / rpn/rpn.py:39-46).
+ * mmt_rb_scales_update: once per training step over the host side's table of producing sites, state[2 i] = scale, state[2 i + 1] =
+ *   pending maximum (what y_amax_next / amax_next accumulated): scale <- the power of two that puts 8 x pending into [2^13, 2^14),
+ *   pending <- 0; sites without a pending maximum keep their scale. */
+int mmt_conv_writes_rb(const mmt_conv_args* a /*[host]*/);
+int mmt_sum_stats_rb(const float* a, const float* b, const float* c, const float* d, float* y, int rows, int W, int C, float* slot,
+                     void* planes, long plane_stride, const float* scale, float* amax_next, void* stream);
+int mmt_rb_scales_update(float* state, int n, void* stream);
 /* Round 5: the plane-fed implicit GEMM (csrc/conv_pgemm.hip) -- the same arithmetic (two-term fp16 split, 3 products, mode 3) for
  * any (KH, KW, stride, pad) with Cin % 16 == 0, Cout > 32, res_mode <= 1, out_stride == 1, no `mul`, fp32 tensors: x_planes = the
  * two fp16 planes of x * s_x with x's NHWC indexing (mmt_split_planes_f16), w_planes = the packed fp16 planes of w * s_w

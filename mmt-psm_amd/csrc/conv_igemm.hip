@@ -80,6 +80,7 @@ __device__ __forceinline__ void conv_amax_commit(const ConvP& p, AmaxAcc a, cons
     for (int i = 1; i < nw; i++) { m = fmaxf(m, red[0][i]); sm += red[1][i]; cn += red[2][i]; }
     const unsigned bits = __builtin_bit_cast(unsigned, m);
     if (m > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, bits);
+    if (p.amax_next && m > 0.f && bits > __hip_atomic_load(p.amax_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_next, bits);
     if (stats && cn > 0.f) {
       const int k = (lin >> 6) & 15;
       atomicAdd((float*)p.amax_out + 1 + k, sm);
@@ -126,6 +127,8 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
         for (int e = 0; e < 4; e++) sc[e] *= inv;
       }
       const bool res_h = p.io & IO_RES, mask_h = p.io & IO_MASK;
+      const RbGeom rbg = rb_geom(p);                       // round 6: y also as row-blocked fp16 planes (host: Cout % 16 == 0)
+      const float rbs = p.yrb ? *p.yrb_s : 1.f;
       // rows in groups of G: every residual / mask / mul load of a group is issued before the first use, so a thread
       // pays one global-load latency per group instead of one per row (the row loop is not unrollable past its stores)
       constexpr int ROWS = BM / RPP, G = ROWS < 4 ? ROWS : 4;
@@ -207,6 +210,7 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
 #pragma unroll
             for (int q = 0; q < 3; q++) *(uint2*)(p.ypl + q * p.ypl_stride + oidx[g]) = o[q];
           }
+          if (p.yrb) rb_store4(p, rbg, m0 + r0 + (g0 + g) * RPP, c, f32x4{v[0], v[1], v[2], v[3]}, rbs);
         }
       }
     }
@@ -1184,6 +1188,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   const int ss0 = 2 * (int)((long)ks * pairs / ksplit), nss = 2 * (int)((long)(ks + 1) * pairs / ksplit) - ss0;
   F16Guard guard = {};
   if constexpr (F16) guard = f16_guard_load(p.guard_x);   // issued here, tested behind the first copies (see conv_fwd_glds_kernel)
+  const float s_lag = (F16 && p.xpl_lag) ? *p.f16_sx : 0.f;   // (round 6) planes written by the producer with a scale fixed beforehand
 
   // ---- copy slots of this wave.  Slots 0 .. SA-1 carry A items (wave + 8 i < NA: plane, strip row r, 32-pixel block),
   // slots SA .. SA+SB-1 B items (tap, plane, 32-channel block).  Everything that does not change from super-step to
@@ -1344,7 +1349,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   for (int i = 0; i < NSLOT; i++) issue_slot(i, 0);
   fill_advance();
   if constexpr (F16) {   // the range guard, in the shadow of the first copies' latency (see conv_fwd_glds_kernel)
-    if (f16_guard_bad(guard)) {
+    if (p.xpl_lag ? f16_guard_bad_lag(guard, s_lag) : f16_guard_bad(guard)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       float* slab = ksplit > 1 ? ws + ((long)tile_lin * ksplit + ks) * (BM * BN) : nullptr;
       conv_slow_tile((img * p.Ho + ho0) * p.Wo + wo0, TW, p.Wo, BM, n0, BN, slab, ks != 0, tid, 512, blockIdx.x);
@@ -3026,6 +3031,8 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   p.xpl = (const unsigned short*)a->x_planes; p.xpl_stride = a->x_plane_stride;
   p.ypl = (unsigned short*)a->y_planes; p.ypl_stride = a->y_plane_stride;
   p.xpl_rb = a->x_planes_layout;
+  p.yrb = (unsigned short*)a->y_rb; p.yrb_stride = a->y_rb_stride; p.yrb_s = a->y_rb_scale;
+  p.amax_next = (unsigned*)a->y_amax_next; p.xpl_lag = a->x_planes_lag;
   p.f16_sx = p.f16_sw = nullptr;
   p.f16_ax = 0;
   p.guard_x = (const float*)a->f16_guard_x; p.guard_dy = (const float*)a->f16_guard_dy;
@@ -3043,6 +3050,9 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   }
   if ((p.io & IO_Y) && (p.ypl || a->mul)) return MMT_EINVAL;
   if (p.ypl && ((a->Cout & 3) || ((size_t)p.ypl & 7) || (p.ypl_stride & 3) || a->out_stride > 1)) return MMT_EINVAL;
+  if (p.yrb && (!p.yrb_s || (a->Cout & 15) || a->out_stride > 1 || (p.io & IO_Y) || ((size_t)p.yrb & 15) || (p.yrb_stride & 7) ||
+                (long)a->N * a->Ho * a->Wo * a->Cout >= (1L << 30) || p.yrb_stride < (long)a->N * a->Ho * a->Wo * a->Cout))
+    return MMT_EINVAL;
   if ((long)p.N * p.Ho * p.Wo > 0x7fffffffL) return MMT_EINVAL;
   if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL || (long)p.N * p.Ho * p.Wo * p.Cout >= 0x7fffffffL ||
       (long)p.Cout * p.KH * p.KW * p.Cin >= 0x7fffffffL) return MMT_EINVAL;  // kernels use 32-bit element offsets
@@ -3562,6 +3572,21 @@ extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x,
 }
 
 static int pick_variant(const ConvP& p);
+// round 6: would the launch this call takes on the fp16 split write row-blocked planes of y from its epilogue (mmt_conv_args.y_rb)?
+// The register-direct, LDS-staged and split-K-finish epilogues do; the patch kernels (layer1's 3x3, the stem) do not
+static bool rb_epilogue_ok(const ConvP& p) {
+  if ((p.Cout & 15) || p.out_stride > 1 || (p.io & IO_Y) || p.mul || (long)p.M * p.Cout >= (1L << 30)) return false;
+  if (c64_shape(p)) return false;
+  if (rows_shape(p, true)) return false;
+  return true;
+}
+extern "C" int mmt_conv_writes_rb(const mmt_conv_args* a) {
+  ConvP p;
+  if (fill(p, a) || precision() != 3 || p.io) return 0;
+  p.f16_ax = 1;
+  p.f16_sx = p.f16_sw = (const float*)16;   // (shape question: placeholders for the shape tests that look at them)
+  return rb_epilogue_ok(p) ? 1 : 0;
+}
 // any convolution the DMA-fed kernel takes (Cin % 16 == 0, Cout > 32), raw fp32 x: x_amax = device max |x|, w_planes = the two
 // fp16 planes of the packed weight, s_w their device scale
 extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_amax, const float* s_w, void* stream) {
@@ -3574,6 +3599,7 @@ extern "C" int mmt_conv_forward_f16x2(const mmt_conv_args* a, const float* x_ama
   if (variant == 0) return MMT_EINVAL;
   p.f16_sx = x_amax; p.f16_sw = s_w; p.f16_ax = 1;
   hipStream_t s = (hipStream_t)stream;
+  if (p.yrb && !rb_epilogue_ok(p)) return MMT_EINVAL;   // (the caller asks mmt_conv_writes_rb first)
   if (c64_shape(p)) return launch_c64(p, s);   // layer1's 3x3, 64 -> 64 channels: the patch kernel (conv_stem.hip, round 5)
   if (rows_shape(p, true)) {   // 1x1 layers with K = 64 / 128 / 256: rows resident in registers as fp16 fragments
     if (p.mask) {
@@ -3682,7 +3708,7 @@ extern "C" int mmt_conv_forward(const mmt_conv_args* a, void* stream) {
   ConvP p;
   int e = fill(p, a);
   if (e) return e;
-  if (!p.y || p.xpl_rb) return MMT_EINVAL;   // (row-blocked planes: the fp16-split entry points only)
+  if (!p.y || p.xpl_rb || p.yrb) return MMT_EINVAL;   // (row-blocked planes: the fp16-split entry points only)
   if (p.M == 0 || p.Cout == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int variant = pick_variant(p);

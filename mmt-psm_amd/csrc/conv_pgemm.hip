@@ -101,6 +101,8 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int HoWo = p.Ho * p.Wo;
   const F16Guard guard = f16_guard_load(p.guard_x);   // issued here, tested behind the prologue's copies
+  const float s_lag = p.xpl_lag ? *p.f16_sx : 0.f;    // (round 6) planes written by the producer with a scale fixed beforehand
+  auto guard_bad = [&]() { return p.xpl_lag ? f16_guard_bad_lag(guard, s_lag) : f16_guard_bad(guard); };
 
   // ---- K range of this wave's group
   const int nkt_all = p.K >> 4, spt = p.Cin >> 4;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
         load_step(setc);
       };
       pg_unroll<0, S>([&](auto ic) { load_step(ic); });
-      if (!f16_guard_bad(guard)) {
+      if (!guard_bad()) {
         pg_unroll<0, S - 1>([&](auto ic) { pump(ic); });   // steps 0 .. S - 2 into stages 0 .. S - 2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // (0) step 0 has landed
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
     } else {
 #pragma unroll
     for (int t = 0; t < S - 1; t++) copy_step(t);      // prologue: steps 0 .. S - 2 into stages 0 .. S - 2
-    if (!f16_guard_bad(guard)) {
+    if (!guard_bad()) {
       wait_copies();
       __builtin_amdgcn_s_barrier();                    // (0) step 0 has landed
       copy_step(S - 1);
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
         }
       }
     };
-    if (!f16_guard_bad(guard)) {
+    if (!guard_bad()) {
       __builtin_amdgcn_s_barrier();                    // (0) step 0 has landed
       f16x8 faP[2][2], fbP[2][2], faQ[2][2], fbQ[2][2];
 #pragma unroll
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  if (f16_guard_bad(guard)) {   // this tensor's dynamic range defeats fp16 (uniform over the grid): exact fp32 products, whole K, by
+  if (guard_bad()) {   // this tensor's dynamic range defeats fp16 (uniform over the grid): exact fp32 products, whole K, by
     if (ks == 0) conv_slow_tile(m0, BM, 0, BM, n0, BN, nullptr, false, tid, NTALL, blockIdx.x);   // the tile's first block
     return;
   }
@@ -438,25 +440,30 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
     if (*flag != (unsigned)(ksplit - 1)) return;
     if (tid == 0) __hip_atomic_store(tickets + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
     if (!copier) {   // (copy waves stay with the block to its last barrier)
-      f32x16 sum[OWN];
+      // the partial tiles are added straight into the accumulator registers (this block's own partial is in its slab like everybody
+      // else's, so the order is 0 .. ksplit - 1 whoever arrives last), four 16-byte loads in flight per owned sub-tile: a separate
+      // sum[OWN] beside acc[2][2] and sixteen loads in flight was 192 live registers of the 168 a 768-thread block has -- the
+      // 16 spilled registers / 107 scratch instructions VERDICT r5 found in <4, 1, 4>
       for (int j = 0; j < ksplit; j++) {
         const unsigned slab_off = tile_off + (unsigned)j * (unsigned)(SLAB16 * 16) + (unsigned)tid * 16u;
-        u32x4 t[OWN * 4];
+        int o = 0;
 #pragma unroll
-        for (int e = 0; e < OWN * 4; e++) t[e] = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(slab_off + (unsigned)(e * NT * 16)), 0, 16);
+        for (int i = 0; i < 4; i++) {
+          if (i % KG == grp) {
+            u32x4 t[4];
 #pragma unroll
-        for (int e = 0; e < OWN * 4; e++) {
-          const f32x4 v = __builtin_bit_cast(f32x4, t[e]);
+            for (int r4 = 0; r4 < 4; r4++) t[r4] = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(slab_off + (unsigned)((o * 4 + r4) * NT * 16)), 0, 16);
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
-            if (j == 0) sum[e >> 2][4 * (e & 3) + c] = v[c]; else sum[e >> 2][4 * (e & 3) + c] += v[c];
+            for (int r4 = 0; r4 < 4; r4++) {
+              const f32x4 v = __builtin_bit_cast(f32x4, t[r4]);
+#pragma unroll
+              for (int c = 0; c < 4; c++) {
+                if (j == 0) acc[i >> 1][i & 1][4 * r4 + c] = v[c]; else acc[i >> 1][i & 1][4 * r4 + c] += v[c];
+              }
+            }
+            o++;
           }
         }
-      }
-      int o = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (i % KG == grp) { acc[i >> 1][i & 1] = sum[o < OWN ? o : 0]; o++; }
       }
     }
   }
@@ -535,6 +542,96 @@ __global__ __launch_bounds__(256) void split_planes_f16_rb_small_kernel(const fl
   const long dst = ((row * (C >> 4) + (c4 >> 2)) * W + w) * 16 + (c4 & 3) * 4;
 #pragma unroll
   for (int q = 0; q < 2; q++) *(uint2*)(pl + q * plane_stride + dst) = o[q];
+}
+
+// ---- round 6: y = a + b (+ c) (+ d) (the gradient of a tensor with several consumers, mmt_sum_stats) that ALSO leaves y as row-blocked
+// fp16 planes of y * *scale for the plane-fed data-gradient launch that consumes it: the split pass of that launch disappears.  Same
+// block shape as split_planes_f16_rb_kernel (32 pixels of an image row x up to 256 channels, planes transposed through LDS); the
+// statistics slot gets max |y| from every block and sum / count from every 16th (as sum_stats_kernel), `next` the same maximum.
+__global__ __launch_bounds__(256) void sum_stats_rb_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                           const float* __restrict__ d, float* __restrict__ y, unsigned short* __restrict__ pl,
+                                                           const long plane_stride, const int W, const int C, const int segs,
+                                                           const float* __restrict__ scale, unsigned* __restrict__ out,
+                                                           unsigned* __restrict__ next) {
+  constexpr int CBS = 1024 + 32;
+  __shared__ __attribute__((aligned(16))) char tile[2 * 16 * CBS];
+  __shared__ float wred[3][4];
+  const float s = *scale;
+  const int row = blockIdx.x / segs, w0 = (blockIdx.x % segs) * 32, c0 = blockIdx.y * 256;
+  const int cc = min(256, C - c0), c4n = cc >> 2, ncb = cc >> 4, npx = min(32, W - w0);
+  const long base = ((long)row * W + w0) * C + c0;
+  const int total = npx * c4n;
+  f32x4 v[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int i = threadIdx.x + 256 * u;
+    const int px = i / c4n, c4 = i - px * c4n;
+    const long o = base + (long)px * C + c4 * 4;
+    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < total) {
+      v[u] = ldg4(a + o) + ldg4(b + o);
+      if (c) v[u] += ldg4(c + o);
+      if (d) v[u] += ldg4(d + o);
+    }
+  }
+  float m = 0.f, sum = 0.f, cnt = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int i = threadIdx.x + 256 * u;
+    if (i < total) {
+      const int px = i / c4n, c4 = i - px * c4n;
+      *(f32x4*)(y + base + (long)px * C + c4 * 4) = v[u];
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
+      sum += (fabsf(v[u][0]) + fabsf(v[u][1])) + (fabsf(v[u][2]) + fabsf(v[u][3]));
+      cnt += 4.f;
+      if (pl) {
+        uint2 o[2];
+        split4h(v[u], s, o);
+#pragma unroll
+        for (int q = 0; q < 2; q++) *(uint2*)(tile + (q * 16 + (c4 >> 2)) * CBS + px * 32 + (c4 & 3) * 8) = o[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); sum += __shfl_xor(sum, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+  if ((threadIdx.x & 63) == 0) { wred[0][threadIdx.x >> 6] = m; wred[1][threadIdx.x >> 6] = sum; wred[2][threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  const int per_cb = npx * 2;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int j = threadIdx.x + 256 * u;
+    if (pl && j < 2 * ncb * per_cb) {
+      const int q = j / (ncb * per_cb), r = j - q * (ncb * per_cb), cb = r / per_cb, k = r - cb * per_cb;
+      const uint4 t = *(const uint4*)(tile + (q * 16 + cb) * CBS + k * 16);
+      *(uint4*)(pl + q * plane_stride + (((long)row * (C >> 4) + (c0 >> 4) + cb) * W + w0) * 16 + k * 8) = t;
+    }
+  }
+  if (threadIdx.x == 0) {
+    const float mm = fmaxf(fmaxf(wred[0][0], wred[0][1]), fmaxf(wred[0][2], wred[0][3]));
+    const unsigned bits = __builtin_bit_cast(unsigned, mm);
+    if (mm > 0.f && bits > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, bits);
+    if (next && mm > 0.f && bits > __hip_atomic_load(next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(next, bits);
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((lin & 15) == 0) {
+      const float sm = (wred[1][0] + wred[1][1]) + (wred[1][2] + wred[1][3]), cn = (wred[2][0] + wred[2][1]) + (wred[2][2] + wred[2][3]);
+      if (cn > 0.f) {
+        const int k = (lin >> 4) & 15;
+        atomicAdd((float*)out + 1 + k, sm);
+        atomicAdd((float*)out + 17 + k, cn);
+      }
+    }
+  }
+}
+
+// the producing sites' scales for the NEXT step (one launch per step): state[i] = {scale, pending maximum (float bits)}; a site that
+// recorded a maximum since the last call gets the power of two that puts 8 x that maximum into [2^13, 2^14) -- three binades of
+// head-room over the largest value any call of the site produced -- and its pending maximum is cleared; sites nobody called keep theirs
+__global__ void rb_scales_update_kernel(float* __restrict__ state, const int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float pend = state[2 * i + 1];
+  if (pend > 0.f && pend < 3.0e38f) state[2 * i] = f16_scale_of_fwd(pend) * 0.125f;
+  state[2 * i + 1] = 0.f;
 }
 
 // is this call one the plane-fed kernel takes?  (shape / epilogue form only; the caller checked planes and arithmetic)
@@ -638,6 +735,28 @@ extern "C" int mmt_split_planes_f16_rb(const float* x, void* planes, long plane_
   return 0;
 }
 
+extern "C" int mmt_sum_stats_rb(const float* a, const float* b, const float* c, const float* d, float* y, int rows, int W, int C,
+                                float* slot, void* planes, long plane_stride, const float* scale, float* amax_next, void* stream) {
+  const long n = (long)rows * W * C;
+  if (!a || !b || !y || !slot || !scale || (!c && d) || rows < 0 || W < 1 || C < 16 || (C & 15) || (planes && plane_stride < n) ||
+      (plane_stride & 7) || ((size_t)planes & 15) || (((size_t)a | (size_t)b | (size_t)c | (size_t)d | (size_t)y) & 15) || n >= (1L << 30))
+    return MMT_EINVAL;
+  if (n == 0) return 0;
+  const int segs = mmt_cdiv(W, 32);
+  hipLaunchKernelGGL(sum_stats_rb_kernel, dim3(rows * segs, mmt_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, d, y,
+                     (unsigned short*)planes, plane_stride, W, C, segs, scale, (unsigned*)slot, (unsigned*)amax_next);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmt_rb_scales_update(float* state, int n, void* stream) {
+  if (!state || n < 0) return MMT_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(rb_scales_update_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, state, n);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmt_conv_forward_pg(const mmt_conv_args* a, const float* s_x, const float* s_w, int tile_rows, int ksplit, void* stream) {
   ConvP p;
   int e = fill(p, a);
@@ -657,6 +776,7 @@ extern "C" int mmt_conv_forward_pg(const mmt_conv_args* a, const float* s_x, con
   if (ksplit > 0) ks = ksplit;
   if (ks < 1 || ks * (256 / rows) > (p.K >> 4)) return MMT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+#ifdef MMT_PG_ABLATE   // (tools only: `make ablate` -> libmmtpsm_ablate.so for tools/bench_pg.py --ablate; the product library carries no DBG arm)
   if (const char* d = af ? nullptr : getenv("MMT_PG_DBG")) {   // ablations of the main loop (wrong results; tools/bench_pg.py --ablate)
     const int dbg = atoi(d);
     if (dbg == 32 || dbg == 64) {
@@ -686,10 +806,15 @@ extern "C" int mmt_conv_forward_pg(const mmt_conv_args* a, const float* s_x, con
       default: break;
     }
   }
+#endif
   if (af) {
+#ifdef MMT_PG_ABLATE   // (round-5 experiment, slower than planes + a split pass and 144 live registers of copy ring: tools build only)
     if (rows == 256) return launch_pg<4, 1, 4, 0, true>(p, s, ks);
     if (rows == 128) return launch_pg<2, 2, 4, 0, true>(p, s, ks);
     return launch_pg<1, 4, 3, 0, true>(p, s, ks);
+#else
+    return MMT_EINVAL;
+#endif
   }
   if (rows == 256) return launch_pg<4, 1, 4>(p, s, ks);
   if (rows == 128) return launch_pg<2, 2, 4>(p, s, ks);

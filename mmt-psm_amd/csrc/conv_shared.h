@@ -36,6 +36,10 @@ struct ConvP {
   int seg_z;
   int staged_epilogue;   // (A/B timing: MMT_DIRECT_EPI=0) the tiled and tap-strip kernels leave through the LDS-staged epilogue
   int xpl_rb;            // xpl is row-blocked: [N * H][Cin / 16][W][16] per plane (conv_pg_kernel only; mmt_conv_args.x_planes_layout)
+  // round 6: y also as two row-blocked fp16 planes of y * *yrb_s ([N Ho][Cout / 16][Wo][16]), written by the epilogue for a plane-fed
+  // consumer; amax_next: the producing site's pending maximum (-> next step's scale); xpl_lag: the scale of xpl was chosen before the
+  // tensor existed (the guard tests it against the recorded statistics, f16_guard_bad_lag)
+  unsigned short* yrb; long yrb_stride; const float* yrb_s; unsigned* amax_next; int xpl_lag;
 };
 constexpr float F16_CREST_HI = 131072.f;   // 2^17: max / mean |x| above which fp16's five exponent bits lose the bulk of the tensor
 constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;
@@ -83,6 +87,18 @@ __device__ __forceinline__ bool f16_guard_bad(const F16Guard& g) {
   return g.amax * cnt > tot * F16_CREST_HI;
 }
 
+// the same decision when the scale `s` of the planes was fixed BEFORE the tensor existed (planes written by the producer's epilogue
+// with last step's maximum x 8 head-room): the fp16 range is tested with the scale actually applied -- max |x| s must stay below the
+// largest fp16 number, and the sampled mean |x| s above 2^-4, which is where the test above puts it for a scale derived from the
+// tensor's own maximum (max |x| s in [2^13, 2^14), crest factor 2^17)
+__device__ __forceinline__ bool f16_guard_bad_lag(const F16Guard& g, const float s) {
+  const float tot = (g.s0 + g.s1) + (g.s2 + g.s3), cnt = (g.c0 + g.c1) + (g.c2 + g.c3);
+  if (!(g.amax == g.amax) || g.amax > 3.0e38f) return true;
+  if (g.amax * s > 60000.f) return true;
+  if (!(tot > 0.f)) return false;
+  return cnt > tot * s * 16.f;
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -122,6 +138,50 @@ __device__ __forceinline__ void split4h(const f32x4 v, const float s, uint2 (&o)
 }
 
 struct AmaxAcc { float amx = 0.f, asum = 0.f, acnt = 0.f; };   // max |y| / sum |y| / count over what a thread stores (p.amax_out)
+
+// ---- round 6: row-blocked fp16 planes of y from the epilogue (ConvP::yrb).  (h, l) of one value packed into a word: h in the low half
+__device__ __forceinline__ unsigned rb_split1(const float v, const float s) {
+  const float r = __builtin_amdgcn_fmed3f(v * s, -65504.f, 65504.f);   // (same clamp as split4h: a stale scale saturates, never inf)
+  const _Float16 h = (_Float16)r;
+  const _Float16 l = (_Float16)(r - (float)h);
+  return __builtin_bit_cast(unsigned, f16x2{h, l});
+}
+// byte offset of (output pixel m, channel c) inside one plane; pixel -> (image row, column) with one float reciprocal (exact for
+// m < 2^22 after the correction step)
+struct RbGeom { int Wo; float rWo; unsigned cb32; };   // cb32 = (Cout / 16) * Wo * 32: bytes of one image row of a plane
+__device__ __forceinline__ RbGeom rb_geom(const ConvP& p) {
+  return RbGeom{p.Wo, 1.f / (float)p.Wo, (unsigned)(p.Cout >> 4) * (unsigned)p.Wo * 32u};
+}
+__device__ __forceinline__ unsigned rb_row_off(const RbGeom& g, const int m) {   // offset of (pixel m, channel 0)
+  int row = (int)(((float)m + 0.5f) * g.rWo);
+  int w = m - row * g.Wo;
+  if (w < 0) { row--; w += g.Wo; } else if (w >= g.Wo) { row++; w -= g.Wo; }
+  return (unsigned)row * g.cb32 + (unsigned)w * 32u;
+}
+// four consecutive channels c .. c + 3 (c % 4 == 0) of pixel m, already split: 8 bytes into each plane
+__device__ __forceinline__ void rb_store4(const ConvP& p, const RbGeom& g, const int m, const int c, const f32x4 v, const float s) {
+  uint2 o[2];
+  split4h(v, s, o);
+  char* const d = (char*)p.yrb + rb_row_off(g, m) + (unsigned)(c >> 4) * ((unsigned)g.Wo * 32u) + (unsigned)(c & 15) * 2u;
+  *(uint2*)d = o[0];
+  *(uint2*)(d + p.yrb_stride * 2) = o[1];
+}
+// 4 x 4 transpose inside every quad of lanes: in[j] of lane k -> out[k] of lane j (two butterfly stages on DPP quad permutes)
+__device__ __forceinline__ void quad_transpose(unsigned (&w)[4], const int lane) {
+  const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+  for (int pr = 0; pr < 2; pr++) {   // pairs (0, 1), (2, 3) with the lane across bit 0
+    const unsigned send = o1 ? w[2 * pr] : w[2 * pr + 1];
+    const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);   // quad_perm [1, 0, 3, 2]
+    if (o1) w[2 * pr] = recv; else w[2 * pr + 1] = recv;
+  }
+#pragma unroll
+  for (int pr = 0; pr < 2; pr++) {   // pairs (0, 2), (1, 3) with the lane across bit 1
+    const unsigned send = o2 ? w[pr] : w[pr + 2];
+    const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);   // quad_perm [2, 3, 0, 1]
+    if (o2) w[pr] = recv; else w[pr + 2] = recv;
+  }
+}
 
 // ---- the fp16 split's slow, exact path (see f16_guard_bad): outputs (row i, column c) of a block's tile, i < rows,
 // c < ncols; row i is output pixel m = m_first + (i / run) * run_stride + (i % run) (one run of consecutive pixels for the tiled
@@ -190,11 +250,19 @@ __device__ __forceinline__ void conv_slow_tile(const int m_first, const int run,
     if (pk->mask) v = pk->mask[oidx] > 0.f ? v * pk->mask_scale : 0.f;
     if (pk->mul) v *= pk->mul[(long)m * pk->Cout + n];
     pk->y[oidx] = v;
+    if (pk->yrb) {   // the planes a plane-fed consumer was promised (one element at a time: this path is ~100 x slower anyway)
+      const unsigned hl = rb_split1(v, *pk->yrb_s);
+      const long row = (long)img * pk->Ho + ho;
+      const long e = ((row * (pk->Cout >> 4) + (n >> 4)) * pk->Wo + wo) * 16 + (n & 15);
+      pk->yrb[e] = (unsigned short)(hl & 0xffffu);
+      pk->yrb[pk->yrb_stride + e] = (unsigned short)(hl >> 16);
+    }
     const float av = fabsf(v);
     amx = fmaxf(amx, av); asum += av; acnt += 1.f;
   }
   if (!raw && pk->amax_out) {
     if (amx > 0.f) atomicMax(pk->amax_out, __builtin_bit_cast(unsigned, amx));
+    if (amx > 0.f && pk->amax_next) atomicMax(pk->amax_next, __builtin_bit_cast(unsigned, amx));
     if (pk->amax_stats && (lin & 63) == 0 && acnt > 0.f) {
       const int k = (lin >> 6) & 15;
       atomicAdd((float*)pk->amax_out + 1 + k, asum);
@@ -246,10 +314,21 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x1
   }
   auto off = [&](int a, int b, int r) { return ybase + (unsigned)(a * 32 + 8 * (r >> 2) + (r & 3)) * cout4 + cb[b]; };
   float amx = 0.f, asum = 0.f, acnt = 0.f;
+  // round 6: y also as row-blocked fp16 planes (p.yrb).  After a 4 x 4 transpose inside every quad of lanes, lane k of a quad holds
+  // the quad's four channels of row (4 j + k) of a register group j: 8 bytes per plane and lane, and the 16 lanes of a 16-channel block
+  // write 4 consecutive pixels x 32 bytes = one 128-byte run (the half wave above: the next four pixels)
+  const bool rb = p.yrb != nullptr;
+  const float rbs = rb ? *p.yrb_s : 1.f;
+  const RbGeom rbg = rb_geom(p);
+  const int rb_bytes = rb ? (int)((long)p.M * p.Cout * 2) : 0;
+  const __amdgpu_buffer_rsrc_t rrb0 = __builtin_amdgcn_make_buffer_rsrc((void*)(rb ? p.yrb : (unsigned short*)p.y), 0, rb_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrb1 = __builtin_amdgcn_make_buffer_rsrc((void*)(rb ? p.yrb + p.yrb_stride : (unsigned short*)p.y), 0, rb_bytes, 0x00020000);
+  const int mrow = (int)(ybase / cout4);   // output pixel of (tile row 0 + 4 (lane / 32))
 #pragma unroll
   for (int i = 0; i < TM * TN; i++) {
     if (!((own >> i) & 1)) continue;
     const int a = i / TN, b = i % TN;
+    float vv[16];
     float ur[16], um[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) { ur[r] = 0.f; um[r] = 1.f; }
@@ -275,6 +354,23 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x1
       asum += av;
       acnt += ok ? 1.f : 0.f;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)(ok ? off(a, b, r) : OOB), 0, 0);
+      vv[r] = v;
+    }
+    if (rb) {   // (one uniform branch per sub-tile: launches without planes pay nothing)
+      const int cq = (c0 + b * 32) & ~3;   // first channel of this lane's quad
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        unsigned w4[4] = {rb_split1(vv[4 * j], rbs), rb_split1(vv[4 * j + 1], rbs), rb_split1(vv[4 * j + 2], rbs), rb_split1(vv[4 * j + 3], rbs)};
+        quad_transpose(w4, lane);
+        const int rr = a * 32 + 8 * j + (lane & 3);
+        const bool ok = cok[b] && rr < rows_left;
+        const unsigned o = ok ? rb_row_off(rbg, mrow + rr) + (unsigned)(cq >> 4) * ((unsigned)rbg.Wo * 32u) + (unsigned)(cq & 15) * 2u : OOB;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 hh = {__builtin_amdgcn_perm(w4[1], w4[0], 0x05040100u), __builtin_amdgcn_perm(w4[3], w4[2], 0x05040100u)};
+        const u32x2 ll = {__builtin_amdgcn_perm(w4[1], w4[0], 0x07060302u), __builtin_amdgcn_perm(w4[3], w4[2], 0x07060302u)};
+        __builtin_amdgcn_raw_buffer_store_b64(hh, rrb0, (int)o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(ll, rrb1, (int)o, 0, 0);
+      }
     }
   }
   // statistics of the output (max |y|; sum |y| and count from every 64th block), reduced through `red`: a second __shared__ object
@@ -295,6 +391,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x1
       for (int i = 1; i < nw; i++) { m = fmaxf(m, red[i]); sm += red[16 + i]; cn += red[32 + i]; }
       const unsigned bits = __builtin_bit_cast(unsigned, m);
       if (m > 0.f && bits > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, bits);
+      if (p.amax_next && m > 0.f && bits > __hip_atomic_load(p.amax_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_next, bits);
       if (stats && cn > 0.f) {
         const int k = (lin >> 6) & 15;
         atomicAdd((float*)p.amax_out + 1 + k, sm);

@@ -46,6 +46,7 @@ struct WgP {
   const float* rowscale; float* dw; float* ws; float* dbias;
   int N, H, W, Cin, Cout, KH, KW, pad, ksplit;
   int dbg;   // (tools: 1 = every copy out of range -- zeros, no memory traffic; 2 = no fragment reads.  Wrong results)
+  int lag;   // round 6: bit 0 / bit 1 -- the planes of x / of dy were written by their producer's epilogue with a scale fixed beforehand
 };
 
 __global__ __launch_bounds__(768) void wgrad_pl_kernel(const WgP p) {
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(768) void wgrad_pl_kernel(const WgP p) {
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
   float bsum[2] = {0.f, 0.f};
   const bool do_bias = p.dbias != nullptr && tile_n == 0 && wn == 0 && !copier;
-  const bool slow = f16_guard_bad(gx) || f16_guard_bad(gd);
+  const bool slow = ((p.lag & 1) ? f16_guard_bad_lag(gx, *p.s_x) : f16_guard_bad(gx)) ||
+                    ((p.lag & 2) ? f16_guard_bad_lag(gd, *p.s_dy) : f16_guard_bad(gd));
 
   if (copier && !slow) {
     // ================================================================ copy wave: 16 of its group's 32 blocks per super-step
@@ -337,6 +339,7 @@ extern "C" int mmt_conv_wgrad_planes(const mmt_conv_args* a, const float* dy, co
   p.guard_x = (const float*)a->f16_guard_x; p.guard_dy = (const float*)a->f16_guard_dy;
   p.rowscale = rowscale; p.dw = dw; p.ws = workspace; p.dbias = dbias;
   p.dbg = getenv("MMT_WGPL_DBG") ? atoi(getenv("MMT_WGPL_DBG")) : 0;
+  p.lag = a->x_planes_lag;
   p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW; p.pad = a->pad; p.ksplit = ks;
   const int NP = a->KH * a->KW * a->Cin;
   const int tiles = (a->Cout >> 7) * (NP >> 7);

@@ -34,7 +34,9 @@ class ConvArgs(ctypes.Structure):
                 ("f16_x_amax", c_void_p), ("f16_dy_amax", c_void_p), ("y_amax_stats", c_int),
                 ("f16_guard_x", c_void_p), ("f16_guard_dy", c_void_p), ("w_src", c_void_p), ("w_src_scale", c_void_p),
                 ("x2", c_void_p), ("dy2", c_void_p), ("f16_x_amax2", c_void_p), ("f16_dy_amax2", c_void_p),
-                ("f16_guard_x2", c_void_p), ("f16_guard_dy2", c_void_p), ("x_planes_layout", c_int)]
+                ("f16_guard_x2", c_void_p), ("f16_guard_dy2", c_void_p), ("x_planes_layout", c_int),
+                ("y_rb", c_void_p), ("y_rb_stride", ctypes.c_long), ("y_rb_scale", c_void_p), ("y_amax_next", c_void_p),
+                ("x_planes_lag", c_int)]
 
 
 IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
@@ -132,6 +134,10 @@ _SIGS = {
     "mmt_split_planes_f16": [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_split_planes_f16_rb": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mmt_replay": [c_void_p, c_int, c_void_p],
+    "mmt_conv_writes_rb": [ctypes.POINTER(ConvArgs)],
+    "mmt_sum_stats_rb": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p,
+                         c_void_p, c_void_p],
+    "mmt_rb_scales_update": [c_void_p, c_int, c_void_p],
     "mmt_conv_wgrad_planes_splits": [ctypes.POINTER(ConvArgs)],
     "mmt_conv_wgrad_planes": [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -194,6 +200,7 @@ def set_f16x2(on):
     _F16W.clear()
     _F16SITE.clear()
     _SITES.clear()
+    rb_reset()
 
 
 # ---- per-tensor statistics of the fp16 split: every producing launch records max |y| AND sum |y| of its output in a slot of
@@ -363,9 +370,11 @@ def stats_of_convex_combination(out, sources):
     out._mmt_amax = (slot, out._version)
 
 
-def sum_stats(ts):
+def sum_stats(ts, rb_site=None):
     """sum of 2..4 equally shaped dense fp32 tensors (same memory order) in one launch; the statistics of the sum are recorded
-    (the consumers of the result then need no reduction pass: fp16-split scale, crest-factor test)"""
+    (the consumers of the result then need no reduction pass: fp16-split scale, crest-factor test).  rb_site (round 6): the sum is an
+    NHWC activation gradient that a plane-fed data-gradient launch consumes -- the same launch leaves its row-blocked fp16 planes
+    (include/mmtpsm.h: mmt_sum_stats_rb; the site's scale as in _rb_produce)"""
     a = ts[0]
     if not (2 <= len(ts) <= 4) or any(t.shape != a.shape or t.stride() != a.stride() or t.dtype != torch.float32 for t in ts):
         raise RuntimeError("sum_stats: 2..4 fp32 tensors of one shape and memory order")
@@ -381,6 +390,26 @@ def sum_stats(ts):
         raise RuntimeError("sum_stats: dense tensors only")
     slot = _amax_slot(a.device)
     p = [t.data_ptr() for t in ts] + [None] * (4 - len(ts))
+    if (rb_site is not None and RB_EPI and PG_RB and a.dim() == 4 and a.shape[1] % 16 == 0 and n < (1 << 30)
+            and a.is_contiguous(memory_format=torch.channels_last)):
+        t, i = _rb_site(rb_site, a.device)
+        if t is not None:
+            t.produced.add(i)
+            nxt = t.base + 8 * i + 4
+            if i in t.ready:
+                N, C, Hh, W = a.shape
+                pl = torch.empty((2, n), dtype=torch.float16, device=a.device)
+                _check(lib().mmt_sum_stats_rb(p[0], p[1], p[2], p[3], y.data_ptr(), N * Hh, W, C, slot.ptr, pl.data_ptr(), n,
+                                              t.base + 8 * i, nxt, _stream()), "mmt_sum_stats_rb")
+                y._mmt_amax = (slot, y._version)
+                y._mmt_rb = (pl, _rb_scale_view(t, i), y._version, "epi")
+                return y
+            # no scale yet: the sum alone (planes NULL); its maximum becomes the site's first pending maximum
+            N, C, Hh, W = a.shape
+            _check(lib().mmt_sum_stats_rb(p[0], p[1], p[2], p[3], y.data_ptr(), N * Hh, W, C, slot.ptr, None, 0, t.base + 8 * i, nxt,
+                                          _stream()), "mmt_sum_stats_rb")
+            y._mmt_amax = (slot, y._version)
+            return y
     _check(lib().mmt_sum_stats(p[0], p[1], p[2], p[3], y.data_ptr(), n, slot.ptr, _stream()), "mmt_sum_stats")
     y._mmt_amax = (slot, y._version)
     return y
@@ -430,17 +459,122 @@ def f16_split(x, site=None):
 
 WG_PLANES = os.environ.get("MMT_WGRAD_PLANES", "1") != "0"   # weight gradients of 3x3 layers from the row-blocked planes of both operands
 _WPLAN_PL = {}
-PG_AF = os.environ.get("MMT_PG_AF", "0") != "0"   # the plane-fed kernel reads fp32 x and splits it in its copy waves: no split pass
 PG_RB = os.environ.get("MMT_PG_RB", "1") != "0"   # input planes of the plane-fed and tap-strip kernels in the row-blocked order (A/B timing: 0)
 
 
+# ---- round 6: planes out of the PRODUCERS' epilogues.  A plane-fed consumer (tap-strip kernel, plane-fed GEMM, the
+# plane-fed weight gradient) used to run one mmt_split_planes_f16_rb pass over its input first: 92 launches and 6.7 GB of traffic per
+# step.  The launch that PRODUCES the tensor now writes the row-blocked planes from its epilogue (mmt_conv_args.y_rb).  The scale it
+# needs before the values exist is the producing SITE's: the largest |y| any call of the site recorded during the previous step, with
+# 8 x head-room (one device word per site, folded once per step by mmt_rb_scales_update: `rb_scales_update`, called by the trainer
+# after the optimiser step).  A consumer tests that scale against the statistics the producer recorded in the SAME launch
+# (x_planes_lag: max |x| s inside the fp16 range, sampled mean above the low term's) and computes the launch with exact fp32 products
+# when it fails -- so a tensor that outgrows the head-room costs time, never accuracy.  A site's first step (no scale yet) and shapes
+# whose producing kernel has no plane store keep the split pass.
+RB_EPI = os.environ.get("MMT_RB_EPI", "1") != "0"
+_RB_MAX = 2048
+_RB = {}            # device ordinal -> _RbTable
+_RB_LOCK = _threading.Lock()
+_RB_EPOCH = [0]     # bumped when a site becomes ready (launch plans recorded before that are re-recorded)
+
+
+class _RbTable(object):
+    __slots__ = ("state", "base", "index", "ready", "produced", "views", "ok")
+
+    def __init__(self, device):
+        self.state = torch.zeros((_RB_MAX, 2), dtype=torch.float32, device=device)   # [site] = (scale, pending max |y| of this step)
+        self.state[:, 0] = 1.0
+        self.base = self.state.data_ptr()
+        self.index, self.ready, self.produced, self.views, self.ok = {}, set(), set(), {}, {}
+
+
+def _rb_site(key, device):
+    """-> (table, index) of the producing site `key` (a weight's address and role); (None, -1): table full"""
+    t = _RB.get(device.index)
+    if t is None:
+        with _RB_LOCK:
+            t = _RB.get(device.index)
+            if t is None:
+                t = _RB[device.index] = _RbTable(device)
+    i = t.index.get(key)
+    if i is None:
+        with _RB_LOCK:
+            i = t.index.get(key)
+            if i is None:
+                if len(t.index) >= _RB_MAX:
+                    return None, -1
+                i = t.index[key] = len(t.index)
+    return t, i
+
+
+def _rb_scale_view(t, i):
+    v = t.views.get(i)
+    if v is None:
+        v = t.views[i] = t.state[i, 0:1]
+    return v
+
+
+def _rb_produce(a, y, key):
+    """the producing half, called with the launch's argument block filled: the site's pending maximum always (y_amax_next); the planes
+    when the site has a scale and the kernel this launch takes writes them -> (planes, scale view) or None"""
+    if not RB_EPI:
+        return None
+    t, i = _rb_site(key, y.device)
+    if t is None:
+        return None
+    a.y_amax_next = t.base + 8 * i + 4
+    t.produced.add(i)
+    if i not in t.ready:
+        return None
+    okk = (i, a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.stride, a.res_mode, a.mask is not None)
+    ok = t.ok.get(okk)
+    if ok is None:
+        ok = t.ok[okk] = (lib().mmt_conv_writes_rb(ctypes.byref(a)) == 1)
+    if not ok:
+        return None
+    n = y.numel()
+    pl = torch.empty((2, n), dtype=torch.float16, device=y.device)
+    a.y_rb, a.y_rb_stride, a.y_rb_scale = pl.data_ptr(), n, t.base + 8 * i
+    return pl, _rb_scale_view(t, i)
+
+
+def rb_scales_update():
+    """once per step, when every launch of the step has been issued and ordered in front of the current stream: the sites' pending
+    maxima become their scales for the next step (include/mmtpsm.h: mmt_rb_scales_update); sites that produced for the first time
+    are ready from now on"""
+    for t in list(_RB.values()):
+        n = len(t.index)
+        if n == 0 or not t.produced:
+            continue
+        _check(lib().mmt_rb_scales_update(t.base, n, _stream()), "mmt_rb_scales_update")
+        new = t.produced - t.ready
+        if new:
+            t.ready |= new
+            _RB_EPOCH[0] += 1
+        t.produced = set()
+
+
+def rb_reset():
+    """forget every site (tests; an arithmetic switch)"""
+    with _RB_LOCK:
+        _RB.clear()
+    _RB_EPOCH[0] += 1
+
+
 def f16_split_pg(x):
-    """x (dense NHWC fp32) -> (planes, scale tensor, layout) for the plane-fed implicit GEMM: the two fp16 planes of x * s in the
-    row-blocked order [N H][C / 16][W][16] (layout 1: mmt_split_planes_f16_rb) -- runs of up to 1 KiB per copy instruction of the
-    kernel instead of 32-byte pieces -- or, MMT_PG_RB=0, indexed like x (layout 0: f16_split).  The same values either way."""
+    """x (dense NHWC fp32) -> (planes, scale tensor, layout, lag) for the plane-fed kernels: the two fp16 planes of x * s in the
+    row-blocked order [N H][C / 16][W][16] (layout 1) -- runs of up to 1 KiB per copy instruction of the kernel instead of 32-byte
+    pieces.  Planes the PRODUCER of x wrote from its epilogue are taken as they are (lag 1: their scale was fixed before the tensor
+    existed, the consumer's guard tests it); else one mmt_split_planes_f16_rb pass, or, MMT_PG_RB=0, planes indexed like x (layout
+    0: f16_split).  The same values either way."""
     if not PG_RB:
         xp, st = f16_split(x)
-        return xp, st, 0
+        return xp, st, 0, 0
+    rb = getattr(x, "_mmt_rb", None)
+    if rb is not None and len(rb) > 3 and rb[2] == x._version and rb[3] == "epi":
+        F16_STATS["rb_epi"] = F16_STATS.get("rb_epi", 0) + 1
+        return rb[0], rb[1], 1, 1
+    F16_STATS["rb_split"] = F16_STATS.get("rb_split", 0) + 1
     # (no reuse of planes an earlier consumer left on the tensor: a launch plan's replay rewrites its result tensors in place without
     # touching their version counters -- the teacher's pyramid levels -- and planes made from the previous step's values would pass)
     N, C, Hh, W = x.shape
@@ -451,8 +585,8 @@ def f16_split_pg(x):
            "mmt_split_planes_f16_rb")
     # the planes stay with the tensor: the weight gradient of the same layer takes BOTH operands from planes (conv_wgrad: the input's
     # from the forward launch, the gradient's from the data-gradient launch) -- alive as long as the tensor is
-    x._mmt_rb = (xp, st, x._version)
-    return xp, st, 1
+    x._mmt_rb = (xp, st, x._version, "split")
+    return xp, st, 1, 0
 
 
 def f16_weight_planes(w, flip_scale=None, flipped=False):
@@ -540,7 +674,7 @@ def _lib_raw():
 # pool, which keeps their addresses for the plan's life; its statistics slots from a block of the plan's own) and REPLAYED from then
 # on: ~70 ctypes calls instead of the Python that derives them (a manual graph: hipGraph replays of the two models serialise in
 # this runtime).  Only the input's address is patched.  Queries are not recorded.
-_NO_RECORD = frozenset(("mmt_conv_wants_planes", "mmt_conv_pg_wanted", "mmt_conv_variant", "mmt_conv_ksplit", "mmt_conv_pg_plan",
+_NO_RECORD = frozenset(("mmt_conv_wants_planes", "mmt_conv_pg_wanted", "mmt_conv_writes_rb", "mmt_conv_variant", "mmt_conv_ksplit", "mmt_conv_pg_plan",
                         "mmt_conv_wgrad_splits", "mmt_get_conv_precision", "mmt_packed_weight_elems", "mmt_set_conv_precision"))
 LAYOUT_EPOCH = [0]    # bumped when a flat model (re)allocates its plane buffers (engine/flat.py)
 LAUNCH_PLANS = os.environ.get("MMT_LAUNCH_PLANS", "1") != "0"
@@ -651,7 +785,7 @@ def planned(tag, fn, x):
     plan: the first call of a (tag, shape, stream, arithmetic) runs as it is (caches warm up: weight planes, folded BN), the second
     is recorded, later ones are replayed.  -> fn's result (replays return the SAME tensor objects, refilled)."""
     env = os.environ.get   # (the library's per-call switches -- A/B timing, parity tests -- choose kernels: part of the key)
-    key = (tag, tuple(x.shape), x.dtype, _stream(), _PLAN_EPOCH[0], PLANES_EPOCH, LAYOUT_EPOCH[0], F16X2, _PREC, _BF16_STORAGE,
+    key = (tag, tuple(x.shape), x.dtype, _stream(), _PLAN_EPOCH[0], PLANES_EPOCH, LAYOUT_EPOCH[0], F16X2, _PREC, _BF16_STORAGE, _RB_EPOCH[0],
            env("MMT_STRIP"), env("MMT_SPLITK"), env("MMT_ROWS"), env("MMT_PG"), env("MMT_C64"), env("MMT_DIRECT_EPI"))
     with _LP_LOCK:
         plan = _LAUNCH_PLANS.pop(key, None)
@@ -1243,7 +1377,7 @@ def _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask):
              _PLAN_EPOCH[0]), src, src if base is None else base)
 
 
-def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_scale, f16_src):
+def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_scale, f16_src, rb_site=None):
     key, src, owner = _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask)
     plan = _PLAN.get(key) if key is not None else None
     if plan is None:
@@ -1279,26 +1413,26 @@ def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_
         a.w = wsrc.data_ptr()
     am = _amax_of(x)
     a.f16_guard_x = _guard(am)
+    yrb = _rb_produce(a, y, rb_site) if rb_site is not None else None   # (round 6: y's row-blocked planes from this launch's epilogue)
     if kind == 0:     # tiled / row-resident kernels: x is split in registers, its recorded maximum gives the scale
         F16_STATS["tiled"] += 1
         _check(lib().mmt_conv_forward_f16x2(ctypes.byref(a), am[0].data_ptr(), sw.data_ptr(), _stream()), "mmt_conv_forward_f16x2")
-    elif kind == 2:   # plane-fed implicit GEMM (3x3 on small maps, mask head): one split pass over x, then the launch
+    elif kind == 2:   # plane-fed implicit GEMM (3x3 on small maps, mask head): x's planes (its producer's, or one split pass), then the launch
         F16_STATS["pg"] += 1
-        if PG_AF:
-            sx = am[0]
-        else:
-            xp16, sx, a.x_planes_layout = f16_split_pg(x)
-            a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+        xp16, sx, a.x_planes_layout, a.x_planes_lag = f16_split_pg(x)
+        a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), 0, 0, _stream()), "mmt_conv_forward_pg")
-    else:             # tap-strip kernel: one split pass over x, then the launch
+    else:             # tap-strip kernel: the same
         F16_STATS["conv"] += 1
         if F16X2_DELAYED:
             xp16, sx = f16_split(x, (wsrc.data_ptr(), flipped))
         else:
-            xp16, sx, a.x_planes_layout = f16_split_pg(x)
+            xp16, sx, a.x_planes_layout, a.x_planes_lag = f16_split_pg(x)
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         _check(lib().mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), _stream()), "mmt_conv3x3_strip_f16x2")
     y._mmt_amax = (slot, y._version)
+    if yrb is not None:
+        y._mmt_rb = (yrb[0], yrb[1], y._version, "epi")
     return y
 
 
@@ -1311,7 +1445,8 @@ def _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, kind,
     t.x = t.y = t.scale = t.shift = t.res = t.mask = t.mul = t.w = None
     t.w_planes = t.x_planes = t.y_planes = t.y_amax = t.f16_x_amax = t.f16_dy_amax = None
     t.f16_guard_x = t.f16_guard_dy = t.w_src = t.w_src_scale = None
-    t.w_plane_stride = t.x_plane_stride = t.y_plane_stride = t.x_planes_layout = 0
+    t.y_rb = t.y_rb_scale = t.y_amax_next = None
+    t.w_plane_stride = t.x_plane_stride = t.y_plane_stride = t.x_planes_layout = t.y_rb_stride = t.x_planes_lag = 0
     t.mask_scale, t.io_bf16, t.y_amax_stats = 1.0, 0, 1
     if len(_PLAN) > 4096:
         _PLAN.clear()
@@ -1334,7 +1469,8 @@ def _epilogue_bytes(y, res, res_mode, mask, mul):
 
 def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=None, res_mode=0,
                  mask=None, mask_scale=1.0, mul=None, out_stride=1, out_hw=None, y_out=None, y_offset=0,
-                 w_shape=None, planes=None, out_size=None, x_planes=None, want_planes=False, out_dtype=None, f16_src=None):
+                 w_shape=None, planes=None, out_size=None, x_planes=None, want_planes=False, out_dtype=None, f16_src=None,
+                 rb_site=None):
     """x (N,Cin,H,W) NHWC-dense; w (Cout,Cin,KH,KW) channels_last-dense ([Cout][KH][KW][Cin] memory).
     y_out/y_offset (elements): write into an existing NHWC tensor at a shifted base (transposed-conv taps).
     w=None with w_shape + planes: the weight exists only as packed bf16 planes (pack_weight_flipped).
@@ -1344,7 +1480,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     fast_ok = (FAST_PLANS and F16X2 and PROFILE is None and y_out is None and mul is None and out_stride == 1 and x_planes is None
                and out_size is None and (out_dtype is None or out_dtype is torch.float32) and _PREC == 3)
     if fast_ok:
-        y = _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_scale, f16_src)
+        y = _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_scale, f16_src, rb_site)
         if y is not None:
             return y
     if x_planes is None:
@@ -1451,6 +1587,9 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if mul is not None:
         mul = nhwc(mul)
         a.mul = mul.data_ptr()
+    yrb = None
+    if rb_site is not None and (pg is not None or f16t is not None or f16 is not None) and amax_slot is not None and mul is None:
+        yrb = _rb_produce(a, y, rb_site)   # (round 6: y's row-blocked planes from this launch's epilogue, see f16_split_pg)
     if pg is not None:
         rec = PROFILE is not None
         if rec:
@@ -1463,12 +1602,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if pg[1]:
             a.w_src, a.w_src_scale = pg[0].data_ptr(), _p(pg[2])
         wp16, sw = f16_weight_planes(pg[0], pg[2], pg[1])
-        if PG_AF:
-            sx = _amax_of(x)[0]
-            a.x_planes, a.x_plane_stride = None, 0
-        else:
-            xp16, sx, a.x_planes_layout = f16_split_pg(x)
-            a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
+        xp16, sx, a.x_planes_layout, a.x_planes_lag = f16_split_pg(x)
+        a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
         if rec:
             ev[1].record()
@@ -1481,6 +1616,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
                             _epilogue_bytes(y, res, res_mode, mask, mul)))
         if amax_slot is not None:
             y._mmt_amax = (amax_slot, y._version)
+        if yrb is not None:
+            y._mmt_rb = (yrb[0], yrb[1], y._version, "epi")
         return y
     if f16t is not None:
         am = _amax_of(x)
@@ -1505,6 +1642,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
                             lib().mmt_conv_ksplit(ctypes.byref(a)), None, _epilogue_bytes(y, res, res_mode, mask, mul)))
         if amax_slot is not None:
             y._mmt_amax = (amax_slot, y._version)
+        if yrb is not None:
+            y._mmt_rb = (yrb[0], yrb[1], y._version, "epi")
         return y
     if f16 is not None:
         rec = PROFILE is not None
@@ -1521,7 +1660,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if F16X2_DELAYED:
             xp16, sx = f16_split(x, (f16[0].data_ptr(), f16[1]))
         else:
-            xp16, sx, a.x_planes_layout = f16_split_pg(x)
+            xp16, sx, a.x_planes_layout, a.x_planes_lag = f16_split_pg(x)
         wp16, sw = f16_weight_planes(f16[0], f16[2], f16[1])
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
         a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
@@ -1537,6 +1676,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
                             _epilogue_bytes(y, res, res_mode, mask, mul)))
         if amax_slot is not None:
             y._mmt_amax = (amax_slot, y._version)
+        if yrb is not None:
+            y._mmt_rb = (yrb[0], yrb[1], y._version, "epi")
         return y
     if PROFILE is not None:
         var = lib().mmt_conv_variant(ctypes.byref(a))
@@ -1609,10 +1750,10 @@ def conv_forward_pg(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, r
         a.w = wsrc.data_ptr()
     a.f16_guard_x = _guard(_amax_of(x))
     wp16, sw = f16_weight_planes(wsrc, fscale, flipped)
-    if xp == "fp32" or (xp is None and PG_AF):   # no planes: the kernel's copy waves split the fp32 rows themselves
+    if xp == "fp32":   # no planes: the kernel's copy waves split the fp32 rows themselves (tools build of the library only: `make ablate`)
         sx = _amax_of(x)[0]
     else:
-        xp16, sx, a.x_planes_layout = f16_split_pg(x) if xp is None else (tuple(xp) + (0,))[:3]
+        xp16, sx, a.x_planes_layout, a.x_planes_lag = f16_split_pg(x) if xp is None else (tuple(xp) + (0, 0))[:4]
         a.x_planes, a.x_plane_stride = xp16.data_ptr(), xp16.stride(0)
     a.w_planes, a.w_plane_stride = wp16.data_ptr(), wp16.stride(0)
     _check(lib().mmt_conv_forward_pg(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), int(tile_rows), int(ksplit), _stream()),
@@ -1809,6 +1950,10 @@ def _conv_wgrad_planes(x, dy, xr, dr, w_shape, stride, pad, dw, rowscale, dbias)
     a = ConvArgs.from_buffer_copy(plan[0])
     a.x = x.data_ptr()
     a.f16_guard_x, a.f16_guard_dy = _guard(ax), _guard(ad)
+    # planes a producer's epilogue wrote carry a scale fixed beforehand: the kernel's guard tests it (bit 0: x, bit 1: dy)
+    a.x_planes_lag = (1 if len(xr) > 3 and xr[3] == "epi" else 0) | (2 if len(dr) > 3 and dr[3] == "epi" else 0)
+    if a.x_planes_lag and (a.f16_guard_x is None or a.f16_guard_dy is None):
+        return False
     splits = plan[1]
     ws = torch.empty((splits * Cout * KH * KW * Cin,), dtype=torch.float32, device=x.device) if splits > 1 else None
     _TLS.last_ws = ws

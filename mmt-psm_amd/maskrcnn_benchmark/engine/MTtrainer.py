@@ -472,6 +472,9 @@ class MTtrainer(object):
         # forward_unlabel's join has ordered the two already; before START_MT (and with no unlabeled batch) nothing else does
         self.sync_teacher()
         self.optimizer.step()
+        # round 6: every launch of the step is ordered in front of this point (teacher joined, weight-gradient stream joined): the
+        # producing sites' maxima of this step become their plane scales for the next one (_hip.rb_scales_update, one launch)
+        H.rb_scales_update()
         if self.lambda_value > 0 and iteration > (self.start_mt - 10):
             self.update_teacher(iteration - (self.start_mt - 10))
             if self.teacher_check_period > 0 and iteration % self.teacher_check_period == 0:

@@ -55,13 +55,13 @@ class Conv2d(nn.Module):
         self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
-    def forward(self, x, relu=False, input_relu=False):
+    def forward(self, x, relu=False, input_relu=False, out_rb=False, din_rb=False):
         if x.numel() == 0:  # empty-batch path of the reference (_NewEmptyTensorOp)
             h = (x.shape[2] + 2 * self.padding[0] - self.kernel_size[0]) // self.stride[0] + 1
             w = (x.shape[3] + 2 * self.padding[1] - self.kernel_size[1]) // self.stride[1] + 1
             return x.new_empty((x.shape[0], self.out_channels, h, w))
         pr = self._parameters   # (not through nn.Module.__getattr__: once per launch on the issuing thread)
-        return fused.conv(x, pr["weight"], pr.get("bias"), self.stride[0], self.padding[0], relu, input_relu)
+        return fused.conv(x, pr["weight"], pr.get("bias"), self.stride[0], self.padding[0], relu, input_relu, out_rb, din_rb)
 
     def extra_repr(self):
         return "{}, {}, kernel_size={}, stride={}, padding={}".format(

@@ -233,9 +233,10 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
 
 
 def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, res=None, res_mode=0, want_planes=False,
-           out_dtype=None):
+           out_dtype=None, rb_site=None):
     """data gradient of y = conv(x, w) (* scale[co]) w.r.t. x, with optional fused (x>0) mask / residual add;
-    out_dtype: the storage type of x (autograd wants the gradient in the tensor's own type: bf16 storage)"""
+    out_dtype: the storage type of x (autograd wants the gradient in the tensor's own type: bf16 storage);
+    rb_site: the result feeds a plane-fed launch -- this launch's epilogue writes its row-blocked fp16 planes (_hip._rb_produce)"""
     kh = w.shape[2]
     if stride != 1 and kh != 1:
         raise RuntimeError("strided data-gradient is implemented for 1x1 convolutions (STRIDE_IN_1X1) only")
@@ -246,7 +247,7 @@ def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, re
     wd = None if planes is not None else H.weight_flip_transpose(w, scale)
     if stride == 1:
         return H.conv_forward(g, wd, stride=1, pad=kh - 1 - pad, mask=mask, mask_scale=mask_scale, res=res,
-                              res_mode=res_mode, want_planes=want_planes, out_dtype=out_dtype, **kw)
+                              res_mode=res_mode, want_planes=want_planes, out_dtype=out_dtype, rb_site=rb_site, **kw)
     return H.conv_forward(g, wd, out_stride=stride, out_hw=tuple(x_shape[2:]), mask=mask, mask_scale=mask_scale,
                           res=res, res_mode=res_mode, out_dtype=out_dtype, **kw)
 
@@ -255,29 +256,32 @@ class ConvFn(torch.autograd.Function):
     """y = relu?(conv(x, w) + b)"""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, relu, input_relu):
+    def forward(ctx, x, w, b, stride, pad, relu, input_relu, out_rb=False, din_rb=False):
+        # out_rb: y feeds a plane-fed 3x3 launch; din_rb: the gradient w.r.t. x feeds one (the data gradient of the 3x3 layer that
+        # produced x) -- this node's launches then write the row-blocked planes from their epilogues (round 6, _hip._rb_produce)
         x = H.nhwc(x)
-        y = H.conv_forward(x, w, None, b, stride, pad, relu=relu)
+        y = H.conv_forward(x, w, None, b, stride, pad, relu=relu, rb_site=("y", w.data_ptr()) if out_rb else None)
         ctx.save_for_backward(x, w)
-        ctx.cfgv = (stride, pad, input_relu, b is not None)
+        ctx.cfgv = (stride, pad, input_relu, b is not None, din_rb)
         ctx.dst = (_dst(w), _dst(b))
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        stride, pad, input_relu, has_b = ctx.cfgv
+        stride, pad, input_relu, has_b, din_rb = ctx.cfgv
         g = H.nhwc(g)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:   # first: on the fp16 split it records max |g|, which the weight gradient then reuses
-            dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None, out_dtype=x.dtype)
+            dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None, out_dtype=x.dtype,
+                        rb_site=("dx", w.data_ptr()) if din_rb else None)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw, db = _wgrad(x, g, w, stride, pad, None, has_b, *ctx.dst)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv(x, w, b=None, stride=1, pad=0, relu=False, input_relu=False):
-    return ConvFn.apply(x, w, b, stride, pad, relu, input_relu)
+def conv(x, w, b=None, stride=1, pad=0, relu=False, input_relu=False, out_rb=False, din_rb=False):
+    return ConvFn.apply(x, w, b, stride, pad, relu, input_relu, out_rb, din_rb)
 
 
 def _carry_stats(src, view):
@@ -345,7 +349,7 @@ def batch_slice(t, lo, hi):
     rb = getattr(t, "_mmt_rb", None)      # row-blocked fp16 planes [N H][C / 16][W][16]: image-major, so a batch slice is a slice
     if rb is not None and rb[2] == t._version:
         per = t.numel() // t.shape[0]
-        v._mmt_rb = (rb[0][:, lo * per:hi * per], rb[1], v._version)
+        v._mmt_rb = (rb[0][:, lo * per:hi * per], rb[1], v._version) + tuple(rb[3:])
     return v
 
 
@@ -357,7 +361,10 @@ def bottleneck_forward(x, w1, w2, w3, wd, bn, stride):
     ho, wo = (x.shape[2] + stride - 1) // stride, (x.shape[3] + stride - 1) // stride
     wp = H.planes_wanted_3x3(x.shape[0], mid, ho, wo, w2.shape[0])
     od = torch.bfloat16 if H.bf16_storage() else None   # bf16 activation storage (mode 1): every tensor of the block
-    o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True, want_planes=wp, out_dtype=od)
+    # (round 6, fp16 split: row-blocked fp16 planes with the site's lagged scale instead -- conv2 runs on the tap-strip / plane-fed
+    # kernel from layer2 on, and its weight gradient takes o1's planes too)
+    o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True, want_planes=wp, out_dtype=od,
+                        rb_site=("o1", w2.data_ptr()) if mid >= 128 else None)
     o2 = H.conv_forward(o1, w2, s2, b2, 1, 1, relu=True, out_dtype=od)
     r = x if wd is None else H.conv_forward(x, wd, sd, bd, stride, 0, out_dtype=od)
     out = H.conv_forward(o2, w3, s3, b3, 1, 0, relu=True, res=r, res_mode=1, out_dtype=od)
@@ -391,7 +398,8 @@ class BottleneckFn(torch.autograd.Function):
         d1, d2, d3, dd = ctx.dst
         dw3, _ = _wgrad(o2, g, w3, 1, 0, s3, dst_w=d3)
         d_o2 = _dgrad(g, w3, o2.shape, 1, 0, s3, mask=o2, out_dtype=o2.dtype,
-                      want_planes=H.planes_wanted_3x3(o2.shape[0], o2.shape[1], o2.shape[2], o2.shape[3], w2.shape[1]))
+                      want_planes=H.planes_wanted_3x3(o2.shape[0], o2.shape[1], o2.shape[2], o2.shape[3], w2.shape[1]),
+                      rb_site=("d_o2", w2.data_ptr()) if o2.shape[1] >= 128 else None)
         dw2, _ = _wgrad(o1, d_o2, w2, 1, 1, s2, dst_w=d2)
         d_o1 = _dgrad(d_o2, w2, o1.shape, 1, 1, s2, mask=o1, out_dtype=o1.dtype)
         dw1, _ = _wgrad(x, d_o1, w1, stride, 0, s1, dst_w=d1)
@@ -414,10 +422,13 @@ def fpn_forward(cs, wi, bi, wl, bl, out_planes=True):
     # inner_k feeds the 3x3 output convolution, P_k the 3x3 RPN head convolution: planes from the producing epilogues
     wp = [H.planes_wanted_3x3(c.shape[0], wi[k].shape[0], c.shape[2], c.shape[3], wl[k].shape[0]) for k, c in enumerate(cs)]
     od = torch.bfloat16 if H.bf16_storage() else None   # bf16 activation storage: laterals and pyramid levels too
-    inner[3] = H.conv_forward(cs[3], wi[3], None, bi[3], want_planes=wp[3], out_dtype=od)
+    # (round 6, fp16 split: the same idea with row-blocked fp16 planes and the site's lagged scale, _hip._rb_produce)
+    inner[3] = H.conv_forward(cs[3], wi[3], None, bi[3], want_planes=wp[3], out_dtype=od, rb_site=("inner", wl[3].data_ptr()))
     for k in (2, 1, 0):
-        inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2, want_planes=wp[k], out_dtype=od)
-    outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes, out_dtype=od) for k in range(4)]
+        inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2, want_planes=wp[k], out_dtype=od,
+                                  rb_site=("inner", wl[k].data_ptr()))
+    outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes, out_dtype=od,
+                           rb_site=("P", wl[k].data_ptr()) if out_planes else None) for k in range(4)]
     return inner, outs
 
 
@@ -500,7 +511,7 @@ class DeconvFn(torch.autograd.Function):
                 db = None if dst_b is not None else db
             dw = None if dst_w is not None else dw
         if ctx.needs_input_grad[0]:
-            dx = H.conv_forward(g, w, stride=2, pad=0, mask=x if input_relu else None)
+            dx = H.conv_forward(g, w, stride=2, pad=0, mask=x if input_relu else None, rb_site=("dx", w.data_ptr()))
         return dx, dw, db, None, None
 
 
@@ -675,34 +686,40 @@ class ForkFn(torch.autograd.Function):
     backward is ONE `mmt_sum_stats` launch that adds them and records max / mean |.| of the sum on the way."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, rb_site=None):
         ctx.set_materialize_grads(False)   # an alias nobody back-propagated through arrives as None, not as a zero-filled tensor
+        ctx.rb_site = rb_site
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *gs):
         gs = [g for g in gs if g is not None]
         if not gs:
-            return None, None
+            return None, None, None
         if len(gs) == 1:
-            return gs[0], None
+            return gs[0], None, None
         if gs[0].dim() == 4:
             gs = [H.nhwc(g) for g in gs]
         else:
             gs = [g.contiguous() for g in gs]
         while len(gs) > 4:
             gs = [H.sum_stats(gs[:4])] + gs[4:]
-        return H.sum_stats(gs), None
+        return H.sum_stats(gs, ctx.rb_site), None, None
 
 
-def fork(x, n):
+def fork(x, n, rb_site=None):
     """n handles of x for n consumers whose gradients are summed in one launch (the fp16-split arithmetic on fp32 tensors only:
-    elsewhere autograd's own accumulation stays)"""
+    elsewhere autograd's own accumulation stays).  rb_site: the summed gradient feeds a plane-fed data-gradient launch -- the sum
+    launch leaves its row-blocked planes (_hip.sum_stats)"""
     if n < 2:
         return (x,) * n
     if not (_FORK_ON and x.requires_grad and x.is_cuda and x.dtype == torch.float32 and H.F16X2 and H.get_conv_precision() == 3):
         return (x,) * n
-    outs = ForkFn.apply(x, n)
+    outs = ForkFn.apply(x, n, rb_site)
+    rb = getattr(x, "_mmt_rb", None)
+    if rb is not None and rb[2] == x._version:
+        for o in outs:
+            o._mmt_rb = (rb[0], rb[1], o._version) + tuple(rb[3:])
     for a in ("_mmt_planes", "_mmt_amax"):   # planes / statistics of the tensor go along with its aliases
         v = getattr(x, a, None)
         if v is not None and v[1] == x._version:
@@ -712,8 +729,9 @@ def fork(x, n):
 
 
 def fork_levels(levels, n):
-    """fork() of every tensor of a pyramid -> n pyramids"""
-    cols = [fork(t, n) for t in levels]
+    """fork() of every tensor of a pyramid -> n pyramids (the summed gradient of a level feeds the data gradient of the FPN's 3x3
+    output convolution: planes from the sum launch)"""
+    cols = [fork(t, n, ("gP", k)) for k, t in enumerate(levels)]
     return [tuple(c[i] for c in cols) for i in range(n)]
 
 

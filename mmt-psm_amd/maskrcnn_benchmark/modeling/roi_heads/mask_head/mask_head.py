@@ -48,7 +48,9 @@ class MaskRCNNFPNFeatureExtractor(nn.Module):
         x = self.pooler(x, proposals)
         pre = x
         for i, name in enumerate(self.blocks):
-            x = getattr(self, name)(x, relu=True, input_relu=(i > 0))
+            # (round 6: a layer's output feeds the next 3x3 layer, its input gradient the previous one's data gradient -- both
+            # plane-fed launches: the producing epilogues write the planes)
+            x = getattr(self, name)(x, relu=True, input_relu=(i > 0), out_rb=(i + 1 < len(self.blocks)), din_rb=(i > 0))
         return x, pre
 
 
