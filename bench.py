@@ -279,6 +279,56 @@ def roofline(mode, ach, traffic, alg_bytes, flops, ms, prof, dt, nsteps, dom="fw
     return r
 
 
+HBM_ACHIEVABLE_TBS = 5.0   # what a copy kernel reaches on this part (profiles/r02_clock_under_load.txt: 4.9 - 5.5); the spec figure is 8
+
+
+def conv_family(rec, steps, nprod):
+    """every bracketed convolution / weight-gradient launch of `steps` single-stream steps (_hip.PROFILE with PROFILE_ALL) -> the
+    FAMILY figure: sum over launches of the time a perfect kernel would need -- max(algorithmic FLOP at 2500 / nprod TFLOP/s,
+    algorithmic bytes (input + weights + output + the fused epilogue's operands, each once) at 5 TB/s) -- against the sum of the
+    measured launch times.  One number for the whole family: it cannot jump when another kernel becomes "dominant" (VERDICT r5
+    weak 3).  Also per group (kind, kernel size, batch), as tools/conv_table.py prints them."""
+    import collections
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+    for r in rec:
+        a = agg[r[3]]
+        a[0] += 1
+        a[1] += r[1].elapsed_time(r[2])
+        a[2] = r[0]
+        a[3] += r[6] if len(r) > 6 else 0.0
+    rows = []
+    for key, (c, ms, fl, eb) in agg.items():
+        kind, N, Hh, W, Cin, Cout, KH, stride, ostride = key
+        Ho, Wo = (Hh + stride - 1) // stride, (W + stride - 1) // stride
+        if kind == "wgrad":
+            byts = 4.0 * N * (Hh * W * Cin + Ho * Wo * Cout) + 4.0 * Cin * Cout * KH * KH
+        else:
+            byts = 4.0 * N * (Hh * W * Cin + Ho * Wo * Cout * (ostride if ostride else 1)) + 6.0 * Cin * Cout * KH * KH
+        byts += eb / c
+        t_m, t_h = fl / (PEAK_BF16_MFMA_TFLOPS * 1e12 / nprod) * 1e3, byts / (HBM_ACHIEVABLE_TBS * 1e12) * 1e3
+        rows.append((key, c / steps, ms / c, fl, t_m, t_h))
+    groups = collections.defaultdict(lambda: [0.0, 0.0, 0.0])
+    for key, c, per, fl, t_m, t_h in rows:
+        k = ("wgrad " if key[0] == "wgrad" else "fwd/dgrad ") + ("fc" if key[2] == 1 else "%dx%d" % (key[6], key[6])) + (
+            " N=%d" % key[1] if key[2] > 1 and key[1] <= 8 else "")
+        g = groups[k]
+        g[0] += c
+        g[1] += c * per
+        g[2] += c * max(t_m, t_h)
+    time_ms = sum(c * per for _, c, per, _, _, _ in rows)
+    bound_ms = sum(c * max(t_m, t_h) for _, c, _, _, t_m, t_h in rows)
+    return rows, {"bound_ms": round(bound_ms, 3), "time_ms": round(time_ms, 3), "frac": round(bound_ms / time_ms, 4) if time_ms else None,
+                  "launches_per_step": round(sum(c for _, c, _, _, _, _ in rows), 1),
+                  "algorithmic_tflop_per_step": round(sum(c * fl for _, c, _, fl, _, _ in rows) / 1e12, 3),
+                  "groups": {k: {"launches": round(v[0], 1), "time_ms": round(v[1], 3), "bound_ms": round(v[2], 3),
+                                 "frac": round(v[2] / v[1], 3) if v[1] else None} for k, v in sorted(groups.items(), key=lambda kv: -kv[1][1])},
+                  "definition": "sum over every convolution / weight-gradient launch of a step of max(2 M N K / (%.0f / %d TFLOP/s), "
+                                "(input + weights + output + fused-epilogue operands) / %.0f TB/s) divided by the sum of their "
+                                "event-bracketed durations, single stream (teacher on the step stream, weight gradients on the step "
+                                "stream), %d steps; the same table as mmt-psm_amd/tools/conv_table.py" % (
+                                    PEAK_BF16_MFMA_TFLOPS, nprod, HBM_ACHIEVABLE_TBS, steps)}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` with no launcher around it: re-execute this command line under torch.distributed.run with
     N ranks on this node (127.0.0.1 rendezvous on a free port).  Fails -- non-zero, before anything is timed -- when the node
@@ -439,6 +489,64 @@ def main():
         trainer.overlap_teacher = True
         if ms1 > 0:
             single = {"ms_per_step": round(dt1 / n1 * 1e3, 3), "steps": n1, "achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2)}
+    family = fwd_leg = None
+    if world == 1 and mode == 3 and not args.supervised and not os.environ.get("MMT_BENCH_NO_FAMILY_LEG"):
+        # (i) the convolution FAMILY against its bound: every conv / weight-gradient launch of three single-stream steps bracketed
+        ov = trainer.overlap_teacher
+        trainer.overlap_teacher = False
+        try:
+            step(nxt)
+            sync()
+            _hip.PROFILE, _hip.PROFILE_ALL = [], True
+            nf = 3
+            for i in range(nf):
+                step(nxt + 1 + i)
+            sync()
+            rec, _hip.PROFILE, _hip.PROFILE_ALL = _hip.PROFILE, None, False
+            nxt += 1 + nf
+            _, family = conv_family(rec, nf, products_of(mode, "fwd4"))
+            # (ii) the FORWARD leg north_star quotes its target on: teacher forward_teacher + the student's supervised and
+            # unsupervised forwards without autograd, one stream; algorithmic FLOP = sum of 2 M N K over its convolution / fc
+            # launches (counted in one bracketed pass), time from un-bracketed passes
+            il, targets, ul = batch()
+            trainer.forward_only(il, targets, ul)
+            sync()
+            _hip.PROFILE, _hip.PROFILE_ALL = [], True
+            il, targets, ul = batch()
+            trainer.forward_only(il, targets, ul)
+            sync()
+            frec, _hip.PROFILE, _hip.PROFILE_ALL = _hip.PROFILE, None, False
+            fl_fwd = sum(q[0] for q in frec)
+            nfw = 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sync()
+            t0 = time.perf_counter()
+            e0.record()
+            for i in range(nfw):
+                il, targets, ul = batch()
+                trainer.forward_only(il, targets, ul)
+            e1.record()
+            sync()
+            wall = (time.perf_counter() - t0) / nfw
+            dev = e0.elapsed_time(e1) / nfw * 1e-3
+            _, ffam = conv_family(frec, 1, products_of(mode, "fwd4"))
+            peak3 = PEAK_BF16_MFMA_TFLOPS / products_of(mode, "fwd4")
+            fwd_leg = {"what": "teacher forward_teacher (K-aug x flip, 8 views) + student supervised forward + student unsupervised "
+                               "forward with their losses, torch.no_grad, one stream: 12 image-forwards of 1000x1000 per pass "
+                               "(the coarse inference reuses view 0's pyramid)",
+                       "passes": nfw, "ms_per_pass": round(wall * 1e3, 3), "device_ms_per_pass": round(dev * 1e3, 3),
+                       "algorithmic_tflop_per_pass": round(fl_fwd / 1e12, 3), "conv_launches_per_pass": len(frec),
+                       "achieved_tflops": round(fl_fwd / wall / 1e12, 2),
+                       "frac_of_833": round(fl_fwd / wall / 1e12 / peak3, 4),
+                       "frac_of_fp32_mfma_peak_157": round(fl_fwd / wall / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                       "conv_family_of_this_leg": {k: ffam[k] for k in ("bound_ms", "time_ms", "frac", "launches_per_step")},
+                       "note": "north_star: >= 0.5 x MFMA roofline on the student+teacher forward.  Against the fp32-input MFMA peak "
+                               "(157.3 TFLOP/s: the roofline of an fp32 network on this part) the leg is far above 0.5; against the "
+                               "fp16 pipe at 3 products per multiply (833) it is what frac_of_833 says; the leg's own bound -- many of "
+                               "its launches are HBM-bound 1x1 layers -- is conv_family_of_this_leg.bound_ms"}
+        finally:
+            trainer.overlap_teacher = ov
+            _hip.PROFILE, _hip.PROFILE_ALL = None, False
     ref_fp32 = None
     if mode != 0 and world == 1 and not os.environ.get("MMT_BENCH_NO_FP32_LEG"):
         # the same workload on the fp32-input MFMA kernels (mode 0), reported next to the headline number
@@ -566,6 +674,10 @@ def main():
             # kernel, same shapes, in a single-stream run of the same step (MMT_OVERLAP_TEACHER=0)
             single["frac"] = round(single["achieved"] / out["roofline"]["peak"], 4)
             out["roofline"]["single_stream"] = single
+        if family is not None:
+            out["roofline"]["family"] = family
+        if fwd_leg is not None:
+            out["forward_leg"] = fwd_leg
         if ref_fp32 is not None:
             out["fp32_mfma_mode"] = ref_fp32
         if use_dist and getattr(trainer._bucketed, "last_trace", None) is not None:

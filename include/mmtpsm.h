@@ -343,6 +343,9 @@ typedef struct {
   const float* y_rb_scale;
   void* y_amax_next;
   int x_planes_lag;
+  /* y_rb for the leading y_rb_rows output pixels only (0 = all N * Ho * Wo): the planes are image-major, so "the first n images" is
+   * n * Ho * Wo -- the teacher's K x flip batch, of which only view 0 feeds a plane-fed launch (the coarse inference's RPN head) */
+  int y_rb_rows;
 } mmt_conv_args;
 
 int mmt_conv_forward(const mmt_conv_args* a /*[host]*/, void* stream);

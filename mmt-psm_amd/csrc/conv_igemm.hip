@@ -210,7 +210,7 @@ __device__ __forceinline__ void conv_epilogue_finish(const ConvP& p, float* lds,
 #pragma unroll
             for (int q = 0; q < 3; q++) *(uint2*)(p.ypl + q * p.ypl_stride + oidx[g]) = o[q];
           }
-          if (p.yrb) rb_store4(p, rbg, m0 + r0 + (g0 + g) * RPP, c, f32x4{v[0], v[1], v[2], v[3]}, rbs);
+          if (p.yrb && m0 + r0 + (g0 + g) * RPP < p.yrb_M) rb_store4(p, rbg, m0 + r0 + (g0 + g) * RPP, c, f32x4{v[0], v[1], v[2], v[3]}, rbs);
         }
       }
     }
@@ -1721,6 +1721,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
       (void*)(p.shift ? p.shift : p.x), 0, p.shift ? p.Cout * 4 : 0, 0x00020000);
   const bool up = p.res_mode == 2, has_res = p.res_mode != 0, has_scale = p.scale != nullptr;
   const float finv = F16 ? 1.f / (sx * *p.f16_sw) : 1.f;
+  // round 6: y also as row-blocked fp16 planes (p.yrb; conv_shared.h: quad_transpose).  After the 4 x 4 transpose inside a quad of
+  // lanes, lane k holds the quad's four channels of row 8 j + k of register group j: this lane's four rows, fixed for the block
+  const bool rb = F16 && p.yrb != nullptr;
+  const float rbs = rb ? *p.yrb_s : 1.f;
+  unsigned rboff[4];
+  {
+    const RbGeom rbg = rb_geom(p);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int m = mlane + 8 * j + (lane & 3);
+      rboff[j] = (rb && m < p.yrb_M) ? rb_row_off(rbg, m) : 0x80000000u;
+    }
+  }
+  const int rb_bytes = rb ? (int)((long)p.yrb_M * p.Cout * 2) : 0;
+  const __amdgpu_buffer_rsrc_t rrb0 = __builtin_amdgcn_make_buffer_rsrc((void*)(rb ? p.yrb : (unsigned short*)p.y), 0, rb_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrb1 = __builtin_amdgcn_make_buffer_rsrc((void*)(rb ? p.yrb + p.yrb_stride : (unsigned short*)p.y), 0, rb_bytes, 0x00020000);
+  const unsigned rb_cstep = (unsigned)p.Wo * 32u;   // bytes from one 16-channel block of an image row to the next
   float amx = 0.f, asum = 0.f, acnt = 0.f;   // max |y| / sum |y| / count over what this thread stores (p.amax_out)
   float ur[LA][16], um[MASK ? LA : 1][16], scn[LA], shn[LA];
   auto row_off = [&](int r) { return (unsigned)(8 * (r >> 2) + (r & 3)) * cout4; };
@@ -1821,6 +1838,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
     const float sh = shn[S];
     if (F16) sc *= finv;   // operands were scaled by powers of two: exact rescale of the accumulated sum
     request_affine(slot, cbn);
+    float vv[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {   // same expressions as conv_epilogue
       float v = acc[r] * sc + sh;
@@ -1834,13 +1852,32 @@ __global__ __launch_bounds__(256, 2) void conv1x1_rows_kernel(const ConvP p, con
       acnt += ok ? 1.f : 0.f;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)(ylane + row_off(r) + cb), 0, 0);
       request(slot, r, cbn);
+      vv[r] = v;
     }
     // planes of the next panel (issued at the top of this iteration): everything issued after them may stay in flight --
-    // 2 + 16 x (store, residual (, mask)) operations; vector memory operations retire in order
+    // 2 + 16 x (store, residual (, mask)) operations (+ 8 plane stores); vector memory operations retire in order
     // (`s_setprio 0` changes nothing: it marks this wait for tests/test_rows_kernel_isa.py, which counts the operations
     // between the copies and the wait in the shipped code object)
-    if constexpr (MASK) asm volatile("s_waitcnt vmcnt(50)\n\ts_setprio 0" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(34)\n\ts_setprio 0" ::: "memory");
+    if (rb) {   // (uniform) round 6: the panel's 32 x 32 values as row-blocked fp16 planes, eight 8-byte stores per lane
+      const int cq = (pn(i) * BN + col_l) & ~3;
+      const unsigned coff = cb != 0x80000000u ? (unsigned)(cq >> 4) * rb_cstep + (unsigned)(cq & 15) * 2u : 0x80000000u;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        unsigned w4[4] = {rb_split1(vv[4 * j], rbs), rb_split1(vv[4 * j + 1], rbs), rb_split1(vv[4 * j + 2], rbs), rb_split1(vv[4 * j + 3], rbs)};
+        quad_transpose(w4, lane);
+        const unsigned o = (rboff[j] | coff) & 0x80000000u ? 0x80000000u : rboff[j] + coff;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 hh = {__builtin_amdgcn_perm(w4[1], w4[0], 0x05040100u), __builtin_amdgcn_perm(w4[3], w4[2], 0x05040100u)};
+        const u32x2 ll = {__builtin_amdgcn_perm(w4[1], w4[0], 0x07060302u), __builtin_amdgcn_perm(w4[3], w4[2], 0x07060302u)};
+        __builtin_amdgcn_raw_buffer_store_b64(hh, rrb0, (int)o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(ll, rrb1, (int)o, 0, 0);
+      }
+      if constexpr (MASK) asm volatile("s_waitcnt vmcnt(58)\n\ts_setprio 0" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(42)\n\ts_setprio 0" ::: "memory");
+    } else {
+      if constexpr (MASK) asm volatile("s_waitcnt vmcnt(50)\n\ts_setprio 0" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(34)\n\ts_setprio 0" ::: "memory");
+    }
   };
   for (int i = 0; i < cnt; i += 2) {   // unrolled by two: register set and ring buffer of a panel are compile-time
     panel(std::integral_constant<int, 0>{}, i);
@@ -3050,8 +3087,9 @@ int fill(ConvP& p, const mmt_conv_args* a) {
   }
   if ((p.io & IO_Y) && (p.ypl || a->mul)) return MMT_EINVAL;
   if (p.ypl && ((a->Cout & 3) || ((size_t)p.ypl & 7) || (p.ypl_stride & 3) || a->out_stride > 1)) return MMT_EINVAL;
+  p.yrb_M = a->y_rb_rows > 0 && (long)a->y_rb_rows < (long)a->N * a->Ho * a->Wo ? a->y_rb_rows : a->N * a->Ho * a->Wo;
   if (p.yrb && (!p.yrb_s || (a->Cout & 15) || a->out_stride > 1 || (p.io & IO_Y) || ((size_t)p.yrb & 15) || (p.yrb_stride & 7) ||
-                (long)a->N * a->Ho * a->Wo * a->Cout >= (1L << 30) || p.yrb_stride < (long)a->N * a->Ho * a->Wo * a->Cout))
+                a->y_rb_rows < 0 || (long)a->N * a->Ho * a->Wo * a->Cout >= (1L << 30) || p.yrb_stride < (long)p.yrb_M * a->Cout))
     return MMT_EINVAL;
   if ((long)p.N * p.Ho * p.Wo > 0x7fffffffL) return MMT_EINVAL;
   if ((long)p.N * p.H * p.W * p.Cin >= 0x7fffffffL || (long)p.N * p.Ho * p.Wo * p.Cout >= 0x7fffffffL ||
@@ -3577,8 +3615,7 @@ static int pick_variant(const ConvP& p);
 static bool rb_epilogue_ok(const ConvP& p) {
   if ((p.Cout & 15) || p.out_stride > 1 || (p.io & IO_Y) || p.mul || (long)p.M * p.Cout >= (1L << 30)) return false;
   if (c64_shape(p)) return false;
-  if (rows_shape(p, true)) return false;
-  return true;
+  return true;   // (the row-resident 1x1 kernel writes them from its register epilogue)
 }
 extern "C" int mmt_conv_writes_rb(const mmt_conv_args* a) {
   ConvP p;

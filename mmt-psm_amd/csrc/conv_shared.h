@@ -40,6 +40,7 @@ struct ConvP {
   // consumer; amax_next: the producing site's pending maximum (-> next step's scale); xpl_lag: the scale of xpl was chosen before the
   // tensor existed (the guard tests it against the recorded statistics, f16_guard_bad_lag)
   unsigned short* yrb; long yrb_stride; const float* yrb_s; unsigned* amax_next; int xpl_lag;
+  int yrb_M;   // output pixels [0, yrb_M) get planes (mmt_conv_args.y_rb_rows; M: all)
 };
 constexpr float F16_CREST_HI = 131072.f;   // 2^17: max / mean |x| above which fp16's five exponent bits lose the bulk of the tensor
 constexpr int IO_X = 1, IO_Y = 2, IO_RES = 4, IO_MASK = 8, IO_DY = 16;
@@ -250,7 +251,7 @@ __device__ __forceinline__ void conv_slow_tile(const int m_first, const int run,
     if (pk->mask) v = pk->mask[oidx] > 0.f ? v * pk->mask_scale : 0.f;
     if (pk->mul) v *= pk->mul[(long)m * pk->Cout + n];
     pk->y[oidx] = v;
-    if (pk->yrb) {   // the planes a plane-fed consumer was promised (one element at a time: this path is ~100 x slower anyway)
+    if (pk->yrb && m < pk->yrb_M) {   // the planes a plane-fed consumer was promised (one element at a time: this path is ~100 x slower anyway)
       const unsigned hl = rb_split1(v, *pk->yrb_s);
       const long row = (long)img * pk->Ho + ho;
       const long e = ((row * (pk->Cout >> 4) + (n >> 4)) * pk->Wo + wo) * 16 + (n & 15);
@@ -320,7 +321,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x1
   const bool rb = p.yrb != nullptr;
   const float rbs = rb ? *p.yrb_s : 1.f;
   const RbGeom rbg = rb_geom(p);
-  const int rb_bytes = rb ? (int)((long)p.M * p.Cout * 2) : 0;
+  const int rb_bytes = rb ? (int)((long)p.yrb_M * p.Cout * 2) : 0;
   const __amdgpu_buffer_rsrc_t rrb0 = __builtin_amdgcn_make_buffer_rsrc((void*)(rb ? p.yrb : (unsigned short*)p.y), 0, rb_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrb1 = __builtin_amdgcn_make_buffer_rsrc((void*)(rb ? p.yrb + p.yrb_stride : (unsigned short*)p.y), 0, rb_bytes, 0x00020000);
   const int mrow = (int)(ybase / cout4);   // output pixel of (tile row 0 + 4 (lane / 32))
@@ -363,7 +364,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x1
         unsigned w4[4] = {rb_split1(vv[4 * j], rbs), rb_split1(vv[4 * j + 1], rbs), rb_split1(vv[4 * j + 2], rbs), rb_split1(vv[4 * j + 3], rbs)};
         quad_transpose(w4, lane);
         const int rr = a * 32 + 8 * j + (lane & 3);
-        const bool ok = cok[b] && rr < rows_left;
+        const bool ok = cok[b] && rr < rows_left && mrow + rr < p.yrb_M;
         const unsigned o = ok ? rb_row_off(rbg, mrow + rr) + (unsigned)(cq >> 4) * ((unsigned)rbg.Wo * 32u) + (unsigned)(cq & 15) * 2u : OOB;
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 hh = {__builtin_amdgcn_perm(w4[1], w4[0], 0x05040100u), __builtin_amdgcn_perm(w4[3], w4[2], 0x05040100u)};

@@ -36,7 +36,7 @@ class ConvArgs(ctypes.Structure):
                 ("x2", c_void_p), ("dy2", c_void_p), ("f16_x_amax2", c_void_p), ("f16_dy_amax2", c_void_p),
                 ("f16_guard_x2", c_void_p), ("f16_guard_dy2", c_void_p), ("x_planes_layout", c_int),
                 ("y_rb", c_void_p), ("y_rb_stride", ctypes.c_long), ("y_rb_scale", c_void_p), ("y_amax_next", c_void_p),
-                ("x_planes_lag", c_int)]
+                ("x_planes_lag", c_int), ("y_rb_rows", c_int)]
 
 
 IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
@@ -516,9 +516,14 @@ def _rb_scale_view(t, i):
 
 def _rb_produce(a, y, key):
     """the producing half, called with the launch's argument block filled: the site's pending maximum always (y_amax_next); the planes
-    when the site has a scale and the kernel this launch takes writes them -> (planes, scale view) or None"""
+    when the site has a scale and the kernel this launch takes writes them -> (planes, scale view, images covered or None) or None.
+    key = (role, id) or (role, id, n): planes for the first n images of the batch only (the teacher's view 0)"""
     if not RB_EPI:
         return None
+    images = None
+    if len(key) > 2:
+        images = int(key[2]) if 0 < int(key[2]) < y.shape[0] else None
+        key = key[:2]
     t, i = _rb_site(key, y.device)
     if t is None:
         return None
@@ -532,10 +537,11 @@ def _rb_produce(a, y, key):
         ok = t.ok[okk] = (lib().mmt_conv_writes_rb(ctypes.byref(a)) == 1)
     if not ok:
         return None
-    n = y.numel()
+    n = y.numel() if images is None else (y.numel() // y.shape[0]) * images
     pl = torch.empty((2, n), dtype=torch.float16, device=y.device)
     a.y_rb, a.y_rb_stride, a.y_rb_scale = pl.data_ptr(), n, t.base + 8 * i
-    return pl, _rb_scale_view(t, i)
+    a.y_rb_rows = 0 if images is None else images * y.shape[2] * y.shape[3]
+    return pl, _rb_scale_view(t, i), images
 
 
 def rb_scales_update():
@@ -571,7 +577,7 @@ def f16_split_pg(x):
         xp, st = f16_split(x)
         return xp, st, 0, 0
     rb = getattr(x, "_mmt_rb", None)
-    if rb is not None and len(rb) > 3 and rb[2] == x._version and rb[3] == "epi":
+    if rb is not None and len(rb) > 3 and rb[2] == x._version and rb[3] == "epi" and (len(rb) < 5 or rb[4] is None or rb[4] >= x.shape[0]):
         F16_STATS["rb_epi"] = F16_STATS.get("rb_epi", 0) + 1
         return rb[0], rb[1], 1, 1
     F16_STATS["rb_split"] = F16_STATS.get("rb_split", 0) + 1
@@ -1432,7 +1438,7 @@ def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_
         _check(lib().mmt_conv3x3_strip_f16x2(ctypes.byref(a), sx.data_ptr(), sw.data_ptr(), _stream()), "mmt_conv3x3_strip_f16x2")
     y._mmt_amax = (slot, y._version)
     if yrb is not None:
-        y._mmt_rb = (yrb[0], yrb[1], y._version, "epi")
+        y._mmt_rb = (yrb[0], yrb[1], y._version, "epi", yrb[2])
     return y
 
 
@@ -1446,7 +1452,7 @@ def _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, kind,
     t.w_planes = t.x_planes = t.y_planes = t.y_amax = t.f16_x_amax = t.f16_dy_amax = None
     t.f16_guard_x = t.f16_guard_dy = t.w_src = t.w_src_scale = None
     t.y_rb = t.y_rb_scale = t.y_amax_next = None
-    t.w_plane_stride = t.x_plane_stride = t.y_plane_stride = t.x_planes_layout = t.y_rb_stride = t.x_planes_lag = 0
+    t.w_plane_stride = t.x_plane_stride = t.y_plane_stride = t.x_planes_layout = t.y_rb_stride = t.x_planes_lag = t.y_rb_rows = 0
     t.mask_scale, t.io_bf16, t.y_amax_stats = 1.0, 0, 1
     if len(_PLAN) > 4096:
         _PLAN.clear()
@@ -1617,7 +1623,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if amax_slot is not None:
             y._mmt_amax = (amax_slot, y._version)
         if yrb is not None:
-            y._mmt_rb = (yrb[0], yrb[1], y._version, "epi")
+            y._mmt_rb = (yrb[0], yrb[1], y._version, "epi", yrb[2])
         return y
     if f16t is not None:
         am = _amax_of(x)
@@ -1643,7 +1649,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if amax_slot is not None:
             y._mmt_amax = (amax_slot, y._version)
         if yrb is not None:
-            y._mmt_rb = (yrb[0], yrb[1], y._version, "epi")
+            y._mmt_rb = (yrb[0], yrb[1], y._version, "epi", yrb[2])
         return y
     if f16 is not None:
         rec = PROFILE is not None
@@ -1677,7 +1683,7 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
         if amax_slot is not None:
             y._mmt_amax = (amax_slot, y._version)
         if yrb is not None:
-            y._mmt_rb = (yrb[0], yrb[1], y._version, "epi")
+            y._mmt_rb = (yrb[0], yrb[1], y._version, "epi", yrb[2])
         return y
     if PROFILE is not None:
         var = lib().mmt_conv_variant(ctypes.byref(a))
@@ -1993,6 +1999,7 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
     if WG_PLANES and pair is None and F16X2 and x.dtype == torch.float32 and dy.dtype == torch.float32:
         xr, dr = getattr(x, "_mmt_rb", None), getattr(dy, "_mmt_rb", None)
         if (xr is not None and dr is not None and xr[2] == x._version and dr[2] == dy._version and get_conv_precision() == 3
+                and (len(xr) < 5 or xr[4] is None) and (len(dr) < 5 or dr[4] is None)
                 and _conv_wgrad_planes(x, dy, xr, dr, w_shape, stride, pad, dw, rowscale, dbias)):
             return
     # the shape half of the argument block and the split count depend on the shapes only: kept after the first call

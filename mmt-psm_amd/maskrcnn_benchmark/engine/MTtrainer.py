@@ -538,6 +538,16 @@ class MTtrainer(object):
     def forward_source(self, image, target, features=None):
         return self.student(image.to(self.device), [t.to(self.device) for t in target], features=features)
 
+    def forward_only(self, data_s, target_s, data_u_list):
+        """the three FORWARDS of one iteration and nothing else, without autograd, on the current stream: [A] supervised student
+        forward with its losses, [B] the teacher's pseudo labels + K-aug x flip pyramids, [C] the student's consistency losses on
+        the unlabeled view -- 2 + 8 + 2 = 12 image-forwards through the backbone at the bench's batch.  What BASELINE.json's
+        north_star quotes its 0.5-of-roofline target on (bench.py: forward_leg); results are not used for training."""
+        with torch.no_grad():
+            out = dict(self.forward_source(data_s, target_s))
+            out.update(self.forward_unlabel(data_u_list, None, None))
+        return out
+
     def _loss_coeff(self, k, w):
         return (w if "mt" in k else 1.0) * (self.balanced_weight[k] if k in self.balanced_weight else 1.0)
 

@@ -347,9 +347,9 @@ def batch_slice(t, lo, hi):
     if am is not None and am[1] == t._version:
         v._mmt_amax = (am[0], v._version)   # max over the whole batch: an upper bound for the slice (fp16 split scale)
     rb = getattr(t, "_mmt_rb", None)      # row-blocked fp16 planes [N H][C / 16][W][16]: image-major, so a batch slice is a slice
-    if rb is not None and rb[2] == t._version:
-        per = t.numel() // t.shape[0]
-        v._mmt_rb = (rb[0][:, lo * per:hi * per], rb[1], v._version) + tuple(rb[3:])
+    if rb is not None and rb[2] == t._version and (len(rb) < 5 or rb[4] is None or hi <= rb[4]):
+        per = t.numel() // t.shape[0]   # (planes that cover only the leading images of the batch: slices inside them)
+        v._mmt_rb = (rb[0][:, lo * per:hi * per], rb[1], v._version) + tuple(rb[3:4]) + ((None,) if len(rb) > 4 else ())
     return v
 
 
@@ -427,8 +427,16 @@ def fpn_forward(cs, wi, bi, wl, bl, out_planes=True):
     for k in (2, 1, 0):
         inner[k] = H.conv_forward(cs[k], wi[k], None, bi[k], res=inner[k + 1], res_mode=2, want_planes=wp[k], out_dtype=od,
                                   rb_site=("inner", wl[k].data_ptr()))
-    outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes, out_dtype=od,
-                           rb_site=("P", wl[k].data_ptr()) if out_planes else None) for k in range(4)]
+    # out_planes: True -- every image's P_k feeds the RPN head (student); an int n -- the first n images' do (the teacher's view 0);
+    # False -- none
+    if out_planes is True:
+        site = lambda k: ("P", wl[k].data_ptr())   # noqa: E731
+    elif out_planes:
+        site = lambda k: ("P", wl[k].data_ptr(), int(out_planes))   # noqa: E731
+    else:
+        site = lambda k: None   # noqa: E731
+    outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes is True, out_dtype=od,
+                           rb_site=site(k)) for k in range(4)]
     return inner, outs
 
 

@@ -31,6 +31,12 @@ class ImageListView(object):
 _NO_READBACK = True
 
 
+def is_teacher_fpn(backbone):
+    """the FPN of a teacher model (built with out_planes False: its levels do not all feed an RPN head)"""
+    fpn = getattr(backbone, "fpn", None)
+    return fpn is not None and getattr(fpn, "out_planes", True) is not True
+
+
 class GeneralizedRCNN(nn.Module):
     def __init__(self, cfg, is_teacher=False, is_student=False):
         super().__init__()
@@ -258,6 +264,10 @@ class GeneralizedRCNN(nn.Module):
                 views.append(img.tensors)
             n = views[0].shape[0]
             if all(v.shape == views[0].shape for v in views):
+                if is_teacher_fpn(self.backbone):
+                    # only view 0's pyramid feeds a plane-fed launch (the coarse inference's RPN head): the FPN's output convolutions
+                    # write row-blocked planes for the first n images of the K x flip batch (layers/fused.py::fpn_forward)
+                    self.backbone.fpn.out_planes = n
                 pyr = self.run_backbone(torch.cat(views, 0))
                 self._batched_pyr = (pyr, n, len(views))
                 # (batch_slice: the statistics slot / planes of a level go along with its slices -- no reduction pass per level

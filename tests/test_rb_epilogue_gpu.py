@@ -82,6 +82,10 @@ PRODUCERS = [
     ((25, 256, 14, 14, 256, 3, 1, 1, ("bias", "relu"), {}), "plane-fed, 14 x 14 maps, ragged M"),
     ((400, 256, 14, 14, 256, 3, 1, 1, ("bias", "relu", "mask"), {}), "plane-fed, 256-row tiles, masked"),
     ((2, 256, 64, 64, 256, 3, 1, 1, ("bias",), {"MMT_PG": "0"}), "small-map 3x3 on the tiled kernel (split-K)"),
+    ((2, 256, 128, 128, 256, 1, 1, 0, ("bias", "up"), {}), "row-resident K = 256, top-down add (the C2 lateral)"),
+    ((2, 64, 128, 128, 256, 1, 1, 0, ("bn", "relu", "res"), {}), "row-resident K = 64, residual + ReLU"),
+    ((2, 128, 64, 64, 512, 1, 1, 0, ("mask",), {}), "row-resident K = 128, masked"),
+    ((3, 256, 36, 44, 128, 1, 1, 0, ("bias",), {}), "row-resident, ragged rows (M % 128 != 0)"),
 ]
 
 
@@ -135,6 +139,36 @@ def test_epilogue_planes_equal_the_split_of_the_result(hip, case, what):
     finally:
         for k in case[9]:
             os.environ.pop(k, None)
+
+
+def test_planes_for_the_leading_images_only(hip):
+    """the teacher's K x flip batch: only view 0 (the first n images) feeds a plane-fed launch -- the producer writes planes for those
+    images' pixels alone; a batch slice inside them carries the planes, the whole tensor does not"""
+    H = hip
+    from maskrcnn_benchmark.layers import fused
+    g = torch.Generator().manual_seed(21)
+    for shape, k in (((8, 256, 64, 64), 3), ((8, 256, 128, 128), 3), ((8, 512, 32, 32), 1)):
+        x = _cl(torch.randn(*shape, generator=g).cuda())
+        w = _cl((torch.randn(256, shape[1], k, k, generator=g) * 0.05).cuda())
+        b = torch.randn(256, generator=g).cuda()
+        site = ("P", shape, 2)
+        H.conv_forward(x, w, None, b, 1, k // 2, rb_site=site)
+        H.rb_scales_update()
+        y = H.conv_forward(x, w, None, b, 1, k // 2, rb_site=site)
+        torch.cuda.synchronize()
+        rb = y._mmt_rb
+        assert rb[3] == "epi" and rb[4] == 2 and rb[0].shape[1] == y[:2].numel()
+        s = float(rb[1][0])
+        h, l = _ref_planes(y[:2], s)
+        assert torch.equal(rb[0][0].view(torch.int16), h.view(torch.int16)) and torch.equal(rb[0][1].view(torch.int16), l.view(torch.int16))
+        v = fused.batch_slice(y, 0, 2)
+        assert H.f16_split_pg(v)[3] == 1                      # the slice: the producer's planes
+        assert H.f16_split_pg(fused.batch_slice(y, 2, 4))[3] == 0 and H.f16_split_pg(y)[3] == 0   # outside / the whole batch: a split pass
+        v1 = fused.batch_slice(y, 1, 2)
+        xp = H.f16_split_pg(v1)
+        assert xp[3] == 1
+        h1, l1 = _ref_planes(y[1:2], s)
+        assert torch.equal(xp[0][0].view(torch.int16), h1.view(torch.int16))
 
 
 def _conv64(x, w, stride, pad):

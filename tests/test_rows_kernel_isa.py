@@ -70,10 +70,14 @@ def test_counted_waits_of_the_rows_kernel(tmp_path):
             if not text.startswith("s_branch") and k + 1 < len(ins):
                 preds[k + 1].append(k)
         marks = [k for k in range(1, len(ins)) if ins[k][1].startswith("s_setprio 0") and ins[k - 1][1].startswith("s_waitcnt vmcnt(")]
-        assert len(marks) == 2, (name, len(marks))   # the loop is unrolled by two
+        # the loop is unrolled by two; on the fp16 split (round 6) a panel ends in one of two waits -- with or without the eight
+        # stores of the row-blocked output planes (a uniform branch on mmt_conv_args.y_rb), each with its own count
+        f16 = "Lb1ELb" in name   # <KT, NS, F16 = true, MASK>
+        counts = sorted(int(re.search(r"vmcnt\((\d+)\)", ins[k - 1][1]).group(1)) for k in marks)
+        base = 50 if masked else 34
+        assert counts == ([base, base, base + 8, base + 8] if f16 else [base, base]), (name, counts)
         for k in marks:
             n = int(re.search(r"vmcnt\((\d+)\)", ins[k - 1][1]).group(1))
-            assert n == (50 if masked else 34), (name, n)
             # Program order is fixed by the source (volatile assembly and compiler barriers): barrier, copies, MFMAs, epilogue,
             # wait.  Walk the control flow graph backwards from the wait to the barrier(s) it can be reached from and count the
             # vector memory operations on the way (the copies themselves excluded): every path must give exactly n.
