@@ -514,16 +514,20 @@ def _rb_scale_view(t, i):
     return v
 
 
+class RbLead(int):
+    """last element of a producing site's key: planes for the first n images of the batch only"""
+
+
 def _rb_produce(a, y, key):
     """the producing half, called with the launch's argument block filled: the site's pending maximum always (y_amax_next); the planes
     when the site has a scale and the kernel this launch takes writes them -> (planes, scale view, images covered or None) or None.
-    key = (role, id) or (role, id, n): planes for the first n images of the batch only (the teacher's view 0)"""
+    key = any hashable tuple naming the site; (..., RbLead(n)): planes for the first n images of the batch only (the teacher's view 0)"""
     if not RB_EPI:
         return None
     images = None
-    if len(key) > 2:
-        images = int(key[2]) if 0 < int(key[2]) < y.shape[0] else None
-        key = key[:2]
+    if type(key[-1]) is RbLead:
+        images = int(key[-1]) if 0 < int(key[-1]) < y.shape[0] else None
+        key = key[:-1]
     t, i = _rb_site(key, y.device)
     if t is None:
         return None

@@ -432,7 +432,7 @@ def fpn_forward(cs, wi, bi, wl, bl, out_planes=True):
     if out_planes is True:
         site = lambda k: ("P", wl[k].data_ptr())   # noqa: E731
     elif out_planes:
-        site = lambda k: ("P", wl[k].data_ptr(), int(out_planes))   # noqa: E731
+        site = lambda k: ("P", wl[k].data_ptr(), H.RbLead(out_planes))   # noqa: E731
     else:
         site = lambda k: None   # noqa: E731
     outs = [H.conv_forward(inner[k], wl[k], None, bl[k], 1, 1, want_planes=wp[k] and out_planes is True, out_dtype=od,

@@ -151,7 +151,7 @@ def test_planes_for_the_leading_images_only(hip):
         x = _cl(torch.randn(*shape, generator=g).cuda())
         w = _cl((torch.randn(256, shape[1], k, k, generator=g) * 0.05).cuda())
         b = torch.randn(256, generator=g).cuda()
-        site = ("P", shape, 2)
+        site = ("P", shape, H.RbLead(2))
         H.conv_forward(x, w, None, b, 1, k // 2, rb_site=site)
         H.rb_scales_update()
         y = H.conv_forward(x, w, None, b, 1, k // 2, rb_site=site)
