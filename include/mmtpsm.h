@@ -237,6 +237,11 @@ int mmt_rpn_loss(const float* obj, const float* reg, const float* labels, const 
  * smooth_l1(breg[i][4 label ..] - regt_i, beta = 1, sum) / R; dlogits, dbreg = their gradients.  out is zeroed here.  One launch. */
 int mmt_box_loss(const float* logits, const float* breg, const int64_t* labels, const float* regt, int R, int NC, float* out,
                  float* dlogits, float* dbreg, void* stream);
+/* the same on a FIXED-CAPACITY batch (round 6, SURVEY f-2: the sampled lists of box_head/loss.py:82-116 without a host read-back):
+ * rows labelled -1 are padding behind an image's sampled set -- no loss, zero gradient --, and both means run over *n_rows (device:
+ * the number of rows with label >= 0; NULL = R, i.e. mmt_box_loss) */
+int mmt_box_loss_rows(const float* logits, const float* breg, const int64_t* labels, const float* regt, int R, int NC,
+                      const int64_t* n_rows, float* out, float* dlogits, float* dbreg, void* stream);
 int mmt_match_targets(const float* cand, const int32_t* cand_off, const float* gt, const int32_t* gt_off,
                       const int64_t* gt_labels, const uint8_t* visible, int N, int A_total, int G_total, int shared_cand,
                       float high, float low, int allow_low_quality, float wx, float wy, float ww, float wh, uint32_t* top_ws,

@@ -372,12 +372,19 @@ extern "C" int mmt_rpn_loss(const float* obj, const float* reg, const float* lab
 __global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__ logits, const float* __restrict__ breg,
                                                        const int64_t* __restrict__ labels, const float* __restrict__ regt, int R,
                                                        int NC, float* __restrict__ out, float* __restrict__ dlogits,
-                                                       float* __restrict__ dbreg) {
-  const float inv = 1.f / (float)R;
+                                                       float* __restrict__ dbreg, const int64_t* __restrict__ n_rows) {
+  // n_rows (device, or null = R): the rows that count -- fixed-capacity lists carry rows labelled -1 behind an image's sampled set
+  // (box_head.py::subsample_fixed); those contribute nothing and are not rows of the mean
+  const float inv = 1.f / (n_rows ? fmaxf((float)*n_rows, 1.f) : (float)R);
   float ce = 0.f, box = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += gridDim.x * 256) {
     const float* l = logits + (long)i * NC;
     const int lab = (int)labels[i];
+    if (lab < 0) {
+      for (int c = 0; c < NC; ++c) dlogits[(long)i * NC + c] = 0.f;
+      for (int c = 0; c < 4 * NC; ++c) dbreg[(long)i * 4 * NC + c] = 0.f;
+      continue;
+    }
     float mx = l[0];
     for (int c = 1; c < NC; ++c) mx = fmaxf(mx, l[c]);
     float se = 0.f;
@@ -406,14 +413,19 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__
   if (threadIdx.x < 2) atomicAdd(out + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * inv);
 }
 
-extern "C" int mmt_box_loss(const float* logits, const float* breg, const int64_t* labels, const float* regt, int R, int NC,
-                            float* out, float* dlogits, float* dbreg, void* stream) {
+extern "C" int mmt_box_loss_rows(const float* logits, const float* breg, const int64_t* labels, const float* regt, int R, int NC,
+                                 const int64_t* n_rows, float* out, float* dlogits, float* dbreg, void* stream) {
   if (!logits || !breg || !labels || !regt || !out || !dlogits || !dbreg || R < 1 || NC < 2) return MMT_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(out, 0, 2 * sizeof(float), s) != hipSuccess) return MMT_EINVAL;
   int blocks = (R + 255) / 256;
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(box_loss_kernel, dim3(blocks), dim3(256), 0, s, logits, breg, labels, regt, R, NC, out, dlogits, dbreg);
+  hipLaunchKernelGGL(box_loss_kernel, dim3(blocks), dim3(256), 0, s, logits, breg, labels, regt, R, NC, out, dlogits, dbreg, n_rows);
   MMT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int mmt_box_loss(const float* logits, const float* breg, const int64_t* labels, const float* regt, int R, int NC,
+                            float* out, float* dlogits, float* dbreg, void* stream) {
+  return mmt_box_loss_rows(logits, breg, labels, regt, R, NC, nullptr, out, dlogits, dbreg, stream);
 }

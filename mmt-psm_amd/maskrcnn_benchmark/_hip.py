@@ -122,6 +122,7 @@ _SIGS = {
     "mmt_rpn_loss": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p,
                      c_void_p, c_void_p],
     "mmt_box_loss": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mmt_box_loss_rows": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mmt_relation_attention_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p, c_void_p, c_void_p],
     "mmt_relation_attention_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
@@ -2110,14 +2111,19 @@ def rpn_loss(obj, reg, labels, regt, pos, neg, beta):
     return ws[4:6], dobj, dreg
 
 
-def box_loss(logits, breg, labels, regt):
-    """include/mmtpsm.h: mmt_box_loss.  logits (R, NC), breg (R, 4 NC), labels (R,) int64, regt (R, 4)
-    -> out (2,) = (classification loss, box loss), d out[0] / d logits, d out[1] / d breg"""
+def box_loss(logits, breg, labels, regt, n_rows=None):
+    """include/mmtpsm.h: mmt_box_loss / mmt_box_loss_rows.  logits (R, NC), breg (R, 4 NC), labels (R,) int64, regt (R, 4)
+    -> out (2,) = (classification loss, box loss), d out[0] / d logits, d out[1] / d breg.  n_rows (device int64 scalar): the batch
+    is a fixed-capacity one -- rows labelled -1 are skipped, the means run over n_rows"""
     logits, breg = _dev(logits, "logits").float().contiguous(), _dev(breg, "breg").float().contiguous()
     labels, regt = labels.to(torch.int64).contiguous(), regt.float().contiguous()
     R, NC = logits.shape
     out = torch.empty((2,), dtype=torch.float32, device=logits.device)
     dl, db = torch.empty_like(logits), torch.empty_like(breg)
+    if n_rows is not None:
+        _check(lib().mmt_box_loss_rows(_p(logits), _p(breg), _p(labels), _p(regt), R, NC, _p(n_rows.to(torch.int64)), _p(out), _p(dl),
+                                       _p(db), _stream()), "mmt_box_loss_rows")
+        return out, dl, db
     _check(lib().mmt_box_loss(_p(logits), _p(breg), _p(labels), _p(regt), R, NC, _p(out), _p(dl), _p(db), _stream()), "mmt_box_loss")
     return out, dl, db
 

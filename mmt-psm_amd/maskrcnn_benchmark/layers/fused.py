@@ -582,15 +582,15 @@ class BoxLossFn(torch.autograd.Function):
     """(classification loss, box loss) of box_head/loss.py:118-162 in one launch, gradients kept from the forward pass"""
 
     @staticmethod
-    def forward(ctx, logits, breg, labels, regt):
-        out, dl, db = H.box_loss(logits, breg, labels, regt)
+    def forward(ctx, logits, breg, labels, regt, n_rows=None):
+        out, dl, db = H.box_loss(logits, breg, labels, regt, n_rows)
         ctx.save_for_backward(dl, db)
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g0, g1):
         dl, db = ctx.saved_tensors
-        return dl * g0, db * g1, None, None
+        return dl * g0, db * g1, None, None, None
 
 
 class PSMLossFn(torch.autograd.Function):

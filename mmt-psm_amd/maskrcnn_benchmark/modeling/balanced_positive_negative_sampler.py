@@ -10,6 +10,9 @@ from maskrcnn_benchmark import _hip as H
 from maskrcnn_benchmark.utils.miscellaneous import dev_const
 
 
+KEY_ROWS = 4096   # lists up to this length draw their keys from a (images, KEY_ROWS) table (see __call__)
+
+
 class BalancedPositiveNegativeSampler(object):
     def __init__(self, batch_size_per_image, positive_fraction):
         self.batch_size_per_image = batch_size_per_image
@@ -35,7 +38,14 @@ class BalancedPositiveNegativeSampler(object):
         off = [0]
         for n in lens:
             off.append(off[-1] + n)
-        keys = torch.rand(labels.shape, device=labels.device, generator=self.generator)
+        if lens and max(lens) <= KEY_ROWS:
+            # short lists (the box head's proposals): the keys of image i are the first len_i entries of row i of a table of fixed
+            # width, so a candidate's key depends on its position only -- a list kept at fixed capacity (rows behind its count are
+            # never sampled) and the same list sliced to its count draw the same keys and give the same sampled set (SURVEY f-2)
+            table = torch.rand((len(lens), KEY_ROWS), device=labels.device, generator=self.generator)
+            keys = torch.cat([table[i, :n] for i, n in enumerate(lens)], 0) if len(lens) > 1 else table[0, :lens[0]]
+        else:
+            keys = torch.rand(labels.shape, device=labels.device, generator=self.generator)
         num_pos = int(self.batch_size_per_image * self.positive_fraction)
         pm, nm, _ = H.sample_fg_bg(labels, keys, dev_const(off, torch.int32, labels.device), self.batch_size_per_image, num_pos)
         return list(pm.split(lens, 0)), list(nm.split(lens, 0))

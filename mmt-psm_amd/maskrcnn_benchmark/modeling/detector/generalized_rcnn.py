@@ -140,6 +140,11 @@ class GeneralizedRCNN(nn.Module):
             self.taps[name] = value
         return value
 
+    def _lists_free(self):
+        """nobody outside the heads looks at the proposal / detection lists of this pass: they may stay at fixed capacity"""
+        return (self.taps is None and getattr(self, "_replay", None) is None and self.relation_nms is None
+                and not self.mask_heads.mask.use_relation)
+
     def set_module_mode(self, mode):
         self.rpn.set_teacher_mode(mode)
         self.box_heads.box.set_teacher_mode(mode)
@@ -159,7 +164,19 @@ class GeneralizedRCNN(nn.Module):
         if self.training and torch.is_grad_enabled():
             # three consumers of every pyramid level: one launch sums their gradients (layers/fused.py::ForkFn)
             f_rpn, f_box, f_mask = fused.fork_levels(features, 3)
-        proposals, proposal_losses = self.rpn(images, f_rpn, targets)
+        # SURVEY f-2 (round 6): the training lists at fixed capacity, counts consumed on the device -- no read-back between the RPN
+        # head and the box head's losses (rpn.py::select, box_head.py::subsample_fixed).  Tests that look at the lists (taps /
+        # replay) and IR-Net (its modules take the sliced lists) keep the reference's sliced form
+        sel = self.rpn.box_selector_train
+        fixed_train = (self.training and _NO_READBACK and self._lists_free() and features[0].is_cuda
+                       and not getattr(sel, "fixed_capacity", False))
+        if fixed_train:
+            sel.fixed_capacity = True
+        try:
+            proposals, proposal_losses = self.rpn(images, f_rpn, targets)
+        finally:
+            if fixed_train:
+                sel.fixed_capacity = False
         proposals = self._tap("rpn_proposals" if self.training else "infer_proposals", proposals)
         x, result, losses, class_logits, box_regression = self.box_heads(f_box, proposals, targets)
         nms_loss = None
@@ -228,7 +245,12 @@ class GeneralizedRCNN(nn.Module):
             from ..roi_heads.box_head.box_head import resolve_counts
             teacher_infer = resolve_counts(teacher_infer)
         self.set_module_mode("train")
-        _, _, _, _, proposals, _, ffi_boxes = self.rpn.forward_teacher(images[0], aug_features[0], teacher_infer)
+        sel_t = self.rpn.box_selector_train
+        sel_t.fixed_capacity = fixed   # (round 6: the train-config lists too -- the box head's sampler takes the counts on the device)
+        try:
+            _, _, _, _, proposals, _, ffi_boxes = self.rpn.forward_teacher(images[0], aug_features[0], teacher_infer)
+        finally:
+            sel_t.fixed_capacity = False
         self.rpn.shared = None
         proposals = self._tap("teacher_proposals", proposals)
         embeddings = self.get_emb_feature(aug_features) if self.cfg.MT.FG_HINT else None

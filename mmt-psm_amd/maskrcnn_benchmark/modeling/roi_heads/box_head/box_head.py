@@ -25,6 +25,19 @@ from maskrcnn_benchmark.utils.miscellaneous import batch_boxlist_hflip
 
 
 
+_ARANGE = {}
+
+
+def _arange(n, dev):
+    """cached int32 arange (a constant of the capacity: no launch per call)"""
+    t = _ARANGE.get((n, dev))
+    if t is None:
+        if len(_ARANGE) > 64:
+            _ARANGE.clear()
+        t = _ARANGE[(n, dev)] = torch.arange(n, device=dev, dtype=torch.int32)
+    return t
+
+
 class MaskRCNNFPNAdaptor(nn.Module):
     """MGD hint adaptors: 5 independent 1x1 convs (roi_box_feature_extractors.py:45-75)"""
 
@@ -141,8 +154,62 @@ class FastRCNNLossComputation(object):
                                       weights=self.box_coder.weights)
         return list(lab.split(A, 0)), list(reg.split(A, 0))
 
+    def subsample_fixed(self, proposals, targets):
+        """box_head/loss.py:82-116 on FIXED-CAPACITY proposal lists (rpn.py::select with `fixed_capacity`: every image has `cap`
+        rows, the rows behind its device-side count are zero boxes) without a host read-back (SURVEY f-2, round 6).  Rows behind the
+        count are labelled -1 -- the sampler's "never" -- so the sampled sets are those of the sliced lists; every image then gets
+        exactly BATCH_SIZE_PER_IMAGE rows, the sampled ones in ascending order like `nonzero`, followed -- only when the image had
+        fewer candidates than that -- by rows labelled -1 that the losses skip (`mmt_box_loss` normalises by the rows it counts).
+        The number of positives per image, which sizes the mask head's input, travels through a pinned buffer behind an event
+        (`n_pos_async`): whoever needs it waits there, after the box head's launches have been queued."""
+        N, cap = len(proposals), len(proposals[0])
+        dev = proposals[0].bbox.device
+        for t in targets:
+            if len(t) == 0:
+                raise ValueError("No ground-truth boxes available for one of the images during training")
+        goff = [0]
+        for t in targets:
+            goff.append(goff[-1] + len(t))
+        cand = torch.cat([p.bbox for p in proposals], 0) if N > 1 else proposals[0].bbox
+        gt = torch.cat([t.bbox.to(dev) for t in targets], 0) if N > 1 else targets[0].bbox.to(dev)
+        gl = torch.cat([t.get_field("labels").to(dev) for t in targets], 0) if N > 1 else targets[0].get_field("labels").to(dev)
+        m = self.proposal_matcher
+        _, lab, reg = H.match_targets(cand, dev_const([i * cap for i in range(N + 1)], torch.int32, dev), gt, dev_ints(goff, dev), N,
+                                      m.high_threshold, m.low_threshold, m.allow_low_quality_matches, gt_labels=gl, box_labels=True,
+                                      weights=self.box_coder.weights)
+        counts = torch.cat([p.count_dev for p in proposals]) if N > 1 else proposals[0].count_dev
+        rows = _arange(cap, dev)
+        lab = torch.where((rows[None, :] < counts[:, None]).reshape(-1), lab, torch.full_like(lab, -1))
+        labels = list(lab.split(cap, 0))
+        pos, neg = self.fg_bg_sampler(labels, tag="roi_sampler")
+        B = self.fg_bg_sampler.batch_size_per_image
+        npos = torch.stack([p_.sum() for p_ in pos])
+        pin = getattr(self, "_npos_pin", None)
+        if pin is None or pin.numel() < N:
+            pin = self._npos_pin = torch.empty((max(N, 8),), dtype=torch.int64).pin_memory()
+        pin[:N].copy_(npos, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        out = []
+        regs = reg.split(cap, 0)
+        for i, (p, lb, rg, pm_, nm_) in enumerate(zip(proposals, labels, regs, pos, neg)):
+            idx = torch.nonzero_static(pm_ | nm_, size=B, fill_value=-1).squeeze(1)
+            ok = idx >= 0
+            idx = idx.clamp(min=0)
+            q = BoxList(p.bbox[idx], p.size, p.mode)
+            for k, v in p.extra_fields.items():
+                q.add_field(k, v[idx])
+            q.add_field("labels", torch.where(ok, lb[idx], torch.full_like(idx, -1).to(lb.dtype)))
+            q.add_field("regression_targets", rg[idx])
+            q.n_pos_async = (pin, ev, i)
+            out.append(q)
+        self._proposals = out
+        return out
+
     def subsample(self, proposals, targets):
         """box_head/loss.py:82-116"""
+        if all(getattr(p, "count_dev", None) is not None for p in proposals):
+            return self.subsample_fixed(proposals, targets)
         labels, regs = self.prepare_targets(proposals, targets)
         pos, neg = self.fg_bg_sampler(labels, tag="roi_sampler")
         out = []
@@ -166,8 +233,10 @@ class FastRCNNLossComputation(object):
         props = self._proposals
         labels = torch.cat([p.get_field("labels") for p in props], 0)
         regt = torch.cat([p.get_field("regression_targets") for p in props], 0)
-        # one launch (csrc/losses.hip: mmt_box_loss); its tensor formulation is the checker in tests/test_hip_kernels.py
-        return fused.BoxLossFn.apply(class_logits, box_regression, labels, regt)
+        # one launch (csrc/losses.hip: mmt_box_loss); its tensor formulation is the checker in tests/test_hip_kernels.py.  Rows
+        # labelled -1 (fixed-capacity lists: subsample_fixed) are not rows of the reference's batch: skipped, not counted
+        fixed = any(getattr(p, "n_pos_async", None) is not None for p in props)
+        return fused.BoxLossFn.apply(class_logits, box_regression, labels, regt, (labels >= 0).sum() if fixed else None)
 
     def evaluatePSM(self, class_logits, class_logits_t, proposals):
         """box_head/loss.py:164-237,267-287: hard-negative mining by teacher disagreement + sharpened soft CE"""
@@ -200,8 +269,8 @@ class FastRCNNLossComputation(object):
             # (:281); reproduced as written: the kernel's "mean over views, then softmax" over ONE pre-averaged view
             if typ == "bce":
                 teacher = torch.softmax(teacher, dim=2).mean(0, keepdim=True).contiguous()
-            roww = torch.ones(labels.shape, device=labels.device)
-            S = dev_const(float(labels.numel()), torch.float32, labels.device)
+            roww = (labels >= 0).to(torch.float32)   # (rows labelled -1: padding of a fixed-capacity list, not rows of the batch)
+            S = roww.sum()
         nc = teacher.shape[2]
         norm = 1.0 / (S * (3.0 if kind == 0 else float(nc)))
         losses = [fused.PSMLossFn.apply(cl, teacher, roww, norm, cfg.MT.TEMP, 1 if cfg.MT.SHARPEN else 0, kind)

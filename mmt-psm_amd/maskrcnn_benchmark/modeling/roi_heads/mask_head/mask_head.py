@@ -24,6 +24,12 @@ def keep_only_positive_boxes(boxes):
     for b in boxes:
         m = b.get_field("labels") > 0
         n_pos = getattr(b, "n_pos", None)  # set by the box head's sampler: no blocking nonzero here
+        na = getattr(b, "n_pos_async", None)
+        if n_pos is None and na is not None:
+            # round 6 (SURVEY f-2): the count left the device through a pinned buffer when the sampler ran; everything the box head
+            # does with the sampled lists has been queued in between -- the wait here is for work long done
+            na[1].synchronize()
+            n_pos = int(na[0][na[2]])
         pos_boxes.append(b[torch.nonzero_static(m, size=n_pos).squeeze(1) if n_pos is not None else m.nonzero().squeeze(1)])
         pos_inds.append(m)
     return pos_boxes, pos_inds

@@ -159,15 +159,22 @@ class RPNPostProcessor(nn.Module):
                                                      c["offs"], own_pre, self.post_nms_top_n, fpn, training, cap, gt, gt_off,
                                                      min_size_filter=self.min_size > 0,
                                                      zero_tails=getattr(self, "fixed_capacity", False))
-        if getattr(self, "fixed_capacity", False) and not training and between is None and not (gt is not None):
-            # SURVEY f-2 (the teacher's coarse inference): no read-back -- every image keeps all `cap` rows, the rows behind its
-            # count are zero boxes, and the count travels as a device scalar (`count_dev`).  The one consumer of these lists,
-            # the box head's inference post-processor, gives those rows probability 0: they can never pass its score threshold,
-            # so the detections are those of the sliced lists (box_head.py::PostProcessor.forward).
+        if getattr(self, "fixed_capacity", False):
+            # SURVEY f-2: no read-back -- every image keeps all `cap` rows, the rows behind its count are zero boxes, and the count
+            # travels as a device scalar (`count_dev`).  Consumers: the box head's inference post-processor gives those rows
+            # probability 0 (they can never pass its score threshold: box_head.py::PostProcessor.forward); round 6, the TRAINING
+            # lists of the student and of the teacher's train-config selector: the box head's sampler labels them -1 = never
+            # sampled (box_head.py::FastRCNNLossComputation.subsample_fixed), so the sampled sets are those of the sliced lists
+            if between is not None:
+                self.between_result = between()
             out = []
             for n in range(N):
                 b = BoxList(ob[n], sizes[n], "xyxy")
                 b.add_field("objectness", osc[n])
+                if self.is_teacher:
+                    b.add_field("box_reg", orr[n])
+                    b.add_field("rpn_topk", oi[n])
+                    b.add_field("rpn_ancher_level", ol[n].to(torch.int64))
                 b.count_dev = oc[n:n + 1]
                 out.append(b)
             return out

@@ -794,3 +794,30 @@ def test_mask_head_targets_one_launch_matching_vs_tensor_formulation(synth):
     assert (lab > 0).any() and (lab == 0).any()
     assert torch.equal(lab, lab_t)
     assert torch.equal(mt, mt_t)
+
+
+def test_box_loss_on_a_fixed_capacity_batch(hip_lib=None):
+    """mmt_box_loss_rows (round 6, SURVEY f-2): rows labelled -1 are padding -- no loss, zero gradient -- and both means run over the
+    counted rows: equal to mmt_box_loss on the batch with those rows removed"""
+    from maskrcnn_benchmark import _hip as H
+    g = torch.Generator().manual_seed(3)
+    R, NC = 1024, 3
+    logits = torch.randn(R, NC, generator=g).cuda()
+    breg = torch.randn(R, 4 * NC, generator=g).cuda()
+    labels = torch.randint(0, NC, (R,), generator=g).cuda()
+    regt = torch.randn(R, 4, generator=g).cuda()
+    pad = torch.zeros(R, dtype=torch.bool)
+    pad[torch.randperm(R, generator=g)[:137]] = True
+    pad = pad.cuda()
+    lab2 = torch.where(pad, torch.full_like(labels, -1), labels)
+    out, dl, db = H.box_loss(logits, breg, lab2, regt, n_rows=(lab2 >= 0).sum())
+    keep = ~pad
+    out0, dl0, db0 = H.box_loss(logits[keep], breg[keep], labels[keep], regt[keep])
+    torch.cuda.synchronize()
+    assert torch.allclose(out, out0, rtol=1e-6, atol=1e-7)
+    assert torch.equal(dl[keep], dl0) and torch.equal(db[keep], db0)
+    assert float(dl[pad].abs().max()) == 0.0 and float(db[pad].abs().max()) == 0.0
+    # all rows counted: the plain entry point, bit for bit
+    o1, d1, b1 = H.box_loss(logits, breg, labels, regt, n_rows=(labels >= 0).sum())
+    o2, d2, b2 = H.box_loss(logits, breg, labels, regt)
+    assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(b1, b2)

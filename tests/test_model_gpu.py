@@ -244,6 +244,77 @@ def test_teacher_without_count_readback_equals_sliced_lists(setup, synth, monkey
     assert sum(int(m.sum()) for m in a["seg_mask"]) > 0
 
 
+def test_student_heads_without_count_readback_equal_sliced_lists(setup, synth, monkeypatch):
+    """SURVEY f-2 (round 6): the student's TRAINING lists at fixed capacity -- RPN selector without its count read-back, the box
+    head's matcher / sampler on `capacity` rows with the rows behind the device-side count labelled -1, exactly
+    BATCH_SIZE_PER_IMAGE sampled rows per image -- against the reference's sliced lists: the same sampled sets, the same losses,
+    the same gradients; and no device tensor is read by the host between the RPN head and the box head's losses (the one wait of
+    the pass is the mask head's, for a count that left the device when the sampler ran)."""
+    from maskrcnn_benchmark.modeling.detector import generalized_rcnn as gr
+    from maskrcnn_benchmark.structures.image_list import to_image_list
+    cfg, student, _ = setup
+    imgs, tgs = synth.make_labeled(2, SIZE, 4, seed=4242)
+    il = to_image_list(list(imgs.cuda()), 32)
+    outs = []
+    for flag in (False, True):
+        monkeypatch.setattr(gr, "_NO_READBACK", flag)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(11)
+        student.set_rng(g)
+        reads = []
+        tolist, item = torch.Tensor.tolist, torch.Tensor.item
+
+        def spy_tolist(self, _f=tolist):
+            if self.is_cuda:
+                reads.append("tolist")
+            return _f(self)
+
+        def spy_item(self, _f=item):
+            if self.is_cuda:
+                reads.append("item")
+            return _f(self)
+
+        sampled = []
+        le = student.box_heads.box.loss_evaluator
+        sub = le.subsample
+
+        def spy_sub(proposals, targets, _sub=sub):
+            out = _sub(proposals, targets)
+            sampled.append([(q.bbox.clone(), q.get_field("labels").clone()) for q in out])
+            return out
+
+        le.subsample = spy_sub
+        torch.Tensor.tolist, torch.Tensor.item = spy_tolist, spy_item
+        try:
+            for p_ in student.parameters():
+                p_.grad = None
+            out = student(il, _targets_product(tgs, "cuda"))
+            n_reads = list(reads)
+            torch.Tensor.tolist, torch.Tensor.item = tolist, item
+            sum(out.values()).backward()
+            torch.cuda.synchronize()
+        finally:
+            torch.Tensor.tolist, torch.Tensor.item = tolist, item
+            le.subsample = sub
+            student.set_rng(None)
+        grads = {k: v.grad.clone() for k, v in student.named_parameters() if v.grad is not None}
+        outs.append(({k: float(v) for k, v in out.items()}, sampled[0], grads, n_reads))
+    (la, sa, ga, ra), (lb, sb, gb, rb) = outs
+    assert rb == [], rb                      # fixed capacity: no device tensor read by the host in the whole forward
+    assert len(ra) >= 1                      # (the sliced form reads its counts)
+    for (ba, laa), (bb, lbb) in zip(sa, sb):
+        assert bb.shape[0] == 512            # exactly BATCH_SIZE_PER_IMAGE rows per image
+        keep = lbb >= 0
+        assert int(keep.sum()) == ba.shape[0]
+        assert torch.equal(bb[keep], ba) and torch.equal(lbb[keep], laa)      # the sampled set, in the reference's order
+    for k in la:
+        assert lb[k] == pytest.approx(la[k], rel=2e-6, abs=1e-7), (k, la[k], lb[k])
+    assert ga.keys() == gb.keys()
+    for k in ga:
+        den = float(ga[k].abs().max())
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-4 * max(den, 1e-6), k   # (ROIAlign backward: atomics in another order)
+
+
 def test_teacher_without_detections(setup, synth):
     """An unlabeled image on which the teacher detects nothing: the coarse inference returns empty BoxLists (with an
     all-zero pseudo mask) and forward_teacher raises the Matcher's ValueError exactly like the reference
