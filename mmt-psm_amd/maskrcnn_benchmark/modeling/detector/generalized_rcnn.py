@@ -29,6 +29,8 @@ class ImageListView(object):
 # read-back before the box head, the detection counts read back behind the queued mask head).  False = sliced lists throughout
 # (tests/test_model_gpu.py compares the two).
 _NO_READBACK = True
+import os as _os
+_FIXED_TRAIN = _os.environ.get("MMT_FIXED_TRAIN_LISTS", "1") != "0"   # round 6 (A/B timing): the TRAINING lists at fixed capacity too
 
 
 def is_teacher_fpn(backbone):
@@ -168,7 +170,7 @@ class GeneralizedRCNN(nn.Module):
         # head and the box head's losses (rpn.py::select, box_head.py::subsample_fixed).  Tests that look at the lists (taps /
         # replay) and IR-Net (its modules take the sliced lists) keep the reference's sliced form
         sel = self.rpn.box_selector_train
-        fixed_train = (self.training and _NO_READBACK and self._lists_free() and features[0].is_cuda
+        fixed_train = (self.training and _NO_READBACK and _FIXED_TRAIN and self._lists_free() and features[0].is_cuda
                        and not getattr(sel, "fixed_capacity", False))
         if fixed_train:
             sel.fixed_capacity = True
@@ -246,7 +248,7 @@ class GeneralizedRCNN(nn.Module):
             teacher_infer = resolve_counts(teacher_infer)
         self.set_module_mode("train")
         sel_t = self.rpn.box_selector_train
-        sel_t.fixed_capacity = fixed   # (round 6: the train-config lists too -- the box head's sampler takes the counts on the device)
+        sel_t.fixed_capacity = fixed and _FIXED_TRAIN   # (round 6: the train-config lists too -- the box head's sampler takes the counts on the device)
         try:
             _, _, _, _, proposals, _, ffi_boxes = self.rpn.forward_teacher(images[0], aug_features[0], teacher_infer)
         finally:
