@@ -3,8 +3,8 @@ products with bf16 activation storage in the backbone + FPN (`bench.py --bf16 --
 [A]-[E] of engine/MTtrainer.py, against the fp32 CPU oracle's trainer (oracle/model.py::Trainer with oracle/irnet.py; pinned
 to the reference by tests/golden/model160_irnet.npz) at bf16 tolerances:
 
-  * every loss of the step (supervised, nms_loss, two-stage loss_seg, mt_fg_loss, mt_classifier) within 1e-2 relative (measured
-    <= 1.6e-3);
+  * every loss of the step (supervised, nms_loss, two-stage loss_seg, mt_fg_loss, mt_classifier) within 4e-3 relative (measured
+    <= 1.6e-3; the bar is stated next to BF16_TOL);
   * the SGD update of a subset of tensors along the whole path (FPN, RPN head, fc7, mask head, relation modules, hint adaptor,
     a layer3 weight) against the oracle's at 0.08 relative in the L2 norm (measured <= 0.056; relation-NMS parameters 0.75: their gradient hangs on
     discrete selections) -- the gradient is d(update): weight decay is 1e-4;
@@ -25,7 +25,14 @@ from conftest import GOLD, ROOT
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, ROOT)
-BF16_TOL = 1e-2   # (round 5: measured <= 1.6e-3 on every loss with the lists substituted where bf16 flipped a decision; was 5e-2)
+# The bar of this configuration.  There is no bf16 oracle to be bit-compared with: the reference has no bf16 path
+# (tools/train_mean_teacher.py runs fp32), so configs[4]'s "bf16 MFMA path" is judged against the fp32 oracle with a stated error
+# budget -- a bf16 product carries 2^-9 relative error per operand, a loss is a mean over >= 10^4 such terms, and the discrete
+# decisions bf16 flips are replayed: every loss within 4e-3 relative = 2.5 x the largest deviation measured since round 3 (1.6e-3).
+# What stays on the fp32-grade arithmetic in this configuration and why: the heads (RPN predictors, fc6 / fc7, mask head on pooled
+# features), every weight gradient and the losses -- their inputs are fp32 tensors produced by fp32 ROIAlign / selection kernels, their
+# time is 15 % of the step, and the relation modules' gradients hang on discrete selections that bf16 already perturbs (below).
+BF16_TOL = 4e-3   # (round 5: 1e-2; round 3: 5e-2)
 
 
 @pytest.fixture()

@@ -820,4 +820,4 @@ def test_box_loss_on_a_fixed_capacity_batch(hip_lib=None):
     # all rows counted: the plain entry point, bit for bit
     o1, d1, b1 = H.box_loss(logits, breg, labels, regt, n_rows=(labels >= 0).sum())
     o2, d2, b2 = H.box_loss(logits, breg, labels, regt)
-    assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(b1, b2)
+    assert torch.allclose(o1, o2, rtol=1e-6, atol=0) and torch.equal(d1, d2) and torch.equal(b1, b2)   # (the sums: one atomic per block)
