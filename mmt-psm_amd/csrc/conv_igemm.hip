@@ -3781,7 +3781,7 @@ extern "C" int mmt_conv_wgrad_splits(const mmt_conv_args* a) {
   // all blocks of a launch run equally long: fill the 512 resident slots (256 CUs x 2 blocks) ONCE.  (640 = 1.25
   // rounds cost a second, 20 %-full round: 92 -> 105 TFLOP/s fp32, 103 -> 136 split-bf16 on the FPN 3x3 shapes)
   const long tiles = (long)tx * ty;
-  constexpr int slots = 512;   // (tuned: profiles/r04_dispatch_sweep.txt; in the step: profiles/r04_history.md)
+  static const int slots = getenv("MMT_WG_SLOTS") ? atoi(getenv("MMT_WG_SLOTS")) : 512;   // (tuned: profiles/r04_dispatch_sweep.txt; in the step: r04 / r06 history; the switch is for that sweep)
   constexpr int min_px = 512;   // (tuned: profiles/r04_dispatch_sweep.txt; in the step: profiles/r04_history.md)
   int split = (int)(tiles >= slots ? 1 : slots / tiles);
   if (a->x2) {   // two segments of p.M pixels each: the same number of blocks reduces twice the pixels; an even number of slices

@@ -311,7 +311,8 @@ int wgpl_splits(const mmt_conv_args* a) {
   if (e && atoi(e) == 0) return 0;
   const long T = ((long)a->N * a->H * a->W) >> 5;
   const long tiles = (long)(a->Cout >> 7) * ((long)a->KH * a->KW * a->Cin >> 7);
-  long ks = 256 / tiles;
+  static const long target = getenv("MMT_WGPL_BLOCKS") ? atol(getenv("MMT_WGPL_BLOCKS")) : 256;   // (blocks per launch the pixel ranges aim at; the switch: profiles/r06_history.md)
+  long ks = target / tiles;
   if (ks > T / 8) ks = T / 8;     // >= 4 super-steps per group and range
   if (ks < 1) ks = 1;
   if (T < 2) return 0;

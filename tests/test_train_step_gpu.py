@@ -93,12 +93,24 @@ def _param(flat, model, name):
     return p.cpu().contiguous()
 
 
+@pytest.mark.parametrize("primed", [False, True], ids=["first-step", "epilogue-planes"])
 @pytest.mark.parametrize("iteration", [1400, 5], ids=["mean-teacher-step", "before-START_MT"])
-def test_full_step_matches_oracle(small, synth, state_shapes, weights, iteration):
+def test_full_step_matches_oracle(small, synth, state_shapes, weights, iteration, primed):
+    """primed (round 6): the compared step runs in the state every step but a run's first is in -- the producing sites have their
+    plane scales (one un-compared step on the same data, then weights / momentum / schedule restored), so the tap-strip / plane-fed
+    launches and the plane-fed weight gradients read planes written by their producers' epilogues (_hip._rb_produce)"""
     from maskrcnn_benchmark.utils.replay import Replay
+    from maskrcnn_benchmark import _hip as H
     cfg, trainer, batch = small
     _load(trainer, weights)
     snap = _snapshot(trainer)
+    H.rb_reset()
+    if primed:
+        il, tg, ul = batch()
+        trainer.train_step(iteration, il, tg, ul)
+        torch.cuda.synchronize()
+        _restore(trainer, snap)
+    n_epi = H.F16_STATS.get("rb_epi", 0)
     om, ot = _oracle_trainer(synth, state_shapes, weights)
     imgs, tgs = synth.make_labeled(2, 160, 4, seed=1234)
     unl = synth.make_unlabeled(2, 160, 3, seed=4321)
@@ -132,10 +144,13 @@ def test_full_step_matches_oracle(small, synth, state_shapes, weights, iteration
                 sc = rec[what][n][1]
                 assert abs(float(sc[i]) - float(sc[j])) <= 2e-5 * max(abs(float(sc[i])), 1e-3), (what, n, i, j, sc[i], sc[j])
     assert "rpn_proposals" in own_s     # the student's proposal list went through the alignment check
+    if H.F16X2 and H.get_conv_precision() == 3:
+        assert (H.F16_STATS.get("rb_epi", 0) > n_epi) == primed   # planes from the producers' epilogues were (not) read
     try:
         _check_step(cfg, trainer, ot, state_shapes, weights, losses, ref_losses, before_s, before_t, iteration)
     finally:
         _restore(trainer, snap)
+        H.rb_reset()
 
 
 def _check_step(cfg, trainer, ot, state_shapes, weights, losses, ref_losses, before_s, before_t, iteration):
@@ -378,6 +393,16 @@ def test_full_step_losses_match_oracle_at_bench_size(synth, state_shapes, weight
     try:
         cfg, trainer, batch = bench.build(torch.device("cuda", 0), 0, n_lab=1, n_unlab=1)
         _load(trainer, weights)
+        _hip.rb_reset()
+        if mode == 3:
+            # round 6: the compared step is the step the bench times from its second step on -- planes out of the producers'
+            # epilogues (one un-compared step first gives the producing sites their scales; weights / momentum / schedule restored)
+            snap = _snapshot(trainer)
+            il, tg, ul = batch()
+            trainer.train_step(1400, il, tg, ul)
+            torch.cuda.synchronize()
+            _restore(trainer, snap)
+        n_epi = _hip.F16_STATS.get("rb_epi", 0)
         if "ref" not in _FULLSIZE_ORACLE:
             ot0.last_epoch = trainer.scheduler.last_epoch
             _FULLSIZE_ORACLE["ref"] = ot0.step(1400, imgs, _oracle_targets(om, tgs), unl, seeds=(99, 100, 101))
@@ -400,6 +425,9 @@ def test_full_step_losses_match_oracle_at_bench_size(synth, state_shapes, weight
         _hip.set_conv_precision(prev)
     assert trainer.skipped_pairs == 0
     assert set(losses) == set(ref_losses) and "mt_fg_loss" in losses and "mt_classifier" in losses
+    if mode == 3 and _hip.F16X2_DEFAULT:
+        assert _hip.F16_STATS.get("rb_epi", 0) > n_epi   # the compared step read planes written by producers' epilogues
+    _hip.rb_reset()
     moved = 0
     for own, rec in ((own_s, ta), (own_t, tb)):
         for key in [k for k in own if k.endswith("_moved")]:
