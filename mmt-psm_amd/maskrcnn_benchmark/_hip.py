@@ -1388,12 +1388,23 @@ def _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask):
              _PLAN_EPOCH[0]), src, src if base is None else base)
 
 
+RB_PG1X1 = os.environ.get("MMT_RB_WIDE", "0") != "0"   # 1x1 layers with K >= 512 on the plane-fed GEMM when their input carries a producer's planes
+
+
+def _epi_planes(x):
+    """does x carry row-blocked planes its producer's epilogue wrote for the whole tensor?"""
+    rb = getattr(x, "_mmt_rb", None)
+    return (rb is not None and len(rb) > 3 and rb[2] == x._version and rb[3] == "epi" and (len(rb) < 5 or rb[4] is None))
+
+
 def _conv_fast(x, w, scale, shift, stride, pad, relu, res, res_mode, mask, mask_scale, f16_src, rb_site=None):
     key, src, owner = _plan_key(x, w, f16_src, stride, pad, relu, res, res_mode, mask)
     plan = _PLAN.get(key) if key is not None else None
     if plan is None:
         return None
-    tmpl, kind, Cout, Ho, Wo, wref = plan
+    tmpl, kind, Cout, Ho, Wo, wref = plan[:6]
+    if kind == 0 and len(plan) > 6 and plan[6] and RB_PG1X1 and _epi_planes(x):
+        kind = 2   # (round 6: a long-K 1x1 layer whose input came with planes: the plane-fed GEMM, no split pass)
     if wref() is not owner or x.dtype != torch.float32 or (res is not None and res.dtype != torch.float32) or (
             mask is not None and mask.dtype != torch.float32):
         return None
@@ -1461,7 +1472,10 @@ def _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, kind,
     t.mask_scale, t.io_bf16, t.y_amax_stats = 1.0, 0, 1
     if len(_PLAN) > 4096:
         _PLAN.clear()
-    _PLAN[key] = (bytes(t), kind, Cout, Ho, Wo, weakref.ref(owner))
+    # (7th: a 1x1 / stride-1 layer with K >= 512 the plane-fed GEMM takes -- chosen per call, when the input carries planes)
+    pg1 = bool(kind == 0 and t.KH == 1 and t.KW == 1 and t.stride == 1 and t.Cin >= 512 and t.res_mode <= 1 and t.N <= 4
+               and conv_pg_plan(t.N, t.Cin, t.H, t.W, t.Cout, 1, 1, 1, 0)[0] > 0)
+    _PLAN[key] = (bytes(t), kind, Cout, Ho, Wo, weakref.ref(owner), pg1)
 
 
 def _epilogue_bytes(y, res, res_mode, mask, mul):
@@ -1566,6 +1580,10 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
     if (f16t is not None and f16 is None and mul is None and out_stride == 1 and res_mode <= 1 and KH * KW >= 4
             and lib().mmt_conv_pg_wanted(ctypes.byref(a)) == 1):
         pg, f16t = f16t, None
+    elif (RB_PG1X1 and f16t is not None and f16 is None and mul is None and out_stride == 1 and res_mode <= 1 and KH == 1 and KW == 1
+          and stride == 1 and Cin >= 512 and N <= 4 and _epi_planes(x) and y_out is None
+          and conv_pg_plan(N, Cin, H, W, Cout, 1, 1, 1, 0)[0] > 0):
+        pg, f16t = f16t, None   # (round 6: a long-K 1x1 layer whose input came with its producer's planes)
     if f16 is not None:
         x_planes = None
     if want_planes and out_stride == 1 and y_out is None and Cout % 4 == 0 and not io:
@@ -1608,7 +1626,8 @@ def conv_forward(x, w, scale=None, shift=None, stride=1, pad=0, relu=False, res=
             ev[0].record()
         F16_STATS["pg"] += 1
         if fast_ok and not io:
-            _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, 2, Cout, Ho, Wo)
+            # (a 1x1 layer is here because THIS input carried planes: its plan is the tiled kernel's, the plane-fed form chosen per call)
+            _plan_record(x, w, f16_src, stride, pad, relu, res, res_mode, mask, a, 2 if KH * KW >= 4 else 0, Cout, Ho, Wo)
         a.f16_guard_x = _guard(_amax_of(x))
         if pg[1]:
             a.w_src, a.w_src_scale = pg[0].data_ptr(), _p(pg[2])

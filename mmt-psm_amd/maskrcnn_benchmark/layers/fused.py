@@ -353,6 +353,17 @@ def batch_slice(t, lo, hi):
     return v
 
 
+# Round 6, second stage (MMT_RB_WIDE=1, off unless measured faster: profiles/r06_history.md): planes ALSO for the operands of the 1x1
+# layers' weight gradients and long-K forward / data-gradient launches -- the block outputs and conv2 outputs of a pass that will be
+# back-propagated, the gradients that flow between blocks -- so that those launches run plane-fed (wgrad_pl_kernel, conv_pg_kernel).
+RB_WIDE = _os.environ.get("MMT_RB_WIDE", "0") != "0"
+_PAIR_FWD = [False]   # inside backbone.forward_pair's no-grad forward (its results are back-propagated through `pre=` nodes)
+
+
+def _wide():
+    return RB_WIDE and (torch.is_grad_enabled() or _PAIR_FWD[0])
+
+
 def bottleneck_forward(x, w1, w2, w3, wd, bn, stride):
     """the 3-4 launches of a bottleneck -> (o1, o2, out)"""
     s1, b1, s2, b2, s3, b3, sd, bd = bn
@@ -365,9 +376,11 @@ def bottleneck_forward(x, w1, w2, w3, wd, bn, stride):
     # kernel from layer2 on, and its weight gradient takes o1's planes too)
     o1 = H.conv_forward(x, w1, s1, b1, stride, 0, relu=True, want_planes=wp, out_dtype=od,
                         rb_site=("o1", w2.data_ptr()) if mid >= 128 else None)
-    o2 = H.conv_forward(o1, w2, s2, b2, 1, 1, relu=True, out_dtype=od)
+    wide = _wide() and mid >= 128
+    o2 = H.conv_forward(o1, w2, s2, b2, 1, 1, relu=True, out_dtype=od, rb_site=("o2", w3.data_ptr()) if wide else None)
     r = x if wd is None else H.conv_forward(x, wd, sd, bd, stride, 0, out_dtype=od)
-    out = H.conv_forward(o2, w3, s3, b3, 1, 0, relu=True, res=r, res_mode=1, out_dtype=od)
+    out = H.conv_forward(o2, w3, s3, b3, 1, 0, relu=True, res=r, res_mode=1, out_dtype=od,
+                         rb_site=("out", w3.data_ptr()) if wide else None)
     return o1, o2, out
 
 
@@ -401,7 +414,8 @@ class BottleneckFn(torch.autograd.Function):
                       want_planes=H.planes_wanted_3x3(o2.shape[0], o2.shape[1], o2.shape[2], o2.shape[3], w2.shape[1]),
                       rb_site=("d_o2", w2.data_ptr()) if o2.shape[1] >= 128 else None)
         dw2, _ = _wgrad(o1, d_o2, w2, 1, 1, s2, dst_w=d2)
-        d_o1 = _dgrad(d_o2, w2, o1.shape, 1, 1, s2, mask=o1, out_dtype=o1.dtype)
+        wide = RB_WIDE and o1.shape[1] >= 128
+        d_o1 = _dgrad(d_o2, w2, o1.shape, 1, 1, s2, mask=o1, out_dtype=o1.dtype, rb_site=("d_o1", w1.data_ptr()) if wide else None)
         dw1, _ = _wgrad(x, d_o1, w1, stride, 0, s1, dst_w=d1)
         dwd = dx = None
         if ctx.has_ds:
@@ -412,7 +426,8 @@ class BottleneckFn(torch.autograd.Function):
                 dx = _dgrad(g, wd, x.shape, stride, 0, sd, mask=x, res=t, res_mode=1, out_dtype=x.dtype) if stride > 1 else \
                     _dgrad(g, wd, x.shape, 1, 0, sd, mask=x, res=t, res_mode=1, out_dtype=x.dtype)
             else:
-                dx = _dgrad(d_o1, w1, x.shape, 1, 0, s1, mask=x, res=g, res_mode=1, out_dtype=x.dtype)
+                dx = _dgrad(d_o1, w1, x.shape, 1, 0, s1, mask=x, res=g, res_mode=1, out_dtype=x.dtype,
+                            rb_site=("dx", w1.data_ptr()) if wide else None)
         return dx, dw1, dw2, dw3, dwd, None, None, None
 
 
@@ -465,12 +480,13 @@ class FPNFn(torch.autograd.Function):
         dwl, dbl, dwi, dbi, dcs = [None] * 4, [None] * 4, [None] * 4, [None] * 4, [None] * 4
         for k in range(4):  # finest first: d_inner_k = dgrad(layer_k) + 2x2-sum(d_inner_{k-1})
             d_in[k] = _dgrad(gs[k], wl[k], inner[k].shape, 1, 1, None, res=d_in[k - 1] if k > 0 else None,
-                             res_mode=3 if k > 0 else 0)
+                             res_mode=3 if k > 0 else 0, rb_site=("d_in", wi[k].data_ptr()) if RB_WIDE else None)
             dwl[k], dbl[k] = _wgrad(inner[k], gs[k], wl[k], 1, 1, None, True, *ctx.dst[1][k])
         for k in range(4):
             dwi[k], dbi[k] = _wgrad(cs[k], d_in[k], wi[k], 1, 0, None, True, *ctx.dst[0][k])
             if ctx.needs_input_grad[k]:
-                dcs[k] = _dgrad(d_in[k], wi[k], cs[k].shape, 1, 0, None, mask=cs[k], out_dtype=cs[k].dtype)  # C_k is a ReLU output
+                dcs[k] = _dgrad(d_in[k], wi[k], cs[k].shape, 1, 0, None, mask=cs[k], out_dtype=cs[k].dtype,  # C_k is a ReLU output
+                                rb_site=("dC", wi[k].data_ptr()) if RB_WIDE and k == 3 else None)
         out = list(dcs)
         for k in range(4):
             out += [dwi[k], dbi[k]]

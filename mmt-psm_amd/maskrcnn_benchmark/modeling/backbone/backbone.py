@@ -168,7 +168,7 @@ class ResNet(nn.Module):
                 x = getattr(self, name)(x)
                 _stage_hook(self, name, x)
             if i >= self.freeze_at and i < len(self.stages):
-                o, x = fused.fork(x, 2)   # the FPN lateral and the next stage: their gradients are summed in one launch
+                o, x = fused.fork(x, 2, ("gC", i) if fused.RB_WIDE else None)   # the FPN lateral and the next stage: their gradients are summed in one launch
                 outs.append(o)
             else:
                 outs.append(x)
@@ -193,6 +193,7 @@ def forward_pair(backbone, xa, xb):
     n = xa.shape[0]
     halves = ((0, n), (n, 2 * n))
     with torch.no_grad():
+        fused._PAIR_FWD[0] = True
         x = body.stem(torch.cat([xa, xb], 0))
         raw = {}     # block -> (o1, o2, out) on the concatenated batch
         frozen = []
@@ -211,6 +212,7 @@ def forward_pair(backbone, xa, xb):
         wl = [getattr(fpn, nm).weight for nm in fpn.layer_blocks]
         bl = [getattr(fpn, nm).bias for nm in fpn.layer_blocks]
         inner_cat, outs_cat = fused.fpn_forward([H.nhwc(c) for c in cs_cat], wi, bi_, wl, bl, getattr(fpn, "out_planes", True))
+        fused._PAIR_FWD[0] = False
     res = []
     for lo, hi in halves:
         outs = []
@@ -223,7 +225,7 @@ def forward_pair(backbone, xa, xb):
                     x = blk(x, pre=tuple(fused.batch_slice(t, lo, hi) for t in raw[(name, bi)]))
                 _stage_hook(body, name, x)
                 if i < len(body.stages):
-                    o, x = fused.fork(x, 2)   # FPN lateral / next stage
+                    o, x = fused.fork(x, 2, ("gC", i) if fused.RB_WIDE else None)   # FPN lateral / next stage
                     outs.append(o)
                     continue
             outs.append(x)
