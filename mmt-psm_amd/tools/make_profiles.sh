@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates profiles/ evidence on the GPU box (writes to gpurun_out/prof; summarize_profiles.py copies what is judged into
-# profiles/r05_*): un-profiled default bench line; per arithmetic (f16x2 = default two-term fp16 split, bf16x3 = MMT_F16X2=0,
+# profiles/r06_*): un-profiled default bench line; per arithmetic (f16x2 = default two-term fp16 split, bf16x3 = MMT_F16X2=0,
 # mode0 = fp32-input MFMA) rocprofv3 kernel stats of the same command; two separate PMC passes (FETCH_SIZE / WRITE_SIZE)
 # reduced per kernel for the default and mode 0; one SQ pass (MFMA busy); the per-shape conv table; other configurations.
 set -u
@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_default.json 2> /tmp/err_default.txt
-export MMT_BENCH_NO_FP32_LEG=1
+export MMT_BENCH_NO_FP32_LEG=1 MMT_BENCH_NO_FAMILY_LEG=1   # (the profiled runs hold the step alone)
 reduce() {  # csv of a --pmc pass -> per-kernel table of one counter
 python3 - "$1" "$2" <<'PY'
 import csv, sys, collections
@@ -59,6 +59,8 @@ for k, c in rows:
         print("   %-28s %.4g" % (n, c[n]))
 PY
 # how the step is put together (no profiler unless noted), other configurations
+python $R/mmt-psm_amd/tools/split_sites.py 2>/dev/null | grep -v amdgpu.ids | cut -c1-260 > $OUT/split_sites.txt
+python $R/mmt-psm_amd/tools/whatif.py 2>/dev/null | grep -v amdgpu.ids > $OUT/whatif.txt
 MMT_WGRAD_STREAM=0 python $R/mmt-psm_amd/tools/conv_table.py > $OUT/conv_table.txt 2>/dev/null
 python $R/mmt-psm_amd/tools/host_phases.py 2>/dev/null | tail -36 > $OUT/host_device_phases.txt
 python $R/mmt-psm_amd/tools/op_sites.py 2>/dev/null | grep -v amdgpu.ids | head -60 > $OUT/library_op_sites.txt

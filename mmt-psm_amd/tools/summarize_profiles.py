@@ -1,9 +1,9 @@
-"""gpurun_out/prof/* (make_profiles.sh) -> profiles/r05_* + profiles/pmc_traffic.json + profiles/r05_summary.md.
+"""gpurun_out/prof/* (make_profiles.sh) -> profiles/r06_* + profiles/pmc_traffic.json + profiles/r06_summary.md.
 The number of steps a kernel trace holds is COUNTED (one `ema_kernel` launch per step), not assumed."""
 import csv, json, os, shutil, sys
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, ROOT)
-SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles"), "r05_"
+SRC, DST, TAG = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles"), "r06_"
 ARITH = {"f16x2": "default: two-term fp16 split, 3 products per multiply (peak 2500 / 3 = 833 TFLOP/s)",
          "bf16x3": "`MMT_F16X2=0` / `--bf16x3`: three-term bf16 split, 6 products (round-2 default, now the per-tensor fall-back; peak 417)",
          "mode0": "`MMT_CONV_PRECISION=0`: fp32-input MFMA (peak 157.3)"}
@@ -21,16 +21,16 @@ def is_library(n):
     return n.startswith("void at::") or n.startswith("at::") or "rocprim" in n or "rocclr" in n or "hipcub" in n
 
 
-out = ["# Round 5 -- profiles of `python bench.py` on 1 x MI355X (state at the end of the round)", "",
+out = ["# Round 6 -- profiles of `python bench.py` on 1 x MI355X (state at the end of the round)", "",
        "Produced by `mmt-psm_amd/tools/make_profiles.sh` (GPU box) + `mmt-psm_amd/tools/summarize_profiles.py`. Files: "
-       "`r05_bench_default.json` (un-profiled `python bench.py`: 10 warm-up + 50 timed steps, median next to the mean, event brackets "
-       "in a separate 10-step leg, CPU baseline 1 + 3 steps); per arithmetic `r05_kernel_stats_<tag>.csv` (rocprofv3 --kernel-trace "
-       "--stats of `bench.py --steps 5 --warmup 2 --profile-steps 5 --no-cpu-baseline`), `r05_bench_under_rocprof_<tag>.json` (the line "
-       "that run printed), `r05_pmc_{FETCH,WRITE}_SIZE_by_kernel_<tag>.csv` (two separate --pmc passes, --kernel-trace only); "
-       "`r05_pmc_mfma_busy.txt` (one SQ pass, single-stream); `pmc_traffic.json` = what bench.py reports as roofline.traffic. "
+       "`r06_bench_default.json` (un-profiled `python bench.py`: 10 warm-up + 50 timed steps, median next to the mean, event brackets "
+       "in a separate 10-step leg, CPU baseline 1 + 3 steps); per arithmetic `r06_kernel_stats_<tag>.csv` (rocprofv3 --kernel-trace "
+       "--stats of `bench.py --steps 5 --warmup 2 --profile-steps 5 --no-cpu-baseline`), `r06_bench_under_rocprof_<tag>.json` (the line "
+       "that run printed), `r06_pmc_{FETCH,WRITE}_SIZE_by_kernel_<tag>.csv` (two separate --pmc passes, --kernel-trace only); "
+       "`r06_pmc_mfma_busy.txt` (one SQ pass, single-stream); `pmc_traffic.json` = what bench.py reports as roofline.traffic. "
        "Tags: " + "; ".join("**%s** = %s" % kv for kv in ARITH.items()) + ".", ""]
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) of `python bench.py "
-                     "--steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline`; per-kernel tables profiles/r05_pmc_*_by_kernel_*.csv",
+                     "--steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline`; per-kernel tables profiles/r06_pmc_*_by_kernel_*.csv",
            "fetch_correction": 2.0, "csrc_sha1": __import__("importlib").import_module("bench").csrc_sha1(),
            "note": "FETCH_SIZE on gfx950 reports 1/2 of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section): "
                    "doubled. WRITE_SIZE uncalibrated, taken as is. Infinity-Cache hits are counted, so this is fabric traffic, an "
@@ -53,6 +53,19 @@ out += ["Un-profiled default run: **%.1f imgs/s, %.2f ms/step** (mean of %d brac
             o.get("kernel", "-").split(" ")[0], o.get("achieved", 0), o.get("frac", 0), o.get("launches_per_step", 0),
             bd.get("fp32_mfma_mode", {}).get("value", float("nan")), bd.get("fp32_mfma_mode", {}).get("ms_per_step", float("nan")),
             bd.get("cpu_baseline", {}).get("cores", 0), bd.get("cpu_baseline", {}).get("value", float("nan"))), ""]
+fam, fl = r.get("family"), bd.get("forward_leg")
+if fam:
+    out += ["**Convolution family** (`roofline.family`: every conv / weight-gradient launch of three single-stream steps, event-bracketed): "
+            "bound %.2f ms / measured %.2f ms = **%.3f** over %.0f launches per step, %.2f TFLOP algorithmic per step.  By group: %s." % (
+                fam["bound_ms"], fam["time_ms"], fam["frac"], fam["launches_per_step"], fam["algorithmic_tflop_per_step"],
+                "; ".join("%s %.2f / %.2f ms (%.2f)" % (k, v["bound_ms"], v["time_ms"], v["frac"]) for k, v in list(fam["groups"].items())[:10])), ""]
+if fl:
+    out += ["**Forward leg** (`forward_leg`: teacher forward_teacher + student supervised + unsupervised forwards, no autograd, one stream, "
+            "12 image-forwards): %.2f ms per pass (device %.2f), %.2f TFLOP algorithmic -> **%.1f TFLOP/s = %.3f of 833** (3 products per "
+            "multiply) = %.2f x the fp32-input MFMA peak of 157.3; the leg's own convolution bound %.2f ms of %.2f ms measured (%.3f)." % (
+                fl["ms_per_pass"], fl["device_ms_per_pass"], fl["algorithmic_tflop_per_pass"], fl["achieved_tflops"], fl["frac_of_833"],
+                fl["frac_of_fp32_mfma_peak_157"], fl["conv_family_of_this_leg"]["bound_ms"], fl["conv_family_of_this_leg"]["time_ms"],
+                fl["conv_family_of_this_leg"]["frac"]), ""]
 for tag in ("f16x2", "bf16x3", "mode0"):
     path = os.path.join(SRC, "kernel_stats_%s.csv" % tag)
     if not os.path.exists(path):
@@ -113,7 +126,9 @@ for tag in ("f16x2", "bf16x3", "mode0"):
             tm["traffic_bytes_per_launch"] = tm["traffic_bytes_per_launch_fwd1"]
     out.append("")
 json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
-extra = [("conv_table.txt", "every convolution call of a step by shape (single-stream, event-bracketed): time, TFLOP/s, MFMA / HBM bound"),
+extra = [("split_sites.txt", "the launches of one step that still run a plane-split pass in front, with the producer of the tensor they split (round 6: 92 -> 10)"),
+         ("whatif.txt", "the step with a family of launches skipped (timing only): what the weight gradients, the optimiser tail and the second stream cost the step"),
+         ("conv_table.txt", "every convolution call of a step by shape (single-stream, event-bracketed): time, TFLOP/s, MFMA / HBM bound"),
          ("host_device_phases.txt", "host issue time and device arrival time of every phase of one overlapped step (no profiler)"),
          ("library_op_sites.txt", "which lines of the package still issue library (ATen) operations in a step, by count (both threads)"),
          ("step_series_bench.txt", "per-step ms over 120 steps with the bench's frozen learning rate"),
@@ -144,6 +159,6 @@ for f, what in extra:
         out.append(line)
 out.append("")
 out += ["## MFMA-busy (single-stream SQ pass)", "", "```"] + [l.rstrip() for l in open(os.path.join(SRC, "pmc_mfma_busy.txt")) if "mfma_busy_fraction" in l or l.startswith("#")] + ["```", ""]
-hist = open(os.path.join(DST, "r05_history.md")).read() if os.path.exists(os.path.join(DST, "r05_history.md")) else ""
-open(os.path.join(DST, "r05_summary.md"), "w").write("\n".join(out) + "\n" + hist)
+hist = open(os.path.join(DST, "r06_history.md")).read() if os.path.exists(os.path.join(DST, "r06_history.md")) else ""
+open(os.path.join(DST, "r06_summary.md"), "w").write("\n".join(out) + "\n" + hist)
 print("\n".join(out)[:6000])
