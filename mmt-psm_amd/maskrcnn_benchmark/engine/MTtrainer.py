@@ -268,7 +268,33 @@ class BucketedAllReduce(object):
                 "exposed_comm_ms": round(max([self._t0.elapsed_time(m[3]) for m in self._marks] + [0.0]) - self._t0.elapsed_time(bw_end), 3),
                 "pieces": [{"range": [lo, hi], "mbytes": round((hi - lo) * 4 / 1e6, 2), "issued_ms": round(self._t0.elapsed_time(a), 3),
                             "arrived_ms": round(self._t0.elapsed_time(b), 3)} for lo, hi, a, b, _ in self._marks]}
+            # (round 6) what the same issue schedule would cost at 8 GPUs under the xGMI model -- a prediction, never a measurement
+            self.last_trace["predicted_8gpu"] = predict_exposed_comm(self.last_trace["pieces"], self.last_trace["backward_end_ms"], 8)
         self.reset()
+
+
+XGMI_LINK_GBS = 153.0   # xGMI is a full mesh, 7 links x ~153 GB/s per GPU
+
+
+def predict_exposed_comm(pieces, backward_end_ms, world=8, link_gbs=XGMI_LINK_GBS, latency_ms=0.05):
+    """What the bucketed exchange would cost a step at `world` GPUs, from the issue times a (world-size-1) trace recorded and SURVEY
+    section 5's xGMI model -- a number for the first real multi-GPU run to be wrong against (no 8-GPU node was
+    ever available to the builder).  Two collective algorithms bracket what RCCL does on a full mesh:
+      ring        2 (world - 1) hops of bytes / world over ONE link each:  t = 2 (world - 1) / world * bytes / link
+      direct      reduce-scatter + all-gather over all world - 1 links at once:  t = 2 / world * bytes / link
+    Pieces go out in issue order on one communicator: piece i starts at max(its issue time, the end of piece i - 1) and takes
+    t(bytes) + a fixed launch / synchronisation latency.  exposed = end of the last piece - end of backward (>= 0).
+    pieces: [{"mbytes", "issued_ms"}, ...] as in `dist_trace`."""
+    out = {}
+    for name, factor in (("ring", 2.0 * (world - 1) / world), ("direct", 2.0 / world)):
+        t = 0.0
+        for p in sorted(pieces, key=lambda q: q["issued_ms"]):
+            t = max(t, p["issued_ms"]) + latency_ms + factor * p["mbytes"] * 1e6 / (link_gbs * 1e9) * 1e3
+        out[name] = {"last_arrival_ms": round(t, 3), "exposed_comm_ms": round(max(0.0, t - backward_end_ms), 3)}
+    out["model"] = ("SURVEY section 5: %d GPUs, full-mesh xGMI at %.0f GB/s per link, %.2f ms fixed cost per collective; ring = "
+                    "2 (N - 1) / N x bytes over one link, direct = 2 / N x bytes over all links; issue times from this run's trace"
+                    % (world, link_gbs, latency_ms))
+    return out
 
 
 def teacher_checksum(flat):

@@ -353,3 +353,18 @@ def test_flat_sgd_touches_only_parameters_with_gradients():
     f.touched.update({"0.weight", "2.weight"})
     r = f.active_ranges(f.touched, 0, f.n_weights)
     assert r == [(f.index["0.weight"][0], f.index["1.weight"][0]), (f.index["2.weight"][0], f.n_weights)]
+
+
+def test_predicted_exposed_communication_model():
+    """engine/MTtrainer.py::predict_exposed_comm (round 6): the xGMI model of SURVEY section 5 applied to a trace's issue times --
+    pieces issued early hide behind the backward pass, a piece issued at its end is exposed by its transfer time"""
+    from maskrcnn_benchmark.engine.MTtrainer import predict_exposed_comm
+    pieces = [{"mbytes": 40.0, "issued_ms": 5.0}, {"mbytes": 60.0, "issued_ms": 9.0}, {"mbytes": 76.0, "issued_ms": 20.0}]
+    p = predict_exposed_comm(pieces, backward_end_ms=20.0, world=8, link_gbs=153.0, latency_ms=0.05)
+    ring_last = 2 * 7 / 8 * 76e6 / 153e9 * 1e3 + 0.05
+    assert abs(p["ring"]["exposed_comm_ms"] - ring_last) < 1e-3          # the two early pieces were done long before
+    assert abs(p["direct"]["exposed_comm_ms"] - (2 / 8 * 76e6 / 153e9 * 1e3 + 0.05)) < 1e-3
+    # back-to-back pieces queue behind each other on the communicator
+    q = predict_exposed_comm([{"mbytes": 100.0, "issued_ms": 0.0}, {"mbytes": 100.0, "issued_ms": 0.0}], 0.0, world=8)
+    assert abs(q["ring"]["last_arrival_ms"] - 2 * (2 * 7 / 8 * 100e6 / 153e9 * 1e3 + 0.05)) < 1e-3
+    assert predict_exposed_comm(pieces, backward_end_ms=100.0)["ring"]["exposed_comm_ms"] == 0.0
