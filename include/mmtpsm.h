@@ -327,7 +327,8 @@ typedef struct {
   const void* f16_dy_amax2;
   const void* f16_guard_x2;
   const void* f16_guard_dy2;
-  /* mmt_conv_forward_pg only (round 5): 0 = x_planes indexed like x ([N][H][W][Cin]); 1 = ROW-BLOCKED planes
+  /* mmt_conv_forward_pg AND mmt_conv3x3_strip_f16x2 (the host side passes 1 to both by default; every other entry point refuses a
+   * non-zero value): 0 = x_planes indexed like x ([N][H][W][Cin]); 1 = ROW-BLOCKED planes
    * [N * H][Cin / 16][W][16] (mmt_split_planes_f16_rb): the 16 channels of a 16-k step of consecutive pixels of an image row are
    * contiguous, so a copy instruction of the kernel reads runs of up to 1 KiB instead of 32-byte pieces of 32 cache lines */
   int x_planes_layout;
@@ -472,12 +473,13 @@ int mmt_sum_stats_rb(const float* a, const float* b, const float* c, const float
 int mmt_rb_scales_update(float* state, int n, void* stream);
 /* Round 5: the plane-fed implicit GEMM (csrc/conv_pgemm.hip) -- the same arithmetic (two-term fp16 split, 3 products, mode 3) for
  * any (KH, KW, stride, pad) with Cin % 16 == 0, Cout > 32, res_mode <= 1, out_stride == 1, no `mul`, fp32 tensors: x_planes = the
- * two fp16 planes of x * s_x with x's NHWC indexing (mmt_split_planes_f16), w_planes = the packed fp16 planes of w * s_w
+ * two fp16 planes of x * s_x with x's NHWC indexing (mmt_split_planes_f16; x_planes_layout 0) or row-blocked (mmt_split_planes_f16_rb
+ * or a producer's y_rb; x_planes_layout 1, with x_planes_lag as the planes' origin demands); x_planes must not be NULL, w_planes = the packed fp16 planes of w * s_w
  * (mmt_pack_weight_f16 / _flipped_f16), s_x / s_w device scalars, `x` (and `w`, or w_src) the fp32 tensors for the range guard's
  * exact path.  Replaces the ATen convolution / addmm behind layers/misc.py:30-43 `Conv2d`, backbone/resnet.py:254-274 (conv2 of
  * layer3 / layer4), backbone/fpn.py:57-66 and rpn/rpn.py:39-46 (3x3 on the small levels),
  * roi_heads/mask_head/roi_mask_feature_extractors.py:131-146, box_head/roi_box_feature_extractors.py:97-98 (fc6 / fc7), forward and
- * data gradient.  tile_rows: 128 | 256 | 0 = the library's choice; ksplit: K ranges (> 1: partial tiles meet in the per-stream
+ * data gradient.  tile_rows: 64 | 128 | 256 (4 / 2 / 1 K groups inside a block) | 0 = the library's choice; ksplit: K ranges (> 1: partial tiles meet in the per-stream
  * workspace inside the SAME launch -- the last block of a tile to arrive adds them in the order 0 .. ksplit - 1 and runs the
  * epilogue), 0 = the library's choice.  Results are bit-identical to mmt_conv_forward_f16x2 on the tiled kernel for an equal number
  * of K ranges.  mmt_conv_pg_plan: the tile height and K ranges the library would pick (both 0: not a shape for this kernel). */
