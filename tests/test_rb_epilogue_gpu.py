@@ -316,7 +316,7 @@ def test_training_steps_with_and_without_epilogue_planes_agree():
     """three iterations of the real trainer (mean-teacher phase) at 320^2: the mechanism on (planes from the second step on) against
     off.  Planes with another power-of-two scale differ from the split pass's in the last bits of the smallest elements, and an
     un-replayed run amplifies last-bit differences through its discrete decisions (NMS ties, sampled sets): step 1 -- no planes yet --
-    is bit-identical, steps 2-3 agree to a few per cent.  The STRICT statement -- a step with epilogue planes against the oracle at
+    is identical (to the order of the loss sums' atomics), steps 2-3 agree to a few per cent.  The STRICT statement -- a step with epilogue planes against the oracle at
     1e-4 with the decisions replayed -- is tests/test_train_step_gpu.py::test_full_step_matches_oracle[...epilogue-planes]; this test
     catches a mechanism that is grossly wrong in the un-replayed trainer."""
     import synthetic
@@ -339,7 +339,8 @@ def test_training_steps_with_and_without_epilogue_planes_agree():
             H.RB_EPI = True
     (l0, s0, t0, st0), (l1, s1, t1, st1) = outs
     assert st1.get("rb_epi", 0) > 0
-    assert l0[0] == l1[0]                       # the first step: no site has a scale yet
+    for k in l0[0]:                             # the first step: no site has a scale yet -- equal up to the order of the losses' atomics
+        assert abs(l0[0][k] - l1[0][k]) <= 2e-6 * max(1.0, abs(l0[0][k])), (k, l0[0][k], l1[0][k])
     for a, b in zip(l0[1:], l1[1:]):
         assert a.keys() == b.keys()
         for k in a:
