@@ -468,6 +468,22 @@ int mmt_split_planes_f16_rb(const float* x, void* planes, long plane_stride, int
  *   pending maximum (what y_amax_next / amax_next accumulated): scale <- the power of two that puts 8 x pending into [2^13, 2^14),
  *   pending <- 0; sites without a pending maximum keep their scale. */
 int mmt_conv_writes_rb(const mmt_conv_args* a /*[host]*/);
+/* Round 6: the weight gradients of a BATCH of layers (what a backward pass hands over at a time) as grouped launches -- replaces the
+ * per-layer conv2d weight gradients autograd issues behind layers/misc.py:30-43 for backbone/resnet.py:202-274, backbone/fpn.py:43-69,
+ * rpn/rpn.py:39-46 and the heads.  Every job is what mmt_conv_wgrad takes (a, dy, rowscale, dw, dbias; a.f16_x_amax / f16_dy_amax and
+ * the guards set for the fp16-split arithmetic) plus, optionally, both operands' row-blocked planes (mmt_conv_wgrad_planes' arguments).
+ * Plane-fed jobs go out in groups of <= 12, fp16-split jobs without planes in groups of <= 6 per pixel-decode form, every slab of the
+ * batch is summed by ONE reduce launch; a job no group takes (other arithmetic, a two-segment job, a group of one) is launched as
+ * mmt_conv_wgrad(_planes) would launch it.  Inside a group the tiles of all layers fill the chip together: a layer is cut into fewer
+ * pixel ranges than alone.  workspace: *floats_out of mmt_conv_wgrad_group_workspace(jobs, n, &floats) floats (0: none needed), alive until the stream has
+ * run the call.  n <= 96.  MMT_WGRAD_GROUP=0 (environment, read per call): every job as its single launch. */
+typedef struct mmt_wgrad_job {
+  mmt_conv_args a;
+  const float* dy; const float* rowscale; float* dw; float* dbias;
+  const void* x_planes; long x_plane_stride; const void* dy_planes; long dy_plane_stride; const float* s_x; const float* s_dy;
+} mmt_wgrad_job;
+int mmt_conv_wgrad_group_workspace(const mmt_wgrad_job* jobs /*[host]*/, int n, long* floats_out /*[host]*/);
+int mmt_conv_wgrad_group(const mmt_wgrad_job* jobs /*[host]*/, int n, float* workspace, long workspace_floats, void* stream);
 int mmt_sum_stats_rb(const float* a, const float* b, const float* c, const float* d, float* y, int rows, int W, int C, float* slot,
                      void* planes, long plane_stride, const float* scale, float* amax_next, void* stream);
 int mmt_rb_scales_update(float* state, int n, void* stream);

@@ -2570,11 +2570,13 @@ __device__ __forceinline__ void wgrad_slow_fill(const float* __restrict__ x, con
 // F16 (opt-in fp16 two-term split, NS == 2): both operands are scaled by the power of two of their recorded maximum
 // (p.f16_sx -> max |x|, p.f16_sw -> max |dy|, device scalars), split into two fp16 terms, multiplied with 3 f16 MFMAs, and the
 // tile is divided by s_x s_dy where it is stored (directly, or in wgrad_reduce_kernel for the split form)
+// (tx, ty, tz, lin: the grid of this launch and the block's linear index in it -- or, in a grouped launch, of its ITEM)
 template <int NS, int MODE, bool VEC4, int BF = 0, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p_in, const float* __restrict__ dy_in,
-                                                                 const float* __restrict__ rowscale,
-                                                                 float* __restrict__ dw, int m_per_split,
-                                                                 float* __restrict__ ws, float* __restrict__ dbias) {
+__device__ __forceinline__ void conv_wgrad_pipe_body(const ConvP& p_in, const float* __restrict__ dy_in,
+                                                     const float* __restrict__ rowscale,
+                                                     float* __restrict__ dw, int m_per_split,
+                                                     float* __restrict__ ws, float* __restrict__ dbias,
+                                                     const int tx, const int ty, const int tz, const int lin) {
   constexpr int PL = 2 * 128 * 16;
   constexpr int STAGE = 2 * NS * PL;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2587,8 +2589,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p_i
   // (consecutive remapped ids) and the slices cross the fabric once instead of once per XCD
   int bx, by, bz;
   {
-    const int tx = gridDim.x, ty = gridDim.y, nwg = tx * ty * (int)gridDim.z;
-    const int lin = blockIdx.x + tx * (blockIdx.y + ty * blockIdx.z);
+    const int nwg = tx * ty * tz;
     const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     bx = id % tx;
@@ -2945,6 +2946,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p_i
       }
     }
   }
+}
+
+template <int NS, int MODE, bool VEC4, int BF = 0, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const ConvP p_in, const float* __restrict__ dy_in,
+                                                                 const float* __restrict__ rowscale,
+                                                                 float* __restrict__ dw, int m_per_split,
+                                                                 float* __restrict__ ws, float* __restrict__ dbias) {
+  conv_wgrad_pipe_body<NS, MODE, VEC4, BF, F16>(p_in, dy_in, rowscale, dw, m_per_split, ws, dbias, (int)gridDim.x, (int)gridDim.y,
+                                                (int)gridDim.z, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)));
+}
+
+// round 6: the register-splitting weight gradient of SEVERAL layers in one launch (the 1x1 layers, whose operands
+// have no planes: 16 tiles each at N = 2, cut into 16 pixel ranges of 16 steps when launched alone).  See wgrad_pl_group_kernel
+// (conv_wgpl.hip) for the idea; items' block ranges start at multiples of 8.
+constexpr int WGP_MAXG = 6;
+struct WgPipeItem { ConvP p; const float* dy; const float* rowscale; float* dw; float* ws; float* dbias; int mps, tx, ty, tz; };
+struct WgPipeGroup { WgPipeItem it[WGP_MAXG]; int first[WGP_MAXG + 1]; int n; };
+static_assert(sizeof(WgPipeGroup) <= 3840, "kernel-argument segment");
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_group_kernel(const WgPipeGroup g) {
+  int i = 0;
+  for (int k = 1; k < g.n; k++) i = (int)blockIdx.x >= g.first[k] ? k : i;
+  const int local = (int)blockIdx.x - g.first[i];
+  const int tx = g.it[i].tx, ty = g.it[i].ty, tz = g.it[i].tz;
+  if (local >= tx * ty * tz) return;   // (padding up to the next multiple of 8)
+  conv_wgrad_pipe_body<2, MODE, true, 0, true>(g.it[i].p, g.it[i].dy, g.it[i].rowscale, g.it[i].dw, g.it[i].mps, g.it[i].ws,
+                                                g.it[i].dbias, tx, ty, tz, local);
 }
 
 // dw[co][n] += rowscale[co] * sum_s ws[s][co][n]
@@ -3895,6 +3923,189 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
     hipLaunchKernelGGL(colsum_kernel, dim3(mmt_cdiv(p.Cout, 64), mmt_cdiv(p.M, rpb)), dim3(256), 0, s, dy, p.M,
                        p.Cout, dbias, rpb);
     MMT_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---- round 6: the weight gradients of a BATCH of layers -- what a backward pass hands to the side stream at a
+// time (layers/fused.py::flush_wgrads) -- as grouped launches: the plane-fed jobs (both operands' row-blocked planes given) in groups of
+// <= 12 on wgrad_pl_group_kernel, the fp16-split jobs without planes in groups of <= 6 per pixel-decode mode on
+// conv_wgrad_pipe_group_kernel, ONE reduce launch for every slab of the batch; whatever fits neither (and any group of one) goes out
+// as the single launch it always was.  Inside a group the tiles of all layers fill the chip together, so a layer is cut into
+// 256 (512) / (tiles of the GROUP) pixel ranges instead of 256 (512) / (its own tiles): longer reductions per block, fewer or no slabs.
+// Summation order: fixed by (the batch's composition, shapes) -- repeatable, but not the single launches' order when ranges differ.
+namespace {
+struct WgJobPlan { int kind; int split; int mps; long ws_off; };   // kind 0: single launch (mmt_conv_wgrad / _planes); 1: plane-fed group; 2 + mode: pipe group
+constexpr int WGJ_MAX = 96;
+
+static bool wg_job_pipe_ok(const mmt_wgrad_job& j, ConvP& p) {
+  if (fill(p, &j.a) || !j.dy || !j.dw || !p.cin4 || p.M == 0 || p.Cout == 0) return false;
+  if (!j.a.f16_x_amax || !j.a.f16_dy_amax || j.a.x2 || precision() != 3 || p.io || (p.Cout & 3)) return false;
+  return (long)p.N * p.H * p.W * p.Cin * 4 < (1L << 31) && (long)p.M * p.Cout * 4 < (1L << 31);
+}
+
+// -> workspace floats; plan[i] filled; chunk boundaries are recomputed by the launcher the same way
+static long wg_plan(const mmt_wgrad_job* jobs, int n, WgJobPlan* plan) {
+  const char* e = getenv("MMT_WGRAD_GROUP");   // read per call (A/B timing, the bit-equality tests of the schedules)
+  const bool on = !(e && atoi(e) == 0);
+  int kind[WGJ_MAX];
+  for (int i = 0; i < n; i++) {
+    ConvP p;
+    kind[i] = 0;
+    if (on && jobs[i].x_planes && jobs[i].dy_planes && !jobs[i].a.x2 && wgpl_eligible_splits(&jobs[i].a) > 0) kind[i] = 1;
+    else if (on && wg_job_pipe_ok(jobs[i], p)) kind[i] = 2 + (!(p.Wo >= 8 && p.Ho >= 8) ? 0 : ((p.Wo & 3) == 0 ? 2 : 1));
+  }
+  // a kind with a single member is a single launch
+  for (int k = 1; k <= 4; k++) {
+    int cnt = 0, last = -1;
+    for (int i = 0; i < n; i++) if (kind[i] == k) { cnt++; last = i; }
+    if (cnt == 1) kind[last] = 0;
+  }
+  long ws = 0;
+  for (int k = 1; k <= 4; k++) {
+    const int cap = k == 1 ? 12 : WGP_MAXG, target = k == 1 ? 256 : 512;
+    int idx[WGJ_MAX], m = 0;
+    for (int i = 0; i < n; i++) if (kind[i] == k) idx[m++] = i;
+    for (int c0 = 0; c0 < m; c0 += cap) {
+      const int c1 = c0 + cap < m ? c0 + cap : m;   // (the launcher cuts its groups at the same counts)
+      long tiles = 0;
+      for (int c = c0; c < c1; c++) {
+        const mmt_conv_args& a = jobs[idx[c]].a;
+        const int NP = a.KH * a.KW * a.Cin;
+        tiles += k == 1 ? (long)(a.Cout >> 7) * (NP >> 7) : (long)mmt_cdiv(NP, 128) * mmt_cdiv(a.Cout, 128);
+      }
+      long f = target / (tiles > 0 ? tiles : 1);
+      if (f < 1) f = 1;
+      for (int c = c0; c < c1; c++) {
+        const int i = idx[c];
+        const mmt_conv_args& a = jobs[i].a;
+        const int NP = a.KH * a.KW * a.Cin;
+        WgJobPlan& pl = plan[i];
+        pl.kind = k; pl.mps = 0;
+        if (k == 1) {
+          long ks = f, T = wgpl_super_steps(&a);
+          if (ks > T / 8) ks = T / 8;
+          if (ks < 1) ks = 1;
+          pl.split = (int)ks;
+        } else {
+          const int M = a.N * a.Ho * a.Wo;
+          long sp = f;
+          const long mx = mmt_cdiv(M, 512);
+          if (sp > mx) sp = mx;
+          if (sp < 1) sp = 1;
+          int mps = mmt_cdiv(M, (int)sp);
+          mps = (mps + 31) / 32 * 32;
+          pl.mps = mps;
+          pl.split = mmt_cdiv(M, mps);
+        }
+        pl.ws_off = ws;
+        if (pl.split > 1) ws += (long)pl.split * a.Cout * NP;
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    if (kind[i] != 0) continue;
+    WgJobPlan& pl = plan[i];
+    const mmt_conv_args& a = jobs[i].a;
+    pl.kind = 0; pl.mps = 0;
+    int sp = 0;
+    if (jobs[i].x_planes && jobs[i].dy_planes && !a.x2) sp = wgpl_eligible_splits(&a);
+    if (sp <= 0) sp = mmt_conv_wgrad_splits(&a);
+    pl.split = sp < 1 ? 1 : sp;
+    pl.ws_off = ws;
+    if (pl.split > 1) ws += (long)pl.split * a.Cout * a.KH * a.KW * a.Cin;
+  }
+  return ws;
+}
+}  // namespace
+
+extern "C" int mmt_conv_wgrad_group_workspace(const mmt_wgrad_job* jobs, int n, long* floats_out) {
+  if (!jobs || !floats_out || n < 0 || n > WGJ_MAX) return MMT_EINVAL;
+  WgJobPlan plan[WGJ_MAX];
+  *floats_out = wg_plan(jobs, n, plan);
+  return 0;
+}
+
+extern "C" int mmt_conv_wgrad_group(const mmt_wgrad_job* jobs, int n, float* workspace, long workspace_floats, void* stream) {
+  if (!jobs || n < 0 || n > WGJ_MAX) return MMT_EINVAL;
+  if (n == 0) return 0;
+  WgJobPlan plan[WGJ_MAX];
+  const long need = wg_plan(jobs, n, plan);
+  if (need > 0 && (!workspace || workspace_floats < need)) return MMT_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  WgReduceItem red[WGJ_MAX];
+  int nred = 0;
+  // plane-fed groups
+  {
+    WgPlJob g[12];
+    int m = 0;
+    auto flush = [&]() -> int {
+      if (m == 0) return 0;
+      const int e = launch_wgpl_group(g, m, s);
+      m = 0;
+      return e;
+    };
+    for (int i = 0; i < n; i++) {
+      if (plan[i].kind != 1) continue;
+      const mmt_wgrad_job& j = jobs[i];
+      float* ws = plan[i].split > 1 ? workspace + plan[i].ws_off : nullptr;
+      g[m++] = WgPlJob{&j.a, j.dy, j.x_planes, j.x_plane_stride, j.dy_planes, j.dy_plane_stride, j.s_x, j.s_dy, j.rowscale, j.dw, j.dbias, ws,
+                       plan[i].split};
+      if (plan[i].split > 1)
+        red[nred++] = WgReduceItem{ws, j.rowscale, j.dw, plan[i].split, j.a.Cout, j.a.KH * j.a.KW * j.a.Cin, 0};
+      if (m == 12) { const int e = flush(); if (e) return e; }
+    }
+    const int e = flush();
+    if (e) return e;
+  }
+  // register-splitting groups, one pixel-decode mode at a time
+  for (int mode = 0; mode < 3; mode++) {
+    WgPipeGroup g;
+    g.n = 0;
+    int nb = 0;
+    auto flush = [&]() -> int {
+      if (g.n == 0) return 0;
+      g.first[g.n] = nb;
+      if (mode == 2) hipLaunchKernelGGL(conv_wgrad_pipe_group_kernel<2>, dim3(nb), dim3(256), (size_t)65536, s, g);
+      else if (mode == 1) hipLaunchKernelGGL(conv_wgrad_pipe_group_kernel<1>, dim3(nb), dim3(256), (size_t)65536, s, g);
+      else hipLaunchKernelGGL(conv_wgrad_pipe_group_kernel<0>, dim3(nb), dim3(256), (size_t)65536, s, g);
+      g.n = 0;
+      nb = 0;
+      MMT_LAUNCH_CHECK();
+      return 0;
+    };
+    for (int i = 0; i < n; i++) {
+      if (plan[i].kind != 2 + mode) continue;
+      const mmt_wgrad_job& j = jobs[i];
+      WgPipeItem& it = g.it[g.n];
+      if (!wg_job_pipe_ok(j, it.p) || (plan[i].mps & 15)) return MMT_EINVAL;
+      it.p.f16_sx = (const float*)j.a.f16_x_amax;
+      it.p.f16_sw = (const float*)j.a.f16_dy_amax;
+      const int NP = it.p.KH * it.p.KW * it.p.Cin;
+      it.dy = j.dy; it.rowscale = j.rowscale; it.dw = j.dw; it.dbias = j.dbias;
+      it.ws = plan[i].split > 1 ? workspace + plan[i].ws_off : nullptr;
+      it.mps = plan[i].mps; it.tx = mmt_cdiv(NP, 128); it.ty = mmt_cdiv(it.p.Cout, 128); it.tz = plan[i].split;
+      if (plan[i].split > 1) red[nred++] = WgReduceItem{it.ws, j.rowscale, j.dw, plan[i].split, it.p.Cout, NP, 0};
+      g.first[g.n] = nb;
+      nb += (it.tx * it.ty * it.tz + 7) & ~7;
+      g.n++;
+      if (g.n == WGP_MAXG) { const int e = flush(); if (e) return e; }
+    }
+    const int e = flush();
+    if (e) return e;
+  }
+  if (nred) { const int e = launch_wgrad_reduce_group(red, nred, s); if (e) return e; }
+  // everything else: the single launches
+  for (int i = 0; i < n; i++) {
+    if (plan[i].kind != 0) continue;
+    const mmt_wgrad_job& j = jobs[i];
+    float* ws = plan[i].split > 1 ? workspace + plan[i].ws_off : nullptr;
+    int e = 1;
+    if (j.x_planes && j.dy_planes && !j.a.x2)
+      e = mmt_conv_wgrad_planes(&j.a, j.dy, j.x_planes, j.x_plane_stride, j.dy_planes, j.dy_plane_stride, j.s_x, j.s_dy, j.rowscale, j.dw,
+                                j.dbias, ws, stream);
+    if (e == 1) e = mmt_conv_wgrad(&j.a, j.dy, j.rowscale, j.dw, j.dbias, ws, stream);
+    if (e) return e;
   }
   return 0;
 }

@@ -55,6 +55,14 @@ struct SplitWs { float* ws; unsigned* tickets; };
 constexpr size_t SPLITK_WS_BYTES = (size_t)1024 * 128 * 128 * 4;  // 1024 partial tiles of 128 x 128 (64 MiB)
 constexpr int SPLITK_TICKETS = 4096;
 SplitWs split_workspace(hipStream_t s);
+// round 6: weight gradients of several layers in one launch (conv_wgpl.hip; orchestrated by mmt_conv_wgrad_group in conv_igemm.hip)
+struct WgReduceItem { const float* ws; const float* rowscale; float* dw; int splits, Cout, NP, pad; };
+int launch_wgrad_reduce_group(const WgReduceItem* items, int n, hipStream_t s);
+struct WgPlJob { const mmt_conv_args* a; const float* dy; const void* xpl; long xpl_stride; const void* dpl; long dpl_stride;
+                 const float* s_x; const float* s_dy; const float* rowscale; float* dw; float* dbias; float* ws; int ksplit; };
+int wgpl_eligible_splits(const mmt_conv_args* a);   // > 0: the plane-fed weight gradient takes the layer
+long wgpl_super_steps(const mmt_conv_args* a);      // 32-pixel super-steps of the layer's reduction
+int launch_wgpl_group(const WgPlJob* jobs, int n, hipStream_t s);
 // layer1's 3x3 (64 -> 64 channels) on the patch kernel of conv_stem.hip: is this call one, and its launch
 bool c64_shape(const ConvP& p);
 int launch_c64(const ConvP& p, hipStream_t s);

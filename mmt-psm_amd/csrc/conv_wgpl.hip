@@ -49,7 +49,8 @@ struct WgP {
   int lag;   // round 6: bit 0 / bit 1 -- the planes of x / of dy were written by their producer's epilogue with a scale fixed beforehand
 };
 
-__global__ __launch_bounds__(768) void wgrad_pl_kernel(const WgP p) {
+// bid_in / nwg: this block's index among the blocks of its launch -- or, in a grouped launch (wgrad_pl_group_kernel), of its item
+__device__ __forceinline__ void wgrad_pl_body(const WgP& p, const int bid_in, const int nwg_in) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* const ring = (char*)lds;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -58,9 +59,9 @@ __global__ __launch_bounds__(768) void wgrad_pl_kernel(const WgP p) {
   const int grp = copier ? (wave - 8) >> 1 : wave >> 2;   // pixel range (K group) this wave works on / serves
   const int gw = wave & 3, wm = gw >> 1, wn = gw & 1;     // matrix waves: 2 x 2 waves of 64 x 64
   const int NP = p.KH * p.KW * p.Cin, tiles_n = NP >> 7;
-  int bid = blockIdx.x;
+  int bid = bid_in;
   {  // XCD-aware order: the ksplit blocks of a tile read the same weight-sized output region, neighbours read the same pixels
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int nwg = nwg_in, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tile = bid % ((p.Cout >> 7) * tiles_n), ks = bid / ((p.Cout >> 7) * tiles_n);
@@ -278,6 +279,56 @@ __global__ __launch_bounds__(768) void wgrad_pl_kernel(const WgP p) {
   }
 }
 
+__global__ __launch_bounds__(768) void wgrad_pl_kernel(const WgP p) { wgrad_pl_body(p, blockIdx.x, gridDim.x); }
+
+// ---- round 6: the weight gradients of SEVERAL layers in one launch.  A backward pass hands its weight-gradient
+// jobs to the side stream a batch at a time (layers/fused.py::flush_wgrads); launched one by one, a 3x3 layer at N = 2 has 36 tiles and
+// is cut into 7 pixel ranges to fill the chip -- 18 super-steps per range between a prologue, an LDS exchange, a 64 KB slab store and a
+// reduce launch.  In a group the tiles of all its layers fill the chip together: few or no pixel ranges per layer, no slabs, and what
+// is left of the reduce work is one launch for the whole group.  A block finds its item by its index (items' block ranges start at
+// multiples of 8: the XCD mapping of wgrad_pl_body stays what it is for a single launch).
+constexpr int WG_MAXG = 12;
+struct WgGroup { WgP it[WG_MAXG]; int first[WG_MAXG + 1]; int n; };
+static_assert(sizeof(WgGroup) <= 3584, "kernel-argument segment");
+__global__ __launch_bounds__(768) void wgrad_pl_group_kernel(const WgGroup g) {
+  int i = 0;
+  for (int k = 1; k < g.n; k++) i = (int)blockIdx.x >= g.first[k] ? k : i;
+  const int local = (int)blockIdx.x - g.first[i];
+  const WgP p = g.it[i];
+  const int real = (p.Cout >> 7) * ((p.KH * p.KW * p.Cin) >> 7) * p.ksplit;
+  if (local >= real) return;   // (padding up to the next multiple of 8)
+  wgrad_pl_body(p, local, real);
+}
+
+// dw_i[co][n] += rowscale_i[co] * sum_s ws_i[s][co][n] for every item of a group in ONE launch (the slabs hold true partial sums)
+constexpr int WG_MAXR = 24;
+struct WgReduceGroup { mmtconv::WgReduceItem it[WG_MAXR]; int first[WG_MAXR + 1]; int n; };
+static_assert(sizeof(WgReduceGroup) <= 3584, "kernel-argument segment");
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const WgReduceGroup g) {
+  int k = 0;
+  for (int j = 1; j < g.n; j++) k = (int)blockIdx.x >= g.first[j] ? j : k;
+  const mmtconv::WgReduceItem it = g.it[k];
+  const int nb = g.first[k + 1] - g.first[k], lb = (int)blockIdx.x - g.first[k];
+  const long n4 = (long)it.Cout * it.NP / 4, slab = (long)it.Cout * it.NP;
+  for (long i = (long)lb * 256 + threadIdx.x; i < n4; i += (long)nb * 256) {
+    f32x4 o = ((f32x4*)it.dw)[i];
+    f32x4 a = ((const f32x4*)it.ws)[i];
+    int s = 1;
+    for (; s + 8 <= it.splits; s += 8) {
+      f32x4 b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) b[u] = *(const f32x4*)(it.ws + (s + u) * slab + i * 4);
+#pragma unroll
+      for (int u = 0; u < 8; u++) a += b[u];
+    }
+    for (; s < it.splits; s++) a += *(const f32x4*)(it.ws + s * slab + i * 4);
+    const float sc = it.rowscale ? it.rowscale[(int)((i * 4) / it.NP)] : 1.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] += a[e] * sc;
+    ((f32x4*)it.dw)[i] = o;
+  }
+}
+
 // dw[co][n] += rowscale[co] * sum_s ws[s][co][n]   (the slabs hold sums already divided by s_x s_dy)
 __global__ __launch_bounds__(256) void wgrad_pl_reduce_kernel(const float* __restrict__ ws, int splits, int Cout, int NP,
                                                               const float* __restrict__ rowscale, float* __restrict__ dw) {
@@ -320,6 +371,67 @@ int wgpl_splits(const mmt_conv_args* a) {
 }
 
 }  // namespace
+
+namespace mmtconv {
+int wgpl_eligible_splits(const mmt_conv_args* a) { return a ? wgpl_splits(a) : 0; }
+long wgpl_super_steps(const mmt_conv_args* a) { return ((long)a->N * a->H * a->W) >> 5; }
+
+int launch_wgrad_reduce_group(const WgReduceItem* items, int n, hipStream_t s) {
+  for (int i0 = 0; i0 < n; i0 += WG_MAXR) {
+    WgReduceGroup g;
+    g.n = n - i0 < WG_MAXR ? n - i0 : WG_MAXR;
+    int nb = 0;
+    for (int i = 0; i < g.n; i++) {
+      g.it[i] = items[i0 + i];
+      g.first[i] = nb;
+      long b = ((long)items[i0 + i].Cout * items[i0 + i].NP / 4 + 255) / 256;
+      nb += (int)(b > 1024 ? 1024 : b);
+    }
+    g.first[g.n] = nb;
+    hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(nb), dim3(256), 0, s, g);
+    MMT_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// the kernel launch of a group of <= WG_MAXG plane-fed jobs with the pixel ranges the caller chose (job.ksplit; slabs job.ws when > 1)
+int launch_wgpl_group(const WgPlJob* jobs, int n, hipStream_t s) {
+  if (n < 1 || n > WG_MAXG) return MMT_EINVAL;
+  WgGroup g;
+  g.n = n;
+  int nb = 0;
+  for (int i = 0; i < n; i++) {
+    const WgPlJob& j = jobs[i];
+    const mmt_conv_args* a = j.a;
+    if (!a->x || !j.dy || !j.xpl || !j.dpl || !j.s_x || !j.s_dy || !j.dw || ((size_t)j.xpl & 15) || ((size_t)j.dpl & 15) ||
+        (j.xpl_stride & 7) || (j.dpl_stride & 7) || j.ksplit < 1 || (j.ksplit > 1 && !j.ws))
+      return MMT_EINVAL;
+    WgP& p = g.it[i];
+    p.x = a->x; p.dy = j.dy;
+    p.xpl = (const unsigned short*)j.xpl; p.xpl_stride = j.xpl_stride;
+    p.dpl = (const unsigned short*)j.dpl; p.dpl_stride = j.dpl_stride;
+    p.s_x = j.s_x; p.s_dy = j.s_dy;
+    p.guard_x = (const float*)a->f16_guard_x; p.guard_dy = (const float*)a->f16_guard_dy;
+    p.rowscale = j.rowscale; p.dw = j.dw; p.ws = j.ws; p.dbias = j.dbias;
+    p.dbg = 0; p.lag = a->x_planes_lag;
+    p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW; p.pad = a->pad; p.ksplit = j.ksplit;
+    g.first[i] = nb;
+    const int blocks = (a->Cout >> 7) * ((a->KH * a->KW * a->Cin) >> 7) * j.ksplit;
+    nb += (blocks + 7) & ~7;
+  }
+  g.first[n] = nb;
+  constexpr size_t lds = (size_t)WG_S * WG_STAGE;
+  static bool done = false;
+  if (!done) {
+    const hipError_t e = hipFuncSetAttribute((const void*)wgrad_pl_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  hipLaunchKernelGGL(wgrad_pl_group_kernel, dim3(nb), dim3(768), lds, s, g);
+  MMT_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace mmtconv
 
 extern "C" int mmt_conv_wgrad_planes_splits(const mmt_conv_args* a) { return a ? wgpl_splits(a) : 0; }
 

@@ -42,6 +42,12 @@ class ConvArgs(ctypes.Structure):
 IO_X, IO_Y, IO_RES, IO_MASK, IO_DY = 1, 2, 4, 8, 16  # include/mmtpsm.h: mmt_conv_args.io_bf16
 
 
+class WgradJob(ctypes.Structure):   # include/mmtpsm.h: mmt_wgrad_job
+    _fields_ = [("a", ConvArgs), ("dy", c_void_p), ("rowscale", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
+                ("x_planes", c_void_p), ("x_plane_stride", ctypes.c_long), ("dy_planes", c_void_p), ("dy_plane_stride", ctypes.c_long),
+                ("s_x", c_void_p), ("s_dy", c_void_p)]
+
+
 class RpnLevel(ctypes.Structure):
     _fields_ = [("head", c_void_p), ("anchors", c_void_p), ("topk", c_void_p), ("HW", c_int), ("k", c_int),
                 ("out_off", c_int), ("pad", c_int)]
@@ -136,6 +142,8 @@ _SIGS = {
     "mmt_split_planes_f16_rb": [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mmt_replay": [c_void_p, c_int, c_void_p],
     "mmt_conv_writes_rb": [ctypes.POINTER(ConvArgs)],
+    "mmt_conv_wgrad_group_workspace": [c_void_p, c_int, ctypes.POINTER(ctypes.c_long)],
+    "mmt_conv_wgrad_group": [c_void_p, c_int, c_void_p, ctypes.c_long, c_void_p],
     "mmt_sum_stats_rb": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p,
                          c_void_p, c_void_p],
     "mmt_rb_scales_update": [c_void_p, c_int, c_void_p],
@@ -685,7 +693,7 @@ def _lib_raw():
 # pool, which keeps their addresses for the plan's life; its statistics slots from a block of the plan's own) and REPLAYED from then
 # on: ~70 ctypes calls instead of the Python that derives them (a manual graph: hipGraph replays of the two models serialise in
 # this runtime).  Only the input's address is patched.  Queries are not recorded.
-_NO_RECORD = frozenset(("mmt_conv_wants_planes", "mmt_conv_pg_wanted", "mmt_conv_writes_rb", "mmt_conv_variant", "mmt_conv_ksplit", "mmt_conv_pg_plan",
+_NO_RECORD = frozenset(("mmt_conv_wants_planes", "mmt_conv_pg_wanted", "mmt_conv_writes_rb", "mmt_conv_wgrad_group_workspace", "mmt_conv_variant", "mmt_conv_ksplit", "mmt_conv_pg_plan",
                         "mmt_conv_wgrad_splits", "mmt_get_conv_precision", "mmt_packed_weight_elems", "mmt_set_conv_precision"))
 LAYOUT_EPOCH = [0]    # bumped when a flat model (re)allocates its plane buffers (engine/flat.py)
 LAUNCH_PLANS = os.environ.get("MMT_LAUNCH_PLANS", "1") != "0"
@@ -2082,6 +2090,100 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
         PROFILE.append((2.0 * n2 * a.Ho * a.Wo * Cout * Cin * KH * KW, e0, e1, ("wgrad", n2, H, W, Cin, Cout, KH, stride, 1)))
         return
     _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _p(ws), _stream()), "mmt_conv_wgrad")
+
+
+WGRAD_GROUP = os.environ.get("MMT_WGRAD_GROUP", "1") != "0"   # a batch of weight gradients as grouped launches (mmt_conv_wgrad_group)
+
+
+def _wgrad_group_job(x, dy, w_shape, stride, pad, dw, rowscale, dbias, keep):
+    """-> a filled WgradJob for mmt_conv_wgrad_group, or None when the job must go out through conv_wgrad (another arithmetic, bf16
+    storage, an operand without a recorded maximum, a site on the bf16 fall-back).  The preparation of conv_wgrad, without the launch."""
+    if not (F16X2 and _PREC == 3 and x.dtype == torch.float32 and dy.dtype == torch.float32):
+        return None
+    Cout, Cin, KH, KW = w_shape
+    N, _, H, W = x.shape
+    if Cout % 4 or Cin % 4:
+        return None
+    ax, ad = getattr(x, "_mmt_amax", None), getattr(dy, "_mmt_amax", None)
+    big = N * H * W * Cin >= WGRAD_F16_MIN_ELEMS
+    if big and (ax is None or ax[1] != x._version):
+        ax = _amax_of(x)
+    if big and (ad is None or ad[1] != dy._version):
+        ad = _amax_of(dy)
+    if ax is None or ad is None or ax[1] != x._version or ad[1] != dy._version:
+        return None
+    if not (_site_ok(("wgx", dw.data_ptr()), x) and _site_ok(("wgd", dw.data_ptr()), dy)):
+        return None
+    j = WgradJob()
+    a = j.a
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW = N, H, W, Cin, Cout, KH, KW
+    a.stride, a.pad, a.Ho, a.Wo = stride, pad, dy.shape[2], dy.shape[3]
+    a.out_stride, a.mask_scale = 1, 1.0
+    a.x = x.data_ptr()
+    a.f16_x_amax, a.f16_dy_amax = ax[0].data_ptr(), ad[0].data_ptr()
+    a.f16_guard_x, a.f16_guard_dy = _guard(ax), _guard(ad)
+    j.dy, j.rowscale, j.dw, j.dbias = dy.data_ptr(), _p(rowscale), dw.data_ptr(), _p(dbias)
+    xr, dr = getattr(x, "_mmt_rb", None), getattr(dy, "_mmt_rb", None)
+    if (WG_PLANES and xr is not None and dr is not None and xr[2] == x._version and dr[2] == dy._version
+            and (len(xr) < 5 or xr[4] is None) and (len(dr) < 5 or dr[4] is None)):
+        lag = (1 if len(xr) > 3 and xr[3] == "epi" else 0) | (2 if len(dr) > 3 and dr[3] == "epi" else 0)
+        if not (lag and (a.f16_guard_x is None or a.f16_guard_dy is None)):
+            a.x_planes_lag = lag
+            j.x_planes, j.x_plane_stride = xr[0].data_ptr(), xr[0].stride(0)
+            j.dy_planes, j.dy_plane_stride = dr[0].data_ptr(), dr[0].stride(0)
+            j.s_x, j.s_dy = xr[1].data_ptr(), dr[1].data_ptr()
+            keep.extend((xr[0], dr[0]))
+    return j
+
+
+def conv_wgrad_group(jobs, side=None, keep=None):
+    """the weight gradients of a batch of layers -- jobs: (x, dy, w_shape, stride, pad, dw, rowscale, dbias[, pair]) -- through
+    mmt_conv_wgrad_group (include/mmtpsm.h: grouped launches); jobs it does not take go out through conv_wgrad, in order.  `side`,
+    `keep` as in conv_wgrad."""
+    if side is not None:
+        _TLS.stream = side.cuda_stream
+        try:
+            return conv_wgrad_group(jobs, None, keep)
+        finally:
+            _TLS.stream = None
+    keep_ = keep if keep is not None else []
+    grouped, single = [], []
+    if WGRAD_GROUP and not (PROFILE is not None and PROFILE_ALL):
+        for job in jobs:
+            x, dy, w_shape, stride, pad, dw, rowscale, dbias = job[:8]
+            pair = job[8] if len(job) > 8 else None
+            wj = None
+            if pair is None:
+                x, dy = nhwc(x), nhwc(dy)
+                wj = _wgrad_group_job(x, dy, w_shape, stride, pad, dw, rowscale, dbias, keep_)
+            if wj is None:
+                single.append(job)
+            else:
+                grouped.append(wj)
+                keep_.extend((x, dy))
+    else:
+        single = list(jobs)
+    for c0 in range(0, len(grouped), 96):
+        chunk = grouped[c0:c0 + 96]
+        arr = (WgradJob * len(chunk))(*chunk)
+        need_c = ctypes.c_long(0)
+        if lib().mmt_conv_wgrad_group_workspace(ctypes.addressof(arr), len(chunk), ctypes.byref(need_c)) != 0:
+            raise RuntimeError("mmt_conv_wgrad_group_workspace failed")
+        need = need_c.value
+        ws = torch.empty((need,), dtype=torch.float32, device=torch.device("cuda", _cur_dev())) if need > 0 else None
+        _check(lib().mmt_conv_wgrad_group(ctypes.addressof(arr), len(chunk), _p(ws), need, _stream()), "mmt_conv_wgrad_group")
+        F16_STATS["wgrad_grouped"] = F16_STATS.get("wgrad_grouped", 0) + len(chunk)
+        if ws is not None:
+            if keep is not None:
+                keep.append(ws)
+            # (callers without `keep` launch on the current stream: the caching allocator orders the buffer's reuse behind it)
+    for job in single:
+        x, dy, w_shape, stride, pad, dw, rowscale, dbias = job[:8]
+        conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale, dbias, pair=job[8] if len(job) > 8 else None)
+        ws = getattr(_TLS, "last_ws", None)
+        if ws is not None and keep is not None:
+            keep.append(ws)
+            _TLS.last_ws = None
 
 
 def colsum(dy2d, out):

@@ -85,14 +85,14 @@ def flush_wgrads(ent, dev):
             return            # the gate's event does not exist yet: the jobs stay collected (the end of the pass hands them over)
         side.wait_event(ev)
     side.wait_stream(torch.cuda.current_stream(dev))
+    # round 6: the batch as grouped launches (include/mmtpsm.h: mmt_conv_wgrad_group) -- the tiles of all its layers fill the chip
+    # together, so a layer is cut into fewer pixel ranges than alone; jobs no group takes go out one by one as before
+    H.conv_wgrad_group(jobs, side=side, keep=keep)
     for job in jobs:
-        x, g, shape, stride, pad, dw, rowscale, db = job[:8]
-        pair = job[8] if len(job) > 8 else None
-        H.conv_wgrad(x, g, shape, stride, pad, dw, rowscale, db, side=side, keep=keep, pair=pair)
-        keep.append(x)    # autograd frees the saved activation / the gradient when the node returns: not before the side
-        keep.append(g)    # stream has been joined
-        if pair is not None:
-            keep.extend(pair)
+        keep.append(job[0])    # autograd frees the saved activation / the gradient when the node returns: not before the side
+        keep.append(job[1])    # stream has been joined
+        if len(job) > 8 and job[8] is not None:
+            keep.extend(job[8])
     ent[1] += len(jobs)
     jobs.clear()
 
