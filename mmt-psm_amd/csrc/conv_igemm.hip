@@ -3948,6 +3948,8 @@ static bool wg_job_pipe_ok(const mmt_wgrad_job& j, ConvP& p) {
 static long wg_plan(const mmt_wgrad_job* jobs, int n, WgJobPlan* plan) {
   const char* e = getenv("MMT_WGRAD_GROUP");   // read per call (A/B timing, the bit-equality tests of the schedules)
   const bool on = !(e && atoi(e) == 0);
+  const bool solo = e && atoi(e) >= 2;   // grouped launches with every job's OWN pixel ranges (2), or 1 / (k - 1) of them (k = 3, 4: the sweep)
+  const int sdiv = solo ? atoi(e) - 1 : 1;
   int kind[WGJ_MAX];
   for (int i = 0; i < n; i++) {
     ConvP p;
@@ -3955,6 +3957,11 @@ static long wg_plan(const mmt_wgrad_job* jobs, int n, WgJobPlan* plan) {
     if (on && jobs[i].x_planes && jobs[i].dy_planes && !jobs[i].a.x2 && wgpl_eligible_splits(&jobs[i].a) > 0) kind[i] = 1;
     else if (on && wg_job_pipe_ok(jobs[i], p)) kind[i] = 2 + (!(p.Wo >= 8 && p.Ho >= 8) ? 0 : ((p.Wo & 3) == 0 ? 2 : 1));
   }
+  // a weight shared by several jobs of the batch (the RPN head over the pyramid levels): only its FIRST job may ride in a group -- the
+  // items of a group run concurrently and accumulate into dw without atomics; the others follow as single launches, in order
+  for (int i = 1; i < n; i++)
+    for (int j = 0; j < i; j++)
+      if (jobs[j].dw == jobs[i].dw || (jobs[i].dbias && jobs[j].dbias == jobs[i].dbias)) { kind[i] = 0; break; }
   // a kind with a single member is a single launch
   for (int k = 1; k <= 4; k++) {
     int cnt = 0, last = -1;
@@ -3976,6 +3983,7 @@ static long wg_plan(const mmt_wgrad_job* jobs, int n, WgJobPlan* plan) {
       }
       long f = target / (tiles > 0 ? tiles : 1);
       if (f < 1) f = 1;
+      if (solo) f = 1L << 20;
       for (int c = c0; c < c1; c++) {
         const int i = idx[c];
         const mmt_conv_args& a = jobs[i].a;
@@ -3984,12 +3992,13 @@ static long wg_plan(const mmt_wgrad_job* jobs, int n, WgJobPlan* plan) {
         pl.kind = k; pl.mps = 0;
         if (k == 1) {
           long ks = f, T = wgpl_super_steps(&a);
+          if (solo) ks = (wgpl_eligible_splits(&a) + sdiv - 1) / sdiv;
           if (ks > T / 8) ks = T / 8;
           if (ks < 1) ks = 1;
           pl.split = (int)ks;
         } else {
           const int M = a.N * a.Ho * a.Wo;
-          long sp = f;
+          long sp = solo ? (mmt_conv_wgrad_splits(&a) + sdiv - 1) / sdiv : f;
           const long mx = mmt_cdiv(M, 512);
           if (sp > mx) sp = mx;
           if (sp < 1) sp = 1;
