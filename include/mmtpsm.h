@@ -474,8 +474,9 @@ int mmt_conv_writes_rb(const mmt_conv_args* a /*[host]*/);
  * the guards set for the fp16-split arithmetic) plus, optionally, both operands' row-blocked planes (mmt_conv_wgrad_planes' arguments).
  * Plane-fed jobs go out in groups of <= 12, fp16-split jobs without planes in groups of <= 6 per pixel-decode form, every slab of the
  * batch is summed by ONE reduce launch; a job no group takes (other arithmetic, a two-segment job, a group of one) is launched as
- * mmt_conv_wgrad(_planes) would launch it.  Inside a group the tiles of all layers fill the chip together: a layer is cut into fewer
- * pixel ranges than alone.  workspace: *floats_out of mmt_conv_wgrad_group_workspace(jobs, n, &floats) floats (0: none needed), alive until the stream has
+ * mmt_conv_wgrad(_planes) would launch it.  Inside a group the tiles of all layers fill the chip together: a layer is cut into a
+ * quarter of the pixel ranges it would use alone (MMT_WGRAD_GROUP_DIV; 0 = as few as fill the chip as a group: measured slower in the
+ * training step, whose latency-bound data-gradient chain shares the GPU with these launches).  workspace: *floats_out of mmt_conv_wgrad_group_workspace(jobs, n, &floats) floats (0: none needed), alive until the stream has
  * run the call.  n <= 96.  MMT_WGRAD_GROUP=0 (environment, read per call): every job as its single launch. */
 typedef struct mmt_wgrad_job {
   mmt_conv_args a;

@@ -3931,8 +3931,8 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
 // time (layers/fused.py::flush_wgrads) -- as grouped launches: the plane-fed jobs (both operands' row-blocked planes given) in groups of
 // <= 12 on wgrad_pl_group_kernel, the fp16-split jobs without planes in groups of <= 6 per pixel-decode mode on
 // conv_wgrad_pipe_group_kernel, ONE reduce launch for every slab of the batch; whatever fits neither (and any group of one) goes out
-// as the single launch it always was.  Inside a group the tiles of all layers fill the chip together, so a layer is cut into
-// 256 (512) / (tiles of the GROUP) pixel ranges instead of 256 (512) / (its own tiles): longer reductions per block, fewer or no slabs.
+// as the single launch it always was.  Inside a group the tiles of all layers fill the chip together, so a layer needs fewer pixel
+// ranges than alone -- a quarter of them by default (see wg_plan): longer reductions per block, a quarter of the slab traffic.
 // Summation order: fixed by (the batch's composition, shapes) -- repeatable, but not the single launches' order when ranges differ.
 namespace {
 struct WgJobPlan { int kind; int split; int mps; long ws_off; };   // kind 0: single launch (mmt_conv_wgrad / _planes); 1: plane-fed group; 2 + mode: pipe group
@@ -3948,8 +3948,15 @@ static bool wg_job_pipe_ok(const mmt_wgrad_job& j, ConvP& p) {
 static long wg_plan(const mmt_wgrad_job* jobs, int n, WgJobPlan* plan) {
   const char* e = getenv("MMT_WGRAD_GROUP");   // read per call (A/B timing, the bit-equality tests of the schedules)
   const bool on = !(e && atoi(e) == 0);
-  const bool solo = e && atoi(e) >= 2;   // grouped launches with every job's OWN pixel ranges (2), or 1 / (k - 1) of them (k = 3, 4: the sweep)
-  const int sdiv = solo ? atoi(e) - 1 : 1;
+  // Pixel ranges per job inside a group: 1 / WG_DIV of what the job would use ALONE (MMT_WGRAD_GROUP_DIV; 0 = as few as fill the chip
+  // as a group).  Measured in the step (profiles/r06_history.md section 7): filling the chip as a group makes blocks that own a CU for
+  // ~150 us and hold up the step stream's latency-bound chain (+2 ms); the jobs' own ranges only save launches and reduces (-0.3 ms);
+  // a quarter of them is the optimum (-0.5 ... -0.75 ms): blocks four times as long, a quarter of the slab traffic, still short
+  const char* dv = getenv("MMT_WGRAD_GROUP_DIV");
+  const int sdiv = dv ? atoi(dv) : 4;
+  const bool solo = sdiv > 0;
+  const int sdiv_pl = getenv("MMT_WGRAD_GROUP_PL") ? atoi(getenv("MMT_WGRAD_GROUP_PL")) : sdiv;       // (sweep: the two kinds apart)
+  const int sdiv_pipe = getenv("MMT_WGRAD_GROUP_PIPE") ? atoi(getenv("MMT_WGRAD_GROUP_PIPE")) : sdiv;
   int kind[WGJ_MAX];
   for (int i = 0; i < n; i++) {
     ConvP p;
@@ -3992,13 +3999,13 @@ static long wg_plan(const mmt_wgrad_job* jobs, int n, WgJobPlan* plan) {
         pl.kind = k; pl.mps = 0;
         if (k == 1) {
           long ks = f, T = wgpl_super_steps(&a);
-          if (solo) ks = (wgpl_eligible_splits(&a) + sdiv - 1) / sdiv;
+          if (solo) ks = (wgpl_eligible_splits(&a) + sdiv_pl - 1) / sdiv_pl;
           if (ks > T / 8) ks = T / 8;
           if (ks < 1) ks = 1;
           pl.split = (int)ks;
         } else {
           const int M = a.N * a.Ho * a.Wo;
-          long sp = solo ? (mmt_conv_wgrad_splits(&a) + sdiv - 1) / sdiv : f;
+          long sp = solo ? (mmt_conv_wgrad_splits(&a) + sdiv_pipe - 1) / sdiv_pipe : f;
           const long mx = mmt_cdiv(M, 512);
           if (sp > mx) sp = mx;
           if (sp < 1) sp = 1;

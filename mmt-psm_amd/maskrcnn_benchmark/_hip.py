@@ -2092,9 +2092,9 @@ def conv_wgrad(x, dy, w_shape, stride, pad, dw, rowscale=None, dbias=None, side=
     _check(lib().mmt_conv_wgrad(ctypes.byref(a), _p(dy), _p(rowscale), _p(dw), _p(dbias), _p(ws), _stream()), "mmt_conv_wgrad")
 
 
-# a batch of weight gradients as grouped launches (mmt_conv_wgrad_group).  OFF by default: measured +2 ms in the step
-# (profiles/r06_history.md section 7) -- long blocks that own a whole CU hold up the step stream's latency-bound chain
-WGRAD_GROUP = os.environ.get("MMT_WGRAD_GROUP", "0") != "0"
+# a batch of weight gradients as grouped launches (mmt_conv_wgrad_group): -0.5 ... -0.75 ms per step with every job cut into a quarter
+# of the pixel ranges it would use alone (profiles/r06_history.md section 7; MMT_WGRAD_GROUP=0: one launch per layer as before)
+WGRAD_GROUP = os.environ.get("MMT_WGRAD_GROUP", "1") != "0"
 
 
 def _wgrad_group_job(x, dy, w_shape, stride, pad, dw, rowscale, dbias, keep):
