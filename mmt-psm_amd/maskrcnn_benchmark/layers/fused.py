@@ -57,7 +57,7 @@ def _touch(*slots):
 import os as _os
 _WG_ON = _os.environ.get("MMT_WGRAD_STREAM", "1") != "0"
 _WG_BF16 = True   # bf16 configuration: only the DEFERRED (supervised-pass) jobs go to the side stream
-_WG_BATCH = 8   # jobs handed over behind one stream wait (measured 1 / 4 / 8 / 16: 36.8 / 36.6 / 36.4 / 36.4 ms per step)
+_WG_BATCH = int(_os.environ.get("MMT_WG_BATCH", "8"))   # jobs handed over behind one stream wait (round 3, single launches: 1 / 4 / 8 / 16 = 36.8 / 36.6 / 36.4 / 36.4 ms per step; round 6, grouped launches: profiles/r06_history.md)
 _WG = {}   # device -> [side stream, launches since the last join, end-of-backward callback queued, pending jobs, kept-alive tensors]
 
 

@@ -305,7 +305,7 @@ def test_student_heads_without_count_readback_equal_sliced_lists(setup, synth, m
             le.subsample = sub
             student.set_rng(None)
         grads = {k: v.grad.clone() for k, v in student.named_parameters() if v.grad is not None}
-        outs.append(({k: float(v) for k, v in out.items()}, sampled[0], grads, n_reads))
+        outs.append(({k: float(v.detach()) for k, v in out.items()}, sampled[0], grads, n_reads))
     (la, sa, ga, ra), (lb, sb, gb, rb) = outs
     assert rb == [], rb                      # fixed capacity: no device tensor read by the host in the whole forward
     assert len(ra) >= 1                      # (the sliced form reads its counts)
