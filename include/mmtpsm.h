@@ -335,7 +335,7 @@ typedef struct {
   /* Round 6: planes out of the PRODUCER's epilogue (the split pass in front of a plane-fed consumer disappears).  y_rb != NULL: the
    * launch also writes y as the two fp16 planes of y * s in the row-blocked order [N * Ho][Cout / 16][Wo][16] (plane q at y_rb +
    * q * y_rb_stride elements), s = *y_rb_scale -- a power of two the CALLER chose before the values exist (the host side keeps one
-   * per producing site: the largest |y| any call of the site recorded during the previous step x 8 head-room, mmt_rb_scales_update).
+   * per producing site: the largest |y| any call of the site recorded during the previous step x 2 head-room, mmt_rb_scales_update).
    * Needs Cout % 16 == 0, out_stride == 1, fp32 y, N * Ho * Wo * Cout < 2^30; honoured by every epilogue form of
    * mmt_conv_forward_f16x2 / mmt_conv3x3_strip_f16x2 / mmt_conv_forward_pg (register-direct, LDS-staged, split-K finish,
    * row-resident), refused (MMT_EINVAL) elsewhere.  y_amax_next: a second device word that receives max |y| like y_amax[0]
@@ -465,7 +465,7 @@ int mmt_split_planes_f16_rb(const float* x, void* planes, long plane_stride, int
  *   replaces autograd's AccumulateGrad additions of a multi-consumer tensor (layers/fused.py::ForkFn) AND the split pass of the
  *   3x3 data gradient behind it (reference: autograd of backbone/fpn.py:57-69 / rpn/rpn.py:39-46).
  * mmt_rb_scales_update: once per training step over the host side's table of producing sites, state[2 i] = scale, state[2 i + 1] =
- *   pending maximum (what y_amax_next / amax_next accumulated): scale <- the power of two that puts 8 x pending into [2^13, 2^14),
+ *   pending maximum (what y_amax_next / amax_next accumulated): scale <- the power of two that puts 2 x pending into [2^13, 2^14),
  *   pending <- 0; sites without a pending maximum keep their scale. */
 int mmt_conv_writes_rb(const mmt_conv_args* a /*[host]*/);
 /* Round 6: the weight gradients of a BATCH of layers (what a backward pass hands over at a time) as grouped launches -- replaces the

@@ -624,13 +624,13 @@ __global__ __launch_bounds__(256) void sum_stats_rb_kernel(const float* __restri
 }
 
 // the producing sites' scales for the NEXT step (one launch per step): state[i] = {scale, pending maximum (float bits)}; a site that
-// recorded a maximum since the last call gets the power of two that puts 8 x that maximum into [2^13, 2^14) -- three binades of
+// recorded a maximum since the last call gets the power of two that puts 2 x that maximum into [2^13, 2^14) -- one binade of
 // head-room over the largest value any call of the site produced -- and its pending maximum is cleared; sites nobody called keep theirs
 __global__ void rb_scales_update_kernel(float* __restrict__ state, const int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float pend = state[2 * i + 1];
-  if (pend > 0.f && pend < 3.0e38f) state[2 * i] = f16_scale_of_fwd(pend) * 0.125f;
+  if (pend > 0.f && pend < 3.0e38f) state[2 * i] = f16_scale_of_fwd(pend) * 0.5f;
   state[2 * i + 1] = 0.f;
 }
 

@@ -475,7 +475,7 @@ PG_RB = os.environ.get("MMT_PG_RB", "1") != "0"   # input planes of the plane-fe
 # plane-fed weight gradient) used to run one mmt_split_planes_f16_rb pass over its input first: 92 launches and 6.7 GB of traffic per
 # step.  The launch that PRODUCES the tensor now writes the row-blocked planes from its epilogue (mmt_conv_args.y_rb).  The scale it
 # needs before the values exist is the producing SITE's: the largest |y| any call of the site recorded during the previous step, with
-# 8 x head-room (one device word per site, folded once per step by mmt_rb_scales_update: `rb_scales_update`, called by the trainer
+# 2 x head-room (one device word per site, folded once per step by mmt_rb_scales_update: `rb_scales_update`, called by the trainer
 # after the optimiser step).  A consumer tests that scale against the statistics the producer recorded in the SAME launch
 # (x_planes_lag: max |x| s inside the fp16 range, sampled mean above the low term's) and computes the launch with exact fp32 products
 # when it fails -- so a tensor that outgrows the head-room costs time, never accuracy.  A site's first step (no scale yet) and shapes
