@@ -211,7 +211,10 @@ def forward_pair(backbone, xa, xb):
         bi_ = [getattr(fpn, nm).bias for nm in fpn.inner_blocks]
         wl = [getattr(fpn, nm).weight for nm in fpn.layer_blocks]
         bl = [getattr(fpn, nm).bias for nm in fpn.layer_blocks]
-        inner_cat, outs_cat = fused.fpn_forward([H.nhwc(c) for c in cs_cat], wi, bi_, wl, bl, getattr(fpn, "out_planes", True))
+        # (P_k's planes for the FIRST half only: the RPN head's 3x3 runs on the labeled pass; the unlabeled half's levels feed the box
+        # pooler and the hint adaptors, which read fp32 -- _hip.RbLead)
+        op = getattr(fpn, "out_planes", True)
+        inner_cat, outs_cat = fused.fpn_forward([H.nhwc(c) for c in cs_cat], wi, bi_, wl, bl, n if op is True else op)
         fused._PAIR_FWD[0] = False
     res = []
     for lo, hi in halves:
