@@ -67,7 +67,7 @@ def _wg_stream(dev):
         # priority -1 like the teacher's stream (engine/MTtrainer.py): HIP deals the streams of a priority class onto a few hardware
         # queues, and once RCCL has created its own a default-priority side stream shares one with the step stream -- under a process
         # group the step cost 37.9 ms with this stream at priority 0 and 36.3 at -1 (world size 1, same box); without one 35.5 either way
-        ent = _WG[dev] = [torch.cuda.Stream(device=dev, priority=-1), 0, False, [], []]
+        ent = _WG[dev] = [torch.cuda.Stream(device=dev, priority=int(_os.environ.get("MMT_WG_PRIO", "-1"))), 0, False, [], []]
     return ent
 
 
