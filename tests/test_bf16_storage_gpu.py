@@ -259,7 +259,7 @@ def test_heads_and_weight_gradients_multiply_in_bf16_in_mode_1(mode1):
     features, the RPN head's 3x3) and every weight gradient multiply bf16-rounded operands with fp32 accumulation like the backbone does;
     only the STORAGE of the heads' activations stays fp32 (they are produced by fp32 ROIAlign / selection kernels).  Shown the way an
     arithmetic can be shown from outside: the result equals the fp64 product of the bf16-ROUNDED operands to fp32-accumulation accuracy
-    (<= 2e-5 of sum |a||b|) and differs from the product of the un-rounded operands by what bf16 rounding must cost (>= 1e-4 of it)."""
+    (<= 2e-5 of sum |a||b|) and lies several times farther from the product of the un-rounded operands -- what bf16 rounding must cost."""
     import torch.nn.functional as F
     H = mode1
     from maskrcnn_benchmark.layers import fused
@@ -272,7 +272,7 @@ def test_heads_and_weight_gradients_multiply_in_bf16_in_mode_1(mode1):
         e_r = ((got.double().cpu() - rounded).abs() / bound).max().item()
         e_x = ((got.double().cpu() - exact).abs() / bound).max().item()
         assert e_r <= 2e-5, (what, e_r)
-        assert e_x >= 1e-4, (what, e_x)
+        assert e_x >= 3.0 * e_r and e_x >= 2e-5, (what, e_x, e_r)   # (the rounding's share shrinks like 1 / sqrt(K): 12 544 terms for fc6)
 
     # fc6-like Linear (R x 12544 -> 1024) through the model's own node
     x = (torch.randn(64, 12544, generator=g)).relu().cuda()
