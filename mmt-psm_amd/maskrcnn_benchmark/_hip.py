@@ -597,13 +597,20 @@ def f16_split_pg(x):
     # (no reuse of planes an earlier consumer left on the tensor: a launch plan's replay rewrites its result tensors in place without
     # touching their version counters -- the teacher's pyramid levels -- and planes made from the previous step's values would pass)
     N, C, Hh, W = x.shape
+    if x.numel() >= (1 << 30) or C % 16:
+        # (beyond the row-blocked pass's 32-bit offsets -- planes indexed like x, which the kernels take as layout 0)
+        xp, st = f16_split(x)
+        return xp, st, 0, 0
     am = _amax_of(x)
     xp = torch.empty((2, x.numel()), dtype=torch.float16, device=x.device)
     st = torch.empty((1,), dtype=torch.float32, device=x.device)
     _check(lib().mmt_split_planes_f16_rb(x.data_ptr(), xp.data_ptr(), xp.stride(0), N * Hh, W, C, am[0].data_ptr(), st.data_ptr(), _stream()),
            "mmt_split_planes_f16_rb")
     # the planes stay with the tensor: the weight gradient of the same layer takes BOTH operands from planes (conv_wgrad: the input's
-    # from the forward launch, the gradient's from the data-gradient launch) -- alive as long as the tensor is
+    # from the forward launch, the gradient's from the data-gradient launch) -- alive as long as the tensor is.  (ADVICE r5 asked to
+    # keep them only where a weight gradient can follow; a backward pass runs with autograd's grad mode OFF like the teacher's forward,
+    # so that test would drop the gradients' planes too -- the RPN head's weight gradients would fall back to the slower kernel.  Since
+    # round 6 few tensors are split here at all: 10 per step, 0.57 GB)
     x._mmt_rb = (xp, st, x._version, "split")
     return xp, st, 1, 0
 
