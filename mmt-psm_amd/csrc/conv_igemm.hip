@@ -3935,6 +3935,13 @@ extern "C" int mmt_conv_wgrad(const mmt_conv_args* a, const float* dy, const flo
 // ranges than alone -- a quarter of them by default (see wg_plan): longer reductions per block, a quarter of the slab traffic.
 // Summation order: fixed by (the batch's composition, shapes) -- repeatable, but not the single launches' order when ranges differ.
 namespace {
+// jobs per grouped launch (MMT_WGRAD_GROUP_CAP_PL / _PIPE: the sweep of profiles/r06_history.md; at most what the kernel-argument segment holds)
+static int wg_cap(int k) {
+  const char* e = getenv(k == 1 ? "MMT_WGRAD_GROUP_CAP_PL" : "MMT_WGRAD_GROUP_CAP_PIPE");
+  const int mx = k == 1 ? 12 : WGP_MAXG;
+  const int v = e ? atoi(e) : mx;
+  return v < 1 ? 1 : (v > mx ? mx : v);
+}
 struct WgJobPlan { int kind; int split; int mps; long ws_off; };   // kind 0: single launch (mmt_conv_wgrad / _planes); 1: plane-fed group; 2 + mode: pipe group
 constexpr int WGJ_MAX = 96;
 
@@ -3977,7 +3984,7 @@ static long wg_plan(const mmt_wgrad_job* jobs, int n, WgJobPlan* plan) {
   }
   long ws = 0;
   for (int k = 1; k <= 4; k++) {
-    const int cap = k == 1 ? 12 : WGP_MAXG, target = k == 1 ? 256 : 512;
+    const int cap = wg_cap(k), target = k == 1 ? 256 : 512;
     int idx[WGJ_MAX], m = 0;
     for (int i = 0; i < n; i++) if (kind[i] == k) idx[m++] = i;
     for (int c0 = 0; c0 < m; c0 += cap) {
@@ -4069,7 +4076,7 @@ extern "C" int mmt_conv_wgrad_group(const mmt_wgrad_job* jobs, int n, float* wor
                        plan[i].split};
       if (plan[i].split > 1)
         red[nred++] = WgReduceItem{ws, j.rowscale, j.dw, plan[i].split, j.a.Cout, j.a.KH * j.a.KW * j.a.Cin, 0};
-      if (m == 12) { const int e = flush(); if (e) return e; }
+      if (m == wg_cap(1)) { const int e = flush(); if (e) return e; }
     }
     const int e = flush();
     if (e) return e;
@@ -4105,7 +4112,7 @@ extern "C" int mmt_conv_wgrad_group(const mmt_wgrad_job* jobs, int n, float* wor
       g.first[g.n] = nb;
       nb += (it.tx * it.ty * it.tz + 7) & ~7;
       g.n++;
-      if (g.n == WGP_MAXG) { const int e = flush(); if (e) return e; }
+      if (g.n == wg_cap(2)) { const int e = flush(); if (e) return e; }
     }
     const int e = flush();
     if (e) return e;
