@@ -221,7 +221,7 @@ __global__ __launch_bounds__(768) void conv_pg_kernel(const ConvP p, const int k
       // n + S into the freed set
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       u32x4 rg[S][NI];
-      const float s_a = AF ? f16_scale_of_fwd(*p.f16_sx) : 1.f;
+      const float s_a = AF ? f16_scale_of(*p.f16_sx) : 1.f;
       auto load_step = [&](auto setc) {
         constexpr int set = decltype(setc)::value;
         const bool real = f_n < nkt;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void split_planes_f16_rb_kernel(const float* _
                                                                   const float* __restrict__ amax, float* __restrict__ s_out) {
   constexpr int CBS = 1024 + 32;   // bytes of one 16-channel block of the tile in LDS (32 pixels x 32 bytes, padded)
   __shared__ __attribute__((aligned(16))) char tile[2 * 16 * CBS];
-  const float s = f16_scale_of_fwd(*amax);
+  const float s = f16_scale_of(*amax);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && s_out) *s_out = s;
   const int row = blockIdx.x / segs, w0 = (blockIdx.x % segs) * 32, c0 = blockIdx.y * 256;
   const int cc = min(256, C - c0), c4n = cc >> 2, ncb = cc >> 4, npx = min(32, W - w0);
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void split_planes_f16_rb_kernel(const float* _
 __global__ __launch_bounds__(256) void split_planes_f16_rb_small_kernel(const float* __restrict__ x, unsigned short* __restrict__ pl,
                                                                         const long plane_stride, const int W, const int C, const long n4,
                                                                         const float* __restrict__ amax, float* __restrict__ s_out) {
-  const float s = f16_scale_of_fwd(*amax);
+  const float s = f16_scale_of(*amax);
   if (blockIdx.x == 0 && threadIdx.x == 0 && s_out) *s_out = s;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
@@ -630,7 +630,7 @@ __global__ void rb_scales_update_kernel(float* __restrict__ state, const int n) 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float pend = state[2 * i + 1];
-  if (pend > 0.f && pend < 3.0e38f) state[2 * i] = f16_scale_of_fwd(pend) * 0.5f;
+  if (pend > 0.f && pend < 3.0e38f) state[2 * i] = f16_scale_of(pend) * 0.5f;
   state[2 * i + 1] = 0.f;
 }
 

@@ -1,4 +1,4 @@
-// Shared by the convolution translation units (conv_igemm.hip, conv_pgemm.hip): the parameter block of every convolution kernel,
+// Shared by the convolution translation units (conv_igemm.hip, conv_wgrad.hip, conv_prep.hip, conv_pgemm.hip, conv_stem.hip, conv_wgpl.hip): the parameter block of every convolution kernel,
 // the fp16 split's range guard and its slow exact path, small vector types.  Device helpers live in an anonymous namespace (one
 // copy per translation unit); the host-side pieces with one definition (conv_igemm.hip) are declared in namespace mmtconv.
 #pragma once
@@ -55,7 +55,7 @@ struct SplitWs { float* ws; unsigned* tickets; };
 constexpr size_t SPLITK_WS_BYTES = (size_t)1024 * 128 * 128 * 4;  // 1024 partial tiles of 128 x 128 (64 MiB)
 constexpr int SPLITK_TICKETS = 4096;
 SplitWs split_workspace(hipStream_t s);
-// round 6: weight gradients of several layers in one launch (conv_wgpl.hip; orchestrated by mmt_conv_wgrad_group in conv_igemm.hip)
+// round 6: weight gradients of several layers in one launch (conv_wgpl.hip; orchestrated by mmt_conv_wgrad_group in conv_wgrad.hip)
 struct WgReduceItem { const float* ws; const float* rowscale; float* dw; int splits, Cout, NP, pad; };
 int launch_wgrad_reduce_group(const WgReduceItem* items, int n, hipStream_t s);
 struct WgPlJob { const mmt_conv_args* a; const float* dy; const void* xpl; long xpl_stride; const void* dpl; long dpl_stride;
@@ -124,8 +124,24 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   const f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
 }
+// x = x0 + x1 (+ x2) in bf16 terms, round-to-nearest at each level, the residuals exact in fp32 (4 values -> NS packed pairs of pairs)
+template <int NS>
+__device__ __forceinline__ void split4(const f32x4 v, uint2 (&o)[NS]) {
+  float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    const unsigned a = pk_bf16(r0, r1), b = pk_bf16(r2, r3);
+    o[q] = uint2{a, b};
+    if (q + 1 < NS) {
+      r0 -= __builtin_bit_cast(float, a << 16);
+      r1 -= __builtin_bit_cast(float, a & 0xffff0000u);
+      r2 -= __builtin_bit_cast(float, b << 16);
+      r3 -= __builtin_bit_cast(float, b & 0xffff0000u);
+    }
+  }
+}
 // power-of-two scale that puts the largest magnitude `amax` into [2^13, 2^14] (an all-zero tensor: 1)
-__device__ __forceinline__ float f16_scale_of_fwd(const float amax) {
+__device__ __forceinline__ float f16_scale_of(const float amax) {
   if (!(amax > 0.f)) return 1.f;
   int e;
   frexpf(amax, &e);
@@ -220,7 +236,7 @@ __device__ __forceinline__ void conv_slow_tile(const int m_first, const int run,
                                             const int tid, const int nthreads, const int lin) {
   const ConvPK pk = kernarg_convp();   // fields are fetched where they are used (scalar loads from the argument segment)
   const int HoWo = pk->Ho * pk->Wo;
-  const float S = (pk->f16_ax ? f16_scale_of_fwd(*pk->f16_sx) : *pk->f16_sx) * *pk->f16_sw;
+  const float S = (pk->f16_ax ? f16_scale_of(*pk->f16_sx) : *pk->f16_sx) * *pk->f16_sw;
   float amx = 0.f, asum = 0.f, acnt = 0.f;
   for (int o = tid; o < rows * ncols; o += nthreads) {
     const int i = o / ncols, c = o - i * ncols;
@@ -319,7 +335,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, const f32x1
   const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(has_mask ? p.mask : p.y), 0, has_mask ? ybytes : 0, 0x00020000);
   float sc[TN], sh[TN];
   // operands scaled by powers of two (fp16 split): exact rescale of the accumulated sum
-  const float inv = p.f16_sx ? 1.f / ((p.f16_ax ? f16_scale_of_fwd(*p.f16_sx) : *p.f16_sx) * *p.f16_sw) : 1.f;
+  const float inv = p.f16_sx ? 1.f / ((p.f16_ax ? f16_scale_of(*p.f16_sx) : *p.f16_sx) * *p.f16_sw) : 1.f;
 #pragma unroll
   for (int b = 0; b < TN; b++) {
     sc[b] = p.scale && cok[b] ? p.scale[c0 + b * 32] : 1.f;

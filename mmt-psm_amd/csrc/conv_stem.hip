@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512) void stem_fused_kernel(const StemP p) {
   const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;              // first convolution output of the tile
   const int sy0 = oy0 - 2, sx0 = ox0 - 2;                      // first space-to-depth pixel of the patch
   const F16Guard guard = f16_guard_load(p.x_slot);
-  const float sx = f16_scale_of_fwd(*p.x_slot);
+  const float sx = f16_scale_of(*p.x_slot);
 
   if (f16_guard_bad(guard)) {   // an image whose dynamic range defeats fp16 (uniform over the grid): exact products, element by element
     float amx = 0.f;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const ConvP p) {
   const int img = bid / tiles_y;
   const int oy0 = ty * 8, ox0 = tx * 16;
   const F16Guard guard = f16_guard_load(p.guard_x);
-  const float sx = f16_scale_of_fwd(*p.f16_sx);
+  const float sx = f16_scale_of(*p.f16_sx);
   if (f16_guard_bad(guard)) {   // (uniform over the grid) exact fp32 products; pixels of a ragged tile that wrap are written twice
     conv_slow_tile((img * p.Ho + oy0) * p.Wo + ox0, 16, p.Wo, 128, 0, 64, nullptr, false, tid, 256, blockIdx.x);
     return;

@@ -2,7 +2,7 @@
 //   dW[co][tap][ci] += rowscale[co] / (s_x s_dy) * sum over pixels  dy[px][co] * x[px + shift(tap)][ci]
 // Replaces autograd's conv2d weight gradient behind maskrcnn_benchmark.layers.Conv2d (layers/misc.py:30-43) for the 3x3 layers whose
 // input planes the forward pass and whose gradient planes the data-gradient launch have already produced (mmt_split_planes_f16_rb:
-// [N H][C / 16][W][16]) -- conv_wgrad_pipe_kernel (conv_igemm.hip) reads the fp32 tensors, splits them in registers and transposes
+// [N H][C / 16][W][16]) -- conv_wgrad_pipe_kernel (conv_wgrad.hip) reads the fp32 tensors, splits them in registers and transposes
 // them through LDS with vector stores: 115 vector instructions per 12 MFMAs, MFMA-busy 0.35.
 //
 // The reduction index of this GEMM is the PIXEL, the strided index of both operands.  Row-blocked planes make it cheap twice:

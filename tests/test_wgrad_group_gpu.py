@@ -1,5 +1,5 @@
 """Round 6: the weight gradients of a BATCH of layers as grouped launches (include/mmtpsm.h: mmt_conv_wgrad_group;
-csrc/conv_wgpl.hip: wgrad_pl_group_kernel, wgrad_reduce_group_kernel; csrc/conv_igemm.hip: conv_wgrad_pipe_group_kernel).
+csrc/conv_wgpl.hip: wgrad_pl_group_kernel, wgrad_reduce_group_kernel; csrc/conv_wgrad.hip: conv_wgrad_pipe_group_kernel).
 
 A backward pass hands its weight-gradient jobs to the side stream a batch at a time; one by one, a layer at N = 2 is cut into as many
 pixel ranges as it takes to fill the chip alone.  In a group the tiles of all layers fill it together.  Checked here, on batches like a
