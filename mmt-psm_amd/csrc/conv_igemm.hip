@@ -1947,7 +1947,8 @@ static int strip_tw(const ConvP& p, bool need_planes = true) {
   const char* e = getenv("MMT_STRIP");  // read per call (A/B timing)
   if (e && atoi(e) == 0) return 0;
   int tw = 0;
-  if (p.Wo % 128 == 0 && p.Ho % 2 == 0) tw = 128;
+  const char* w64 = getenv("MMT_STRIP_TW64");   // A/B: 4 image rows x 64 pixels per tile (6 input rows for 4: halo x 1.5) instead of 2 x 128 (4 for 2: x 2)
+  if (p.Wo % 128 == 0 && p.Ho % 2 == 0 && !(w64 && atoi(w64) && p.Ho % 4 == 0)) tw = 128;
   else if (p.Wo % 64 == 0 && p.Ho % 4 == 0) tw = 64;
   constexpr int minc = 128;   // (tuned: profiles/r04_dispatch_sweep.txt)
   if (!tw || p.Cin < minc) return 0;  // K = 576 (the 64-channel layer1 convs): 12 super-steps do not amortise the fill

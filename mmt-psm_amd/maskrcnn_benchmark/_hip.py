@@ -1928,6 +1928,11 @@ def _weight_planes(w, a):
     return pl
 
 
+WEIGHTS_GEN = [0]    # bumped by every library call that writes parameters through raw pointers (sgd_momentum, ema_update: those bump no tensor
+                     # version) and at the start of every training step (engine/MTtrainer.py)
+_LOOSE_FLIPS = {}    # weight address -> ((version, shape, scale address, scale version, stream), flipped fp32 weights)
+
+
 _PREC = None   # the library's mode, mirrored here (asked several times per launch)
 
 
@@ -2202,13 +2207,25 @@ def colsum(dy2d, out):
     _check(lib().mmt_colsum(_p(dy2d), M, C, _p(out), _stream()), "mmt_colsum")
 
 
-def weight_flip_transpose(w, scale=None):
-    """w (Cout,Cin,KH,KW) channels_last-dense -> (Cin,Cout,KH,KW) channels_last-dense, taps flipped, rows scaled"""
-    w = nhwc(w)
+def weight_flip_transpose(w, scale=None, owner=None):
+    """w (Cout,Cin,KH,KW) channels_last-dense -> (Cin,Cout,KH,KW) channels_last-dense, taps flipped, rows scaled
+    owner: the Parameter object `w` is (a backward pass sees its saved tensors as new Python objects; the forward keeps the object)"""
+    w0, w = (w if owner is None else owner), nhwc(w)
     Cout, Cin, KH, KW = w.shape
+    # the RPN predictors' data gradient runs once per pyramid level with the same weights: flipped once per version and stream
+    # (identity of the Parameter object, not its address: a freed tensor's address comes back with another tensor's values)
+    ptr = w.data_ptr()
+    key = (w._version, WEIGHTS_GEN[0], (Cout, Cin, KH, KW), _p(scale), None if scale is None else scale._version, _stream())
+    hit = _LOOSE_FLIPS.get(ptr)
+    if hit is not None and hit[0] == key and hit[2]() is w0:
+        return hit[1]
     wd = empty_nhwc(Cin, Cout, KH, KW, w.device)
     _check(lib().mmt_weight_flip_transpose(_p(w), _p(scale), _p(wd), Cout, KH, KW, Cin, _stream()),
            "mmt_weight_flip_transpose")
+    if scale is None and isinstance(w0, torch.nn.Parameter) and w0.data_ptr() == ptr and w0._version == w._version:
+        if len(_LOOSE_FLIPS) >= 64:
+            _LOOSE_FLIPS.clear()
+        _LOOSE_FLIPS[ptr] = (key, wd, weakref.ref(w0))
     return wd
 
 
@@ -2340,12 +2357,14 @@ def ema_update(teacher_flat, student_flat, alpha):
     _dev(teacher_flat)
     _dev(student_flat)
     assert teacher_flat.numel() == student_flat.numel() and teacher_flat.is_contiguous() and student_flat.is_contiguous()
+    WEIGHTS_GEN[0] += 1
     _check(lib().mmt_ema_update(_p(teacher_flat), _p(student_flat), teacher_flat.numel(), float(alpha), _stream()),
            "mmt_ema_update")
 
 
 def sgd_momentum(p, g, buf, lr, wd, momentum, first):
     _dev(p)
+    WEIGHTS_GEN[0] += 1
     _check(lib().mmt_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), float(lr), float(wd), float(momentum),
                                   1 if first else 0, _stream()), "mmt_sgd_momentum")
 

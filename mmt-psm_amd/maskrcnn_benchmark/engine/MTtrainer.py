@@ -380,6 +380,7 @@ class MTtrainer(object):
     def train_step(self, iteration, data_s, target_s, data_u_list=None):
         use_mt = iteration > self.start_mt and self.lambda_value > 0 and data_u_list is not None
         fused._WG_PARKED.clear()   # (jobs a failed step left parked must not meet this step's)
+        H.WEIGHTS_GEN[0] += 1      # (what _hip derived from loose weights during the last step is not trusted across steps)
         bucketed = self._bucketed_allreduce()
         if bucketed is not None:
             bucketed.install()  # the stage hooks are registered by the forward passes below

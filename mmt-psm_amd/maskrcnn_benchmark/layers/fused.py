@@ -233,7 +233,7 @@ def _wgrad(x, g, w, stride, pad, rowscale=None, with_bias=False, dst_w=None, dst
 
 
 def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, res=None, res_mode=0, want_planes=False,
-           out_dtype=None, rb_site=None):
+           out_dtype=None, rb_site=None, w_owner=None):
     """data gradient of y = conv(x, w) (* scale[co]) w.r.t. x, with optional fused (x>0) mask / residual add;
     out_dtype: the storage type of x (autograd wants the gradient in the tensor's own type: bf16 storage);
     rb_site: the result feeds a plane-fed launch -- this launch's epilogue writes its row-blocked fp16 planes (_hip._rb_produce)"""
@@ -244,7 +244,7 @@ def _dgrad(g, w, x_shape, stride, pad, scale=None, mask=None, mask_scale=1.0, re
     # data gradient (one launch, nothing materialised in fp32), else as an fp32 tensor
     planes = H.pack_weight_flipped(w, scale)
     kw = dict(w_shape=(w.shape[1], w.shape[0], kh, w.shape[3]), planes=planes, f16_src=(w, scale)) if planes is not None else {}
-    wd = None if planes is not None else H.weight_flip_transpose(w, scale)
+    wd = None if planes is not None else H.weight_flip_transpose(w, scale, owner=w_owner)
     if stride == 1:
         return H.conv_forward(g, wd, stride=1, pad=kh - 1 - pad, mask=mask, mask_scale=mask_scale, res=res,
                               res_mode=res_mode, want_planes=want_planes, out_dtype=out_dtype, rb_site=rb_site, **kw)
@@ -264,6 +264,7 @@ class ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.cfgv = (stride, pad, input_relu, b is not None, din_rb)
         ctx.dst = (_dst(w), _dst(b))
+        ctx.w_owner = w if isinstance(w, torch.nn.Parameter) else None   # (identity for _hip.weight_flip_transpose's per-version cache)
         return y
 
     @staticmethod
@@ -274,7 +275,7 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:   # first: on the fp16 split it records max |g|, which the weight gradient then reuses
             dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None, out_dtype=x.dtype,
-                        rb_site=("dx", w.data_ptr()) if din_rb else None)
+                        rb_site=("dx", w.data_ptr()) if din_rb else None, w_owner=ctx.w_owner)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw, db = _wgrad(x, g, w, stride, pad, None, has_b, *ctx.dst)
         return dx, dw, db, None, None, None, None, None, None

@@ -23,8 +23,16 @@ hist = collections.Counter()
 _orig = H._check
 
 
+SITES = set(os.environ.get("MMT_CALL_SITES", "").split(",")) - {""}   # symbols whose callers are listed (MMT_CALL_SITES=mmt_pack_weight,...)
+sites = collections.Counter()
+
+
 def _counting(code, what):
     hist[what] += 1
+    if what in SITES:
+        import traceback
+        fr = [f for f in traceback.extract_stack()[:-1] if "maskrcnn_benchmark" in f.filename and not f.filename.endswith("_hip.py")][-3:]
+        sites[(what, " < ".join("%s:%d %s" % (os.path.basename(f.filename), f.lineno, f.name) for f in reversed(fr)))] += 1
     return _orig(code, what)
 
 
@@ -40,6 +48,8 @@ direct = sum(hist.values()) / n
 print("library calls per step: %.1f  (direct %.1f, replayed from launch plans %.1f)" % (total, direct, total - direct))
 for k, v in hist.most_common():
     print("  %-40s %7.1f" % (k, v / n))
+for (what, where), v in sites.most_common():
+    print("  site %-28s %5.1f  %s" % (what, v / n, where))
 with H._LP_LOCK:
     plans = list(H._LAUNCH_PLANS.values())
 for p in plans:
