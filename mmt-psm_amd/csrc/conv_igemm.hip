@@ -1138,7 +1138,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
 // (three taps = 72 MFMAs per wave), placed before the last tap: the fragments of that tap are in registers by then, so the
 // stage is free for the copies of super-step s + 2 while tap 0 of s + 1 is pre-read from the other stage.
 template <int TW, int NS, bool F16 = false>  // F16: the planes hold the two fp16 terms of x * s_x / w * s_w (default arithmetic of mode 3)
-__global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, const int ksplit, float* __restrict__ ws) {
+__global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, const int ksplit_arg, float* __restrict__ ws) {
+  // bit 30 of the argument: super-steps in (channel slab, kh) order instead of (kh, channel slab) -- the three kh of a slab read the
+  // same input rows shifted by one, so in slab-major order a row is fetched once and found in the L2 twice; in kh-major order the
+  // whole input streams through the L2 three times (round 6: FETCH_SIZE of this kernel was 3 x its input, tools/_ab_tw.sh)
+  const int ksplit = ksplit_arg & 0x3fffffff;
+  const bool slab_major = (ksplit_arg >> 30) & 1;
   constexpr int BM = 256, BN = 128, R = BM / TW, SW = TW + 32, TM = 2, TN = 2;
   constexpr int PA = R * SW * 32;              // bytes of one A plane of a stage (strip rows x 32 B)
   constexpr int PB = BN * 32;                  // one B plane of one tap
@@ -1227,7 +1232,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   const int row_bytes = p.W * p.Cin * 2;
   const int a_step = p.xpl_rb ? p.W * 32 : 32;   // bytes from one 16-channel slab to the next
   unsigned vo_a[SA];
-  int f_kh = ss0 / slabs, f_cs = ss0 % slabs;   // (kh, slab) of the super-step whose copies are being issued
+  int f_kh = slab_major ? ss0 % 3 : ss0 / slabs, f_cs = slab_major ? ss0 / 3 : ss0 % slabs;   // (kh, slab) of the super-step whose copies are being issued
   const int b_step = (int)(kt_stride * 2);
   int soff_a = 0;                               // its scalar byte offsets: A = max(kh - 1, 0) rows + slab,
   int soff_b = (f_kh * 3 * slabs + f_cs) * b_step;   // B = (kh * 3 * slabs + slab) steps
@@ -1242,6 +1247,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   };
   fill_enter_kh();
   auto fill_advance = [&]() {      // next super-step to fill
+    if (slab_major) {
+      if (++f_kh == 3) { f_kh = 0; ++f_cs; }
+      soff_b = (f_kh * 3 * slabs + f_cs) * b_step;
+      fill_enter_kh();
+      return;
+    }
     soff_a += a_step;
     soff_b += b_step;
     if (++f_cs == slabs) {
@@ -1940,6 +1951,12 @@ static int strip_ksplit(const ConvP& p, int tw) {
 }
 
 // 3x3 / stride 1 / pad 1 with both operands as planes: which strip width (0 = not taken)
+// K order of the tap-strip kernel (bit 30 of its ksplit argument): slab-major unless MMT_STRIP_KORDER=0 (read per call: A/B timing)
+static int strip_korder() {
+  const char* e = getenv("MMT_STRIP_KORDER");
+  return (e && atoi(e) == 0) ? 0 : (1 << 30);
+}
+
 static int strip_tw(const ConvP& p, bool need_planes = true) {
   if ((need_planes && !p.xpl) || !p.wpl || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.out_stride != 1 || p.Ho != p.H ||
       p.Wo != p.W || (p.Cin & 31) || p.Cout <= 32 || ((size_t)p.xpl & 15) || (p.xpl_stride & 7))
@@ -1972,7 +1989,7 @@ int launch_strip(const ConvP& p, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
   }
   const int tiles = p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
-  hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit, w.ws);
+  hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit | strip_korder(), w.ws);
   MMT_LAUNCH_CHECK();
   if (ksplit > 1) {  // Wo == TW: tile t covers the 256 consecutive pixels [256 t', 256 t' + 256) of its channel block
     launch_finish<256, 128>(p, tiles, ksplit, w.ws, s);
@@ -2114,7 +2131,7 @@ extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x,
     const size_t lds = ring > epi ? ring : epi;
     const hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (er != hipSuccess) return (int)er;
-    hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit, w.ws);
+    hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit | strip_korder(), w.ws);
     return 0;
   };
   if (tw == 128) e = go(conv3x3_strip_kernel<128, NS, true>, 128);

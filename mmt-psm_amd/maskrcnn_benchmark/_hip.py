@@ -2209,7 +2209,8 @@ def colsum(dy2d, out):
 
 def weight_flip_transpose(w, scale=None, owner=None):
     """w (Cout,Cin,KH,KW) channels_last-dense -> (Cin,Cout,KH,KW) channels_last-dense, taps flipped, rows scaled
-    owner: the Parameter object `w` is (a backward pass sees its saved tensors as new Python objects; the forward keeps the object)"""
+    owner: the tensor object the forward pass was given as `w` (a backward pass sees its saved tensors as new Python objects; the
+    node keeps the forward's): with it the result is kept for the next launch with the same object, version and parameter generation"""
     w0, w = (w if owner is None else owner), nhwc(w)
     Cout, Cin, KH, KW = w.shape
     # the RPN predictors' data gradient runs once per pyramid level with the same weights: flipped once per version and stream
@@ -2222,7 +2223,7 @@ def weight_flip_transpose(w, scale=None, owner=None):
     wd = empty_nhwc(Cin, Cout, KH, KW, w.device)
     _check(lib().mmt_weight_flip_transpose(_p(w), _p(scale), _p(wd), Cout, KH, KW, Cin, _stream()),
            "mmt_weight_flip_transpose")
-    if scale is None and isinstance(w0, torch.nn.Parameter) and w0.data_ptr() == ptr and w0._version == w._version:
+    if scale is None and owner is not None and w0.data_ptr() == ptr and w0._version == w._version:
         if len(_LOOSE_FLIPS) >= 64:
             _LOOSE_FLIPS.clear()
         _LOOSE_FLIPS[ptr] = (key, wd, weakref.ref(w0))

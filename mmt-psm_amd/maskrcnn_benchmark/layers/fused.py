@@ -264,7 +264,7 @@ class ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.cfgv = (stride, pad, input_relu, b is not None, din_rb)
         ctx.dst = (_dst(w), _dst(b))
-        ctx.w_owner = w if isinstance(w, torch.nn.Parameter) else None   # (identity for _hip.weight_flip_transpose's per-version cache)
+        ctx.w_owner = w   # (the object's identity: _hip.weight_flip_transpose keeps the flipped weights between launches with the same one)
         return y
 
     @staticmethod

@@ -39,12 +39,15 @@ def test_flipped_weights_cached_per_parameter_generation():
         w.mul_(2.0)
     d = H.weight_flip_transpose(w.detach(), owner=w)
     assert torch.equal(d, _ref(w))
-    # no owner / not a Parameter: never cached
+    # no owner: never cached; a computed tensor (the RPN head's concatenated predictor weights) as its own owner: cached while it lives
     t = torch.randn(15, 256, 1, 1, generator=g).cuda().contiguous(memory_format=torch.channels_last)
     c0 = H.C_CALLS[0]
     H.weight_flip_transpose(t)
     H.weight_flip_transpose(t)
     assert H.C_CALLS[0] - c0 == 2
+    H.weight_flip_transpose(t.detach(), owner=t)
+    H.weight_flip_transpose(t.detach(), owner=t)
+    assert H.C_CALLS[0] - c0 == 3
     # another Parameter that lands on the address of a dead one
     ptr = w.data_ptr()
     shape = tuple(w.shape)
