@@ -1134,14 +1134,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
 //   * tile = 256 output pixels (R = 256 / TW image rows x TW pixels) x 128 channels on EIGHT waves (2 per SIMD, 64 x 64
 //     each): the weight planes of a step feed twice the pixels -- B traffic per multiply / 2.
 //   -> 11 KB per 128x128x16 step-equivalent instead of 24.
-// K order: (kh, channel slab, kw) -- the packed weight planes are indexed, not re-packed.  One barrier per super-step
+// K order: (channel slab, kh, kw) since round 6 ((kh, channel slab, kw) before: bit 30 of the ksplit argument) -- the packed weight
+// planes are indexed, not re-packed.  One barrier per super-step
 // (three taps = 72 MFMAs per wave), placed before the last tap: the fragments of that tap are in registers by then, so the
 // stage is free for the copies of super-step s + 2 while tap 0 of s + 1 is pre-read from the other stage.
 template <int TW, int NS, bool F16 = false>  // F16: the planes hold the two fp16 terms of x * s_x / w * s_w (default arithmetic of mode 3)
 __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, const int ksplit_arg, float* __restrict__ ws) {
   // bit 30 of the argument: super-steps in (channel slab, kh) order instead of (kh, channel slab) -- the three kh of a slab read the
   // same input rows shifted by one, so in slab-major order a row is fetched once and found in the L2 twice; in kh-major order the
-  // whole input streams through the L2 three times (round 6: FETCH_SIZE of this kernel was 3 x its input, tools/_ab_tw.sh)
+  // whole input streams through the L2 three times (round 6: FETCH_SIZE of this kernel was 3 x its input, profiles/r06_history.md section 9)
   const int ksplit = ksplit_arg & 0x3fffffff;
   const bool slab_major = (ksplit_arg >> 30) & 1;
   constexpr int BM = 256, BN = 128, R = BM / TW, SW = TW + 32, TM = 2, TN = 2;
