@@ -1140,11 +1140,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
 // stage is free for the copies of super-step s + 2 while tap 0 of s + 1 is pre-read from the other stage.
 template <int TW, int NS, bool F16 = false>  // F16: the planes hold the two fp16 terms of x * s_x / w * s_w (default arithmetic of mode 3)
 __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, const int ksplit_arg, float* __restrict__ ws) {
-  // bit 30 of the argument: super-steps in (channel slab, kh) order instead of (kh, channel slab) -- the three kh of a slab read the
-  // same input rows shifted by one, so in slab-major order a row is fetched once and found in the L2 twice; in kh-major order the
-  // whole input streams through the L2 three times (round 6: FETCH_SIZE of this kernel was 3 x its input, profiles/r06_history.md section 9)
-  const int ksplit = ksplit_arg & 0x3fffffff;
-  const bool slab_major = (ksplit_arg >> 30) & 1;
+  // bits 24-30 of the argument = G: super-steps in (group of G channel slabs, kh, slab of the group) order; 0 = (kh, slab), the order of
+  // rounds 2-5.  The three kh of a slab read the same input rows shifted by one: with kh outermost the whole input streams through the
+  // L2 three times (FETCH_SIZE of this kernel was 3 x its input), with a small group outermost a row is fetched once and found in
+  // the L2 twice, 3 G super-steps apart at most (profiles/r06_history.md section 9)
+  const int ksplit = ksplit_arg & 0xffffff;
+  const int korder_g = (ksplit_arg >> 24) & 127;
   constexpr int BM = 256, BN = 128, R = BM / TW, SW = TW + 32, TM = 2, TN = 2;
   constexpr int PA = R * SW * 32;              // bytes of one A plane of a stage (strip rows x 32 B)
   constexpr int PB = BN * 32;                  // one B plane of one tap
@@ -1233,7 +1234,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   const int row_bytes = p.W * p.Cin * 2;
   const int a_step = p.xpl_rb ? p.W * 32 : 32;   // bytes from one 16-channel slab to the next
   unsigned vo_a[SA];
-  int f_kh = slab_major ? ss0 % 3 : ss0 / slabs, f_cs = slab_major ? ss0 / 3 : ss0 % slabs;   // (kh, slab) of the super-step whose copies are being issued
+  const int G = (korder_g == 0 || korder_g > slabs) ? slabs : korder_g;   // (slabs % G == 0: the host picks a power of two <= 8, slabs is a multiple of 8)
+  int f_grp = ss0 / (3 * G), f_kh = (ss0 % (3 * G)) / G, f_sub = ss0 % G;   // super-step ss0 = (group, kh, slab of the group)
+  int f_cs = f_grp * G + f_sub;                 // (kh, slab) of the super-step whose copies are being issued
   const int b_step = (int)(kt_stride * 2);
   int soff_a = 0;                               // its scalar byte offsets: A = max(kh - 1, 0) rows + slab,
   int soff_b = (f_kh * 3 * slabs + f_cs) * b_step;   // B = (kh * 3 * slabs + slab) steps
@@ -1248,20 +1251,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_strip_kernel(const ConvP p, co
   };
   fill_enter_kh();
   auto fill_advance = [&]() {      // next super-step to fill
-    if (slab_major) {
-      if (++f_kh == 3) { f_kh = 0; ++f_cs; }
-      soff_b = (f_kh * 3 * slabs + f_cs) * b_step;
-      fill_enter_kh();
+    if (++f_sub < G) {             // the next slab of the group, same kh
+      ++f_cs;
+      soff_a += a_step;
+      soff_b += b_step;
       return;
     }
-    soff_a += a_step;
-    soff_b += b_step;
-    if (++f_cs == slabs) {
-      f_cs = 0;
-      ++f_kh;
-      soff_b += 2 * slabs * b_step;  // the weight steps of kw = 1, 2 of the finished kh lie in between
-      fill_enter_kh();
-    }
+    f_sub = 0;
+    if (++f_kh == 3) { f_kh = 0; ++f_grp; }
+    f_cs = f_grp * G;
+    soff_b = (f_kh * 3 * slabs + f_cs) * b_step;   // (the weight steps of kw = 1, 2 of a kh lie between those of kw = 0 of two kh)
+    fill_enter_kh();
   };
   auto issue_slot = [&](int i, int stage) {
     char* const st = ring + stage * STAGE;
@@ -1952,10 +1952,16 @@ static int strip_ksplit(const ConvP& p, int tw) {
 }
 
 // 3x3 / stride 1 / pad 1 with both operands as planes: which strip width (0 = not taken)
-// K order of the tap-strip kernel (bit 30 of its ksplit argument): slab-major unless MMT_STRIP_KORDER=0 (read per call: A/B timing)
-static int strip_korder() {
+// K order of the tap-strip kernel (bits 24-30 of its ksplit argument = slabs per group, 0 = kh outermost as in rounds 2-5):
+// MMT_STRIP_KORDER = 0 | 1 | 2 | 4 | 8 (read per call: A/B timing).  Default 4 (tools/strip_korder.py, profiles/r06_strip_korder.txt):
+// the fabric reads of 1 (141 MB per launch instead of 278) at the cycle count of 0 -- every change of kh recomputes the copy slots'
+// row offsets, which costs 7 % of the kernel's cycles when it happens every super-step and 1 % every fourth
+static int strip_korder(const ConvP& p) {
   const char* e = getenv("MMT_STRIP_KORDER");
-  return (e && atoi(e) == 0) ? 0 : (1 << 30);
+  int g = e ? atoi(e) : 4;
+  if (g != 0 && g != 1 && g != 2 && g != 4 && g != 8) g = 4;
+  while (g > 1 && ((p.Cin >> 4) % g) != 0) g >>= 1;
+  return g << 24;
 }
 
 static int strip_tw(const ConvP& p, bool need_planes = true) {
@@ -1990,7 +1996,7 @@ int launch_strip(const ConvP& p, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
   }
   const int tiles = p.N * (p.Ho * p.Wo / 256) * mmt_cdiv(p.Cout, 128);
-  hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit | strip_korder(), w.ws);
+  hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit | strip_korder(p), w.ws);
   MMT_LAUNCH_CHECK();
   if (ksplit > 1) {  // Wo == TW: tile t covers the 256 consecutive pixels [256 t', 256 t' + 256) of its channel block
     launch_finish<256, 128>(p, tiles, ksplit, w.ws, s);
@@ -2132,7 +2138,7 @@ extern "C" int mmt_conv3x3_strip_f16x2(const mmt_conv_args* a, const float* s_x,
     const size_t lds = ring > epi ? ring : epi;
     const hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (er != hipSuccess) return (int)er;
-    hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit | strip_korder(), w.ws);
+    hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(512), lds, s, p, ksplit | strip_korder(p), w.ws);
     return 0;
   };
   if (tw == 128) e = go(conv3x3_strip_kernel<128, NS, true>, 128);

@@ -64,6 +64,7 @@ python $R/mmt-psm_amd/tools/whatif.py 2>/dev/null | grep -v amdgpu.ids > $OUT/wh
 MMT_WGRAD_STREAM=0 python $R/mmt-psm_amd/tools/conv_table.py > $OUT/conv_table.txt 2>/dev/null
 python $R/mmt-psm_amd/tools/host_phases.py 2>/dev/null | tail -36 > $OUT/host_device_phases.txt
 python $R/mmt-psm_amd/tools/op_sites.py 2>/dev/null | grep -v amdgpu.ids | head -60 > $OUT/library_op_sites.txt
+python $R/mmt-psm_amd/tools/call_hist.py 5 2>/dev/null | grep -v amdgpu.ids > $OUT/call_hist.txt
 STEPS=120 python $R/mmt-psm_amd/tools/step_series.py 2>/dev/null | tail -3 > $OUT/step_series_bench.txt
 python $R/bench.py --bf16x3 --no-cpu-baseline > $OUT/bench_bf16x3.json 2>/dev/null
 python $R/bench.py --bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2>/dev/null

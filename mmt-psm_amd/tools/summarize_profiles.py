@@ -131,6 +131,7 @@ extra = [("split_sites.txt", "the launches of one step that still run a plane-sp
          ("conv_table.txt", "every convolution call of a step by shape (single-stream, event-bracketed): time, TFLOP/s, MFMA / HBM bound"),
          ("host_device_phases.txt", "host issue time and device arrival time of every phase of one overlapped step (no profiler)"),
          ("library_op_sites.txt", "which lines of the package still issue library (ATen) operations in a step, by count (both threads)"),
+         ("call_hist.txt", "the C-ABI calls of a step by symbol (`library_calls_per_step` of the bench line), direct and replayed from launch plans"),
          ("step_series_bench.txt", "per-step ms over 120 steps with the bench's frozen learning rate"),
          ("clock_under_load.txt", "shader clock and board power of the GPU under the dominant kernel back to back, the fp32-input MFMA kernel, an HBM copy, the bench step"),
          ("precision_f16x2.txt", "time and error against fp64 of the default arithmetic, the 3-term bf16 split and the fp32-input MFMA on the strip and tiled shapes, for activation-like, gradient-like, extreme-scale and outlier-laden operands; launches of a step on the fp16 split and the tensors that still take a reduction pass of their own"),
