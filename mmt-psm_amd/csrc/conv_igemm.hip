@@ -1134,7 +1134,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_pp_kernel(const ConvP p, cons
 //   * tile = 256 output pixels (R = 256 / TW image rows x TW pixels) x 128 channels on EIGHT waves (2 per SIMD, 64 x 64
 //     each): the weight planes of a step feed twice the pixels -- B traffic per multiply / 2.
 //   -> 11 KB per 128x128x16 step-equivalent instead of 24.
-// K order: (channel slab, kh, kw) since round 6 ((kh, channel slab, kw) before: bit 30 of the ksplit argument) -- the packed weight
+// K order: (group of G channel slabs, kh, slab of the group, kw) since round 6 ((kh, channel slab, kw) before = one group of all
+// slabs; G in bits 24-30 of the ksplit argument) -- the packed weight
 // planes are indexed, not re-packed.  One barrier per super-step
 // (three taps = 72 MFMAs per wave), placed before the last tap: the fragments of that tap are in registers by then, so the
 // stage is free for the copies of super-step s + 2 while tap 0 of s + 1 is pre-read from the other stage.
