@@ -37,6 +37,12 @@ __device__ __forceinline__ f16x8 tr_pair(const char* p) {   // 8 consecutive pix
   return __builtin_bit_cast(f16x8, v);
 }
 
+#ifdef MMT_PG_ABLATE
+#define WGPL_DBG(p) ((p).dbg)
+#else
+#define WGPL_DBG(p) 0
+#endif
+
 struct WgP {
   const float* x; const float* dy;                       // fp32 tensors (the slow, exact path)
   const unsigned short* xpl; long xpl_stride;            // row-blocked planes of x * s_x
@@ -45,7 +51,8 @@ struct WgP {
   const float* guard_x; const float* guard_dy;           // statistics slots (range guard) or null
   const float* rowscale; float* dw; float* ws; float* dbias;
   int N, H, W, Cin, Cout, KH, KW, pad, ksplit;
-  int dbg;   // (tools: 1 = every copy out of range -- zeros, no memory traffic; 2 = no fragment reads.  Wrong results)
+  int dbg;   // (tools build only, -DMMT_PG_ABLATE = `make ablate`: 1 = every copy out of range -- zeros, no memory traffic; 2 = no fragment
+             // reads.  Wrong results; the product library compiles the arms out, WGPL_DBG below)
   int lag;   // round 6: bit 0 / bit 1 -- the planes of x / of dy were written by their producer's epilogue with a scale fixed beforehand
 };
 
@@ -104,7 +111,7 @@ __device__ __forceinline__ void wgrad_pl_body(const WgP& p, const int bid_in, co
     const int px = lane >> 1;
     int f_t = 0;                                       // super-steps issued so far
     auto copy_step = [&](int stage) {
-      const bool real = f_t < nt && !(p.dbg & 1);
+      const bool real = f_t < nt && !(WGPL_DBG(p) & 1);
       const int t = t0 + (real ? f_t : 0);
       const int row = t / segs, w0 = (t - row * segs) << 5;   // image row (n H + h), first pixel
       unsigned vo = (unsigned)lane * 16u;
@@ -156,7 +163,7 @@ __device__ __forceinline__ void wgrad_pl_body(const WgP& p, const int bid_in, co
           for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-              if ((p.dbg & 2) && t > 0) continue;
+              if ((WGPL_DBG(p) & 2) && t > 0) continue;
               fa[q][a] = tr_pair(sa + (q * 8 + a * 2) * WG_BLK + k2 * 512);
               fb[q][a] = tr_pair(sb + (q * 8 + a * 2) * WG_BLK + k2 * 512);
             }
@@ -451,7 +458,11 @@ extern "C" int mmt_conv_wgrad_planes(const mmt_conv_args* a, const float* dy, co
   p.s_x = s_x; p.s_dy = s_dy;
   p.guard_x = (const float*)a->f16_guard_x; p.guard_dy = (const float*)a->f16_guard_dy;
   p.rowscale = rowscale; p.dw = dw; p.ws = workspace; p.dbias = dbias;
+#ifdef MMT_PG_ABLATE
   p.dbg = getenv("MMT_WGPL_DBG") ? atoi(getenv("MMT_WGPL_DBG")) : 0;
+#else
+  p.dbg = 0;
+#endif
   p.lag = a->x_planes_lag;
   p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW; p.pad = a->pad; p.ksplit = ks;
   const int NP = a->KH * a->KW * a->Cin;
