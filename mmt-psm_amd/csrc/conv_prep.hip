@@ -334,9 +334,14 @@ __global__ __launch_bounds__(256) void pack_many_amax_kernel(const float* __rest
       if (cur >= 0) wave_amax_commit(m, (unsigned*)stat + 2 * cur);
       cur = di; m = 0.f; d = descs[di];
     }
-    f32x4 v0, v1;
-    load_pack_unit(base + d.src_off, d.Cout, d.K, unit - d.unit0, lane, v0, v1);
-    m = fmaxf(m, amax8(v0, v1));
+    // the maximum does not care about the order: unit u of a matrix reads the u-th 2 KiB of the matrix as it lies in memory (one
+    // coalesced run per wave) instead of the 32-byte pieces of 32 rows the packing launch needs (64 us -> 40 for 44 M parameters);
+    // a matrix has at least as many units as it has 512-element runs (its packed image is padded to 32 rows)
+    const long e = (long)(unit - d.unit0) * 512 + lane * 8, numel = (long)d.Cout * d.K;
+    if (e < numel) {   // (K % 16 == 0: the 8 elements of a lane lie inside the matrix)
+      const float* src = base + d.src_off + e;
+      m = fmaxf(m, amax8(ldg4(src), ldg4(src + 4)));
+    }
   }
   if (cur >= 0) wave_amax_commit(m, (unsigned*)stat + 2 * cur);
 }
@@ -368,9 +373,20 @@ __global__ __launch_bounds__(256) void pack_flip_many_amax_kernel(const FlipDesc
       if (cur >= 0) wave_amax_commit(m, (unsigned*)stat + 2 * cur);
       cur = di; m = 0.f; d = descs[di];
     }
-    f32x4 v0, v1;
-    load_flip_unit(d.w, d.scale, d.Cout, d.KH, d.KW, d.Cin, unit - d.unit0, lane, v0, v1);
-    m = fmaxf(m, amax8(v0, v1));
+    // (as above: max |w[co][tap][ci] * scale[co]| over the matrix in memory order -- the flipped / transposed gather of the packing
+    // launch costs 8 strided scalar loads per lane, 148 us per step for a number that does not depend on the order)
+    const int rowlen = d.KH * d.KW * d.Cin;
+    const long e = (long)(unit - d.unit0) * 512 + lane * 8, numel = (long)d.Cout * rowlen;
+    if (e < numel) {
+      if ((rowlen & 7) == 0) {   // the 8 elements of a lane share their output channel
+        const float sc = d.scale ? d.scale[e / rowlen] : 1.f;
+        const f32x4 a = ldg4(d.w + e), b = ldg4(d.w + e + 4);
+        m = fmaxf(m, amax8(f32x4{a[0] * sc, a[1] * sc, a[2] * sc, a[3] * sc}, f32x4{b[0] * sc, b[1] * sc, b[2] * sc, b[3] * sc}));
+      } else {
+        for (int j = 0; j < 8 && e + j < numel; j++)
+          m = fmaxf(m, fabsf(d.w[e + j] * (d.scale ? d.scale[(e + j) / rowlen] : 1.f)));
+      }
+    }
   }
   if (cur >= 0) wave_amax_commit(m, (unsigned*)stat + 2 * cur);
 }

@@ -141,7 +141,9 @@ class FlatParams(object):
         if t is None or self.__dict__.get("_flip16_gen") != self.plane_gen:
             return None
         e = self._flip16_entries.get(w.data_ptr())
-        if e is None or e[1] is not scale or e[0] is not w:
+        # (the address lies inside this buffer, which outlives the entry: the same address with the same dimensions IS the same
+        # matrix -- a Linear layer hands its weight over as a fresh 4-D view every call, identity of the object would never match)
+        if e is None or e[1] is not scale or (w.shape[0], w.shape[2], w.shape[3], w.shape[1]) != tuple(e[3]):
             return None
         v = t[5].get(w.data_ptr())
         if v is None:

@@ -571,6 +571,57 @@ def test_packed_weight_planes_bookkeeping(hip, restore_mode, arith):
     assert (g3.double() - r3).abs().max().item() < 1e-5 * r3.abs().max().item()
 
 
+def test_batch_pack_maxima_are_the_matrices_maxima(hip, restore_mode):
+    """mmt_pack_weights_f16 / mmt_pack_weights_flipped_f16 derive every matrix's power-of-two scale from max |w| (max |w * scale[co]|
+    for the data-gradient form), found by a reduction launch that reads the matrices in memory order (round 6: the maximum does not
+    care about the packing order): exact, for matrices whose row count is not a multiple of 32, several tap counts, with and
+    without a row scale; the planes built on it reproduce the layer"""
+    from torch import nn
+    from maskrcnn_benchmark.layers import Conv2d
+    from maskrcnn_benchmark.engine.flat import flatten_model
+    hip.set_conv_precision(3)
+    hip.set_f16x2(True)
+    try:
+        torch.manual_seed(11)
+        m = nn.Sequential(Conv2d(64, 80, 3, 1, 1), Conv2d(80, 48, 1, 1, 0), Conv2d(48, 144, 3, 1, 1), Conv2d(144, 64, 1, 1, 0)).cuda()
+        with torch.no_grad():
+            for i, l in enumerate(m):
+                l.weight.mul_(10.0 ** (i - 2))          # maxima four decades apart: a mixed-up matrix would show
+                l.weight[-1, -1, -1, -1] = 3.0 * l.weight.abs().max()   # ... and the maximum in the last element of the matrix in memory
+        flat = flatten_model(m)
+        x = cl(torch.randn(2, 64, 24, 24)).requires_grad_(True)
+        h = x
+        for l in m:
+            h = l(h)
+        h.sum().backward()                               # registers the data-gradient forms with the flat buffer
+        flat.refresh_planes()
+        torch.cuda.synchronize()
+        mats = [p for _, p in flat._named if p.dim() >= 2 and p.shape[0] > 32 and (p.numel() // p.shape[0]) % 16 == 0]
+        assert flat.stat16 is not None and flat.stat16.shape[0] == len(mats) == 4
+        for d, p in enumerate(mats):
+            assert flat.stat16[d, 0].item() == p.detach().abs().max().item(), d
+        t = flat.__dict__.get("_flip16_table")
+        assert t is not None and len(t[3]) >= 3
+        for w, scale, planes, dims in flat._flip16_entries.values():
+            want = (w.detach() * (scale.view(-1, 1, 1, 1) if scale is not None else 1.0)).abs().max().item()
+            assert t[4][t[3][w.data_ptr()], 0].item() == want, dims
+        # the planes reproduce the layers (forward and data gradient) after the bulk re-pack
+        x2 = cl(torch.randn(2, 64, 24, 24)).requires_grad_(True)
+        h = x2
+        for l in m:
+            h = l(h)
+        h.sum().backward()
+        xr = x2.detach().double().requires_grad_(True)
+        hr = xr
+        for l in m:
+            hr = F.conv2d(hr, l.weight.double(), l.bias.double(), 1, l.weight.shape[2] // 2)
+        hr.sum().backward()
+        assert (h.double() - hr).abs().max().item() < 1e-5 * hr.abs().max().item()
+        assert (x2.grad.double() - xr.grad).abs().max().item() < 1e-5 * xr.grad.abs().max().item()
+    finally:
+        hip.set_f16x2(None)
+
+
 # ------------------------------------------------------------------------------------------ target assignment
 @pytest.mark.parametrize("lowq", [False, True])
 def test_match_targets_against_tensor_formulation(hip, lowq):
