@@ -79,10 +79,22 @@ for tag in ("f16x2", "bf16x3", "mode0"):
     tot = sum(float(x["TotalDurationNs"]) for x in rows)
     nl = sum(int(x["Calls"]) for x in rows)
     lib = [x for x in rows if is_library(x["Name"])]
+    # the same launches by the profiler's own clock (first wave in to last wave out): the kernel the line names, and for a kernel
+    # that finishes split-K shapes in a second launch that launch too (bench.py's brackets hold both)
+    kname = b["roofline"]["kernel"].split("<")[0].split(" ")[0]
+    pref = KERN[tag].get("fwd4" if "strip" in kname else "fwd1", kname + "<")
+    kr = [x for x in rows if pref in x["Name"]]
+    kcalls, kns = sum(int(x["Calls"]) for x in kr), sum(float(x["TotalDurationNs"]) for x in kr)
+    prof_avg = kns / max(kcalls, 1) / 1e6
+    flop = b["roofline"].get("algorithmic_flop_per_launch")
     out += ["## %s -- %s" % (tag, ARITH[tag]), "",
-            "bench line under the profiler: %.2f imgs/s, %.1f ms/step; roofline (`%s`): %.1f TFLOP/s (frac %.3f), avg launch %.4f ms"
+            "bench line under the profiler: %.2f imgs/s, %.1f ms/step; roofline (`%s`): %.1f TFLOP/s (frac %.3f), avg launch %.4f ms "
+            "by the event brackets on the launch stream; rocprofv3's own average over the same %d launches: **%.4f ms**%s -- the brackets "
+            "start when the stream reaches the launch and so hold its wait for free CUs beside the other two streams, the profiler's "
+            "duration starts with the first wave"
             % (b["value"], b["ms_per_step"], b["roofline"]["kernel"].split(" ")[0], b["roofline"]["achieved"], b["roofline"]["frac"],
-               b["roofline"]["avg_launch_ms"]), "",
+               b["roofline"]["avg_launch_ms"], kcalls, prof_avg,
+               (" (= %.1f TFLOP/s, %.3f of %.0f)" % (flop / prof_avg / 1e9, flop / prof_avg / 1e9 / b["roofline"]["peak"], b["roofline"]["peak"])) if flop and prof_avg else ""), "",
             "%d steps traced (= `ema_kernel` launches): %.1f ms of kernel time = **%.1f ms/step** (sum over all streams), **%d launches/step**, "
             "of which library (ATen / rocprim / runtime copies) %d launches and %.2f ms per step" % (
                 nsteps, tot / 1e6, tot / 1e6 / max(nsteps, 1), nl // max(nsteps, 1), sum(int(x["Calls"]) for x in lib) // max(nsteps, 1),
