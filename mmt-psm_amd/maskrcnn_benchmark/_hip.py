@@ -967,13 +967,16 @@ def roi_align_forward(feats, scales, rois, levels, ph, pw, sr):
     return out
 
 
-def roi_align_backward(grad_out, shapes, scales, rois, levels, ph, pw, sr):
-    """-> list of zero-initialised-then-accumulated gradients, one per level (N,C,H,W) NHWC-dense"""
+def roi_align_backward(grad_out, shapes, scales, rois, levels, ph, pw, sr, into=None):
+    """-> list of zero-initialised-then-accumulated gradients, one per level (N,C,H,W) NHWC-dense
+    into: per level an existing fp32 gradient tensor of that shape to accumulate into (the atomics add to what is there), or None"""
     g = nhwc(grad_out)
     rois = _dev(rois).float().contiguous()
     levels = _dev(levels).to(torch.int32).contiguous()
     K = rois.shape[0]
-    if g.is_cuda and g.dtype == torch.float32 and os.environ.get("MMT_ROI_BWD_DENSE", "0") != "0":
+    if into is not None and not any(t is not None for t in into):
+        into = None
+    if into is None and g.is_cuda and g.dtype == torch.float32 and os.environ.get("MMT_ROI_BWD_DENSE", "0") != "0":
         # opt-in: the tile-gather form writes every element of every level once -- no clear, no atomics, repeatable (csrc/roi_align.hip)
         grads = [empty_nhwc(s[0], s[1], s[2], s[3], g.device) for s in shapes]
         p = _pyramid(grads, scales, grads)
@@ -982,7 +985,12 @@ def roi_align_backward(grad_out, shapes, scales, rois, levels, ph, pw, sr):
             return grads
         if rc != 1:
             _check(rc, "mmt_roi_align_backward_dense")
-    grads = [empty_nhwc(s[0], s[1], s[2], s[3], g.device, zero=True) for s in shapes]
+    grads = [into[i] if (into is not None and into[i] is not None) else empty_nhwc(s[0], s[1], s[2], s[3], g.device, zero=True)
+             for i, s in enumerate(shapes)]
+    if into is not None:
+        for t, s in zip(grads, shapes):
+            if tuple(t.shape) != tuple(s) or t.dtype != torch.float32 or not t.is_contiguous(memory_format=torch.channels_last):
+                raise RuntimeError("roi_align_backward: `into` must hold dense NHWC fp32 tensors of the levels' shapes")
     if K:
         p = _pyramid(grads, scales, grads)
         _check(lib().mmt_roi_align_backward(ctypes.byref(p), _p(rois), _p(levels), K, ph, pw, sr, _p(g), _stream()),

@@ -259,6 +259,7 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, stride, pad, relu, input_relu, out_rb=False, din_rb=False):
         # out_rb: y feeds a plane-fed 3x3 launch; din_rb: the gradient w.r.t. x feeds one (the data gradient of the 3x3 layer that
         # produced x) -- this node's launches then write the row-blocked planes from their epilogues (round 6, _hip._rb_produce)
+        ctx.acc = getattr(x, "_mmt_acc", None)   # x is an alias of a fork(): its gradient accumulates (_ForkAcc)
         x = H.nhwc(x)
         y = H.conv_forward(x, w, None, b, stride, pad, relu=relu, rb_site=("y", w.data_ptr()) if out_rb else None)
         ctx.save_for_backward(x, w)
@@ -274,11 +275,23 @@ class ConvFn(torch.autograd.Function):
         g = H.nhwc(g)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:   # first: on the fp16 split it records max |g|, which the weight gradient then reuses
-            dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None, out_dtype=x.dtype,
-                        rb_site=("dx", w.data_ptr()) if din_rb else None, w_owner=ctx.w_owner)
+            h = ctx.acc if (stride == 1 and not input_relu and x.dtype == torch.float32) else None
+            if h is not None:
+                # what the other consumers of x have accumulated so far rides in as this launch's residual operand; the result is
+                # the sum, with its statistics (and, where the fork's consumer is plane-fed, its planes) from this epilogue
+                dx = _dgrad(g, w, x.shape, stride, pad, None, None, out_dtype=x.dtype, res=h.buf, res_mode=1 if h.buf is not None else 0,
+                            rb_site=h.rb_site if h.rb_site is not None else (("dx", w.data_ptr()) if din_rb else None), w_owner=ctx.w_owner)
+                if not h.put(dx, True):
+                    dx_ret = None
+                else:
+                    dx_ret = dx
+            else:
+                dx = _dgrad(g, w, x.shape, stride, pad, None, x if input_relu else None, out_dtype=x.dtype,
+                            rb_site=("dx", w.data_ptr()) if din_rb else None, w_owner=ctx.w_owner)
+                dx_ret = dx
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dw, db = _wgrad(x, g, w, stride, pad, None, has_b, *ctx.dst)
-        return dx, dw, db, None, None, None, None, None, None
+        return (dx_ret if ctx.needs_input_grad[0] else None), dw, db, None, None, None, None, None, None
 
 
 def conv(x, w, b=None, stride=1, pad=0, relu=False, input_relu=False, out_rb=False, din_rb=False):
@@ -552,17 +565,27 @@ class RoiAlignFpnFn(torch.autograd.Function):
         ctx.save_for_backward(rois, levels)
         ctx.cfgv = (res, scales, sr, [tuple(f.shape) for f in feats])
         ctx.fdt = feats[0].dtype
+        ctx.acc = [getattr(f, "_mmt_acc", None) for f in feats]   # levels that are aliases of a fork(): their gradient accumulates (_ForkAcc)
         return out
 
     @staticmethod
     def backward(ctx, g):
         rois, levels = ctx.saved_tensors
         res, scales, sr, shapes = ctx.cfgv
-        grads = H.roi_align_backward(g, shapes, scales, rois, levels, res, res, sr)   # fp32 atomics
+        acc = ctx.acc if ctx.fdt == torch.float32 else [None] * len(shapes)
+        into = [h.buf if (h is not None and ctx.needs_input_grad[5 + i]) else None for i, h in enumerate(acc)]
+        grads = H.roi_align_backward(g, shapes, scales, rois, levels, res, res, sr, into=into)   # fp32 atomics
         if ctx.fdt != torch.float32:
             grads = [gr.to(ctx.fdt) for gr in grads]   # bf16 storage: the gradient in the level's own type
-        return (None, None, None, None, None) + tuple(
-            gr if ctx.needs_input_grad[5 + i] else None for i, gr in enumerate(grads))
+        out = []
+        for i, gr in enumerate(grads):
+            if not ctx.needs_input_grad[5 + i]:
+                out.append(None)
+            elif acc[i] is None:
+                out.append(gr)
+            else:   # the first contribution travels through autograd, the later ones are in it already
+                out.append(gr if acc[i].put(gr, False) else None)
+        return (None, None, None, None, None) + tuple(out)
 
 
 class MaskBCEFn(torch.autograd.Function):
@@ -705,31 +728,65 @@ def split_batch(x, n):
 _FORK_ON = True
 
 
+_FORK_ACC = _os.environ.get("MMT_FORK_ACC", "1") != "0"
+
+
+class _ForkAcc(object):
+    """the gradient of a forked tensor, ACCUMULATED by the consumers that know how instead of written once per consumer and summed
+    (round 6): a ROIAlign backward adds its atomics to what is there, a convolution's data gradient takes what is there as its
+    residual operand.  buf: the sum so far (None: nobody yet); fresh: buf carries the statistics / planes of its current values (a
+    convolution wrote it last); seen: every tensor that ever was `buf` (autograd still hands the first one to ForkFn.backward)"""
+    __slots__ = ("buf", "fresh", "seen", "rb_site")
+
+    def __init__(self, rb_site):
+        self.buf, self.fresh, self.seen, self.rb_site = None, False, [], rb_site
+
+    def put(self, t, fresh):
+        first = self.buf is None
+        if t is not self.buf:
+            self.seen.append(t)
+        self.buf, self.fresh = t, fresh
+        if not fresh:   # changed in place through raw pointers: what its producer recorded about it no longer holds
+            for a in ("_mmt_amax", "_mmt_rb", "_mmt_planes"):
+                if getattr(t, a, None) is not None:
+                    setattr(t, a, None)
+        return first
+
+
 class ForkFn(torch.autograd.Function):
     """x -> n aliases of x, one per consumer.  Autograd would add the consumers' gradients pairwise with library launches
     (n - 1 of them) and the first fp16-split consumer of the sum would then take a reduction pass for its scale; here the
     backward is ONE `mmt_sum_stats` launch that adds them and records max / mean |.| of the sum on the way."""
 
     @staticmethod
-    def forward(ctx, x, n, rb_site=None):
+    def forward(ctx, x, n, rb_site=None, acc=None):
         ctx.set_materialize_grads(False)   # an alias nobody back-propagated through arrives as None, not as a zero-filled tensor
         ctx.rb_site = rb_site
+        ctx.acc = acc
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *gs):
         gs = [g for g in gs if g is not None]
+        h = ctx.acc
+        if h is not None and h.buf is not None:
+            # the consumers that accumulate handed over ONE tensor between them (the first of them) and None since: what counts is
+            # the accumulator as it stands now; consumers that do not know the protocol sent tensors of their own
+            gs = [g for g in gs if not any(g is b for b in h.seen)]
+            if not gs and h.fresh:
+                return h.buf, None, None, None   # a convolution wrote it last: statistics and planes are those of the sum
+            gs = [h.buf] + gs
         if not gs:
-            return None, None, None
+            return None, None, None, None
         if len(gs) == 1:
-            return gs[0], None, None
+            return gs[0], None, None, None
         if gs[0].dim() == 4:
             gs = [H.nhwc(g) for g in gs]
         else:
             gs = [g.contiguous() for g in gs]
         while len(gs) > 4:
             gs = [H.sum_stats(gs[:4])] + gs[4:]
-        return H.sum_stats(gs, ctx.rb_site), None, None
+        return H.sum_stats(gs, ctx.rb_site), None, None, None
 
 
 def fork(x, n, rb_site=None):
@@ -740,7 +797,11 @@ def fork(x, n, rb_site=None):
         return (x,) * n
     if not (_FORK_ON and x.requires_grad and x.is_cuda and x.dtype == torch.float32 and H.F16X2 and H.get_conv_precision() == 3):
         return (x,) * n
-    outs = ForkFn.apply(x, n, rb_site)
+    acc = _ForkAcc(rb_site) if (_FORK_ACC and x.dim() == 4) else None
+    outs = ForkFn.apply(x, n, rb_site, acc)
+    if acc is not None:
+        for o in outs:
+            o._mmt_acc = acc
     rb = getattr(x, "_mmt_rb", None)
     if rb is not None and rb[2] == x._version:
         for o in outs:
