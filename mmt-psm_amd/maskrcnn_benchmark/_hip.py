@@ -794,6 +794,32 @@ class LaunchPlan(object):
         # (what _Slot / _site_ok look at: a pool whose statistics never travel to the host)
         self.base, self.gen, self.host_gen, self.event, self.host = self.slot_buf.data_ptr(), 0, -2, None, None
 
+    def __del__(self):
+        # A plan sits in a reference cycle (its result tensors carry statistics slots whose pool it is), so it dies in the cyclic
+        # collector -- at ANY allocation, also in the middle of another plan's recording, i.e. inside torch.cuda.use_mem_pool(): a
+        # MemPool destroyed there aborts the process in the caching allocator (seen once in ~10 runs of the GPU suite, "Fatal Python
+        # error: Aborted / Garbage-collecting" under planned()).  The pool is handed to a graveyard instead and destroyed at the next
+        # safe point: the entry of planned(), outside every pool context (_drain_pools).
+        try:
+            p = self.pool
+            if p is not None:
+                self.pool = None
+                _POOL_GRAVE.append(p)
+        except Exception:   # (interpreter shutdown: the module's globals may be gone)
+            pass
+
+
+_POOL_GRAVE = []   # MemPool objects of dead plans, destroyed by _drain_pools
+
+
+def _drain_pools():
+    """destroy the memory pools of plans that died since the last call (never inside a pool context: see LaunchPlan.__del__)"""
+    while _POOL_GRAVE:
+        try:
+            _POOL_GRAVE.pop()
+        except IndexError:   # (another thread drained it)
+            break
+
 
 def record_torch(fn):
     """inside a pass that may be recorded: `fn()` -- a library (ATen) operation on tensors of the pass, already executed by the
@@ -813,6 +839,8 @@ def planned(tag, fn, x):
     env = os.environ.get   # (the library's per-call switches -- A/B timing, parity tests -- choose kernels: part of the key)
     key = (tag, tuple(x.shape), x.dtype, _stream(), _PLAN_EPOCH[0], PLANES_EPOCH, LAYOUT_EPOCH[0], F16X2, _PREC, _BF16_STORAGE, _RB_EPOCH[0],
            env("MMT_STRIP"), env("MMT_SPLITK"), env("MMT_ROWS"), env("MMT_PG"), env("MMT_C64"), env("MMT_DIRECT_EPI"))
+    if getattr(_TLS, "rec", None) is None and _POOL_GRAVE:
+        _drain_pools()
     with _LP_LOCK:
         plan = _LAUNCH_PLANS.pop(key, None)
         if plan is None:
@@ -841,7 +869,9 @@ def planned(tag, fn, x):
         # the input must have reached the recorded launches as a direct pointer argument -- the only thing a replay patches.  A pass
         # that read it through a tensor operation or an argument block would replay the recorded batch for ever: never replayed
         if not any(type(a) is int and a == plan.in_ptr for _f, args in plan.calls for a in args):
-            plan.dead, plan.calls, plan.pool = True, [], None
+            dead_pool, plan.pool = plan.pool, None
+            plan.dead, plan.calls = True, []
+            del dead_pool   # (outside the pool context: destroyed here and now)
         return plan.result
     plan.slot_buf.zero_()
     old, new = plan.in_ptr, x.data_ptr()

@@ -144,3 +144,39 @@ def test_only_the_fused_stem_is_planned_and_new_weights_retire_a_plan(det):
         outs = [H.planned(("indirect",), indirect, x)[0].clone() for x in xs]
         assert len(seen) == len(xs) and not torch.equal(outs[2], outs[3])
         assert len(H._LAUNCH_PLANS) <= H._LP_MAX
+
+
+def test_dead_plans_give_up_their_memory_pools_at_a_safe_point(det):
+    """A plan sits in a reference cycle (its result tensors carry statistics slots whose pool it is) and dies in the cyclic collector,
+    which may run at any allocation -- also in the middle of ANOTHER plan's recording, inside torch.cuda.use_mem_pool(), where a
+    destroyed MemPool aborts the process in the caching allocator (round 6: once in ten runs of this suite).  LaunchPlan.__del__ hands
+    the pool to a graveyard that planned() empties on entry, outside every pool context.  Here: more shapes than the LRU holds, each
+    recorded and replayed, with a collector that runs every few allocations; the process must survive, evicted plans must have left
+    the table, and their pools must be gone after the next entry."""
+    import gc
+    H, m = det
+    old = gc.get_threshold()
+    g = torch.Generator().manual_seed(2)
+    shapes = [(2, 3, 128, 160), (2, 3, 160, 128), (1, 3, 192, 128), (2, 3, 128, 128), (1, 3, 128, 192), (1, 3, 160, 160), (2, 3, 192, 192)]
+    assert len(shapes) > H._LP_MAX
+    gc.set_threshold(20, 2, 2)
+    try:
+        with torch.no_grad():
+            for rnd in range(2):
+                for s in shapes:
+                    for _ in range(3):   # plain, recorded, replayed
+                        x = (torch.randn(*s, generator=g) * 50.0).cuda()
+                        got = m.run_backbone(x)
+                        H.LAUNCH_PLANS = False
+                        want = m.run_backbone(x)
+                        H.LAUNCH_PLANS = True
+                        for a, b in zip(got, want):
+                            assert torch.equal(a, b)
+                    del got, want
+        gc.collect()
+    finally:
+        gc.set_threshold(*old)
+    assert len(H._LAUNCH_PLANS) <= H._LP_MAX
+    with torch.no_grad():
+        m.run_backbone((torch.randn(*shapes[0], generator=g) * 50.0).cuda())   # an entry of planned(): the graveyard is emptied
+    assert len(H._POOL_GRAVE) == 0
